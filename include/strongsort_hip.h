@@ -1,0 +1,142 @@
+/*
+ * strongsort_hip.h — C ABI of the MI355X (gfx950) StrongSORT hot path.
+ *
+ * The reference has no plugin / FFI interface: its only crossings into the
+ * hot path are two Python calls into the third-party `ultralytics` package,
+ *     /root/reference/yolo_multi_model.py:41    results = model.track(image, ..., persist=True, tracker=...)
+ *     /root/reference/yolo_multi_model.py:173   results = model.predict(image, ...)
+ * configured by /root/reference/yolo_multi_model.py:18-21 (conf, iou, agnostic_nms, max_det).
+ * Every entry point below replaces one stage that runs inside those two calls; the Python host
+ * side (strongsort_yolo_amd/yolo.py `YOLO.track/.predict`, strongsort_yolo_amd/tracker.py
+ * `StrongSORT.update(dets, frame)`) binds them with ctypes — see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes; `d_` = device memory owned by the caller; every call is
+ * asynchronous on the context's HIP stream unless it says "synchronous"; return 0 or a negative
+ * SS_ERR_* code, never a C++ exception; one context is not thread safe.
+ */
+#ifndef STRONGSORT_HIP_H
+#define STRONGSORT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_OK 0
+#define SS_ERR_INVALID (-1)      /* bad argument */
+#define SS_ERR_CAPACITY (-2)     /* more tracks / detections / candidates than the context holds */
+#define SS_ERR_HIP (-3)          /* HIP runtime error (see ss_last_error) */
+#define SS_ERR_INFEASIBLE (-4)   /* assignment problem has no finite solution */
+
+#define SS_FEAT_DIM 512
+#define SS_MAX_TRACKS 256        /* track slots per stream */
+#define SS_MAX_DETS 128          /* detections per stream per frame */
+#define SS_OUT_COLS 8            /* x1,y1,x2,y2,track_id,class_id,conf,det_idx */
+
+typedef struct ss_ctx ss_ctx;
+
+/* Tracker constants (oracle/DECISIONS.md D-02..D-11).  Replaces the tracker YAML that
+ * yolo_multi_model.py:41 names (`tracker="botsort.yaml"`). */
+typedef struct ss_config {
+    double max_dist;             /* 0.2    cosine matching threshold            */
+    double max_iou_distance;     /* 0.7    IoU-stage threshold on 1-IoU          */
+    double mc_lambda;            /* 0.995  appearance / motion blend            */
+    double gating_threshold;     /* 9.4877 chi2inv95[4]                          */
+    double gated_cost;           /* 1e5                                          */
+    double std_weight_position;  /* 1/20                                         */
+    double std_weight_velocity;  /* 1/160                                        */
+    double ema_alpha;            /* 0.9  (a=(float)alpha, 1-a=(float)(1.0-alpha))  */
+    int    max_age;              /* 30                                           */
+    int    n_init;               /* 3                                            */
+    int    nn_budget;            /* 100 (<= 128)                                 */
+    int    n_streams;            /* independent video streams held by this context */
+    int    debug;                /* !=0: keep stage intermediates for ss_get_debug */
+} ss_config;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int  ss_create(const ss_config* cfg, int device, ss_ctx** out);
+void ss_destroy(ss_ctx* ctx);
+const char* ss_last_error(const ss_ctx* ctx);            /* NULL ctx: last global error */
+int  ss_set_hip_stream(ss_ctx* ctx, void* hip_stream);   /* e.g. torch.cuda.current_stream().cuda_stream */
+int  ss_reset(ss_ctx* ctx, int stream);                  /* stream < 0: all streams */
+int  ss_synchronize(ss_ctx* ctx);
+
+/* ---- a1  letterbox / preprocess  (inside model.track/.predict, yolo_multi_model.py:41,:173) ---
+ * BGR u8 [h][w][3] (row_stride bytes) -> RGB planar [3][out_h][out_w], /255, pad 114.
+ * dst_f16 != 0 writes IEEE half, else float. */
+int ss_letterbox(ss_ctx* ctx, const uint8_t* d_src, int h, int w, int row_stride, void* d_dst,
+                 int dst_f16, int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left,
+                 int pad_value);
+
+/* ---- a3  NMS  (inside model.track/.predict; thresholds = yolo_multi_model.py:18-21) -----------
+ * d_pred: YOLOv8 head layout [(4+nc+n_extra)][n_anchors] float (xywh, class scores, extra rows).
+ * Writes up to max_det rows [x1,y1,x2,y2,conf,cls, extra...] in ORIGINAL-image pixels
+ * (scale_boxes with gain/pad, clipped to w0 x h0), the kept anchor indices and the count. */
+int ss_nms(ss_ctx* ctx, const float* d_pred, int n_anchors, int nc, int n_extra, float conf_thres,
+           float iou_thres, int agnostic, float max_wh, int max_det, float gain, float pad_x,
+           float pad_y, float w0, float h0, float* d_rows, int row_stride, int* d_keep, int* d_count);
+
+/* ---- a4  ReID crop-extract  (StrongSORT._get_features, inside model.track) ---------------------
+ * For each detection row (x1,y1,x2,y2,... ; det_stride floats) crop + bilinear to 256x128,
+ * /255, ImageNet mean/std, RGB planar [n][3][256][128].  n from *d_count when d_count != NULL. */
+int ss_crop_norm(ss_ctx* ctx, const uint8_t* d_frame, int h, int w, int row_stride,
+                 const float* d_dets, int det_stride, int n, const int* d_count, void* d_out,
+                 int out_f16);
+
+/* ---- a6..a10  tracker update  (tracker.update inside model.track, yolo_multi_model.py:41) -----
+ * One frame for EVERY stream of the context in one batch of launches:
+ *   d_dets   [n_streams][SS_MAX_DETS][6]   x1,y1,x2,y2,conf,cls (original pixels, float)
+ *   d_ndets  [n_streams]                   detections per stream (device ints)
+ *   d_feats  [n_streams][SS_MAX_DETS][512] raw ReID embeddings (normalised on device)
+ *   d_img_hw [n_streams][2]                frame height, width (device ints; output clipping)
+ * Results stay on the device: d_out [n_streams][SS_MAX_TRACKS][8], d_nout [n_streams]. */
+int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const float* d_feats,
+                    const int* d_img_hw, float* d_out, int* d_nout);
+
+/* Synchronous convenience for one stream with host buffers (used by StrongSORT.update). */
+int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, const float* h_feats,
+                         int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
+
+/* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
+int ss_check_errors(ss_ctx* ctx);
+
+/* ---- stage entry points for known-answer tests (device pointers, natural layouts) ------------- */
+int ss_feat_normalize(ss_ctx* ctx, const float* d_raw, int n, float* d_unit);
+int ss_ema(ss_ctx* ctx, const float* d_smooth, const float* d_feat, int n, float* d_out);
+int ss_kf_predict(ss_ctx* ctx, double* d_mean, double* d_cov, int n);
+int ss_kf_update(ss_ctx* ctx, double* d_mean, double* d_cov, const double* d_z, const double* d_conf, int n);
+int ss_kf_initiate(ss_ctx* ctx, const double* d_z, int n, double* d_mean, double* d_cov);
+/* gallery rows natural [T][B][512] -> fragment-major [T][4][16384] used by ss_assoc_cost */
+int ss_gallery_pack(ss_ctx* ctx, const float* d_gallery, int T, int B, float* d_frag);
+/* fused a7+a8: cosine-gallery-min + Mahalanobis gate + blend + threshold.
+ * d_counts [T] valid gallery rows; d_feats [D][512] unit rows; d_mean/d_cov predicted states;
+ * d_xyah [D][4].  Outputs [T][D]: cost (f64), cosine (f32), maha (f64), gated (u8). */
+int ss_assoc_cost(ss_ctx* ctx, const float* d_gallery_frag, const int* d_counts, int T,
+                  const float* d_feats, int D, const double* d_mean, const double* d_cov,
+                  const double* d_xyah, double* d_cost, float* d_cos, double* d_maha, uint8_t* d_gated);
+int ss_iou_cost(ss_ctx* ctx, const double* d_track_tlwh, int T, const double* d_det_tlwh, int D,
+                double* d_cost);
+/* a9: rectangular LSAP on a [nr][nc] float64 matrix; d_row_to_col[nr] = column or -1. */
+int ss_lsap(ss_ctx* ctx, const double* d_cost, int nr, int nc, int* d_row_to_col);
+
+/* ---- inspection (synchronous; parity tests) ----------------------------------------------------
+ * Track table of one stream in track-list order (arrays may be NULL). */
+int ss_get_tracks(ss_ctx* ctx, int stream, int cap, int* n_tracks, int* next_id, int* track_id,
+                  int* state, int* hits, int* age, int* tsu, int* class_id, float* conf,
+                  double* mean, double* cov, float* smooth, int* gal_count);
+/* Stage intermediates of the last frame (ctx created with debug != 0).
+ * counts[4] = n_conf, n_cand, n_cols_b, n_dets; matrices are [SS_MAX_TRACKS][SS_MAX_DETS] strided. */
+int ss_get_debug(ss_ctx* ctx, int stream, int* counts, float* cos, double* maha, uint8_t* gated,
+                 double* cost_a, double* cost_b, int* lists /* [4][SS_MAX_TRACKS] */);
+/* Gallery of one track (by position in the track list) in natural [count][512] order of slots. */
+int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int cap_rows, int* count);
+
+/* ---- profiling support ----------------------------------------------------------------------- */
+/* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
+ * call, measured with HIP events on the context stream; also returns the launch count. */
+int ss_assoc_timing(ss_ctx* ctx, int enable, float* mean_ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,440 @@
+// ss_api.hip — C ABI (include/strongsort_hip.h) over the gfx950 kernels.  No torch types, no
+// exceptions across the boundary; the context owns all device-resident tracker state.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ss_common.h"
+
+// launchers implemented in ss_track.hip / ss_front.hip
+size_t ss_step_lds_bytes();
+size_t ss_lsap_lds_bytes();
+void ss_launch_frame(const SSDev&, const SSParams&, int, hipStream_t, hipEvent_t, hipEvent_t);
+void ss_launch_normalize(const float*, int, float*, hipStream_t);
+void ss_launch_ema(const float*, const float*, int, float, float, float*, hipStream_t);
+void ss_launch_kf(int, double*, double*, const double*, const double*, int, double, double, hipStream_t);
+void ss_launch_pack(const float*, int, int, float*, hipStream_t);
+void ss_launch_assoc(const float*, const int*, int, const float*, int, const double*, const double*,
+                     const double*, const SSParams&, float*, float*, double*, float*, double*, uint8_t*, hipStream_t);
+void ss_launch_iou(const double*, int, const double*, int, double, double*, hipStream_t);
+void ss_launch_lsap(const double*, int, int, int*, double*, int*, hipStream_t);
+int  ss_front_init();
+void ss_launch_letterbox(const uint8_t*, int, int, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
+int  ss_launch_nms(const float*, int, int, int, float, float, int, float, int, float, float, float, float,
+                   float, float*, int, int*, int*, void* ws, size_t ws_bytes, hipStream_t);
+size_t ss_nms_workspace_bytes();
+void ss_launch_crop(const uint8_t*, int, int, int, const float*, int, int, const int*, void*, int, hipStream_t);
+extern "C" void ss_step_kernel_attr();
+
+static std::string g_last_error;
+
+struct ss_ctx {
+    ss_config cfg;
+    SSParams prm;
+    SSDev dev;
+    int device;
+    hipStream_t stream;
+    std::vector<void*> allocs;
+    std::string err;
+    // staging for the host convenience path
+    float *d_dets, *d_feats, *d_out;
+    int *d_ndets, *d_imghw, *d_nout;
+    // KAT scratch
+    float *kat_featfrag, *kat_partmin;
+    double* kat_lsap_t;
+    int* kat_err;
+    void* nms_ws;
+    size_t nms_ws_bytes;
+    int tracks_ub;              // host upper bound of live tracks per stream (grid sizing)
+    // association-kernel timing
+    bool timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used;
+};
+
+static int fail(ss_ctx* c, int code, const std::string& msg)
+{
+    g_last_error = msg;
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPCHK(c, x)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (x);                                                                \
+        if (e_ != hipSuccess)                                                               \
+            return fail(c, SS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+template <typename T>
+static int dalloc(ss_ctx* c, T** p, size_t n, bool zero = true)
+{
+    void* q = nullptr;
+    HIPCHK(c, hipMalloc(&q, n * sizeof(T)));
+    if (zero) HIPCHK(c, hipMemsetAsync(q, 0, n * sizeof(T), c->stream));
+    c->allocs.push_back(q);
+    *p = (T*)q;
+    return SS_OK;
+}
+
+extern "C" const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
+{
+    if (!cfg || !out) return fail(nullptr, SS_ERR_INVALID, "ss_create: null argument");
+    if (cfg->n_streams < 1 || cfg->nn_budget < 1 || cfg->nn_budget > SS_NRT * SS_TILE)
+        return fail(nullptr, SS_ERR_INVALID, "ss_create: n_streams >= 1 and 1 <= nn_budget <= 128 required");
+    ss_ctx* c = new ss_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->stream = nullptr;
+    c->timing = false;
+    c->ev_used = 0;
+    c->tracks_ub = 0;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
+    SSParams& p = c->prm;
+    p.max_dist = cfg->max_dist; p.max_iou_distance = cfg->max_iou_distance; p.mc_lambda = cfg->mc_lambda;
+    p.gating_threshold = cfg->gating_threshold; p.gated_cost = cfg->gated_cost;
+    p.wp = cfg->std_weight_position; p.wv = cfg->std_weight_velocity;
+    p.ema_alpha = (float)cfg->ema_alpha; p.ema_one_minus_alpha = (float)(1.0 - cfg->ema_alpha);
+    p.max_age = cfg->max_age; p.n_init = cfg->n_init; p.nn_budget = cfg->nn_budget; p.debug = cfg->debug;
+    const size_t S = cfg->n_streams, T = SS_MAXT, D = SS_MAXD;
+    SSDev& d = c->dev;
+    memset(&d, 0, sizeof d);
+    d.S = (int)S;
+    int rc = SS_OK;
+#define A(field, n) if (rc == SS_OK) rc = dalloc(c, &d.field, (n))
+    A(n_tracks, S); A(next_id, S); A(frame, S); A(err, S); A(order, S * T);
+    A(slot_used, S * T); A(track_id, S * T); A(state, S * T); A(hits, S * T); A(age, S * T); A(tsu, S * T);
+    A(class_id, S * T); A(det_idx, S * T); A(gal_count, S * T); A(gal_head, S * T); A(conf, S * T);
+    A(mean, S * T * 8); A(cov, S * T * 64); A(smooth, S * T * SS_F);
+    A(gallery, S * T * SS_NRT * SS_TILE_FLOATS);
+    A(feat_unit, S * D * SS_F); A(feat_frag, S * SS_NCT * SS_TILE_FLOATS);
+    A(tlwh, S * D * 4); A(xyah, S * D * 4); A(chol, S * T * 16); A(ttlwh, S * T * 4);
+    A(n_conf, S); A(conf_list, S * T); A(part_min, S * T * SS_NRT * D);
+    if (cfg->debug) {
+        A(dbg_cos, S * T * D); A(dbg_maha, S * T * D); A(dbg_cost_a, S * T * D); A(dbg_cost_b, S * T * D);
+        A(dbg_gated, S * T * D); A(dbg_lists, S * 4 * T); A(dbg_counts, S * 4);
+    }
+#undef A
+    if (rc == SS_OK) rc = dalloc(c, &c->d_dets, S * D * 6);
+    if (rc == SS_OK) rc = dalloc(c, &c->d_feats, S * D * SS_F);
+    if (rc == SS_OK) rc = dalloc(c, &c->d_out, S * T * 8);
+    if (rc == SS_OK) rc = dalloc(c, &c->d_ndets, S);
+    if (rc == SS_OK) rc = dalloc(c, &c->d_imghw, S * 2);
+    if (rc == SS_OK) rc = dalloc(c, &c->d_nout, S);
+    if (rc == SS_OK) rc = dalloc(c, &c->kat_featfrag, (size_t)SS_NCT * SS_TILE_FLOATS);
+    if (rc == SS_OK) rc = dalloc(c, &c->kat_partmin, T * SS_NRT * D);
+    if (rc == SS_OK) rc = dalloc(c, &c->kat_lsap_t, (size_t)256 * 256);
+    if (rc == SS_OK) rc = dalloc(c, &c->kat_err, 4);
+    c->nms_ws_bytes = ss_nms_workspace_bytes();
+    if (rc == SS_OK) { char* w; rc = dalloc(c, &w, c->nms_ws_bytes); c->nms_ws = w; }
+    if (rc == SS_OK) { ss_step_kernel_attr(); if (ss_front_init() != 0) rc = fail(c, SS_ERR_HIP, "kernel attribute setup failed"); }
+    if (rc == SS_OK) { hipError_t e2 = hipStreamSynchronize(c->stream); if (e2 != hipSuccess) rc = fail(c, SS_ERR_HIP, hipGetErrorString(e2)); }
+    if (rc != SS_OK) { std::string m = c->err; ss_destroy(c); g_last_error = m; return rc; }
+    // next_id starts at 1
+    std::vector<int> ones(S, 1);
+    hipMemcpy(d.next_id, ones.data(), S * sizeof(int), hipMemcpyHostToDevice);
+    *out = c;
+    return SS_OK;
+}
+
+extern "C" void ss_destroy(ss_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (void* p : c->allocs) hipFree(p);
+    delete c;
+}
+
+extern "C" int ss_set_hip_stream(ss_ctx* c, void* s)
+{
+    if (!c) return SS_ERR_INVALID;
+    c->stream = (hipStream_t)s;
+    return SS_OK;
+}
+
+extern "C" int ss_synchronize(ss_ctx* c)
+{
+    if (!c) return SS_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SS_OK;
+}
+
+extern "C" int ss_reset(ss_ctx* c, int stream)
+{
+    if (!c || stream >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_reset: bad stream");
+    SSDev& d = c->dev;
+    const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? d.S : stream + 1;
+    const size_t T = SS_MAXT;
+    for (int s = s0; s < s1; ++s) {
+        int one = 1;
+        HIPCHK(c, hipMemsetAsync(d.n_tracks + s, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.frame + s, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.err + s, 0, 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.slot_used + s * T, 0, T * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.gal_count + s * T, 0, T * 4, c->stream));
+        HIPCHK(c, hipMemsetAsync(d.gal_head + s * T, 0, T * 4, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d.next_id + s, &one, 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->tracks_ub = 0;
+    return SS_OK;
+}
+
+// ---- tracker -----------------------------------------------------------------------------------
+extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndets, const float* d_feats,
+                               const int* d_img_hw, float* d_out, int* d_nout)
+{
+    if (!c || !d_dets || !d_ndets || !d_feats || !d_img_hw || !d_out || !d_nout)
+        return fail(c, SS_ERR_INVALID, "ss_track_update: null argument");
+    SSDev dev = c->dev;
+    dev.dets = d_dets; dev.n_dets = d_ndets; dev.feats_raw = d_feats; dev.img_hw = (int*)d_img_hw;
+    dev.out_rows = d_out; dev.n_out = d_nout;
+    // grid upper bound on confirmed tracks: no host sync; grows by at most MAXD per frame and is
+    // refreshed whenever the host reads the table (ss_track_update_host / ss_get_tracks).
+    c->tracks_ub = c->tracks_ub + SS_MAXD > SS_MAXT ? SS_MAXT : c->tracks_ub + SS_MAXD;
+    const int grid_tracks = c->tracks_ub < 1 ? 1 : c->tracks_ub;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used == c->ev.size()) {
+            hipEvent_t a, b;
+            HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
+            c->ev.emplace_back(a, b);
+        }
+        e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
+    }
+    ss_launch_frame(dev, c->prm, grid_tracks, c->stream, e0, e1);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, int n, const float* h_feats,
+                                    int img_h, int img_w, float* h_out, int cap_rows, int* n_out)
+{
+    if (!c || stream < 0 || stream >= c->dev.S || n < 0 || !n_out) return fail(c, SS_ERR_INVALID, "ss_track_update_host: bad argument");
+    if (n > SS_MAXD) return fail(c, SS_ERR_CAPACITY, "ss_track_update_host: more than SS_MAX_DETS detections");
+    const int S = c->dev.S;
+    // other streams see 0 detections this call only if they are not driven: to keep streams
+    // independent the host path requires a single-stream context.
+    if (S != 1) return fail(c, SS_ERR_INVALID, "ss_track_update_host: context must hold exactly one stream");
+    int hw[2] = { img_h, img_w };
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_dets, h_dets, (size_t)n * 6 * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_feats, h_feats, (size_t)n * SS_F * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ndets, &n, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_imghw, hw, 8, hipMemcpyHostToDevice, c->stream));
+    int rc = ss_track_update(c, c->d_dets, c->d_ndets, c->d_feats, c->d_imghw, c->d_out, c->d_nout);
+    if (rc) return rc;
+    int cnt[2] = { 0, 0 }, nt = 0, err = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt[0], c->d_nout, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&nt, c->dev.n_tracks, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&err, c->dev.err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tracks_ub = nt;
+    if (err) return fail(c, err, err == SS_ERR_CAPACITY ? "tracker capacity exceeded on device" : "assignment infeasible on device");
+    *n_out = cnt[0];
+    if (cnt[0] > cap_rows) return fail(c, SS_ERR_CAPACITY, "ss_track_update_host: output buffer too small");
+    if (cnt[0]) HIPCHK(c, hipMemcpy(h_out, c->d_out, (size_t)cnt[0] * 8 * 4, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+extern "C" int ss_check_errors(ss_ctx* c)
+{
+    if (!c) return SS_ERR_INVALID;
+    std::vector<int> e(c->dev.S), nt(c->dev.S);
+    HIPCHK(c, hipMemcpyAsync(e.data(), c->dev.err, e.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nt.data(), c->dev.n_tracks, nt.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int ub = 0;
+    for (int v : nt) ub = v > ub ? v : ub;
+    c->tracks_ub = ub;
+    for (size_t s = 0; s < e.size(); ++s)
+        if (e[s]) return fail(c, e[s], "device error flag on stream " + std::to_string(s));
+    return SS_OK;
+}
+
+// ---- stage entry points ---------------------------------------------------------------------------
+extern "C" int ss_feat_normalize(ss_ctx* c, const float* raw, int n, float* unit)
+{ if (!c) return SS_ERR_INVALID; ss_launch_normalize(raw, n, unit, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_ema(ss_ctx* c, const float* s, const float* f, int n, float* o)
+{ if (!c) return SS_ERR_INVALID; ss_launch_ema(s, f, n, c->prm.ema_alpha, c->prm.ema_one_minus_alpha, o, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_kf_predict(ss_ctx* c, double* mean, double* cov, int n)
+{ if (!c) return SS_ERR_INVALID; ss_launch_kf(0, mean, cov, nullptr, nullptr, n, c->prm.wp, c->prm.wv, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_kf_update(ss_ctx* c, double* mean, double* cov, const double* z, const double* conf, int n)
+{ if (!c) return SS_ERR_INVALID; ss_launch_kf(1, mean, cov, z, conf, n, c->prm.wp, c->prm.wv, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_kf_initiate(ss_ctx* c, const double* z, int n, double* mean, double* cov)
+{ if (!c) return SS_ERR_INVALID; ss_launch_kf(2, mean, cov, z, nullptr, n, c->prm.wp, c->prm.wv, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_gallery_pack(ss_ctx* c, const float* nat, int T, int B, float* frag)
+{
+    if (!c || B > SS_NRT * SS_TILE) return fail(c, SS_ERR_INVALID, "ss_gallery_pack: B > 128");
+    ss_launch_pack(nat, T, B, frag, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK;
+}
+
+extern "C" int ss_assoc_cost(ss_ctx* c, const float* gal, const int* counts, int T, const float* feats, int D,
+                             const double* mean, const double* cov, const double* xyah, double* cost,
+                             float* cosd, double* maha, uint8_t* gated)
+{
+    if (!c) return SS_ERR_INVALID;
+    if (T > SS_MAXT || D > SS_MAXD) return fail(c, SS_ERR_CAPACITY, "ss_assoc_cost: T <= 256, D <= 128");
+    ss_launch_assoc(gal, counts, T, feats, D, mean, cov, xyah, c->prm, c->kat_featfrag, c->kat_partmin,
+                    cost, cosd, maha, gated, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_iou_cost(ss_ctx* c, const double* t, int T, const double* d, int D, double* cost)
+{ if (!c) return SS_ERR_INVALID; ss_launch_iou(t, T, d, D, c->prm.max_iou_distance, cost, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_lsap(ss_ctx* c, const double* cost, int nr, int nc, int* r2c)
+{
+    if (!c) return SS_ERR_INVALID;
+    if (nr > 256 || nc > 256) return fail(c, SS_ERR_CAPACITY, "ss_lsap: at most 256 x 256");
+    if (nr == 0) return SS_OK;
+    HIPCHK(c, hipMemsetAsync(c->kat_err, 0, 4, c->stream));
+    ss_launch_lsap(cost, nr, nc, r2c, c->kat_lsap_t, c->kat_err, c->stream);
+    HIPCHK(c, hipGetLastError());
+    int e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->kat_err, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e) return fail(c, e, "ss_lsap: infeasible cost matrix");
+    return SS_OK;
+}
+
+// ---- front end ----------------------------------------------------------------------------------------
+extern "C" int ss_letterbox(ss_ctx* c, const uint8_t* src, int h, int w, int stride, void* dst, int f16,
+                            int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left, int pad_value)
+{
+    if (!c || !src || !dst || new_h < 1 || new_w < 1) return fail(c, SS_ERR_INVALID, "ss_letterbox: bad argument");
+    ss_launch_letterbox(src, h, w, stride, dst, f16, out_h, out_w, new_h, new_w, pad_top, pad_left, pad_value, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_nms(ss_ctx* c, const float* pred, int n_anchors, int nc, int n_extra, float conf_thres,
+                      float iou_thres, int agnostic, float max_wh, int max_det, float gain, float pad_x,
+                      float pad_y, float w0, float h0, float* rows, int row_stride, int* keep, int* count)
+{
+    if (!c || !pred || !rows || !keep || !count || row_stride < 6 + n_extra)
+        return fail(c, SS_ERR_INVALID, "ss_nms: bad argument");
+    int rc = ss_launch_nms(pred, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh, max_det, gain,
+                           pad_x, pad_y, w0, h0, rows, row_stride, keep, count, c->nms_ws, c->nms_ws_bytes, c->stream);
+    if (rc) return fail(c, rc, "ss_nms: anchors exceed the workspace (n_anchors <= 32768)");
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_crop_norm(ss_ctx* c, const uint8_t* frame, int h, int w, int stride, const float* dets,
+                            int det_stride, int n, const int* d_count, void* out, int f16)
+{
+    if (!c || !frame || !dets || !out) return fail(c, SS_ERR_INVALID, "ss_crop_norm: null argument");
+    ss_launch_crop(frame, h, w, stride, dets, det_stride, n, d_count, out, f16, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+// ---- inspection ----------------------------------------------------------------------------------------
+extern "C" int ss_get_tracks(ss_ctx* c, int s, int cap, int* n_tracks, int* next_id, int* track_id, int* state,
+                             int* hits, int* age, int* tsu, int* class_id, float* conf, double* mean,
+                             double* cov, float* smooth, int* gal_count)
+{
+    if (!c || s < 0 || s >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_get_tracks: bad stream");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SSDev& d = c->dev;
+    int nt = 0, nid = 0;
+    HIPCHK(c, hipMemcpy(&nt, d.n_tracks + s, 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&nid, d.next_id + s, 4, hipMemcpyDeviceToHost));
+    if (n_tracks) *n_tracks = nt;
+    if (next_id) *next_id = nid;
+    c->tracks_ub = c->dev.S == 1 ? nt : c->tracks_ub;
+    if (nt > cap) return fail(c, SS_ERR_CAPACITY, "ss_get_tracks: cap too small");
+    const size_t T = SS_MAXT, sb = (size_t)s * T;
+    std::vector<int> order(T), tmp(T);
+    HIPCHK(c, hipMemcpy(order.data(), d.order + sb, T * 4, hipMemcpyDeviceToHost));
+    auto gather_i = [&](const int* src, int* dst) -> int {
+        if (!dst) return 0;
+        if (hipMemcpy(tmp.data(), src + sb, T * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        for (int i = 0; i < nt; ++i) dst[i] = tmp[order[i]];
+        return 0;
+    };
+    if (gather_i(d.track_id, track_id) || gather_i(d.state, state) || gather_i(d.hits, hits) || gather_i(d.age, age) ||
+        gather_i(d.tsu, tsu) || gather_i(d.class_id, class_id) || gather_i(d.gal_count, gal_count))
+        return fail(c, SS_ERR_HIP, "ss_get_tracks: copy failed");
+    if (conf) {
+        std::vector<float> t(T);
+        HIPCHK(c, hipMemcpy(t.data(), d.conf + sb, T * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nt; ++i) conf[i] = t[order[i]];
+    }
+    for (int i = 0; i < nt; ++i) {
+        const size_t g = sb + order[i];
+        if (mean) HIPCHK(c, hipMemcpy(mean + (size_t)i * 8, d.mean + g * 8, 64, hipMemcpyDeviceToHost));
+        if (cov) HIPCHK(c, hipMemcpy(cov + (size_t)i * 64, d.cov + g * 64, 512, hipMemcpyDeviceToHost));
+        if (smooth) HIPCHK(c, hipMemcpy(smooth + (size_t)i * SS_F, d.smooth + g * SS_F, SS_F * 4, hipMemcpyDeviceToHost));
+    }
+    return SS_OK;
+}
+
+extern "C" int ss_get_debug(ss_ctx* c, int s, int* counts, float* cosd, double* maha, uint8_t* gated,
+                            double* cost_a, double* cost_b, int* lists)
+{
+    if (!c || s < 0 || s >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_get_debug: bad stream");
+    if (!c->cfg.debug) return fail(c, SS_ERR_INVALID, "ss_get_debug: context created without debug");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SSDev& d = c->dev;
+    const size_t n = (size_t)SS_MAXT * SS_MAXD, o = (size_t)s * n;
+    if (counts) HIPCHK(c, hipMemcpy(counts, d.dbg_counts + s * 4, 16, hipMemcpyDeviceToHost));
+    if (cosd) HIPCHK(c, hipMemcpy(cosd, d.dbg_cos + o, n * 4, hipMemcpyDeviceToHost));
+    if (maha) HIPCHK(c, hipMemcpy(maha, d.dbg_maha + o, n * 8, hipMemcpyDeviceToHost));
+    if (gated) HIPCHK(c, hipMemcpy(gated, d.dbg_gated + o, n, hipMemcpyDeviceToHost));
+    if (cost_a) HIPCHK(c, hipMemcpy(cost_a, d.dbg_cost_a + o, n * 8, hipMemcpyDeviceToHost));
+    if (cost_b) HIPCHK(c, hipMemcpy(cost_b, d.dbg_cost_b + o, n * 8, hipMemcpyDeviceToHost));
+    if (lists) HIPCHK(c, hipMemcpy(lists, d.dbg_lists + (size_t)s * 4 * SS_MAXT, 4 * SS_MAXT * 4, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+extern "C" int ss_get_gallery(ss_ctx* c, int s, int track_index, float* rows, int cap_rows, int* count)
+{
+    if (!c || s < 0 || s >= c->dev.S || track_index < 0 || track_index >= SS_MAXT) return fail(c, SS_ERR_INVALID, "ss_get_gallery: bad argument");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    SSDev& d = c->dev;
+    int slot = 0, cnt = 0;
+    HIPCHK(c, hipMemcpy(&slot, d.order + (size_t)s * SS_MAXT + track_index, 4, hipMemcpyDeviceToHost));
+    const size_t g = (size_t)s * SS_MAXT + slot;
+    HIPCHK(c, hipMemcpy(&cnt, d.gal_count + g, 4, hipMemcpyDeviceToHost));
+    if (count) *count = cnt;
+    if (!rows) return SS_OK;
+    if (cnt > cap_rows) return fail(c, SS_ERR_CAPACITY, "ss_get_gallery: cap too small");
+    std::vector<float> frag((size_t)SS_NRT * SS_TILE_FLOATS);
+    HIPCHK(c, hipMemcpy(frag.data(), d.gallery + g * SS_NRT * SS_TILE_FLOATS, frag.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < cnt; ++b)
+        for (int k = 0; k < SS_F; ++k)
+            rows[(size_t)b * SS_F + k] = frag[(size_t)(b / SS_TILE) * SS_TILE_FLOATS + ss_frag_index(b % SS_TILE, k)];
+    return SS_OK;
+}
+
+extern "C" int ss_assoc_timing(ss_ctx* c, int enable, float* mean_ms, int* launches)
+{
+    if (!c) return SS_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second));
+        tot += ms;
+    }
+    if (mean_ms) *mean_ms = c->ev_used ? (float)(tot / c->ev_used) : 0.f;
+    if (launches) *launches = (int)c->ev_used;
+    c->ev_used = 0;
+    c->timing = enable != 0;
+    return SS_OK;
+}

@@ -1,0 +1,266 @@
+// ss_common.h — shared definitions of the gfx950 StrongSORT hot path (device math + layouts).
+//
+// Every arithmetic helper here follows the operation order frozen in oracle/DECISIONS.md
+// ("exactness contract"); the library is compiled with -ffp-contract=off so only the explicit
+// fma()/fmaf()/MFMA calls fuse, exactly as in the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/strongsort_hip.h"
+
+#define SS_F 512              // feature width (OSNet)
+#define SS_SEG 64             // dot-product segment (one wave of the cosine kernel per segment)
+#define SS_NSEG (SS_F / SS_SEG)
+#define SS_TILE 32            // MFMA 32x32 tile edge
+#define SS_NRT 4              // gallery row tiles per track  (capacity 128 rows >= nn_budget)
+#define SS_TILE_FLOATS (SS_F * SS_TILE)   // 16384 floats = 64 KiB per (track,row tile) / (col tile)
+#define SS_MAXT 256           // track slots per stream
+#define SS_MAXD 128           // detections per stream per frame
+#define SS_NCT (SS_MAXD / SS_TILE)
+#define SS_COST_CAP 14336     // LDS-resident cost entries (f64) of the assignment kernel
+
+#define SS_TENTATIVE 1
+#define SS_CONFIRMED 2
+#define SS_DELETED 3
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Fragment-major feature layout (gallery row tiles and detection column tiles):
+//   float index = ((q*2 + h)*32 + i)*4 + c   holds element k = 8q + 2c + h of row i of the tile,
+// so lane l = h*32+i of a wave reads float4 #(q*64 + l): 1 KiB contiguous per wave instruction,
+// and component c of that float4 is the operand of v_mfma_f32_32x32x2_f32 number 4*(q%8)+c of
+// k-segment q/8 — ascending k, the order of oracle so_dot().
+__host__ __device__ inline int ss_frag_index(int i, int k)
+{
+    return (((k >> 3) * 2 + (k & 1)) * 32 + i) * 4 + ((k & 7) >> 1);
+}
+
+struct SSParams {
+    double max_dist, max_iou_distance, mc_lambda, gating_threshold, gated_cost, wp, wv;
+    float ema_alpha, ema_one_minus_alpha;
+    int max_age, n_init, nn_budget;
+    int debug;
+};
+
+// Device-resident tracker state + per-frame scratch for S streams (all pointers device memory).
+struct SSDev {
+    int S;
+    // persistent per stream
+    int *n_tracks, *next_id, *frame, *err;
+    int* order;                 // [S][MAXT] slot ids in track-list order
+    // persistent per slot  [S][MAXT]
+    int *slot_used, *track_id, *state, *hits, *age, *tsu, *class_id, *det_idx, *gal_count, *gal_head;
+    float* conf;
+    double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]
+    float* smooth;              // [S][MAXT][512]
+    float* gallery;             // [S][MAXT][NRT][TILE_FLOATS]  fragment-major
+    // per-frame inputs
+    const float* dets;          // [S][MAXD][6]
+    const int* n_dets;          // [S]
+    const float* feats_raw;     // [S][MAXD][512]
+    // per-frame scratch
+    float* feat_unit;           // [S][MAXD][512]
+    float* feat_frag;           // [S][NCT][TILE_FLOATS]
+    double *tlwh, *xyah;        // [S][MAXD][4]
+    double* chol;               // [S][MAXT][16]  10 L entries + 4 projected mean (by track index)
+    double* ttlwh;              // [S][MAXT][4]   predicted track box (by track index)
+    int *n_conf, *conf_list;    // [S], [S][MAXT] track indices of confirmed tracks
+    float* part_min;            // [S][MAXT][NRT][MAXD]
+    // outputs
+    float* out_rows;            // [S][MAXT][8]
+    int* n_out;                 // [S]
+    int* img_hw;                // [S][2]
+    // debug (stage intermediates of the last frame)
+    float* dbg_cos;             // [S][MAXT][MAXD]
+    double *dbg_maha, *dbg_cost_a, *dbg_cost_b;   // [S][MAXT][MAXD]
+    uint8_t* dbg_gated;
+    int* dbg_lists;             // [S][4][MAXT]: pairs_a(det per conf row), cand, cols_b, pairs_b
+    int* dbg_counts;            // [S][4]: n_conf, n_cand, n_cols, unused
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+#define SS_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ inline float ss_wave_sumsq_reduce(float p)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kalman filter (float64), mirrors oracle so_kf_* line by line
+// ---------------------------------------------------------------------------------------------
+__device__ inline void ss_kf_initiate(const double z[4], double wp, double wv, double* mean, double* cov)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mean[i] = z[i]; mean[4 + i] = 0.0; }
+    double h = z[3];
+    double sd[8] = { 2.0 * wp * h, 2.0 * wp * h, 1e-2, 2.0 * wp * h,
+                     10.0 * wv * h, 10.0 * wv * h, 1e-5, 10.0 * wv * h };
+    for (int i = 0; i < 64; ++i) cov[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cov[i * 8 + i] = sd[i] * sd[i];
+}
+
+__device__ inline void ss_kf_predict(double* mean, double* cov, double wp, double wv)
+{
+    double h = mean[3];
+    double sp = wp * h, sv = wv * h;
+    double sd[8] = { sp, sp, 1e-2, sp, sv, sv, 1e-5, sv };
+    double P[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) P[i] = cov[i];
+    // A = P F^T (in place on the left half), B = F A (in place on the top half)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[i * 8 + j] = P[i * 8 + j] + P[i * 8 + j + 4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[i * 8 + j] = P[i * 8 + j] + P[(i + 4) * 8 + j];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) P[i * 8 + i] = P[i * 8 + i] + sd[i] * sd[i];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) cov[i] = P[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mean[i] = mean[i] + mean[i + 4];
+}
+
+__device__ inline void ss_kf_project(const double* mean, const double* cov, double conf, double wp,
+                                     double m4[4], double S[16])
+{
+    double h = mean[3];
+    double sd[4] = { wp * h, wp * h, 1e-1, wp * h };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m4[i] = mean[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[i * 4 + j] = cov[i * 8 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double s = (1.0 - conf) * sd[i];
+        S[i * 4 + i] = S[i * 4 + i] + s * s;
+    }
+}
+
+__device__ inline void ss_chol4(const double S[16], double L[16])
+{
+#pragma unroll
+    for (int i = 0; i < 16; ++i) L[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = S[i * 4 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum = fma(-L[i * 4 + k], L[j * 4 + k], sum);
+            L[i * 4 + j] = (i == j) ? sqrt(sum) : sum / L[j * 4 + j];
+        }
+}
+
+// squared Mahalanobis distance given L (lower Cholesky of the projected covariance) and m4
+__device__ inline double ss_maha(const double L[16], const double m4[4], const double z[4])
+{
+    double y[4], acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double sum = z[i] - m4[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum = fma(-L[i * 4 + k], y[k], sum);
+        y[i] = sum / L[i * 4 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = fma(y[i], y[i], acc);
+    return acc;
+}
+
+__device__ inline void ss_kf_update(double* mean, double* cov, const double z[4], double conf, double wp)
+{
+    double m4[4], S[16], L[16], K[32], M[32], y[4];
+    ss_kf_project(mean, cov, conf, wp, m4, S);
+    ss_chol4(S, L);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        double w[4], x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sum = cov[r * 8 + i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) sum = fma(-L[i * 4 + k], w[k], sum);
+            w[i] = sum / L[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            double sum = w[i];
+#pragma unroll
+            for (int k = 3; k > i; --k) sum = fma(-L[k * 4 + i], x[k], sum);
+            x[i] = sum / L[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) K[r * 4 + i] = x[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = z[i] - m4[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(S[i * 4 + k], K[c * 4 + k], acc);
+            M[i * 8 + c] = acc;
+        }
+    double nm[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = fma(y[k], K[r * 4 + k], acc);
+        nm[r] = mean[r] + acc;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc = fma(K[r * 4 + k], M[k * 8 + c], acc);
+            cov[r * 8 + c] = cov[r * 8 + c] - acc;
+        }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) mean[r] = nm[r];
+}
+
+// gate + blend + threshold of one entry (oracle so_blend)
+__device__ inline double ss_blend(float cosd, double maha, const SSParams& p, int* gated)
+{
+    double oml = 1.0 - p.mc_lambda, repl = p.max_dist + 1e-5;
+    int g = maha > p.gating_threshold;
+    double c = g ? p.gated_cost : (double)cosd;
+    double t1 = p.mc_lambda * c, t2 = oml * maha;
+    double v = t1 + t2;
+    if (v > p.max_dist) v = repl;
+    *gated = g;
+    return v;
+}
+
+// IoU cost of one (track tlwh, det tlwh) pair (oracle so_iou_cost)
+__device__ inline double ss_iou_cost(const double t[4], const double c[4], double max_dist)
+{
+    double repl = max_dist + 1e-5;
+    double tbr0 = t[0] + t[2], tbr1 = t[1] + t[3], tarea = t[2] * t[3];
+    double cbr0 = c[0] + c[2], cbr1 = c[1] + c[3];
+    double tl0 = fmax(t[0], c[0]), tl1 = fmax(t[1], c[1]);
+    double br0 = fmin(tbr0, cbr0), br1 = fmin(tbr1, cbr1);
+    double w = fmax(0.0, br0 - tl0), h = fmax(0.0, br1 - tl1);
+    double inter = w * h, carea = c[2] * c[3];
+    double iou = inter / (tarea + carea - inter);
+    double v = 1.0 - iou;
+    if (v > max_dist) v = repl;
+    return v;
+}

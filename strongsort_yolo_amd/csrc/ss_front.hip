@@ -1,0 +1,314 @@
+// ss_front.hip — frame-side kernels of the hot path: letterbox (a1), NMS (a3), ReID crop (a4).
+// Arithmetic follows oracle/csrc/ss_oracle.c (so_letterbox / so_nms / so_scale_boxes / so_crop_norm)
+// operation for operation; results are bit-identical (tests/test_gpu_front.py).
+#include <hip/hip_fp16.h>
+#include "ss_common.h"
+
+// ---- shared bilinear helpers (oracle so_axis / so_bilerp_u8) ---------------------------------------
+__device__ inline void ss_axis(int d, float scale, int n_src, int& i0, int& i1, float& frac)
+{
+    float t = (float)d + 0.5f;
+    float s = t * scale;
+    float f = s - 0.5f;
+    int i = (int)floorf(f);
+    float fr = f - (float)i;
+    if (i < 0) { i = 0; fr = 0.0f; }
+    if (i >= n_src - 1) { i = n_src - 1; fr = 0.0f; i1 = i; } else i1 = i + 1;
+    i0 = i; frac = fr;
+}
+
+__device__ inline float ss_bilerp_u8(float p00, float p01, float p10, float p11, float fx, float fy)
+{
+    float a = fmaf(fx, p01 - p00, p00);
+    float b = fmaf(fx, p11 - p10, p10);
+    float v = fmaf(fy, b - a, a);
+    float q = floorf(v + 0.5f);
+    return fminf(fmaxf(q, 0.0f), 255.0f);
+}
+
+template <typename T> __device__ inline T ss_cvt(float v);
+template <> __device__ inline float ss_cvt<float>(float v) { return v; }
+template <> __device__ inline __half ss_cvt<__half>(float v) { return __float2half(v); }
+
+// =================================================================================================
+// a1 letterbox: one thread per output pixel column pair; writes 3 planes
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ src, int H, int W, int stride,
+                                                   T* __restrict__ dst, int out_h, int out_w, int new_h,
+                                                   int new_w, int pad_top, int pad_left, float padv)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= out_w) return;
+    const size_t plane = (size_t)out_h * out_w, o = (size_t)y * out_w + x;
+    const int ry = y - pad_top, rx = x - pad_left;
+    if (ry < 0 || ry >= new_h || rx < 0 || rx >= new_w) {
+        T p = ss_cvt<T>(padv);
+        dst[o] = p; dst[plane + o] = p; dst[2 * plane + o] = p;
+        return;
+    }
+    const float sx = (float)W / (float)new_w, sy = (float)H / (float)new_h;
+    int y0, y1, x0, x1; float fy, fx;
+    ss_axis(ry, sy, H, y0, y1, fy);
+    ss_axis(rx, sx, W, x0, x1, fx);
+    const uint8_t* r0 = src + (size_t)y0 * stride;
+    const uint8_t* r1 = src + (size_t)y1 * stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sc = 2 - c;
+        float p00 = r0[x0 * 3 + sc], p01 = r0[x1 * 3 + sc], p10 = r1[x0 * 3 + sc], p11 = r1[x1 * 3 + sc];
+        dst[c * plane + o] = ss_cvt<T>(ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f);
+    }
+}
+
+void ss_launch_letterbox(const uint8_t* src, int h, int w, int stride, void* dst, int f16, int out_h, int out_w,
+                         int new_h, int new_w, int pad_top, int pad_left, int pad_value, hipStream_t st)
+{
+    dim3 grid((out_w + 255) / 256, out_h), block(256);
+    float padv = (float)pad_value / 255.0f;
+    if (f16) hipLaunchKernelGGL(k_letterbox<__half>, grid, block, 0, st, src, h, w, stride, (__half*)dst, out_h, out_w, new_h, new_w, pad_top, pad_left, padv);
+    else     hipLaunchKernelGGL(k_letterbox<float>, grid, block, 0, st, src, h, w, stride, (float*)dst, out_h, out_w, new_h, new_w, pad_top, pad_left, padv);
+}
+
+// =================================================================================================
+// a4 ReID crop: grid (x tiles, out rows, dets); one thread per output pixel
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, int H, int W, int stride,
+                                              const float* __restrict__ dets, int det_stride, int n,
+                                              const int* __restrict__ d_count, T* __restrict__ dst)
+{
+    const int out_w = 128, out_h = 256;
+    const int d = blockIdx.z;
+    const int cnt = d_count ? *d_count : n;
+    if (d >= cnt) return;
+    const int x = threadIdx.x, y = blockIdx.y;
+    const float* b = dets + (size_t)d * det_stride;
+    int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];
+    if (x1 < 0) x1 = 0; if (y1 < 0) y1 = 0;
+    if (x2 > W - 1) x2 = W - 1; if (y2 > H - 1) y2 = H - 1;
+    if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
+    int cw = x2 - x1, ch = y2 - y1;
+    if (cw < 1) cw = 1; if (ch < 1) ch = 1;
+    const float sx = (float)cw / (float)out_w, sy = (float)ch / (float)out_h;
+    int yy0, yy1, xx0, xx1; float fy, fx;
+    ss_axis(y, sy, ch, yy0, yy1, fy);
+    ss_axis(x, sx, cw, xx0, xx1, fx);
+    const uint8_t* r0 = src + (size_t)(y1 + yy0) * stride;
+    const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride;
+    const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
+    const size_t plane = (size_t)out_h * out_w;
+    T* o = dst + (size_t)d * 3 * plane + (size_t)y * out_w + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sc = 2 - c;
+        float p00 = r0[(x1 + xx0) * 3 + sc], p01 = r0[(x1 + xx1) * 3 + sc];
+        float p10 = r1[(x1 + xx0) * 3 + sc], p11 = r1[(x1 + xx1) * 3 + sc];
+        float q = ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f;
+        o[c * plane] = ss_cvt<T>((q - mean[c]) / sd[c]);
+    }
+}
+
+void ss_launch_crop(const uint8_t* frame, int h, int w, int stride, const float* dets, int det_stride, int n,
+                    const int* d_count, void* out, int f16, hipStream_t st)
+{
+    if (n <= 0) return;
+    dim3 grid(1, 256, n), block(128);
+    if (f16) hipLaunchKernelGGL(k_crop<__half>, grid, block, 0, st, frame, h, w, stride, dets, det_stride, n, d_count, (__half*)out);
+    else     hipLaunchKernelGGL(k_crop<float>, grid, block, 0, st, frame, h, w, stride, dets, det_stride, n, d_count, (float*)out);
+}
+
+// =================================================================================================
+// a3 NMS
+// =================================================================================================
+#define NMS_MAX_ANCHORS 32768
+#define NMS_MAX_CAND 8192
+#define NMS_WORDS (NMS_MAX_CAND / 64)
+
+struct NmsWs {
+    unsigned long long* keys;     // [MAX_ANCHORS] candidate keys (unsorted), then sorted in place [MAX_CAND]
+    int* cand_cls;                // [MAX_ANCHORS] class per anchor (indexed by anchor)
+    float* box;                   // [MAX_CAND][4] offset boxes, sorted order
+    float* area;                  // [MAX_CAND]
+    unsigned long long* mask;     // [MAX_CAND][NMS_WORDS]
+    int* counters;                // [0] candidates, [1] error
+};
+
+size_t ss_nms_workspace_bytes()
+{
+    return (size_t)NMS_MAX_ANCHORS * 8 + (size_t)NMS_MAX_ANCHORS * 4 + (size_t)NMS_MAX_CAND * 16 +
+           (size_t)NMS_MAX_CAND * 4 + (size_t)NMS_MAX_CAND * NMS_WORDS * 8 + 64;
+}
+
+static NmsWs carve_nms(void* ws)
+{
+    NmsWs w; char* p = (char*)ws;
+    w.keys = (unsigned long long*)p; p += (size_t)NMS_MAX_ANCHORS * 8;
+    w.mask = (unsigned long long*)p; p += (size_t)NMS_MAX_CAND * NMS_WORDS * 8;
+    w.box = (float*)p; p += (size_t)NMS_MAX_CAND * 16;
+    w.area = (float*)p; p += (size_t)NMS_MAX_CAND * 4;
+    w.cand_cls = (int*)p; p += (size_t)NMS_MAX_ANCHORS * 4;
+    w.counters = (int*)p;
+    return w;
+}
+
+// candidate filter: best class per anchor, score > conf.  key = (~score_bits, anchor): ascending
+// key order == descending score, ties by ascending anchor (stable order of the oracle's sort).
+__global__ __launch_bounds__(256) void k_nms_filter(const float* __restrict__ pred, int N, int nc, float conf, NmsWs w)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N) return;
+    float best = pred[(size_t)4 * N + a]; int bc = 0;
+    for (int k = 1; k < nc; ++k) {
+        float s = pred[(size_t)(4 + k) * N + a];
+        if (s > best) { best = s; bc = k; }
+    }
+    if (best > conf) {
+        int slot = atomicAdd(&w.counters[0], 1);
+        w.keys[slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)a;
+        w.cand_cls[a] = bc;
+    }
+}
+
+// single-block bitonic sort of the candidate keys in LDS, then offset boxes / areas in sorted order
+__global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ pred, int N, int agnostic, float max_wh, NmsWs w)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* k = (unsigned long long*)smem;
+    int n = w.counters[0];
+    if (n > NMS_MAX_CAND) { if (threadIdx.x == 0) { w.counters[1] = SS_ERR_CAPACITY; } n = 0; }
+    int np = 1; while (np < n) np <<= 1;
+    for (int i = threadIdx.x; i < np; i += 1024) k[i] = i < n ? w.keys[i] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= np; size <<= 1)
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+            for (int i = threadIdx.x; i < np / 2; i += 1024) {
+                int lo = 2 * i - (i & (strd - 1)), hi = lo + strd;
+                bool up = (lo & size) == 0;
+                unsigned long long a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        unsigned long long key = k[i];
+        w.keys[i] = key;
+        const int a = (int)(key & 0xffffffffu);
+        float cx = pred[a], cy = pred[(size_t)N + a], bw = pred[(size_t)2 * N + a], bh = pred[(size_t)3 * N + a];
+        float hw = bw / 2.0f, hh = bh / 2.0f;
+        float off = agnostic ? 0.0f : (float)w.cand_cls[a] * max_wh;
+        float x1 = (cx - hw) + off, y1 = (cy - hh) + off, x2 = (cx + hw) + off, y2 = (cy + hh) + off;
+        w.box[i * 4 + 0] = x1; w.box[i * 4 + 1] = y1; w.box[i * 4 + 2] = x2; w.box[i * 4 + 3] = y2;
+        w.area[i] = (x2 - x1) * (y2 - y1);
+    }
+}
+
+// suppression bit matrix: mask[i][jb] bit t set when j = jb*64+t > i and IoU(i,j) > thr
+__global__ __launch_bounds__(64) void k_nms_mask(float iou_thres, NmsWs w)
+{
+    __shared__ float sb[64 * 4];
+    __shared__ float sa[64];
+    const int n = min(w.counters[0], NMS_MAX_CAND);
+    const int ib = blockIdx.y, jb = blockIdx.x;
+    if (ib * 64 >= n || jb * 64 >= n || jb < ib) return;
+    const int t = threadIdx.x;
+    const int j = jb * 64 + t;
+    if (j < n) { sb[t * 4] = w.box[j * 4]; sb[t * 4 + 1] = w.box[j * 4 + 1]; sb[t * 4 + 2] = w.box[j * 4 + 2]; sb[t * 4 + 3] = w.box[j * 4 + 3]; sa[t] = w.area[j]; }
+    __syncthreads();
+    const int i = ib * 64 + t;
+    if (i >= n) return;
+    const float x1 = w.box[i * 4], y1 = w.box[i * 4 + 1], x2 = w.box[i * 4 + 2], y2 = w.box[i * 4 + 3], ai = w.area[i];
+    unsigned long long bits = 0;
+    const int jn = min(64, n - jb * 64);
+    for (int q = 0; q < jn; ++q) {
+        if (jb * 64 + q <= i) continue;
+        float xx1 = fmaxf(x1, sb[q * 4]), yy1 = fmaxf(y1, sb[q * 4 + 1]);
+        float xx2 = fminf(x2, sb[q * 4 + 2]), yy2 = fminf(y2, sb[q * 4 + 3]);
+        float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
+        float inter = iw * ih;
+        float iou = inter / (ai + sa[q] - inter);
+        if (iou > iou_thres) bits |= 1ull << q;
+    }
+    w.mask[(size_t)i * NMS_WORDS + jb] = bits;
+}
+
+// greedy scan (one wave) + output rows in original-image pixels
+__global__ __launch_bounds__(64) void k_nms_scan(const float* __restrict__ pred, int N, int nc, int n_extra,
+                                                 int max_det, float gain, float pad_x, float pad_y, float w0,
+                                                 float h0, float* __restrict__ rows, int row_stride,
+                                                 int* __restrict__ keep, int* __restrict__ count, NmsWs w)
+{
+    __shared__ int kept_sorted[1024];
+    const int n = min(w.counters[0], NMS_MAX_CAND);
+    const int l = threadIdx.x;
+    const int nw = (n + 63) / 64;
+    unsigned long long rem0 = 0, rem1 = 0;       // removed bits of words l and l+64
+    int kept = 0;
+    const int cap = min(max_det, 1024);
+    for (int ib = 0; ib < nw && kept < cap; ++ib) {
+        // removed word of block ib lives in lane ib%64 (rem0 or rem1)
+        unsigned long long rw = __shfl((ib < 64) ? rem0 : rem1, ib & 63);
+        // diagonal block: resolve dependencies inside the 64-block sequentially on the scalar side
+        const int i0 = ib * 64;
+        const int cnt = min(64, n - i0);
+        unsigned long long diag = (l < cnt) ? w.mask[(size_t)(i0 + l) * NMS_WORDS + ib] : 0ull;
+        unsigned long long keptbits = 0;
+        for (int q = 0; q < cnt && kept < cap; ++q) {
+            if (!((rw >> q) & 1ull)) {
+                keptbits |= 1ull << q;
+                if (l == 0) kept_sorted[kept] = i0 + q;
+                ++kept;
+                rw |= __shfl(diag, q);
+            }
+        }
+        // OR the rows of the kept boxes into the removed words of the later blocks
+        for (int q = 0; q < cnt; ++q) {
+            if (!((keptbits >> q) & 1ull)) continue;
+            const unsigned long long* mr = w.mask + (size_t)(i0 + q) * NMS_WORDS;
+            if (l > ib && l < nw) rem0 |= mr[l];
+            if (l + 64 > ib && l + 64 < nw) rem1 |= mr[l + 64];
+        }
+    }
+    __syncthreads();
+    if (l == 0) { *count = kept; }
+    for (int kk = l; kk < kept; kk += 64) {
+        const int i = kept_sorted[kk];
+        const unsigned long long key = w.keys[i];
+        const int a = (int)(key & 0xffffffffu);
+        const float score = __uint_as_float(~(unsigned)(key >> 32));
+        float cx = pred[a], cy = pred[(size_t)N + a], bw = pred[(size_t)2 * N + a], bh = pred[(size_t)3 * N + a];
+        float hw = bw / 2.0f, hh = bh / 2.0f;
+        float x1 = ((cx - hw) - pad_x) / gain, y1 = ((cy - hh) - pad_y) / gain;
+        float x2 = ((cx + hw) - pad_x) / gain, y2 = ((cy + hh) - pad_y) / gain;
+        float* r = rows + (size_t)kk * row_stride;
+        r[0] = fminf(fmaxf(x1, 0.0f), w0); r[1] = fminf(fmaxf(y1, 0.0f), h0);
+        r[2] = fminf(fmaxf(x2, 0.0f), w0); r[3] = fminf(fmaxf(y2, 0.0f), h0);
+        r[4] = score; r[5] = (float)w.cand_cls[a];
+        for (int e = 0; e < n_extra; ++e) r[6 + e] = pred[(size_t)(4 + nc + e) * N + a];
+        keep[kk] = a;
+    }
+}
+
+int ss_front_init()
+{
+    hipError_t e = hipFuncSetAttribute((const void*)k_nms_sort, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_CAND * 8);
+    return e == hipSuccess ? 0 : 1;
+}
+
+int ss_launch_nms(const float* pred, int N, int nc, int n_extra, float conf, float iou, int agnostic, float max_wh,
+                  int max_det, float gain, float pad_x, float pad_y, float w0, float h0, float* rows, int row_stride,
+                  int* keep, int* count, void* ws, size_t ws_bytes, hipStream_t st)
+{
+    if (N > NMS_MAX_ANCHORS || ws_bytes < ss_nms_workspace_bytes()) return SS_ERR_CAPACITY;
+    NmsWs w = carve_nms(ws);
+    hipMemsetAsync(w.counters, 0, 16, st);
+    hipLaunchKernelGGL(k_nms_filter, dim3((N + 255) / 256), dim3(256), 0, st, pred, N, nc, conf, w);
+    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), NMS_MAX_CAND * 8, st, pred, N, agnostic, max_wh, w);
+    // mask grid sized for the worst case the filter could produce; blocks beyond n exit at once
+    const int nbmax = (min(N, NMS_MAX_CAND) + 63) / 64;
+    hipLaunchKernelGGL(k_nms_mask, dim3(nbmax, nbmax), dim3(64), 0, st, iou, w);
+    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, st, pred, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
+                       rows, row_stride, keep, count, w);
+    return 0;
+}

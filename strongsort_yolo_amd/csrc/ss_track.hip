@@ -1,0 +1,760 @@
+// ss_track.hip — device-resident StrongSORT tracker update for S independent streams.
+//
+// Per frame three launches cover rows a6..a10 of SURVEY.md §8(a) for every stream at once:
+//   k_pre     one block per stream: Kalman predict of all live tracks (+ Cholesky of the projected
+//             covariance for the gate, confirmed-track list); further blocks: L2-normalise the
+//             detection embeddings and write them row-major and fragment-major.
+//   k_cosine  one 8-wave block per (confirmed track, 32-row gallery tile): streams the gallery
+//             tile with coalesced 16-B loads straight into v_mfma_f32_32x32x2_f32 operands
+//             (one k-segment per wave), combines the segments in LDS, min over gallery rows
+//             (registers -> wave shuffle -> LDS).  This is the HBM-bound association kernel.
+//   k_step    one block per stream: gate/blend cost matrix into LDS, LSAP (single wave, SciPy's
+//             scan order), IoU stage + LSAP, Kalman/EMA updates, births, deletions, gallery append,
+//             output rows.  No host round trip anywhere in the frame.
+#include <hip/hip_ext.h>
+#include "ss_common.h"
+
+// =================================================================================================
+// k_pre
+// =================================================================================================
+__device__ inline void block_scan256(int flag, int* wtot /*LDS[4]*/, int& pos, int& total)
+{
+    unsigned long long m = __ballot(flag);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inwave = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();                       // protect wtot from the previous scan's readers
+    if (lane == 0) wtot[w] = __popcll(m);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int c = wtot[i]; if (i < w) off += c; tot += c; }
+    pos = off + inwave;
+    total = tot;
+}
+
+__global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
+{
+    __shared__ int wtot[4];
+    __shared__ float rowbuf[4][SS_F];
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (blockIdx.y == 0) {
+        // ---- predict all live tracks of stream s (thread = position in the track list) ----
+        const int nT = dev.n_tracks[s];
+        int confirmed = 0;
+        if (tid < nT) {
+            const int slot = dev.order[s * SS_MAXT + tid];
+            const size_t g = (size_t)s * SS_MAXT + slot;
+            double mean[8], cov[64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
+            ss_kf_predict(mean, cov, prm.wp, prm.wv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
+            dev.age[g] += 1;
+            dev.tsu[g] += 1;
+            dev.det_idx[g] = -1;
+            // gate factorisation (projection with conf = 0) and predicted box, by track index
+            double m4[4], S[16], L[16];
+            ss_kf_project(mean, cov, 0.0, prm.wp, m4, S);
+            ss_chol4(S, L);
+            double* ch = dev.chol + ((size_t)s * SS_MAXT + tid) * 16;
+            ch[0] = L[0]; ch[1] = L[4]; ch[2] = L[5]; ch[3] = L[8]; ch[4] = L[9]; ch[5] = L[10];
+            ch[6] = L[12]; ch[7] = L[13]; ch[8] = L[14]; ch[9] = L[15];
+            ch[10] = m4[0]; ch[11] = m4[1]; ch[12] = m4[2]; ch[13] = m4[3];
+            double w = mean[2] * mean[3];
+            double* tb = dev.ttlwh + ((size_t)s * SS_MAXT + tid) * 4;
+            tb[0] = mean[0] - w / 2; tb[1] = mean[1] - mean[3] / 2; tb[2] = w; tb[3] = mean[3];
+            confirmed = dev.state[g] == SS_CONFIRMED;
+        }
+        int pos, total;
+        block_scan256(confirmed, wtot, pos, total);
+        if (confirmed) dev.conf_list[s * SS_MAXT + pos] = tid;
+        if (tid == 0) dev.n_conf[s] = total;
+        return;
+    }
+    // ---- detection prep: one wave per detection ----
+    const int w = tid >> 6, l = tid & 63;
+    const int d = (blockIdx.y - 1) * 4 + w;
+    const int D = dev.n_dets[s];
+    const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
+    if (d >= Dpad) return;
+    float* frag = dev.feat_frag + ((size_t)s * SS_NCT + d / SS_TILE) * SS_TILE_FLOATS;
+    const int jj = d % SS_TILE;
+    float4 lo, hi;
+    if (d < D) {
+        const float* raw = dev.feats_raw + ((size_t)s * SS_MAXD + d) * SS_F;
+        float v[8], a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = raw[l + 64 * j]; a = fmaf(v[j], v[j], a); }
+        float n = sqrtf(ss_wave_sumsq_reduce(a));
+        float* unit = dev.feat_unit + ((size_t)s * SS_MAXD + d) * SS_F;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float u = v[j] / n; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }
+        SS_WAVE_SYNC();
+        const float* rb = rowbuf[w] + 8 * l;      // lane l owns q = l : k = 8l .. 8l+7
+        lo = make_float4(rb[0], rb[2], rb[4], rb[6]);
+        hi = make_float4(rb[1], rb[3], rb[5], rb[7]);
+        if (l == 0) {
+            const float* b = dev.dets + ((size_t)s * SS_MAXD + d) * 6;
+            double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+            double bw = x2 - x1, bh = y2 - y1;
+            double* t = dev.tlwh + ((size_t)s * SS_MAXD + d) * 4;
+            double* z = dev.xyah + ((size_t)s * SS_MAXD + d) * 4;
+            t[0] = x1; t[1] = y1; t[2] = bw; t[3] = bh;
+            z[0] = x1 + bw / 2; z[1] = y1 + bh / 2; z[2] = bw / bh; z[3] = bh;
+        }
+    } else {
+        lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    reinterpret_cast<float4*>(frag)[(l * 2 + 0) * 32 + jj] = lo;
+    reinterpret_cast<float4*>(frag)[(l * 2 + 1) * 32 + jj] = hi;
+}
+
+// =================================================================================================
+// k_cosine — the association kernel (gallery stream + f32 MFMA + min over gallery rows)
+// =================================================================================================
+// part_min[s][r][rt][d] = min over the valid rows b of gallery tile rt of (1 - g_b . f_d).
+// Shared by the tracker (gallery addressed through conf_list/order) and the KAT entry point
+// (tracks addressed directly): slot_of(r) abstracts that.
+struct CosineArgs {
+    const float* gallery;       // fragment-major tiles, [track][NRT][TILE_FLOATS]
+    const int* gal_count;       // per track
+    const float* feat_frag;     // [NCT][TILE_FLOATS] of this stream
+    float* part_min;            // [r][NRT][MAXD]
+    int n_rows;                 // tracks to process
+    int D;
+};
+
+__device__ inline void cosine_tile(const float4* __restrict__ gal, int count, int rt,
+                                   const float* __restrict__ feat_frag, int D, float* __restrict__ out,
+                                   float* lds_part, float* lds_red)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = gal[(8 * w + j) * 64 + l];
+    const int nct = (D + SS_TILE - 1) / SS_TILE;
+    for (int ct = 0; ct < nct; ++ct) {
+        const float4* fb = reinterpret_cast<const float4*>(feat_frag + (size_t)ct * SS_TILE_FLOATS);
+        float4 b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = fb[(8 * w + j) * 64 + l];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds_part[(w * 16 + r) * 64 + l] = acc[r];
+        __syncthreads();
+        float m = INFINITY;
+#pragma unroll
+        for (int rr = 2 * w; rr < 2 * w + 2; ++rr) {
+            float tot = lds_part[rr * 64 + l];
+#pragma unroll
+            for (int sg = 1; sg < SS_NSEG; ++sg) tot = tot + lds_part[(sg * 16 + rr) * 64 + l];
+            float dist = 1.0f - tot;
+            int row = rt * SS_TILE + (rr & 3) + 8 * (rr >> 2) + 4 * (l >> 5);
+            if (row >= count) dist = INFINITY;
+            m = fminf(m, dist);
+        }
+        m = fminf(m, __shfl_xor(m, 32));
+        if (l < 32) lds_red[w * 32 + l] = m;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float f = lds_red[threadIdx.x];
+#pragma unroll
+            for (int w2 = 1; w2 < 8; ++w2) f = fminf(f, lds_red[w2 * 32 + threadIdx.x]);
+            int d = ct * SS_TILE + threadIdx.x;
+            if (d < D) out[d] = f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_cosine(SSDev dev)
+{
+    __shared__ float lds_part[SS_NSEG * 16 * 64];
+    __shared__ float lds_red[8 * 32];
+    const int rt = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
+    const int D = dev.n_dets[s];
+    if (r >= dev.n_conf[s] || D == 0) return;
+    const int slot = dev.order[s * SS_MAXT + dev.conf_list[s * SS_MAXT + r]];
+    const size_t g = (size_t)s * SS_MAXT + slot;
+    const int count = dev.gal_count[g];
+    if (rt * SS_TILE >= count) return;
+    const float4* gal = reinterpret_cast<const float4*>(dev.gallery + (g * SS_NRT + rt) * SS_TILE_FLOATS);
+    cosine_tile(gal, count, rt, dev.feat_frag + (size_t)s * SS_NCT * SS_TILE_FLOATS, D,
+                dev.part_min + (((size_t)s * SS_MAXT + r) * SS_NRT + rt) * SS_MAXD, lds_part, lds_red);
+}
+
+__global__ __launch_bounds__(512) void k_cosine_kat(CosineArgs a)
+{
+    __shared__ float lds_part[SS_NSEG * 16 * 64];
+    __shared__ float lds_red[8 * 32];
+    const int rt = blockIdx.x, r = blockIdx.y;
+    const int count = a.gal_count[r];
+    if (rt * SS_TILE >= count) return;
+    const float4* gal = reinterpret_cast<const float4*>(a.gallery + ((size_t)r * SS_NRT + rt) * SS_TILE_FLOATS);
+    cosine_tile(gal, count, rt, a.feat_frag, a.D, a.part_min + ((size_t)r * SS_NRT + rt) * SS_MAXD,
+                lds_part, lds_red);
+}
+
+// =================================================================================================
+// LSAP on one wave — shortest augmenting path in SciPy's scan order (oracle so_lsap)
+// =================================================================================================
+struct LsapLds {
+    double *u, *v, *sp;                          // [256] each
+    int *path, *row4col, *col4row, *remaining;   // [256] each
+    unsigned char *SR, *SC;                      // [256] each
+};
+
+// cost: [nr][nc] (nr <= nc <= 256) in LDS or global.  Result col4row[0..nr).  Returns 0 / -1.
+__device__ inline int lsap_wave(int nr, int nc, const double* cost, const LsapLds& L)
+{
+    const int l = threadIdx.x & 63;
+    for (int j = l; j < nc; j += 64) { L.v[j] = 0.0; L.path[j] = -1; L.row4col[j] = -1; }
+    for (int i = l; i < nr; i += 64) { L.u[i] = 0.0; L.col4row[i] = -1; }
+    SS_WAVE_SYNC();
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int it = l; it < nc; it += 64) { L.remaining[it] = nc - it - 1; L.sp[it] = INFINITY; L.SC[it] = 0; }
+        for (int i = l; i < nr; i += 64) L.SR[i] = 0;
+        SS_WAVE_SYNC();
+        double minVal = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        while (sink == -1) {
+            if (l == 0) L.SR[i] = 1;
+            const double ui = L.u[i];
+            const double* crow = cost + (size_t)i * nc;
+            double bval = INFINITY;
+            int bscore = -1, bit = -1;
+            for (int it = l; it < num_remaining; it += 64) {
+                int j = L.remaining[it];
+                double r = minVal + crow[j] - ui - L.v[j];
+                double spj = L.sp[j];
+                if (r < spj) { L.path[j] = i; L.sp[j] = r; spj = r; }
+                int score = (L.row4col[j] == -1) ? (1024 + it) : (1023 - it);
+                if (spj < bval || (spj == bval && score > bscore)) { bval = spj; bscore = score; bit = it; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                double oval = __shfl_xor(bval, off);
+                int oscore = __shfl_xor(bscore, off);
+                int oit = __shfl_xor(bit, off);
+                if (oval < bval || (oval == bval && oscore > bscore)) { bval = oval; bscore = oscore; bit = oit; }
+            }
+            minVal = bval;
+            if (!(minVal < INFINITY)) return -1;       // infeasible
+            SS_WAVE_SYNC();
+            int j = L.remaining[bit];
+            int rj = L.row4col[j];
+            if (rj == -1) sink = j; else i = rj;
+            --num_remaining;
+            if (l == 0) { L.SC[j] = 1; L.remaining[bit] = L.remaining[num_remaining]; }
+            SS_WAVE_SYNC();
+        }
+        // dual updates
+        if (l == 0) L.u[cur] += minVal;
+        for (int r = l; r < nr; r += 64)
+            if (L.SR[r] && r != cur) L.u[r] += minVal - L.sp[L.col4row[r]];
+        for (int j = l; j < nc; j += 64)
+            if (L.SC[j]) L.v[j] -= minVal - L.sp[j];
+        SS_WAVE_SYNC();
+        // augment
+        if (l == 0) {
+            int j = sink;
+            for (;;) {
+                int r = L.path[j];
+                L.row4col[j] = r;
+                int t = L.col4row[r]; L.col4row[r] = j; j = t;
+                if (r == cur) break;
+            }
+        }
+        SS_WAVE_SYNC();
+    }
+    return 0;
+}
+
+__device__ inline LsapLds carve_lsap(char*& p)
+{
+    LsapLds L;
+    L.u = (double*)p; p += 256 * 8; L.v = (double*)p; p += 256 * 8; L.sp = (double*)p; p += 256 * 8;
+    L.path = (int*)p; p += 256 * 4; L.row4col = (int*)p; p += 256 * 4;
+    L.col4row = (int*)p; p += 256 * 4; L.remaining = (int*)p; p += 256 * 4;
+    L.SR = (unsigned char*)p; p += 256; L.SC = (unsigned char*)p; p += 256;
+    return L;
+}
+
+// stand-alone LSAP (KAT entry point): one wave, cost read from global memory
+__global__ __launch_bounds__(64) void k_lsap_kat(const double* cost, int nr0, int nc0, int* row_to_col,
+                                                  double* scratch_t, int* err)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* p = smem;
+    LsapLds L = carve_lsap(p);
+    const int l = threadIdx.x;
+    const bool tr = nc0 < nr0;
+    const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
+    for (int i = l; i < nr0; i += 64) row_to_col[i] = -1;
+    if (nr == 0) return;
+    const double* c = cost;
+    if (tr) {
+        for (int idx = l; idx < nr0 * nc0; idx += 64) { int i = idx / nc0, j = idx % nc0; scratch_t[j * nr0 + i] = cost[idx]; }
+        __threadfence_block();
+        __syncthreads();
+        c = scratch_t;
+    }
+    int rc = lsap_wave(nr, nc, c, L);
+    if (rc) { if (l == 0) *err = SS_ERR_INFEASIBLE; return; }
+    for (int i = l; i < nr; i += 64) {
+        if (tr) row_to_col[L.col4row[i]] = i; else row_to_col[i] = L.col4row[i];
+    }
+}
+
+// =================================================================================================
+// k_step — per-stream association, assignment and bookkeeping
+// =================================================================================================
+__device__ inline void ema_wave(const float* smooth_in, const float* feat, float a, float b, float* out)
+{
+    const int l = threadIdx.x & 63;
+    float v[8], acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t1 = a * smooth_in[l + 64 * j];
+        float t2 = b * feat[l + 64 * j];
+        v[j] = t1 + t2;
+        acc = fmaf(v[j], v[j], acc);
+    }
+    float n = sqrtf(ss_wave_sumsq_reduce(acc));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[l + 64 * j] = v[j] / n;
+}
+
+// append row-major unit row `src` (global) as gallery row b of a track (fragment-major tiles)
+__device__ inline void gallery_append_wave(float* gal_track, int b, const float* src)
+{
+    const int l = threadIdx.x & 63;
+    const float4* s4 = reinterpret_cast<const float4*>(src + 8 * l);
+    float4 x = s4[0], y = s4[1];
+    float4* tile = reinterpret_cast<float4*>(gal_track + (size_t)(b / SS_TILE) * SS_TILE_FLOATS);
+    const int i = b % SS_TILE;
+    tile[(l * 2 + 0) * 32 + i] = make_float4(x.x, x.z, y.x, y.z);
+    tile[(l * 2 + 1) * 32 + i] = make_float4(x.y, x.w, y.y, y.w);
+}
+
+__global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* p = smem;
+    double* cost = (double*)p; p += (size_t)SS_COST_CAP * 8;
+    LsapLds L = carve_lsap(p);
+    int* matchdet = (int*)p; p += 256 * 4;     // by track index: matched detection or -1
+    int* dettrk = (int*)p; p += 256 * 4;       // by detection: matched track index or -1
+    int* asg = (int*)p; p += 256 * 4;          // LSAP result by original row
+    int* cand = (int*)p; p += 256 * 4;         // IoU-stage rows (track indices)
+    int* cols = (int*)p; p += 256 * 4;         // IoU-stage columns (detection indices)
+    int* neworder = (int*)p; p += 256 * 4;
+    int* freelist = (int*)p; p += 256 * 4;
+    int* conf_l = (int*)p; p += 256 * 4;
+    int* wtot = (int*)p; p += 16;
+    int* flags = (int*)p; p += 16;
+
+    const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int nT = dev.n_tracks[s], D = dev.n_dets[s], nC = dev.n_conf[s];
+    const size_t sb = (size_t)s * SS_MAXT;
+    const size_t db = (size_t)s * SS_MAXD;
+    matchdet[tid] = -1; dettrk[tid] = -1; asg[tid] = -1;
+    if (tid < nC) conf_l[tid] = dev.conf_list[sb + tid];
+    if (tid == 0) { flags[0] = 0; }
+    int myslot = (tid < nT) ? dev.order[sb + tid] : -1;
+    int mystate = (tid < nT) ? dev.state[sb + myslot] : 0;
+    int mytsu = (tid < nT) ? dev.tsu[sb + myslot] : 0;
+    if (prm.debug) { dev.dbg_lists[(s * 4 + 0) * SS_MAXT + tid] = -1; dev.dbg_lists[(s * 4 + 3) * SS_MAXT + tid] = -1; }
+    __syncthreads();
+
+    // ---------------- stage A: appearance + motion cost, LSAP --------------------------------
+    if (nC > 0 && D > 0) {
+        const bool tr = D < nC;
+        const int nr = tr ? D : nC, nc = tr ? nC : D;
+        if (nr * nc > SS_COST_CAP) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; }
+        else {
+            for (int idx = tid; idx < nC * D; idx += 256) {
+                const int r = idx / D, d = idx % D;
+                const int ti = conf_l[r];
+                const int slot = dev.order[sb + ti];
+                const int count = dev.gal_count[sb + slot];
+                const float* pm = dev.part_min + ((sb + r) * SS_NRT) * SS_MAXD + d;
+                float c = pm[0];
+                for (int rt = 1; rt * SS_TILE < count; ++rt) c = fminf(c, pm[(size_t)rt * SS_MAXD]);
+                const double* ch = dev.chol + (sb + ti) * 16;
+                double Lm[16] = { ch[0], 0, 0, 0, ch[1], ch[2], 0, 0, ch[3], ch[4], ch[5], 0, ch[6], ch[7], ch[8], ch[9] };
+                double m4[4] = { ch[10], ch[11], ch[12], ch[13] };
+                const double* zz = dev.xyah + (db + d) * 4;
+                double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+                double maha = ss_maha(Lm, m4, z);
+                int g;
+                double v = ss_blend(c, maha, prm, &g);
+                cost[tr ? d * nc + r : r * nc + d] = v;
+                if (prm.debug) {
+                    size_t o = (sb + r) * SS_MAXD + d;
+                    dev.dbg_cos[o] = c; dev.dbg_maha[o] = maha; dev.dbg_gated[o] = (uint8_t)g; dev.dbg_cost_a[o] = v;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int rc = lsap_wave(nr, nc, cost, L);
+                if (rc) { if (tid == 0) dev.err[s] = SS_ERR_INFEASIBLE; }
+                else for (int i = tid; i < nr; i += 64) { if (tr) asg[L.col4row[i]] = i; else asg[i] = L.col4row[i]; }
+            }
+            __syncthreads();
+            if (tid < nC) {
+                int d = asg[tid];
+                if (d >= 0) {
+                    double v = cost[tr ? d * nc + tid : tid * nc + d];
+                    if (!(v > prm.max_dist)) { matchdet[conf_l[tid]] = d; dettrk[d] = conf_l[tid]; }
+                    else d = -1;
+                }
+                if (prm.debug) dev.dbg_lists[(s * 4 + 0) * SS_MAXT + tid] = d;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- stage B: IoU association ----------------------------------------------
+    int pos, nU, nC1, nCols;
+    const int isU = (tid < nT) && (mystate != SS_CONFIRMED);
+    block_scan256(isU, wtot, pos, nU);
+    if (isU) cand[pos] = tid;
+    const int isC1 = (tid < nT) && (mystate == SS_CONFIRMED) && (matchdet[tid] < 0) && (mytsu == 1);
+    block_scan256(isC1, wtot, pos, nC1);
+    if (isC1) cand[nU + pos] = tid;
+    const int nCand = nU + nC1;
+    const int isCol = (tid < D) && (dettrk[tid] < 0);
+    block_scan256(isCol, wtot, pos, nCols);
+    if (isCol) cols[pos] = tid;
+    asg[tid] = -1;
+    __syncthreads();
+    if (prm.debug) {
+        if (tid < nCand) dev.dbg_lists[(s * 4 + 1) * SS_MAXT + tid] = cand[tid];
+        if (tid < nCols) dev.dbg_lists[(s * 4 + 2) * SS_MAXT + tid] = cols[tid];
+        if (tid == 0) { int* c = dev.dbg_counts + s * 4; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; }
+    }
+    if (nCand > 0 && nCols > 0) {
+        const bool tr = nCols < nCand;
+        const int nr = tr ? nCols : nCand, nc = tr ? nCand : nCols;
+        if (nr * nc > SS_COST_CAP) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; }
+        else {
+            for (int idx = tid; idx < nCand * nCols; idx += 256) {
+                const int r = idx / nCols, c = idx % nCols;
+                const int ti = cand[r];
+                const double* tb = dev.ttlwh + (sb + ti) * 4;
+                const double* cb = dev.tlwh + (db + cols[c]) * 4;
+                double t[4] = { tb[0], tb[1], tb[2], tb[3] }, cc[4] = { cb[0], cb[1], cb[2], cb[3] };
+                double v = (dev.tsu[sb + dev.order[sb + ti]] > 1) ? prm.max_iou_distance + 1e-5
+                                                                : ss_iou_cost(t, cc, prm.max_iou_distance);
+                cost[tr ? c * nc + r : r * nc + c] = v;
+                if (prm.debug) dev.dbg_cost_b[(sb + r) * SS_MAXD + c] = v;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                int rc = lsap_wave(nr, nc, cost, L);
+                if (rc) { if (tid == 0) dev.err[s] = SS_ERR_INFEASIBLE; }
+                else for (int i = tid; i < nr; i += 64) { if (tr) asg[L.col4row[i]] = i; else asg[i] = L.col4row[i]; }
+            }
+            __syncthreads();
+            if (tid < nCand) {
+                int c = asg[tid];
+                if (c >= 0) {
+                    double v = cost[tr ? c * nc + tid : tid * nc + c];
+                    if (!(v > prm.max_iou_distance)) { matchdet[cand[tid]] = cols[c]; dettrk[cols[c]] = cand[tid]; }
+                    else c = -1;
+                }
+                if (prm.debug) dev.dbg_lists[(s * 4 + 3) * SS_MAXT + tid] = c;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- stage C: matched / missed tracks ---------------------------------------
+    int alive = 0;
+    if (tid < nT) {
+        const size_t g = sb + myslot;
+        const int d = matchdet[tid];
+        if (d >= 0) {
+            double mean[8], cov[64];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
+            const double* zz = dev.xyah + (db + d) * 4;
+            double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+            const float* det = dev.dets + (db + d) * 6;
+            ss_kf_update(mean, cov, z, (double)det[4], prm.wp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
+            dev.conf[g] = det[4];
+            dev.class_id[g] = (int)det[5];
+            int h = dev.hits[g] + 1;
+            dev.hits[g] = h;
+            dev.tsu[g] = 0; mytsu = 0;
+            dev.det_idx[g] = d;
+            if (mystate == SS_TENTATIVE && h >= prm.n_init) mystate = SS_CONFIRMED;
+        } else {
+            if (mystate == SS_TENTATIVE || mytsu > prm.max_age) mystate = SS_DELETED;
+        }
+        dev.state[g] = mystate;
+        alive = mystate != SS_DELETED;
+        if (!alive) { dev.slot_used[g] = 0; dev.gal_count[g] = 0; dev.gal_head[g] = 0; }
+    }
+    // EMA of matched tracks: one wave per track
+    for (int ti = wave; ti < nT; ti += 4) {
+        const int d = matchdet[ti];
+        if (d < 0) continue;
+        float* sm = dev.smooth + (sb + dev.order[sb + ti]) * SS_F;
+        ema_wave(sm, dev.feat_unit + (db + d) * SS_F, prm.ema_alpha, prm.ema_one_minus_alpha, sm);
+    }
+    __threadfence_block();
+    // survivors keep their order
+    int nSurv;
+    block_scan256(alive, wtot, pos, nSurv);
+    if (alive) neworder[pos] = myslot;
+    // births: unmatched detections in ascending index
+    int nNew, nFree;
+    const int isNew = (tid < D) && (dettrk[tid] < 0);
+    int rank;
+    block_scan256(isNew, wtot, rank, nNew);
+    const int isFree = !dev.slot_used[sb + tid];      // includes slots freed above (same thread wrote or fenced)
+    __syncthreads();
+    block_scan256(isFree, wtot, pos, nFree);
+    if (isFree) freelist[pos] = tid;
+    __syncthreads();
+    if (nSurv + nNew > SS_MAXT || nNew > nFree) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; nNew = min(nNew, min(nFree, SS_MAXT - nSurv)); }
+    const int nid0 = dev.next_id[s];
+    if (isNew && rank < nNew) {
+        const int slot = freelist[rank];
+        const size_t g = sb + slot;
+        const double* zz = dev.xyah + (db + tid) * 4;
+        double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+        double mean[8], cov[64];
+        ss_kf_initiate(z, prm.wp, prm.wv, mean, cov);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
+        for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
+        const float* det = dev.dets + (db + tid) * 6;
+        dev.track_id[g] = nid0 + rank;
+        dev.state[g] = SS_TENTATIVE; dev.hits[g] = 1; dev.age[g] = 1; dev.tsu[g] = 0;
+        dev.class_id[g] = (int)det[5]; dev.conf[g] = det[4]; dev.det_idx[g] = tid;
+        dev.gal_count[g] = 0; dev.gal_head[g] = 0; dev.slot_used[g] = 1;
+        neworder[nSurv + rank] = slot;
+        cols[rank] = tid;                         // detection of the rank-th birth (for the feature copy)
+    }
+    __syncthreads();
+    const int nTot = nSurv + nNew;
+    for (int k = wave; k < nNew; k += 4) {          // smooth feature of a new track = its unit feature
+        const float* src = dev.feat_unit + (db + cols[k]) * SS_F;
+        float* dst = dev.smooth + (sb + neworder[nSurv + k]) * SS_F;
+        const int l = tid & 63;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[l + 64 * j] = src[l + 64 * j];
+    }
+    if (tid < nTot) dev.order[sb + tid] = neworder[tid];
+    if (tid == 0) { dev.n_tracks[s] = nTot; dev.next_id[s] = nid0 + nNew; dev.frame[s] += 1; }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---------------- stage D: gallery append (every confirmed track) + output rows -----------
+    for (int k = wave; k < nSurv; k += 4) {
+        const size_t g = sb + neworder[k];
+        if (dev.state[g] != SS_CONFIRMED) continue;
+        int head = dev.gal_head[g], cnt = dev.gal_count[g];
+        gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, head, dev.smooth + g * SS_F);
+        if ((tid & 63) == 0) {
+            dev.gal_head[g] = (head + 1 == prm.nn_budget) ? 0 : head + 1;
+            dev.gal_count[g] = min(cnt + 1, prm.nn_budget);
+        }
+    }
+    int emit = 0;
+    size_t g = 0;
+    if (tid < nTot) {
+        g = sb + neworder[tid];
+        emit = (dev.state[g] == SS_CONFIRMED) && (dev.tsu[g] <= 1);
+    }
+    int nOut;
+    block_scan256(emit, wtot, pos, nOut);
+    if (emit) {
+        const double* m = dev.mean + g * 8;
+        double w = m[2] * m[3];
+        double x = m[0] - w / 2, y = m[1] - m[3] / 2;
+        const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];
+        int x1 = max((int)x, 0), y1 = max((int)y, 0);
+        int x2 = min((int)(x + w), W - 1), y2 = min((int)(y + m[3]), H - 1);
+        float* o = dev.out_rows + (sb + pos) * 8;
+        o[0] = (float)x1; o[1] = (float)y1; o[2] = (float)x2; o[3] = (float)y2;
+        o[4] = (float)dev.track_id[g]; o[5] = (float)dev.class_id[g]; o[6] = dev.conf[g];
+        o[7] = (float)dev.det_idx[g];
+    }
+    if (tid == 0) dev.n_out[s] = nOut;
+}
+
+// =================================================================================================
+// stage KAT kernels (thin wrappers over the same device functions)
+// =================================================================================================
+__global__ void k_kat_normalize(const float* raw, int n, float* unit)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+    if (w >= n) return;
+    float v[8], a = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = raw[(size_t)w * SS_F + l + 64 * j]; a = fmaf(v[j], v[j], a); }
+    float nn = sqrtf(ss_wave_sumsq_reduce(a));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) unit[(size_t)w * SS_F + l + 64 * j] = v[j] / nn;
+}
+
+__global__ void k_kat_ema(const float* smooth, const float* feat, int n, float a, float b, float* out)
+{
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= n) return;
+    ema_wave(smooth + (size_t)w * SS_F, feat + (size_t)w * SS_F, a, b, out + (size_t)w * SS_F);
+}
+
+__global__ void k_kat_kf(int op, double* mean, double* cov, const double* z, const double* conf, int n,
+                         double wp, double wv)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double m[8], c[64];
+    if (op == 2) {
+        double zz[4] = { z[i * 4], z[i * 4 + 1], z[i * 4 + 2], z[i * 4 + 3] };
+        ss_kf_initiate(zz, wp, wv, m, c);
+    } else {
+        for (int k = 0; k < 8; ++k) m[k] = mean[(size_t)i * 8 + k];
+        for (int k = 0; k < 64; ++k) c[k] = cov[(size_t)i * 64 + k];
+        if (op == 0) ss_kf_predict(m, c, wp, wv);
+        else {
+            double zz[4] = { z[i * 4], z[i * 4 + 1], z[i * 4 + 2], z[i * 4 + 3] };
+            ss_kf_update(m, c, zz, conf[i], wp);
+        }
+    }
+    for (int k = 0; k < 8; ++k) mean[(size_t)i * 8 + k] = m[k];
+    for (int k = 0; k < 64; ++k) cov[(size_t)i * 64 + k] = c[k];
+}
+
+__global__ void k_kat_pack(const float* nat, int T, int B, float* frag)
+{
+    // nat [T][B][512] -> frag [T][NRT][TILE_FLOATS]; one wave per gallery row
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= T * B) return;
+    const int t = w / B, b = w % B;
+    gallery_append_wave(frag + (size_t)t * SS_NRT * SS_TILE_FLOATS, b, nat + (size_t)w * SS_F);
+}
+
+__global__ void k_kat_featfrag(const float* unit, int D, float* frag)
+{
+    // unit [D][512] -> fragment-major column tiles (zero padded)
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+    const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
+    if (w >= Dpad) return;
+    float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+    if (w < D) {
+        const float4* s4 = reinterpret_cast<const float4*>(unit + (size_t)w * SS_F + 8 * l);
+        float4 x = s4[0], y = s4[1];
+        lo = make_float4(x.x, x.z, y.x, y.z); hi = make_float4(x.y, x.w, y.y, y.w);
+    }
+    float4* tile = reinterpret_cast<float4*>(frag + (size_t)(w / SS_TILE) * SS_TILE_FLOATS);
+    tile[(l * 2 + 0) * 32 + w % SS_TILE] = lo;
+    tile[(l * 2 + 1) * 32 + w % SS_TILE] = hi;
+}
+
+__global__ void k_kat_gate(const float* part_min, const int* counts, int T, int D, const double* mean,
+                           const double* cov, const double* xyah, SSParams prm, double* cost, float* cosd,
+                           double* maha, uint8_t* gated)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * D) return;
+    const int r = idx / D, d = idx % D;
+    const float* pm = part_min + ((size_t)r * SS_NRT) * SS_MAXD + d;
+    float c = INFINITY;
+    for (int rt = 0; rt * SS_TILE < counts[r]; ++rt) c = fminf(c, pm[(size_t)rt * SS_MAXD]);
+    double m[8], cv[64], m4[4], S[16], L[16];
+    for (int k = 0; k < 8; ++k) m[k] = mean[(size_t)r * 8 + k];
+    for (int k = 0; k < 64; ++k) cv[k] = cov[(size_t)r * 64 + k];
+    ss_kf_project(m, cv, 0.0, prm.wp, m4, S);
+    ss_chol4(S, L);
+    double z[4] = { xyah[d * 4], xyah[d * 4 + 1], xyah[d * 4 + 2], xyah[d * 4 + 3] };
+    double mh = ss_maha(L, m4, z);
+    int g;
+    double v = ss_blend(c, mh, prm, &g);
+    cost[idx] = v; cosd[idx] = c; maha[idx] = mh; gated[idx] = (uint8_t)g;
+}
+
+__global__ void k_kat_iou(const double* ttlwh, int T, const double* dtlwh, int D, double max_dist, double* cost)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * D) return;
+    const int r = idx / D, d = idx % D;
+    double t[4] = { ttlwh[r * 4], ttlwh[r * 4 + 1], ttlwh[r * 4 + 2], ttlwh[r * 4 + 3] };
+    double c[4] = { dtlwh[d * 4], dtlwh[d * 4 + 1], dtlwh[d * 4 + 2], dtlwh[d * 4 + 3] };
+    cost[idx] = ss_iou_cost(t, c, max_dist);
+}
+
+// ---- launch helpers used by ss_api.hip -------------------------------------------------------------
+size_t ss_step_lds_bytes()
+{
+    return (size_t)SS_COST_CAP * 8 + (3 * 256 * 8 + 4 * 256 * 4 + 512) + 8 * 256 * 4 + 32;
+}
+size_t ss_lsap_lds_bytes() { return 3 * 256 * 8 + 4 * 256 * 4 + 512; }
+
+extern "C" void ss_step_kernel_attr()
+{
+    hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_step_lds_bytes());
+    hipFuncSetAttribute((const void*)k_lsap_kat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_lsap_lds_bytes());
+}
+
+void ss_launch_frame(const SSDev& dev, const SSParams& prm, int grid_tracks, hipStream_t st,
+                     hipEvent_t ev0, hipEvent_t ev1)
+{
+    hipLaunchKernelGGL(k_pre, dim3(dev.S, 1 + SS_MAXD / 4), dim3(256), 0, st, dev, prm);
+    if (ev0)   // start/stop events bound to this one dispatch: the association kernel's own duration
+        hipExtLaunchKernelGGL(k_cosine, dim3(SS_NRT, grid_tracks, dev.S), dim3(512), 0, st, ev0, ev1, 0, dev);
+    else
+        hipLaunchKernelGGL(k_cosine, dim3(SS_NRT, grid_tracks, dev.S), dim3(512), 0, st, dev);
+    hipLaunchKernelGGL(k_step, dim3(dev.S), dim3(256), ss_step_lds_bytes(), st, dev, prm);
+}
+
+void ss_launch_normalize(const float* raw, int n, float* unit, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(k_kat_normalize, dim3((n + 3) / 4), dim3(256), 0, st, raw, n, unit); }
+void ss_launch_ema(const float* s, const float* f, int n, float a, float b, float* o, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(k_kat_ema, dim3((n + 3) / 4), dim3(256), 0, st, s, f, n, a, b, o); }
+void ss_launch_kf(int op, double* mean, double* cov, const double* z, const double* conf, int n, double wp, double wv, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(k_kat_kf, dim3((n + 63) / 64), dim3(64), 0, st, op, mean, cov, z, conf, n, wp, wv); }
+void ss_launch_pack(const float* nat, int T, int B, float* frag, hipStream_t st)
+{ if (T * B) hipLaunchKernelGGL(k_kat_pack, dim3((T * B + 3) / 4), dim3(256), 0, st, nat, T, B, frag); }
+void ss_launch_assoc(const float* gal_frag, const int* counts, int T, const float* feats, int D,
+                     const double* mean, const double* cov, const double* xyah, const SSParams& prm,
+                     float* feat_frag_scratch, float* part_min_scratch, double* cost, float* cosd,
+                     double* maha, uint8_t* gated, hipStream_t st)
+{
+    if (T == 0 || D == 0) return;
+    const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
+    hipLaunchKernelGGL(k_kat_featfrag, dim3((Dpad + 3) / 4), dim3(256), 0, st, feats, D, feat_frag_scratch);
+    CosineArgs a{ gal_frag, counts, feat_frag_scratch, part_min_scratch, T, D };
+    hipLaunchKernelGGL(k_cosine_kat, dim3(SS_NRT, T), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(k_kat_gate, dim3((T * D + 255) / 256), dim3(256), 0, st, part_min_scratch, counts, T, D,
+                       mean, cov, xyah, prm, cost, cosd, maha, gated);
+}
+void ss_launch_iou(const double* t, int T, const double* d, int D, double md, double* cost, hipStream_t st)
+{ if (T * D) hipLaunchKernelGGL(k_kat_iou, dim3((T * D + 255) / 256), dim3(256), 0, st, t, T, d, D, md, cost); }
+void ss_launch_lsap(const double* cost, int nr, int nc, int* r2c, double* scratch, int* err, hipStream_t st)
+{ hipLaunchKernelGGL(k_lsap_kat, dim3(1), dim3(64), ss_lsap_lds_bytes(), st, cost, nr, nc, r2c, scratch, err); }

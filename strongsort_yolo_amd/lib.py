@@ -1,0 +1,112 @@
+"""ctypes binding of libstrongsort_hip.so (include/strongsort_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this module
+raises.  Device memory is managed with torch tensors; their data_ptr() values cross the C ABI as
+plain pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libstrongsort_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+SS_OK, SS_ERR_INVALID, SS_ERR_CAPACITY, SS_ERR_HIP, SS_ERR_INFEASIBLE = 0, -1, -2, -3, -4
+MAX_TRACKS, MAX_DETS, FEAT_DIM, OUT_COLS = 256, 128, 512, 8
+
+EXPORTS = [
+    "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
+    "ss_letterbox", "ss_nms", "ss_crop_norm", "ss_track_update", "ss_track_update_host",
+    "ss_check_errors", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
+    "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
+    "ss_get_gallery", "ss_assoc_timing",
+]
+
+
+class SSError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"strongsort_hip error {code}: {msg}")
+        self.code = code
+
+
+class ss_config(C.Structure):
+    _fields_ = [
+        ("max_dist", C.c_double), ("max_iou_distance", C.c_double), ("mc_lambda", C.c_double),
+        ("gating_threshold", C.c_double), ("gated_cost", C.c_double),
+        ("std_weight_position", C.c_double), ("std_weight_velocity", C.c_double),
+        ("ema_alpha", C.c_double), ("max_age", C.c_int), ("n_init", C.c_int), ("nn_budget", C.c_int),
+        ("n_streams", C.c_int), ("debug", C.c_int),
+    ]
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "strongsort_hip.h"))
+    stale = (not os.path.exists(SO_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"] + (["-B"] if force else []))
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise SSError(SS_ERR_INVALID, f"{SO_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(SO_PATH)
+    vp, ip, fp, dp, u8 = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # device pointers
+    i, f, d = C.c_int, C.c_float, C.c_double
+    L.ss_create.argtypes = [C.POINTER(ss_config), i, C.POINTER(vp)]
+    L.ss_destroy.argtypes = [vp]; L.ss_destroy.restype = None
+    L.ss_last_error.argtypes = [vp]; L.ss_last_error.restype = C.c_char_p
+    L.ss_set_hip_stream.argtypes = [vp, vp]
+    L.ss_reset.argtypes = [vp, i]
+    L.ss_synchronize.argtypes = [vp]
+    L.ss_letterbox.argtypes = [vp, u8, i, i, i, vp, i, i, i, i, i, i, i, i]
+    L.ss_nms.argtypes = [vp, fp, i, i, i, f, f, i, f, i, f, f, f, f, f, fp, i, ip, ip]
+    L.ss_crop_norm.argtypes = [vp, u8, i, i, i, fp, i, i, ip, vp, i]
+    L.ss_track_update.argtypes = [vp, fp, ip, fp, ip, fp, ip]
+    hf, hi = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    L.ss_track_update_host.argtypes = [vp, i, hf, i, hf, i, i, hf, i, hi]
+    L.ss_check_errors.argtypes = [vp]
+    L.ss_feat_normalize.argtypes = [vp, fp, i, fp]
+    L.ss_ema.argtypes = [vp, fp, fp, i, fp]
+    L.ss_kf_predict.argtypes = [vp, dp, dp, i]
+    L.ss_kf_update.argtypes = [vp, dp, dp, dp, dp, i]
+    L.ss_kf_initiate.argtypes = [vp, dp, i, dp, dp]
+    L.ss_gallery_pack.argtypes = [vp, fp, i, i, fp]
+    L.ss_assoc_cost.argtypes = [vp, fp, ip, i, fp, i, dp, dp, dp, dp, fp, dp, u8]
+    L.ss_iou_cost.argtypes = [vp, dp, i, dp, i, dp]
+    L.ss_lsap.argtypes = [vp, dp, i, i, ip]
+    hd, hu8 = C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    L.ss_get_tracks.argtypes = [vp, i, i, hi, hi, hi, hi, hi, hi, hi, hi, hf, hd, hd, hf, hi]
+    L.ss_get_debug.argtypes = [vp, i, hi, hf, hd, hu8, hd, hd, hi]
+    L.ss_get_gallery.argtypes = [vp, i, i, hf, i, hi]
+    L.ss_assoc_timing.argtypes = [vp, i, hf, hi]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("ss_destroy", "ss_last_error"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc != SS_OK:
+        msg = load().ss_last_error(ctx)
+        raise SSError(rc, msg.decode() if msg else "?")
+
+
+def make_config(cfg, n_streams=1, debug=False) -> ss_config:
+    return ss_config(cfg.max_dist, cfg.max_iou_distance, cfg.mc_lambda, cfg.gating_threshold, cfg.gated_cost,
+                     cfg.std_weight_position, cfg.std_weight_velocity, cfg.ema_alpha, cfg.max_age, cfg.n_init,
+                     cfg.nn_budget, n_streams, int(debug))

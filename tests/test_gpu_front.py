@@ -1,0 +1,118 @@
+"""Frame-side kernels through the C ABI vs the C oracle: letterbox (a1), NMS (a3), ReID crop (a4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cexact
+from strongsort_yolo_amd.config import DetectConfig
+from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
+from strongsort_yolo_amd.synth import make_stream, synth_prediction
+from tests.gpu_util import engine, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = engine(debug=False)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("wh", [(1280, 720), (1920, 1080), (640, 480), (333, 517)])
+def test_letterbox_bit_exact(eng, wh):
+    W, H = wh
+    rng = np.random.default_rng(W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    g = letterbox_geometry(H, W)
+    got = eng.letterbox(torch.from_numpy(img).to(eng.device), g).cpu().numpy()
+    ref = cexact.letterbox(img, g.out_h, g.out_w, g.new_h, g.new_w, g.pad_top, g.pad_left)
+    assert got.shape == ref.shape == (3, g.out_h, g.out_w)
+    assert bits_equal(got, ref)
+    half = eng.letterbox(torch.from_numpy(img).to(eng.device), g, half=True).cpu().numpy()
+    assert bits_equal(half, ref.astype(np.float16))
+
+
+def test_letterbox_geometry_matches_survey():
+    g = letterbox_geometry(720, 1280)
+    assert (g.out_h, g.out_w) == (384, 640)
+    g = letterbox_geometry(1080, 1920)
+    assert (g.out_h, g.out_w) == (384, 640)
+    g = letterbox_geometry(480, 640)
+    assert (g.out_h, g.out_w) == (480, 640)
+
+
+@pytest.mark.parametrize("n_ids,wh,nc", [(30, (1280, 720), 80), (100, (1920, 1080), 80), (5, (640, 480), 1)])
+def test_nms_bit_exact_and_recovers_truth(eng, n_ids, wh, nc):
+    W, H = wh
+    dcfg = DetectConfig()
+    g = letterbox_geometry(H, W)
+    gain, px, py = scale_geometry(g, H, W)
+    N = (g.out_h // 8) * (g.out_w // 8) + (g.out_h // 16) * (g.out_w // 16) + (g.out_h // 32) * (g.out_w // 32)
+    s = make_stream(3, W, H, n_ids, n_classes=min(nc, 3))
+    fr = s.next_frame()
+    rng = np.random.default_rng(9)
+    pred = synth_prediction(fr.dets, N, nc, gain, (px, py), rng)
+    rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, gain, px, py, W, H)
+    k = int(count.item())
+    rows, keep = rows.cpu().numpy()[:k], keep.cpu().numpy()[:k]
+    rkeep, rrows = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+    rrows = cexact.scale_boxes(rrows, gain, px, py, W, H)
+    assert np.array_equal(keep, rkeep)                       # integer outputs: exact
+    assert bits_equal(rows, rrows)
+    # every survivor is one of the true boxes (overlapping same-class truths may suppress each other)
+    assert 0 < k <= len(fr.dets)
+    for r in rows:
+        err = np.abs(fr.dets[:, :4] - r[:4]).max(axis=1)
+        j = int(err.argmin())
+        assert err[j] < 0.01 and fr.dets[j, 5] == r[5] and abs(fr.dets[j, 4] - r[4]) < 1e-6
+
+
+def test_nms_edge_cases(eng):
+    dcfg = DetectConfig()
+    N, nc = 5040, 80
+    rng = np.random.default_rng(0)
+    # nothing above threshold
+    pred = rng.uniform(0, 0.2, (4 + nc, N)).astype(np.float32)
+    _, _, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 0.5, 0.0, 12.0, 1280, 720)
+    assert int(count.item()) == 0
+    # many identical boxes + identical scores (ties): lowest anchor index must survive
+    pred = np.zeros((4 + nc, N), np.float32)
+    pred[0:4, :] = np.array([[100.0], [100.0], [50.0], [80.0]], np.float32)
+    pred[4, :3000] = 0.9
+    rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 0.5, 0.0, 12.0, 1280, 720)
+    rkeep, _ = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, False, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+    assert int(count.item()) == 1 and keep.cpu().numpy()[0] == 0 == rkeep[0]
+    # dense random field: hundreds of survivors, idempotence (NMS of the survivors keeps all)
+    pred = np.zeros((4 + nc, N), np.float32)
+    pred[0] = rng.uniform(0, 640, N); pred[1] = rng.uniform(0, 384, N)
+    pred[2] = rng.uniform(10, 80, N); pred[3] = rng.uniform(10, 80, N)
+    pred[4:6] = rng.uniform(0, 1, (2, N))
+    rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 1.0, 0.0, 0.0, 640, 384)
+    k = int(count.item())
+    rkeep, rrows = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, False, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+    assert k == len(rkeep) and np.array_equal(keep.cpu().numpy()[:k], rkeep)
+    assert bits_equal(rows.cpu().numpy()[:k], cexact.scale_boxes(rrows, 1.0, 0.0, 0.0, 640, 384))
+    scores = rows.cpu().numpy()[:k, 4]
+    assert np.all(np.diff(scores) <= 0)                      # sortedness
+    sub = pred[:, keep.cpu().numpy()[:k]].copy()
+    _, _, c2 = eng.nms(torch.from_numpy(np.ascontiguousarray(sub)).to(eng.device), nc, dcfg, 1.0, 0.0, 0.0, 640, 384)
+    assert int(c2.item()) == k                               # idempotence
+
+
+@pytest.mark.parametrize("wh,n", [((1280, 720), 30), ((1920, 1080), 100), ((640, 480), 3)])
+def test_crop_norm_bit_exact(eng, wh, n):
+    W, H = wh
+    s = make_stream(4, W, H, n)
+    fr = s.next_frame()
+    img = s.frame_pixels(0)
+    dets = fr.dets.copy()
+    dets[0, :4] = [-5.0, -3.0, 20.5, 30.2]                   # clipped at the border
+    if len(dets) > 1:
+        dets[1, :4] = [W - 10.0, H - 12.0, W + 50.0, H + 50.0]
+    if len(dets) > 2:
+        dets[2, :4] = [100.0, 100.0, 100.4, 100.3]           # degenerate (sub-pixel) box
+    dt = torch.from_numpy(dets).to(eng.device)
+    got = eng.crop_norm(torch.from_numpy(img).to(eng.device), dt, len(dets)).cpu().numpy()
+    ref = cexact.crop_norm(img, dets)
+    assert bits_equal(got, ref)

@@ -1,0 +1,120 @@
+"""Sequence parity: device-resident tracker vs the oracle on seeded synthetic streams.
+ids / det indices / classes exact; boxes exact (int-truncated Kalman state); track table and every
+stage intermediate (cosine, Mahalanobis, cost matrices, assignment lists) bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.strongsort_np import OracleStrongSort
+from strongsort_yolo_amd.config import StrongSortConfig
+from strongsort_yolo_amd.synth import make_stream
+from tests.gpu_util import engine, bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_frame(eng, orc, rows_g, rows_o, k, s=0):
+    assert rows_g.shape == rows_o.shape, f"frame {k}: {rows_g.shape} vs {rows_o.shape}"
+    assert bits_equal(rows_g, rows_o), f"frame {k}: output rows differ"
+    dbg, last = eng.debug(s), orc.last
+    assert dbg["n_conf"] == len(last["confirmed"])
+    assert bits_equal(dbg["cos"], last["cos"]), f"frame {k}: cosine"
+    assert bits_equal(dbg["maha"], last["maha"]), f"frame {k}: maha"
+    assert np.array_equal(dbg["gated"], last["gated"])
+    assert bits_equal(dbg["cost_a"], last["cost_a"]), f"frame {k}: cost_a"
+    pa = np.full(len(last["confirmed"]), -1, np.int32)
+    for r, c in last["pairs_a"]:
+        pa[r] = c
+    assert np.array_equal(dbg["pairs_a"], pa)
+    assert np.array_equal(dbg["cand"], np.asarray(last["cand"], np.int32))
+    assert np.array_equal(dbg["cols_b"], np.asarray(last["cols_b"], np.int32))
+    if dbg["n_cand"] and dbg["n_cols"]:
+        assert bits_equal(dbg["cost_b"], last["cost_b"]), f"frame {k}: cost_b"
+
+
+def _compare_table(eng, orc, s=0):
+    t, o = eng.tracks(s), orc.snapshot()
+    for key in ("track_id", "state", "hits", "age", "tsu", "gal_count"):
+        assert np.array_equal(t[key], o[key]), key
+    assert t["next_id"] == o["next_id"]
+    assert bits_equal(t["mean"], o["mean"]) and bits_equal(t["cov"], o["cov"])
+    assert bits_equal(t["smooth"], o["smooth"])
+
+
+@pytest.mark.parametrize("n_ids,wh,frames,seed", [(30, (1280, 720), 150, 0), (100, (1920, 1080), 40, 1), (8, (640, 480), 60, 2)])
+def test_stream_parity(n_ids, wh, frames, seed):
+    W, H = wh
+    cfg = StrongSortConfig()
+    eng = engine(cfg)
+    orc = OracleStrongSort(cfg, "c")
+    sg, so = make_stream(seed, W, H, n_ids), make_stream(seed, W, H, n_ids)
+    for k in range(frames):
+        fg, fo = sg.next_frame(), so.next_frame()
+        rows_g = eng.update_host(fg.dets, fg.feats, (H, W))
+        rows_o = orc.update(fo.dets, fo.feats, (H, W))
+        _compare_frame(eng, orc, rows_g, rows_o, k)
+        if k % 10 == 9:
+            _compare_table(eng, orc)
+    _compare_table(eng, orc)
+    # gallery content as a set of rows (ring order is irrelevant to the min)
+    for i, t in enumerate(orc.tracks[:5]):
+        g = eng.gallery(0, i)
+        assert len(g) == len(t.gallery)
+        a = {r.tobytes() for r in g}
+        assert a == {r.tobytes() for r in t.gallery}
+    eng.close()
+
+
+def test_births_deaths_and_empty_frames():
+    cfg = StrongSortConfig(max_age=5)
+    eng, orc = engine(cfg), OracleStrongSort(cfg, "c")
+    sg, so = make_stream(7, 640, 480, 10, p_vanish=0.15, vanish_max=12), make_stream(7, 640, 480, 10, p_vanish=0.15, vanish_max=12)
+    empty = (np.zeros((0, 6), np.float32), np.zeros((0, 512), np.float32))
+    for k in range(120):
+        fg, fo = sg.next_frame(), so.next_frame()
+        if k % 17 == 16:                                # drop every detection now and then
+            rg, ro = eng.update_host(*empty, (480, 640)), orc.update(*empty, (480, 640))
+        else:
+            rg, ro = eng.update_host(fg.dets, fg.feats, (480, 640)), orc.update(fo.dets, fo.feats, (480, 640))
+        _compare_frame(eng, orc, rg, ro, k)
+    _compare_table(eng, orc)
+    assert orc.next_id > 11                             # re-births happened
+    eng.close()
+
+
+def test_multi_stream_batch_equals_single_streams():
+    """S streams in one context (one batch of launches) == each stream run alone."""
+    import torch
+    cfg = StrongSortConfig()
+    S, W, H = 3, 1280, 720
+    eng = engine(cfg, n_streams=S, debug=False)
+    orcs = [OracleStrongSort(cfg, "c") for _ in range(S)]
+    streams = [make_stream(10 + s, W, H, 20 + 5 * s) for s in range(S)]
+    streams_o = [make_stream(10 + s, W, H, 20 + 5 * s) for s in range(S)]
+    dev = eng.device
+    dets = torch.zeros(S, 128, 6, device=dev)
+    feats = torch.zeros(S, 128, 512, device=dev)
+    nd = torch.zeros(S, dtype=torch.int32, device=dev)
+    hw = torch.tensor([[H, W]] * S, dtype=torch.int32, device=dev)
+    for k in range(40):
+        ref = []
+        for s in range(S):
+            f, fo = streams[s].next_frame(), streams_o[s].next_frame()
+            n = len(f.dets)
+            dets[s, :n] = torch.from_numpy(f.dets).to(dev)
+            feats[s, :n] = torch.from_numpy(f.feats).to(dev)
+            nd[s] = n
+            ref.append(orcs[s].update(fo.dets, fo.feats, (H, W)))
+        out, nout = eng.update_device(dets, nd, feats, hw)
+        eng.check_errors()
+        out, nout = out.cpu().numpy(), nout.cpu().numpy()
+        for s in range(S):
+            assert bits_equal(out[s, :nout[s]], ref[s]), f"stream {s} frame {k}"
+    eng.close()
+
+
+def test_capacity_error_is_loud():
+    from strongsort_yolo_amd.lib import SSError
+    eng = engine()
+    with pytest.raises(SSError):
+        eng.update_host(np.zeros((129, 6), np.float32), np.zeros((129, 512), np.float32), (480, 640))
+    eng.close()
