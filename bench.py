@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""bench.py — tracked frames/s of the MI355X StrongSORT pipeline on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one frame of every stream owned by the rank through the whole hot path
+(letterbox -> detector -> NMS -> ReID crops -> OSNet -> StrongSORT update), inputs resident in HBM.
+Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synthetic, 30 identities
+(~30 det/frame), 1 stream per GPU.  Streams are independent, so N GPUs = N x the work ("weak"); no
+data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
+
+Synthetic data (no weights / decoder offline): the detector and OSNet are seeded random-init nets
+of the published shapes and run on every frame for load; the detections the tracker sees come from
+the HIP NMS applied to a synthetic head tensor that encodes the stream's ground-truth boxes, and
+the features are the synthetic identity features of the anchors that survive NMS.
+
+The JSON line also carries
+  roofline      association kernel (k_cosine): algorithmic bytes per launch / mean launch duration
+                measured with HIP start/stop events on the kernel's own dispatches inside the timed
+                region; traffic = HBM bytes per launch from the rocprofv3 PMC summary committed
+                under profiles/ (null until that file exists)
+  cpu_baseline  the oracle ("port": NumPy/SciPy tracker + C-oracle frame stages + CPU-torch nets)
+                timed on this box's host cores on a bounded sample (rank 0, N=1 only)
+  id_match_rate fraction of output rows identical to the exact-order C oracle on the same input
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PRESETS = {
+    # name: (detector, W, H, identities, reid_batch)
+    "c2": ("yolov8n", 1280, 720, 30, 32),      # BASELINE.json configs[1] (the metric's configuration)
+    "c3": ("yolov8s", 1280, 720, 30, 32),      # configs[2] per GPU
+    "c4": ("yolov7", 1920, 1080, 100, 128),    # configs[3] crowded scene
+}
+PREFILL = 103      # frames before any timing so galleries hold nn_budget rows
+
+
+def make_workload(seed, W, H, n_ids, n_frames, geom_scale, nc, n_anchors):
+    """Host arrays for one stream: head tensors, anchor->identity maps, identity features."""
+    from strongsort_yolo_amd.synth import make_stream, synth_prediction
+    gain, px, py = geom_scale
+    st = make_stream(seed, W, H, n_ids)
+    rng = np.random.default_rng(seed + 104729)
+    preds = np.empty((n_frames, 4 + nc, n_anchors), np.float32)
+    agt = np.empty((n_frames, n_anchors), np.int64)
+    feats = np.zeros((n_frames, 128, 512), np.float32)
+    ndet = 0
+    for k in range(n_frames):
+        fr = st.next_frame()
+        preds[k], agt[k] = synth_prediction(fr.dets, n_anchors, nc, gain, (px, py), rng)
+        feats[k, :len(fr.dets)] = fr.feats
+        ndet += len(fr.dets)
+    pixels = np.stack([st.frame_pixels(i) for i in range(st.cfg.frame_pool)])
+    return dict(preds=preds, agt=agt, feats=feats, pixels=pixels, mean_dets=ndet / n_frames)
+
+
+def oracle_rows(wl, n_frames, W, H, geom_scale, nc, cfg, dcfg):
+    """The same frames through the exact-order C oracle (NMS + scale_boxes + tracker)."""
+    from oracle import cexact
+    from oracle.strongsort_np import OracleStrongSort
+    gain, px, py = geom_scale
+    orc = OracleStrongSort(cfg, "c")
+    rows = []
+    for k in range(n_frames):
+        keep, r = cexact.nms(wl["preds"][k], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh,
+                             dcfg.max_nms, min(dcfg.max_det, 128))
+        r = cexact.scale_boxes(r, gain, px, py, W, H)
+        f = wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
+        rows.append(orc.update(r, f, (H, W)))
+    return rows
+
+
+def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budget_s=22.0):
+    """Reference-style CPU path on the host cores, bounded sample.  kind = "port"."""
+    import torch
+    from oracle import cexact
+    from oracle.strongsort_np import OracleStrongSort
+    from strongsort_yolo_amd import nets
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                     # pragma: no cover
+        threadpool_limits = None
+    gain, px, py = geom_scale
+    ncores = os.cpu_count() or 1
+    nthr = min(ncores, 32)
+    torch.set_num_threads(nthr)
+    det = nets.build_detector(detector_name, 0).float()
+    reid = nets.build_reid(1).float()
+    orc = OracleStrongSort(cfg, "numpy")
+    ctx = threadpool_limits(limits=1, user_api="blas") if threadpool_limits else None
+    if ctx:
+        ctx.__enter__()
+
+    def track_only(k):
+        keep, r = cexact.nms(wl["preds"][k], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 128)
+        r = cexact.scale_boxes(r, gain, px, py, W, H)
+        f = wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
+        return r, f
+
+    k = 0
+    for k in range(PREFILL):                               # untimed: fill the galleries
+        r, f = track_only(k)
+        orc.update(r, f, (H, W))
+    # tracker-only timing
+    t0 = time.perf_counter(); n_t = 0
+    while n_t < 40 and k + 1 < len(wl["preds"]):
+        k += 1
+        r, f = track_only(k)
+        orc.update(r, f, (H, W)); n_t += 1
+    t_track = (time.perf_counter() - t0) / max(n_t, 1)
+    # full pipeline timing
+    t0 = time.perf_counter(); n_f = 0
+    with torch.no_grad():
+        while time.perf_counter() - t0 < budget_s and n_f < 60 and k + 1 < len(wl["preds"]):
+            k += 1
+            img = wl["pixels"][k % len(wl["pixels"])]
+            lb = cexact.letterbox(img, geom.out_h, geom.out_w, geom.new_h, geom.new_w, geom.pad_top, geom.pad_left)
+            det(torch.from_numpy(lb)[None])                                    # random-init: output unused
+            r, f = track_only(k)
+            crops = cexact.crop_norm(img, r)
+            if len(crops):
+                reid(torch.from_numpy(crops))
+            orc.update(r, f, (H, W)); n_f += 1
+    t_full = (time.perf_counter() - t0) / max(n_f, 1)
+    if ctx:
+        ctx.__exit__(None, None, None)
+    return {"value": round(1.0 / t_full, 2), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"{n_f} frames of the same stream after {PREFILL} untimed warm-up frames: C-oracle letterbox/NMS/crop, "
+                      f"CPU-torch fp32 {detector_name}+OSNet-x0.25 ({nthr} threads), NumPy/SciPy StrongSORT update (1 BLAS thread)",
+            "tracker_only_frames_per_s": round(1.0 / t_track, 1), "host_cores": ncores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=1, help="streams per GPU (configs[1] = 1)")
+    ap.add_argument("--preset", default="c2", choices=sorted(PRESETS))
+    ap.add_argument("--graph", default="front", choices=["front", "all", "none"])
+    ap.add_argument("--no-nets", action="store_true", help="skip detector/ReID (tracker-path microbench; not the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from strongsort_yolo_amd.config import StrongSortConfig, DetectConfig
+    from strongsort_yolo_amd.engine import scale_geometry
+    from strongsort_yolo_amd.pipeline import FramePipeline
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev_index = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+
+    detector, W, H, n_ids, rb = PRESETS[args.preset]
+    cfg, dcfg = StrongSortConfig(), DetectConfig()
+    S, K, Wm = args.streams, args.steps, args.warmup
+    total = PREFILL + Wm + K
+    pipe = FramePipeline(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
+                         det_source="synthetic", feat_source="by_anchor", graph=args.graph,
+                         run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32))
+    gs = scale_geometry(pipe.geom, H, W)
+    nc, A = pipe.nc, pipe.n_anchors
+    wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
+    dev = pipe.dev
+    pools = [dict(preds=torch.from_numpy(w["preds"]).to(dev), agt=torch.from_numpy(w["agt"]).to(dev),
+                  feats=torch.from_numpy(w["feats"]).to(dev), pixels=torch.from_numpy(w["pixels"]).to(dev)) for w in wls]
+    out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
+    nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
+
+    def feed(k):
+        for s, p in enumerate(pools):
+            pipe.frames[s].copy_(p["pixels"][k % p["pixels"].shape[0]])
+            pipe.pred_in[s].copy_(p["preds"][k])
+            pipe.anchor_gt[s].copy_(p["agt"][k])
+            pipe.gt_feats[s].copy_(p["feats"][k])
+
+    def one(k):
+        feed(k)
+        pipe.step()
+        out_host[k].copy_(pipe.out, non_blocking=True)
+        nout_host[k].copy_(pipe.nout, non_blocking=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(PREFILL):                     # untimed: galleries reach nn_budget rows
+        one(k)
+    for k in range(PREFILL, PREFILL + Wm):       # W untimed warm-up steps
+        one(k)
+    torch.cuda.synchronize()
+    pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(PREFILL + Wm, total):         # exactly K timed steps
+        one(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
+    pipe.eng.check_errors()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # ---- roofline of the association kernel (algorithmic bytes of one launch) ----
+    T_conf = []
+    for s in range(S):
+        t = pipe.eng.tracks(s)
+        T_conf.append((int((t["state"] == 2).sum()), float(t["gal_count"][t["state"] == 2].mean()) if (t["state"] == 2).any() else 0.0))
+    Dm = float(np.mean([w["mean_dets"] for w in wls]))
+    alg_bytes = sum(Tc * B * 512 * 4 + Dm * 512 * 4 + Tc * Dm * 4 * max(1, int(np.ceil(B / 32))) for Tc, B in T_conf)
+    roofline = None
+    if assoc_n > 0 and assoc_ms > 0:
+        ach = alg_bytes / (assoc_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_assoc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "k_cosine (association: gallery stream + f32 MFMA + row min)", "bound": "hbm",
+                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n,
+                    "tracks_confirmed_per_stream": [t for t, _ in T_conf], "gallery_rows": [round(b, 1) for _, b in T_conf]}
+
+    if rank == 0:
+        # ---- identical-ID rate vs the exact-order oracle on stream 0 ----
+        nchk = min(args.check_frames, total)
+        ref = oracle_rows(wls[0], nchk, W, H, gs, nc, cfg, dcfg)
+        tot = same = 0
+        exact_frames = 0
+        for k in range(nchk):
+            n = int(nout_host[k, 0])
+            got = out_host[k, 0, :n].numpy()
+            r = ref[k]
+            tot += max(len(r), n)
+            if got.shape == r.shape:
+                eq = (got[:, [4, 5, 7]] == r[:, [4, 5, 7]]).all(axis=1) & (np.abs(got[:, :4] - r[:, :4]).max(axis=1) == 0)
+                same += int(eq.sum())
+                exact_frames += int(got.tobytes() == r.tobytes())
+        res = {
+            "metric": "tracked frames/sec (whole node), 1280x720@30det" if args.preset != "c4" else "tracked frames/sec (whole node), 1920x1080@100det",
+            "value": round(world * S * K / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
+            "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
+                                   f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
+                       "streams_per_gpu": S, "graph": args.graph, "nets": not args.no_nets, "prefill_frames": PREFILL,
+                       "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
+            "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wls[0], W, H, pipe.geom, gs, nc, cfg, dcfg, detector)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    pipe.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,8 @@ struct ss_ctx {
     void* nms_ws;
     size_t nms_ws_bytes;
     int tracks_ub;              // host upper bound of live tracks per stream (grid sizing)
+    int fixed_grid;             // >0: use this grid instead (graph capture)
+    int cos_grid;               // persistent workgroups of the association kernel
     // association-kernel timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -92,6 +94,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->timing = false;
     c->ev_used = 0;
     c->tracks_ub = 0;
+    c->fixed_grid = 0;
+    c->cos_grid = 512;           // persistent workgroups (2 per CU)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -114,6 +118,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(feat_unit, S * D * SS_F); A(feat_frag, S * SS_NCT * SS_TILE_FLOATS);
     A(tlwh, S * D * 4); A(xyah, S * D * 4); A(chol, S * T * 16); A(ttlwh, S * T * 4);
     A(n_conf, S); A(conf_list, S * T); A(part_min, S * T * SS_NRT * D);
+    A(tiles, 2 * S * T * SS_NRT); A(tile_count, 4);
     if (cfg->debug) {
         A(dbg_cos, S * T * D); A(dbg_maha, S * T * D); A(dbg_cost_a, S * T * D); A(dbg_cost_b, S * T * D);
         A(dbg_gated, S * T * D); A(dbg_lists, S * 4 * T); A(dbg_counts, S * 4);
@@ -182,6 +187,8 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
         HIPCHK(c, hipMemcpyAsync(d.next_id + s, &one, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
+    HIPCHK(c, hipMemsetAsync(d.tile_count, 0, 16, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tracks_ub = 0;
     return SS_OK;
 }
@@ -198,7 +205,11 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
     // grid upper bound on confirmed tracks: no host sync; grows by at most MAXD per frame and is
     // refreshed whenever the host reads the table (ss_track_update_host / ss_get_tracks).
     c->tracks_ub = c->tracks_ub + SS_MAXD > SS_MAXT ? SS_MAXT : c->tracks_ub + SS_MAXD;
-    const int grid_tracks = c->tracks_ub < 1 ? 1 : c->tracks_ub;
+    const int grid_tracks = c->fixed_grid > 0 ? c->fixed_grid : (c->tracks_ub < 1 ? 1 : c->tracks_ub);
+    dev.grid_tracks = grid_tracks;
+    dev.cos_grid = c->cos_grid;
+    dev.stream_mode = c->dev.S >= 4 ? 1 : 0;                // throughput form once enough streams share the launch
+    if (const char* g = getenv("SS_STREAM_MODE")) dev.stream_mode = atoi(g);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -208,6 +219,7 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
+    if (const char* g = getenv("SS_COS_GRID")) dev.cos_grid = atoi(g) > 0 ? atoi(g) : dev.cos_grid;
     ss_launch_frame(dev, c->prm, grid_tracks, c->stream, e0, e1);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
@@ -241,6 +253,13 @@ extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, 
     *n_out = cnt[0];
     if (cnt[0] > cap_rows) return fail(c, SS_ERR_CAPACITY, "ss_track_update_host: output buffer too small");
     if (cnt[0]) HIPCHK(c, hipMemcpy(h_out, c->d_out, (size_t)cnt[0] * 8 * 4, hipMemcpyDeviceToHost));
+    return SS_OK;
+}
+
+extern "C" int ss_set_track_grid(ss_ctx* c, int n)
+{
+    if (!c || n < 0 || n > SS_MAXT) return fail(c, SS_ERR_INVALID, "ss_set_track_grid: 0 <= n <= 256");
+    c->fixed_grid = n;
     return SS_OK;
 }
 

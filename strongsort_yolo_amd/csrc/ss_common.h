@@ -11,9 +11,9 @@
 #define SS_F 512              // feature width (OSNet)
 #define SS_SEG 64             // dot-product segment (one wave of the cosine kernel per segment)
 #define SS_NSEG (SS_F / SS_SEG)
-#define SS_TILE 32            // MFMA 32x32 tile edge
-#define SS_NRT 4              // gallery row tiles per track  (capacity 128 rows >= nn_budget)
-#define SS_TILE_FLOATS (SS_F * SS_TILE)   // 16384 floats = 64 KiB per (track,row tile) / (col tile)
+#define SS_TILE 16            // MFMA 16x16 tile edge (v_mfma_f32_16x16x4_f32)
+#define SS_NRT 8              // gallery row tiles per track  (capacity 128 rows >= nn_budget)
+#define SS_TILE_FLOATS (SS_F * SS_TILE)   // 8192 floats = 32 KiB per (track,row tile) / (col tile)
 #define SS_MAXT 256           // track slots per stream
 #define SS_MAXD 128           // detections per stream per frame
 #define SS_NCT (SS_MAXD / SS_TILE)
@@ -23,16 +23,17 @@
 #define SS_CONFIRMED 2
 #define SS_DELETED 3
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Fragment-major feature layout (gallery row tiles and detection column tiles):
-//   float index = ((q*2 + h)*32 + i)*4 + c   holds element k = 8q + 2c + h of row i of the tile,
-// so lane l = h*32+i of a wave reads float4 #(q*64 + l): 1 KiB contiguous per wave instruction,
-// and component c of that float4 is the operand of v_mfma_f32_32x32x2_f32 number 4*(q%8)+c of
-// k-segment q/8 — ascending k, the order of oracle so_dot().
+// Fragment-major feature layout (16-row gallery tiles and 16-detection column tiles):
+//   float index = ((q*4 + ks)*16 + i)*4 + c   holds element k = 16q + 4c + ks of row i of the tile
+// (q = k/16, ks = k%4, c = (k%16)/4), so lane l = ks*16+i of a wave reads float4 #(q*64 + l):
+// 1 KiB contiguous per wave instruction, and component c of that float4 is the A (or B) operand of
+// v_mfma_f32_16x16x4_f32 number 4*(q%4)+c of k-segment q/4 — the instruction consumes k = 16q+4c+{0..3}
+// in ascending order, i.e. the fmaf chain of oracle so_dot().
 __host__ __device__ inline int ss_frag_index(int i, int k)
 {
-    return (((k >> 3) * 2 + (k & 1)) * 32 + i) * 4 + ((k & 7) >> 1);
+    return (((k >> 4) * 4 + (k & 3)) * 16 + i) * 4 + ((k & 15) >> 2);
 }
 
 struct SSParams {
@@ -45,6 +46,8 @@ struct SSParams {
 // Device-resident tracker state + per-frame scratch for S streams (all pointers device memory).
 struct SSDev {
     int S;
+    int grid_tracks;            // confirmed-track capacity assumed by this launch
+    int cos_grid;               // workgroups of the persistent association kernel
     // persistent per stream
     int *n_tracks, *next_id, *frame, *err;
     int* order;                 // [S][MAXT] slot ids in track-list order
@@ -66,6 +69,10 @@ struct SSDev {
     double* ttlwh;              // [S][MAXT][4]   predicted track box (by track index)
     int *n_conf, *conf_list;    // [S], [S][MAXT] track indices of confirmed tracks
     float* part_min;            // [S][MAXT][NRT][MAXD]
+    int4* tiles;                // [2][S*MAXT*NRT] association work lists: {stream, conf row, slot, count | rt<<8 | D<<16}
+                                //   list 0 -> k_cosine_stream (wave per tile, D <= 32), list 1 -> k_cosine_wg
+    int* tile_count;            // [2] valid entries per list (re-armed by k_step)
+    int stream_mode;            // route D <= 32 tiles to the wave-per-tile kernel (throughput mode)
     // outputs
     float* out_rows;            // [S][MAXT][8]
     int* n_out;                 // [S]

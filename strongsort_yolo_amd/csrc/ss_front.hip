@@ -155,14 +155,26 @@ static NmsWs carve_nms(void* ws)
 
 // candidate filter: best class per anchor, score > conf.  key = (~score_bits, anchor): ascending
 // key order == descending score, ties by ascending anchor (stable order of the oracle's sort).
-__global__ __launch_bounds__(256) void k_nms_filter(const float* __restrict__ pred, int N, int nc, float conf, NmsWs w)
+__global__ __launch_bounds__(512) void k_nms_filter(const float* __restrict__ pred, int N, int nc, float conf, NmsWs w)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= N) return;
-    float best = pred[(size_t)4 * N + a]; int bc = 0;
-    for (int k = 1; k < nc; ++k) {
-        float s = pred[(size_t)(4 + k) * N + a];
-        if (s > best) { best = s; bc = k; }
+    // 64 anchors per block; wave g scans classes g, g+8, ... (coalesced over anchors), LDS combine
+    __shared__ float sbest[8][64];
+    __shared__ int scls[8][64];
+    const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int a = blockIdx.x * 64 + l;
+    float best = -INFINITY; int bc = 0x7fffffff;
+    if (a < N)
+        for (int k = g; k < nc; k += 8) {
+            float s = pred[(size_t)(4 + k) * N + a];
+            if (s > best) { best = s; bc = k; }
+        }
+    sbest[g][l] = best; scls[g][l] = bc;
+    __syncthreads();
+    if (g != 0 || a >= N) return;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) {
+        float s = sbest[q][l]; int c = scls[q][l];
+        if (s > best || (s == best && c < bc)) { best = s; bc = c; }       // first maximum = lowest class
     }
     if (best > conf) {
         int slot = atomicAdd(&w.counters[0], 1);
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(64) void k_nms_scan(const float* __restrict__ pred,
         }
     }
     __syncthreads();
-    if (l == 0) { *count = kept; }
+    if (l == 0) { *count = kept; w.counters[0] = 0; }     // re-arm the candidate counter for the next call
     for (int kk = l; kk < kept; kk += 64) {
         const int i = kept_sorted[kk];
         const unsigned long long key = w.keys[i];
@@ -302,8 +314,8 @@ int ss_launch_nms(const float* pred, int N, int nc, int n_extra, float conf, flo
 {
     if (N > NMS_MAX_ANCHORS || ws_bytes < ss_nms_workspace_bytes()) return SS_ERR_CAPACITY;
     NmsWs w = carve_nms(ws);
-    hipMemsetAsync(w.counters, 0, 16, st);
-    hipLaunchKernelGGL(k_nms_filter, dim3((N + 255) / 256), dim3(256), 0, st, pred, N, nc, conf, w);
+    // the candidate counter is re-armed by k_nms_scan itself (no memset node: graph-capture safe)
+    hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64), dim3(512), 0, st, pred, N, nc, conf, w);
     hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), NMS_MAX_CAND * 8, st, pred, N, agnostic, max_wh, w);
     // mask grid sized for the worst case the filter could produce; blocks beyond n exit at once
     const int nbmax = (min(N, NMS_MAX_CAND) + 63) / 64;

@@ -32,18 +32,55 @@ __device__ inline void block_scan256(int flag, int* wtot /*LDS[4]*/, int& pos, i
     total = tot;
 }
 
+// Write one 512-float row (LDS or global) as row i of a fragment-major tile (see ss_frag_index).
+// lane l owns block q = l/2 (k = 16q..16q+15) and k-slots 2*(l&1), 2*(l&1)+1.
+__device__ __forceinline__ void frag_write_row(float4* tile, int i, const float* row, bool zero)
+{
+    const int l = threadIdx.x & 63, q = l >> 1, ks0 = 2 * (l & 1);
+    float r[16];
+    if (zero) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r[k] = 0.0f;
+    } else {
+        const float4* s4 = reinterpret_cast<const float4*>(row + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float4 v = s4[j]; r[4 * j] = v.x; r[4 * j + 1] = v.y; r[4 * j + 2] = v.z; r[4 * j + 3] = v.w; }
+    }
+    tile[(q * 4 + ks0) * 16 + i] = make_float4(r[ks0], r[4 + ks0], r[8 + ks0], r[12 + ks0]);
+    tile[(q * 4 + ks0 + 1) * 16 + i] = make_float4(r[ks0 + 1], r[5 + ks0], r[9 + ks0], r[13 + ks0]);
+}
+
+// exclusive prefix sum of small non-negative ints over the 256 threads of a block
+__device__ inline void block_scan_sum256(int v, int* wtot /*LDS[4]*/, int& excl, int& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    __syncthreads();
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int c = wtot[i]; if (i < w) off += c; tot += c; }
+    excl = off + inc - v;
+    total = tot;
+}
+
 __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
 {
     __shared__ int wtot[4];
-    __shared__ float rowbuf[4][SS_F];
+    __shared__ int tile_base;
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     if (blockIdx.y == 0) {
         // ---- predict all live tracks of stream s (thread = position in the track list) ----
         const int nT = dev.n_tracks[s];
-        int confirmed = 0;
+        int confirmed = 0, myslot = 0, mycount = 0;
         if (tid < nT) {
             const int slot = dev.order[s * SS_MAXT + tid];
+            myslot = slot;
             const size_t g = (size_t)s * SS_MAXT + slot;
             double mean[8], cov[64];
 #pragma unroll
@@ -70,11 +107,25 @@ __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
             double* tb = dev.ttlwh + ((size_t)s * SS_MAXT + tid) * 4;
             tb[0] = mean[0] - w / 2; tb[1] = mean[1] - mean[3] / 2; tb[2] = w; tb[3] = mean[3];
             confirmed = dev.state[g] == SS_CONFIRMED;
+            mycount = dev.gal_count[g];
         }
         int pos, total;
         block_scan256(confirmed, wtot, pos, total);
         if (confirmed) dev.conf_list[s * SS_MAXT + pos] = tid;
-        if (tid == 0) dev.n_conf[s] = total;
+        // association work list: one entry per (confirmed track, 32-row gallery tile) that has rows
+        const int D = dev.n_dets[s];
+        const int ntile = (confirmed && D > 0) ? (mycount + SS_TILE - 1) / SS_TILE : 0;
+        const int tlist = (dev.stream_mode && D <= 2 * SS_TILE) ? 0 : 1;
+        int toff, ttot;
+        block_scan_sum256(ntile, wtot, toff, ttot);
+        if (tid == 0) {
+            dev.n_conf[s] = total;
+            tile_base = ttot ? atomicAdd(dev.tile_count + tlist, ttot) + tlist * dev.S * SS_MAXT * SS_NRT : 0;
+            if (total > dev.grid_tracks) dev.err[s] = SS_ERR_CAPACITY;
+        }
+        __syncthreads();
+        for (int rt = 0; rt < ntile; ++rt)
+            dev.tiles[tile_base + toff + rt] = make_int4(s, pos, myslot, mycount | (rt << 8) | (D << 16));
         return;
     }
     // ---- detection prep: one wave per detection ----
@@ -83,9 +134,8 @@ __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
     const int D = dev.n_dets[s];
     const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
     if (d >= Dpad) return;
-    float* frag = dev.feat_frag + ((size_t)s * SS_NCT + d / SS_TILE) * SS_TILE_FLOATS;
+    float4* frag = reinterpret_cast<float4*>(dev.feat_frag + ((size_t)s * SS_NCT + d / SS_TILE) * SS_TILE_FLOATS);
     const int jj = d % SS_TILE;
-    float4 lo, hi;
     if (d < D) {
         const float* raw = dev.feats_raw + ((size_t)s * SS_MAXD + d) * SS_F;
         float v[8], a = 0.0f;
@@ -96,9 +146,7 @@ __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { float u = v[j] / n; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }
         SS_WAVE_SYNC();
-        const float* rb = rowbuf[w] + 8 * l;      // lane l owns q = l : k = 8l .. 8l+7
-        lo = make_float4(rb[0], rb[2], rb[4], rb[6]);
-        hi = make_float4(rb[1], rb[3], rb[5], rb[7]);
+        frag_write_row(frag, jj, rowbuf[w], false);
         if (l == 0) {
             const float* b = dev.dets + ((size_t)s * SS_MAXD + d) * 6;
             double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
@@ -109,10 +157,8 @@ __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
             z[0] = x1 + bw / 2; z[1] = y1 + bh / 2; z[2] = bw / bh; z[3] = bh;
         }
     } else {
-        lo = hi = make_float4(0.f, 0.f, 0.f, 0.f);
+        frag_write_row(frag, jj, nullptr, true);
     }
-    reinterpret_cast<float4*>(frag)[(l * 2 + 0) * 32 + jj] = lo;
-    reinterpret_cast<float4*>(frag)[(l * 2 + 1) * 32 + jj] = hi;
 }
 
 // =================================================================================================
@@ -130,83 +176,278 @@ struct CosineArgs {
     int D;
 };
 
-__device__ inline void cosine_tile(const float4* __restrict__ gal, int count, int rt,
-                                   const float* __restrict__ feat_frag, int D, float* __restrict__ out,
-                                   float* lds_part, float* lds_red)
+// A operand of one (track, 16-row tile) for this wave's k-segment: 4 coalesced 16-B loads per lane.
+// Lanes whose gallery row is not valid do not touch memory (the ragged last tile costs only its rows).
+__device__ __forceinline__ void load_a(const float4* __restrict__ tile, int valid_rows, float4 a[4])
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    float4 a[8];
+    const bool ok = (l & 15) < valid_rows;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = gal[(8 * w + j) * 64 + l];
-    const int nct = (D + SS_TILE - 1) / SS_TILE;
-    for (int ct = 0; ct < nct; ++ct) {
-        const float4* fb = reinterpret_cast<const float4*>(feat_frag + (size_t)ct * SS_TILE_FLOATS);
-        float4 b[8];
+    for (int j = 0; j < 4; ++j) a[j] = ok ? tile[(4 * w + j) * 64 + l] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// workgroup barrier that orders LDS traffic only: outstanding global loads (the next tile's prefetch) stay in
+// flight across it (__syncthreads() would drain vmcnt to 0 here)
+#define SS_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+#define SS_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// B operand (detections) of column tiles ct, ct+1 for this wave's k-segment
+__device__ __forceinline__ void load_b(const float* __restrict__ feat_frag, int ct, bool two, float4 b0[4], float4 b1[4])
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const float4* fb0 = reinterpret_cast<const float4*>(feat_frag + (size_t)ct * SS_TILE_FLOATS);
+    const float4* fb1 = reinterpret_cast<const float4*>(feat_frag + (size_t)(ct + (two ? 1 : 0)) * SS_TILE_FLOATS);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = fb[(8 * w + j) * 64 + l];
-        f32x16 acc;
+    for (int j = 0; j < 4; ++j) { b0[j] = fb0[(4 * w + j) * 64 + l]; b1[j] = fb1[(4 * w + j) * 64 + l]; }
+}
+
+// One pair of column tiles: 16 + 16 MFMAs (two independent accumulation chains), then
+//   LDS: per-segment partial tiles -> summed left to right (oracle order) -> 1 - dot -> min over rows.
+__device__ __forceinline__ void cosine_pair(const float4 a[4], const float4 b0[4], const float4 b1[4], int count, int rt,
+                                            int ct, bool two, int D, float* __restrict__ out, float* lds_part,
+                                            float* lds_red)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int j = 0; j < 4; ++j) {
+        acc0 = SS_MFMA16(a[j].x, b0[j].x, acc0); acc1 = SS_MFMA16(a[j].x, b1[j].x, acc1);
+        acc0 = SS_MFMA16(a[j].y, b0[j].y, acc0); acc1 = SS_MFMA16(a[j].y, b1[j].y, acc1);
+        acc0 = SS_MFMA16(a[j].z, b0[j].z, acc0); acc1 = SS_MFMA16(a[j].z, b1[j].z, acc1);
+        acc0 = SS_MFMA16(a[j].w, b0[j].w, acc0); acc1 = SS_MFMA16(a[j].w, b1[j].w, acc1);
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[j].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[j].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[j].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[j].w, acc, 0, 0, 0);
-        }
+    for (int r = 0; r < 4; ++r) {
+        lds_part[((0 * 8 + w) * 4 + r) * 64 + l] = acc0[r];
+        lds_part[((1 * 8 + w) * 4 + r) * 64 + l] = acc1[r];
+    }
+    SS_LDS_BARRIER();
+    // thread (ctl, reg, lane): sum the 8 segment partials of one accumulator element, left to right
+    const int ctl = threadIdx.x >> 8, reg = (threadIdx.x >> 6) & 3;
+    float tot = lds_part[((ctl * 8 + 0) * 4 + reg) * 64 + l];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lds_part[(w * 16 + r) * 64 + l] = acc[r];
-        __syncthreads();
-        float m = INFINITY;
-#pragma unroll
-        for (int rr = 2 * w; rr < 2 * w + 2; ++rr) {
-            float tot = lds_part[rr * 64 + l];
-#pragma unroll
-            for (int sg = 1; sg < SS_NSEG; ++sg) tot = tot + lds_part[(sg * 16 + rr) * 64 + l];
-            float dist = 1.0f - tot;
-            int row = rt * SS_TILE + (rr & 3) + 8 * (rr >> 2) + 4 * (l >> 5);
-            if (row >= count) dist = INFINITY;
-            m = fminf(m, dist);
-        }
-        m = fminf(m, __shfl_xor(m, 32));
-        if (l < 32) lds_red[w * 32 + l] = m;
-        __syncthreads();
-        if (threadIdx.x < 32) {
-            float f = lds_red[threadIdx.x];
-#pragma unroll
-            for (int w2 = 1; w2 < 8; ++w2) f = fminf(f, lds_red[w2 * 32 + threadIdx.x]);
-            int d = ct * SS_TILE + threadIdx.x;
-            if (d < D) out[d] = f;
-        }
+    for (int sg = 1; sg < SS_NSEG; ++sg) tot = tot + lds_part[((ctl * 8 + sg) * 4 + reg) * 64 + l];
+    float m = 1.0f - tot;
+    const int row = rt * SS_TILE + 4 * (l >> 4) + reg;             // C/D layout of 16x16x4: row = 4*(lane/16)+reg
+    if (row >= count) m = INFINITY;
+    m = fminf(m, __shfl_xor(m, 16));
+    m = fminf(m, __shfl_xor(m, 32));
+    if (l < 16) lds_red[(ctl * 4 + reg) * 16 + l] = m;
+    SS_LDS_BARRIER();
+    if (threadIdx.x < 32) {
+        const int c2 = threadIdx.x >> 4, j = threadIdx.x & 15;
+        float f = fminf(fminf(lds_red[(c2 * 4 + 0) * 16 + j], lds_red[(c2 * 4 + 1) * 16 + j]),
+                        fminf(lds_red[(c2 * 4 + 2) * 16 + j], lds_red[(c2 * 4 + 3) * 16 + j]));
+        const int d = (ct + c2) * SS_TILE + j;
+        if ((c2 == 0 || two) && d < D) out[d] = f;
     }
 }
 
-__global__ __launch_bounds__(512) void k_cosine(SSDev dev)
+// One gallery tile against every detection column tile (generic: B re-read from L2 per pair).
+__device__ __forceinline__ void cosine_tile(const float4 a[4], int count, int rt, const float* __restrict__ feat_frag,
+                                            int D, float* __restrict__ out, float* lds_part, float* lds_red)
 {
-    __shared__ float lds_part[SS_NSEG * 16 * 64];
-    __shared__ float lds_red[8 * 32];
-    const int rt = blockIdx.x, r = blockIdx.y, s = blockIdx.z;
-    const int D = dev.n_dets[s];
-    if (r >= dev.n_conf[s] || D == 0) return;
-    const int slot = dev.order[s * SS_MAXT + dev.conf_list[s * SS_MAXT + r]];
-    const size_t g = (size_t)s * SS_MAXT + slot;
-    const int count = dev.gal_count[g];
-    if (rt * SS_TILE >= count) return;
-    const float4* gal = reinterpret_cast<const float4*>(dev.gallery + (g * SS_NRT + rt) * SS_TILE_FLOATS);
-    cosine_tile(gal, count, rt, dev.feat_frag + (size_t)s * SS_NCT * SS_TILE_FLOATS, D,
-                dev.part_min + (((size_t)s * SS_MAXT + r) * SS_NRT + rt) * SS_MAXD, lds_part, lds_red);
+    const int nct = (D + SS_TILE - 1) / SS_TILE;
+    for (int ct = 0; ct < nct; ct += 2) {
+        float4 b0[4], b1[4];
+        load_b(feat_frag, ct, ct + 1 < nct, b0, b1);
+        cosine_pair(a, b0, b1, count, rt, ct, ct + 1 < nct, D, out, lds_part, lds_red);
+    }
+}
+
+// ---- association kernel, latency form (work list 1) ------------------------------------------------
+// One 8-wave workgroup per gallery tile, one k-segment per wave: the shortest critical path for a
+// single stream (a tile's 256 MFMAs are spread over 8 waves).  Persistent over chunks of the list with a
+// register prefetch of the next tile; used for small batches and for D > 32.
+__global__ __launch_bounds__(512) void k_cosine_wg(SSDev dev)
+{
+    __shared__ float lds_part[2 * 8 * 4 * 64];
+    __shared__ float lds_red[2 * 4 * 16];
+    const int4* tiles = dev.tiles + (size_t)dev.S * SS_MAXT * SS_NRT;
+    const int G = gridDim.x;
+    const int4 spec = tiles[blockIdx.x];             // speculative: right whenever ntiles <= G (chunk == 1)
+    const int ntiles = dev.tile_count[1];
+    const int chunk = (ntiles + G - 1) / G;
+    const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, ntiles);
+    if (t0 >= t1) return;
+    auto tile_ptr = [&](int s, int slot, int rt) {
+        return reinterpret_cast<const float4*>(dev.gallery + (((size_t)s * SS_MAXT + slot) * SS_NRT + rt) * SS_TILE_FLOATS);
+    };
+    int4 v0 = (chunk == 1) ? spec : tiles[t0];
+    int s0 = __builtin_amdgcn_readfirstlane(v0.x), r0 = __builtin_amdgcn_readfirstlane(v0.y);
+    int sl0 = __builtin_amdgcn_readfirstlane(v0.z), cw0 = __builtin_amdgcn_readfirstlane(v0.w);
+    int s1 = s0, r1 = r0, sl1 = sl0, cw1 = cw0;
+    if (t0 + 1 < t1) {
+        int4 v1 = tiles[t0 + 1];
+        s1 = __builtin_amdgcn_readfirstlane(v1.x); r1 = __builtin_amdgcn_readfirstlane(v1.y);
+        sl1 = __builtin_amdgcn_readfirstlane(v1.z); cw1 = __builtin_amdgcn_readfirstlane(v1.w);
+    }
+    float4 a_cur[4], a_nxt[4], b0[4], b1[4];
+    int sB = -1;
+    load_a(tile_ptr(s0, sl0, (cw0 >> 8) & 7), (cw0 & 0xff) - ((cw0 >> 8) & 7) * SS_TILE, a_cur);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a_nxt[j] = a_cur[j]; b0[j] = a_cur[j]; b1[j] = a_cur[j]; }
+    for (int t = t0; t < t1; ++t) {
+        int4 v2 = make_int4(s1, r1, sl1, cw1);
+        if (t + 2 < t1) v2 = tiles[t + 2];                                   // consumed at the end of the iteration
+        const int count = cw0 & 0xff, rt = (cw0 >> 8) & 7, D = cw0 >> 16;
+        const int nct = (D + SS_TILE - 1) / SS_TILE;
+        const float* ff = dev.feat_frag + (size_t)s0 * SS_NCT * SS_TILE_FLOATS;
+        float* out = dev.part_min + (((size_t)s0 * SS_MAXT + r0) * SS_NRT + rt) * SS_MAXD;
+        if (nct <= 2) {
+            if (sB != s0) { load_b(ff, 0, nct == 2, b0, b1); sB = s0; }      // before the prefetch: vmcnt is in-order
+            if (t + 1 < t1)
+                load_a(tile_ptr(s1, sl1, (cw1 >> 8) & 7), (cw1 & 0xff) - ((cw1 >> 8) & 7) * SS_TILE, a_nxt);
+            cosine_pair(a_cur, b0, b1, count, rt, 0, nct == 2, D, out, lds_part, lds_red);
+        } else {
+            sB = -1;
+            cosine_tile(a_cur, count, rt, ff, D, out, lds_part, lds_red);
+            if (t + 1 < t1)
+                load_a(tile_ptr(s1, sl1, (cw1 >> 8) & 7), (cw1 & 0xff) - ((cw1 >> 8) & 7) * SS_TILE, a_nxt);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
+        s0 = s1; r0 = r1; sl0 = sl1; cw0 = cw1;
+        s1 = __builtin_amdgcn_readfirstlane(v2.x); r1 = __builtin_amdgcn_readfirstlane(v2.y);
+        sl1 = __builtin_amdgcn_readfirstlane(v2.z); cw1 = __builtin_amdgcn_readfirstlane(v2.w);
+    }
+}
+
+// ---- association kernel, throughput form (work list 0, D <= 32) ------------------------------------
+// One WAVE per gallery tile: the wave walks the tile's 8 k-segments itself (8 x 16 MFMAs per column
+// tile), adds the segment sums left to right in registers and reduces min-over-rows with two shuffles.
+// No LDS combine, no barriers in steady state, waves fully decoupled.  The gallery is one continuous
+// stream of 4-KiB segment pieces per wave, prefetched 3 pieces ahead through a 4-deep register ring
+// (ordinary loads, so hipcc's counted vmcnt keeps 3 pieces in flight); the stream's detection operand
+// B (2 x 32 KiB fragment tiles) sits in LDS, shared by the 8 waves of the workgroup.
+__global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int G = gridDim.x;
+    const int ntiles = dev.tile_count[0];
+    const int chunk = (ntiles + G - 1) / G;
+    const int c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, ntiles);
+    if (c0 >= c1) return;
+    int4* desc = reinterpret_cast<int4*>(smem + 2 * SS_TILE_FLOATS * 4);     // [512] descriptors of this pass
+    for (int p0 = c0; p0 < c1; p0 += 512) {
+    const int p1 = min(p0 + 512, c1);
+    __syncthreads();
+    if (p0 + (int)threadIdx.x < p1) desc[threadIdx.x] = dev.tiles[p0 + threadIdx.x];   // one parallel read, then LDS only
+    __syncthreads();
+    const int4* tiles = desc - p0;                                           // tiles[t] for t in [p0, p1)
+    int t0 = p0;
+    while (t0 < p1) {
+        // sub-range [t0, t1) of the pass that belongs to one stream
+        const int s = __builtin_amdgcn_readfirstlane(tiles[t0].x);
+        const int D = __builtin_amdgcn_readfirstlane(tiles[t0].w) >> 16;
+        int t1 = t0 + 1;
+        for (;;) {                                                           // 64 descriptors per step
+            const int tt = t1 + l;
+            const unsigned long long diff = __ballot(tt < p1 && tiles[tt].x != s);
+            if (diff) { t1 += __builtin_ctzll(diff); break; }
+            if (t1 + 64 >= p1) { t1 = p1; break; }
+            t1 += 64;
+        }
+        const bool two = D > SS_TILE;
+        // stage B of stream s in LDS
+        __syncthreads();
+        {
+            const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (size_t)s * SS_NCT * SS_TILE_FLOATS);
+            const int n4 = (two ? 2 : 1) * (SS_TILE_FLOATS / 4);
+            for (int i = threadIdx.x; i < n4; i += 512) bl[i] = ff[i];
+        }
+        __syncthreads();
+        // this wave's tiles: t0 + w, t0 + w + 8, ...
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        const int nmine = (t1 - t0 - wu + 7) / 8;                    // may be <= 0
+        if (nmine > 0) {
+            // descriptors live in SGPRs; a tile is addressed as (uniform byte base) + (per-lane offset)
+            auto rd = [&](int t, int& r, int& cw, const char*& base) {
+                const int4 v = tiles[t];
+                const int sl = __builtin_amdgcn_readfirstlane(v.z);
+                r = __builtin_amdgcn_readfirstlane(v.y); cw = __builtin_amdgcn_readfirstlane(v.w);
+                base = reinterpret_cast<const char*>(dev.gallery) +
+                       ((((size_t)s * SS_MAXT + sl) * SS_NRT + ((cw >> 8) & 7)) * SS_TILE_FLOATS) * 4;
+            };
+            // lanes of rows past the gallery count re-read row 0 of the tile (same cache lines, no extra HBM
+            // traffic, no select); those rows are masked to +inf below
+            auto lane_off = [&](int cw) {
+                const bool ok = (l & 15) < (cw & 0xff) - ((cw >> 8) & 7) * SS_TILE;
+                return (unsigned)((ok ? l : (l & ~15)) * 16);
+            };
+            auto ld = [&](const char* base, unsigned voff, int sg, float4 a[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + voff + sg * 4096 + j * 1024);
+            };
+            int r0, cw0, r1 = 0, cw1 = 0;
+            const char *base0, *base1 = nullptr;
+            rd(t0 + wu, r0, cw0, base0);
+            unsigned vo0 = lane_off(cw0), vo1 = 0;
+            float4 ra[4][4];                                          // 4-deep ring of segment pieces
+            ld(base0, vo0, 0, ra[0]); ld(base0, vo0, 1, ra[1]); ld(base0, vo0, 2, ra[2]);
+            const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
+            const char* bls1 = bls + (two ? 32768 : 0);          // single column tile: read tile 0 twice (result unused)
+            for (int k = 0; k < nmine; ++k) {
+                const bool more = k + 1 < nmine;
+                if (more) { rd(t0 + wu + 8 * (k + 1), r1, cw1, base1); vo1 = lane_off(cw1); }
+                f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg) {
+                    // prefetch piece sg+3 (possibly of the next tile) into ring slot (sg+3)%4
+                    if (sg + 3 < 8) ld(base0, vo0, sg + 3, ra[(sg + 3) & 3]);
+                    else if (more) ld(base1, vo1, sg + 3 - 8, ra[(sg + 3) & 3]);
+                    const float4* a = ra[sg & 3];
+                    f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(bls + (4 * sg + j) * 1024);
+                        const float4 b1 = *reinterpret_cast<const float4*>(bls1 + (4 * sg + j) * 1024);
+                        acc0 = SS_MFMA16(a[j].x, b0.x, acc0); acc1 = SS_MFMA16(a[j].x, b1.x, acc1);
+                        acc0 = SS_MFMA16(a[j].y, b0.y, acc0); acc1 = SS_MFMA16(a[j].y, b1.y, acc1);
+                        acc0 = SS_MFMA16(a[j].z, b0.z, acc0); acc1 = SS_MFMA16(a[j].z, b1.z, acc1);
+                        acc0 = SS_MFMA16(a[j].w, b0.w, acc0); acc1 = SS_MFMA16(a[j].w, b1.w, acc1);
+                    }
+                    if (sg == 0) { tot0 = acc0; tot1 = acc1; }
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
+                }
+                // 1 - dot, mask rows past the gallery count, min over the tile's 16 rows
+                const int count = cw0 & 0xff, rt = (cw0 >> 8) & 7;
+                float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = rt * SS_TILE + 4 * (l >> 4) + r < count;
+                    m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
+                    m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                }
+                m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
+                m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
+                float* out = dev.part_min + (((size_t)s * SS_MAXT + r0) * SS_NRT + rt) * SS_MAXD;
+                if (l < 16) { if (l < D) out[l] = m0; }
+                else if (l < 32) { if (l < D) out[l] = m1; }
+                r0 = r1; cw0 = cw1; base0 = base1; vo0 = vo1;
+            }
+        }
+        t0 = t1;
+    }
+    }
 }
 
 __global__ __launch_bounds__(512) void k_cosine_kat(CosineArgs a)
 {
-    __shared__ float lds_part[SS_NSEG * 16 * 64];
-    __shared__ float lds_red[8 * 32];
+    __shared__ float lds_part[2 * 8 * 4 * 64];
+    __shared__ float lds_red[2 * 4 * 16];
     const int rt = blockIdx.x, r = blockIdx.y;
     const int count = a.gal_count[r];
     if (rt * SS_TILE >= count) return;
-    const float4* gal = reinterpret_cast<const float4*>(a.gallery + ((size_t)r * SS_NRT + rt) * SS_TILE_FLOATS);
-    cosine_tile(gal, count, rt, a.feat_frag, a.D, a.part_min + ((size_t)r * SS_NRT + rt) * SS_MAXD,
-                lds_part, lds_red);
+    float4 av[4];
+    load_a(reinterpret_cast<const float4*>(a.gallery + ((size_t)r * SS_NRT + rt) * SS_TILE_FLOATS), count - rt * SS_TILE, av);
+    cosine_tile(av, count, rt, a.feat_frag, a.D, a.part_min + ((size_t)r * SS_NRT + rt) * SS_MAXD, lds_part, lds_red);
 }
 
 // =================================================================================================
@@ -342,13 +583,7 @@ __device__ inline void ema_wave(const float* smooth_in, const float* feat, float
 // append row-major unit row `src` (global) as gallery row b of a track (fragment-major tiles)
 __device__ inline void gallery_append_wave(float* gal_track, int b, const float* src)
 {
-    const int l = threadIdx.x & 63;
-    const float4* s4 = reinterpret_cast<const float4*>(src + 8 * l);
-    float4 x = s4[0], y = s4[1];
-    float4* tile = reinterpret_cast<float4*>(gal_track + (size_t)(b / SS_TILE) * SS_TILE_FLOATS);
-    const int i = b % SS_TILE;
-    tile[(l * 2 + 0) * 32 + i] = make_float4(x.x, x.z, y.x, y.z);
-    tile[(l * 2 + 1) * 32 + i] = make_float4(x.y, x.w, y.y, y.w);
+    frag_write_row(reinterpret_cast<float4*>(gal_track + (size_t)(b / SS_TILE) * SS_TILE_FLOATS), b % SS_TILE, src, false);
 }
 
 __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
@@ -605,6 +840,7 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
         o[7] = (float)dev.det_idx[g];
     }
     if (tid == 0) dev.n_out[s] = nOut;
+    if (tid == 0 && s == 0) { dev.tile_count[0] = 0; dev.tile_count[1] = 0; }          // re-arm the association work list for the next frame
 }
 
 // =================================================================================================
@@ -662,19 +898,12 @@ __global__ void k_kat_pack(const float* nat, int T, int B, float* frag)
 
 __global__ void k_kat_featfrag(const float* unit, int D, float* frag)
 {
-    // unit [D][512] -> fragment-major column tiles (zero padded)
-    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, l = threadIdx.x & 63;
+    // unit [D][512] -> fragment-major column tiles (zero padded); one wave per detection
+    const int w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
     if (w >= Dpad) return;
-    float4 lo = make_float4(0, 0, 0, 0), hi = lo;
-    if (w < D) {
-        const float4* s4 = reinterpret_cast<const float4*>(unit + (size_t)w * SS_F + 8 * l);
-        float4 x = s4[0], y = s4[1];
-        lo = make_float4(x.x, x.z, y.x, y.z); hi = make_float4(x.y, x.w, y.y, y.w);
-    }
-    float4* tile = reinterpret_cast<float4*>(frag + (size_t)(w / SS_TILE) * SS_TILE_FLOATS);
-    tile[(l * 2 + 0) * 32 + w % SS_TILE] = lo;
-    tile[(l * 2 + 1) * 32 + w % SS_TILE] = hi;
+    frag_write_row(reinterpret_cast<float4*>(frag + (size_t)(w / SS_TILE) * SS_TILE_FLOATS), w % SS_TILE,
+                   unit + (size_t)w * SS_F, w >= D);
 }
 
 __global__ void k_kat_gate(const float* part_min, const int* counts, int T, int D, const double* mean,
@@ -715,21 +944,28 @@ size_t ss_step_lds_bytes()
     return (size_t)SS_COST_CAP * 8 + (3 * 256 * 8 + 4 * 256 * 4 + 512) + 8 * 256 * 4 + 32;
 }
 size_t ss_lsap_lds_bytes() { return 3 * 256 * 8 + 4 * 256 * 4 + 512; }
+size_t ss_cosine_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 512 * 16; }
 
 extern "C" void ss_step_kernel_attr()
 {
     hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_step_lds_bytes());
     hipFuncSetAttribute((const void*)k_lsap_kat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_lsap_lds_bytes());
+    hipFuncSetAttribute((const void*)k_cosine_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_cosine_lds_bytes());
 }
 
 void ss_launch_frame(const SSDev& dev, const SSParams& prm, int grid_tracks, hipStream_t st,
                      hipEvent_t ev0, hipEvent_t ev1)
 {
     hipLaunchKernelGGL(k_pre, dim3(dev.S, 1 + SS_MAXD / 4), dim3(256), 0, st, dev, prm);
-    if (ev0)   // start/stop events bound to this one dispatch: the association kernel's own duration
-        hipExtLaunchKernelGGL(k_cosine, dim3(SS_NRT, grid_tracks, dev.S), dim3(512), 0, st, ev0, ev1, 0, dev);
-    else
-        hipLaunchKernelGGL(k_cosine, dim3(SS_NRT, grid_tracks, dev.S), dim3(512), 0, st, dev);
+    // the association kernel that carries the gallery bytes of this launch gets the start/stop events
+    if (dev.stream_mode) {
+        if (ev0) hipExtLaunchKernelGGL(k_cosine_stream, dim3(dev.cos_grid), dim3(512), ss_cosine_lds_bytes(), st, ev0, ev1, 0, dev);
+        else     hipLaunchKernelGGL(k_cosine_stream, dim3(dev.cos_grid), dim3(512), ss_cosine_lds_bytes(), st, dev);
+        hipLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, dev);          // D > 32 leftovers (usually empty)
+    } else {
+        if (ev0) hipExtLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, ev0, ev1, 0, dev);
+        else     hipLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, dev);
+    }
     hipLaunchKernelGGL(k_step, dim3(dev.S), dim3(256), ss_step_lds_bytes(), st, dev, prm);
 }
 

@@ -90,6 +90,9 @@ class TrackerEngine:
     def reset(self, stream: int = -1):
         self._ck(self.L.ss_reset(self.ctx, stream))
 
+    def set_track_grid(self, n: int):
+        self._ck(self.L.ss_set_track_grid(self.ctx, n))
+
     def check_errors(self):
         self._ck(self.L.ss_check_errors(self.ctx))
 

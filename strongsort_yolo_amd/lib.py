@@ -20,7 +20,7 @@ MAX_TRACKS, MAX_DETS, FEAT_DIM, OUT_COLS = 256, 128, 512, 8
 EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
     "ss_letterbox", "ss_nms", "ss_crop_norm", "ss_track_update", "ss_track_update_host",
-    "ss_check_errors", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
+    "ss_check_errors", "ss_set_track_grid", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
     "ss_get_gallery", "ss_assoc_timing",
 ]
@@ -60,6 +60,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime: it must be the first one mapped into the process, or the
+    # library would bind the system libamdhip64 and see no device.
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise SSError(SS_ERR_INVALID, f"{SO_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(SO_PATH)
@@ -78,6 +81,7 @@ def load():
     hf, hi = C.POINTER(C.c_float), C.POINTER(C.c_int)
     L.ss_track_update_host.argtypes = [vp, i, hf, i, hf, i, i, hf, i, hi]
     L.ss_check_errors.argtypes = [vp]
+    L.ss_set_track_grid.argtypes = [vp, i]
     L.ss_feat_normalize.argtypes = [vp, fp, i, fp]
     L.ss_ema.argtypes = [vp, fp, fp, i, fp]
     L.ss_kf_predict.argtypes = [vp, dp, dp, i]

@@ -1,0 +1,361 @@
+"""Detector and ReID backbones (rows a2 / a5 of SURVEY.md §8a) as plain PyTorch modules.
+
+These are the dense-conv part of the path: on MI355X they run through PyTorch-ROCm (MIOpen /
+hipBLASLt -> MFMA) and are *not* hand-written HIP (north_star: "PyTorch-ROCm for the YOLOv5/7/8
+detector and OSNet-x0.25 ReID backbones").  No weights exist offline, so they are
+seeded random-init networks of the published architectures; their job is to load the GPU with the
+real layer shapes.  Conv+BN pairs are built in their fused inference form (conv with bias).
+
+They stand behind `YOLO(weights)` (/root/reference/yolo_multi_model.py:14-17) and the forward pass
+inside model.track / model.predict (:41, :173).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# YOLO building blocks
+# --------------------------------------------------------------------------------------------------
+class Conv(nn.Module):
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, k // 2 if p is None else p, groups=g, bias=True)
+        self.act = nn.SiLU(inplace=True) if act else nn.Identity()
+
+    def forward(self, x):
+        return self.act(self.conv(x))
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, c1, c2, shortcut=True, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1, self.cv2 = Conv(c1, c_, k[0]), Conv(c_, c2, k[1])
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        return x + self.cv2(self.cv1(x)) if self.add else self.cv2(self.cv1(x))
+
+
+class C2f(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=False):
+        super().__init__()
+        self.c = c2 // 2
+        self.cv1 = Conv(c1, 2 * self.c, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, e=1.0) for _ in range(n))
+
+    def forward(self, x):
+        y = list(self.cv1(x).chunk(2, 1))
+        for m in self.m:
+            y.append(m(y[-1]))
+        return self.cv2(torch.cat(y, 1))
+
+
+class C3(nn.Module):
+    def __init__(self, c1, c2, n=1, shortcut=True):
+        super().__init__()
+        c_ = c2 // 2
+        self.cv1, self.cv2, self.cv3 = Conv(c1, c_, 1), Conv(c1, c_, 1), Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, k=(1, 3), e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+
+class SPPF(nn.Module):
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1, self.cv2 = Conv(c1, c_, 1), Conv(c_ * 4, c2, 1)
+        self.m = nn.MaxPool2d(k, 1, k // 2)
+
+    def forward(self, x):
+        y = [self.cv1(x)]
+        y.extend(self.m(y[-1]) for _ in range(3))
+        return self.cv2(torch.cat(y, 1))
+
+
+class Detect(nn.Module):
+    """Anchor-free v8 head with DFL decode.  Output [B, 4+nc(+nk), A] (xywh in input pixels)."""
+
+    def __init__(self, nc, ch, nk=0):
+        super().__init__()
+        self.nc, self.nk, self.reg_max = nc, nk, 16
+        c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 64, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, nc, 1)) for x in ch)
+        if nk:
+            c4 = max(ch[0] // 4, nk)
+            self.cv4 = nn.ModuleList(nn.Sequential(Conv(x, c4, 3), Conv(c4, c4, 3), nn.Conv2d(c4, nk, 1)) for x in ch)
+        self.strides = (8, 16, 32)
+        self.register_buffer("proj", torch.arange(16, dtype=torch.float32).view(1, 1, 16, 1), persistent=False)
+        self._anchors = None
+
+    def _make_anchors(self, feats):
+        pts, strd = [], []
+        for f, s in zip(feats, self.strides):
+            h, w = f.shape[2:]
+            sx = torch.arange(w, device=f.device, dtype=f.dtype) + 0.5
+            sy = torch.arange(h, device=f.device, dtype=f.dtype) + 0.5
+            yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+            pts.append(torch.stack((xx, yy), 0).view(2, -1))
+            strd.append(torch.full((1, h * w), float(s), device=f.device, dtype=f.dtype))
+        return torch.cat(pts, 1).unsqueeze(0), torch.cat(strd, 1).unsqueeze(0)
+
+    def forward(self, feats):
+        B = feats[0].shape[0]
+        box = torch.cat([self.cv2[i](f).view(B, 64, -1) for i, f in enumerate(feats)], 2)
+        cls = torch.cat([self.cv3[i](f).view(B, self.nc, -1) for i, f in enumerate(feats)], 2)
+        if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:
+            self._anchors = self._make_anchors(feats)
+        anchors, strides = self._anchors
+        d = box.view(B, 4, 16, -1).softmax(2)
+        d = (d * self.proj.to(d.dtype)).sum(2)                       # DFL expectation, [B,4,A]
+        lt, rb = d[:, :2], d[:, 2:]
+        x1y1, x2y2 = anchors - lt, anchors + rb
+        out = [torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides, cls.sigmoid()]
+        if self.nk:
+            out.append(torch.cat([self.cv4[i](f).view(B, self.nk, -1) for i, f in enumerate(feats)], 2))
+        return torch.cat(out, 1)
+
+
+_V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768)}
+
+
+class YOLOv8(nn.Module):
+    def __init__(self, scale="n", nc=80, nk=0):
+        super().__init__()
+        d, w, mc = _V8_SCALES[scale]
+        c = lambda x: int(math.ceil(min(x, mc) * w / 8) * 8)
+        n = lambda x: max(round(x * d), 1)
+        self.b0, self.b1 = Conv(3, c(64), 3, 2), Conv(c(64), c(128), 3, 2)
+        self.b2 = C2f(c(128), c(128), n(3), True)
+        self.b3, self.b4 = Conv(c(128), c(256), 3, 2), C2f(c(256), c(256), n(6), True)
+        self.b5, self.b6 = Conv(c(256), c(512), 3, 2), C2f(c(512), c(512), n(6), True)
+        self.b7, self.b8 = Conv(c(512), c(1024), 3, 2), C2f(c(1024), c(1024), n(3), True)
+        self.b9 = SPPF(c(1024), c(1024))
+        self.h12 = C2f(c(1024) + c(512), c(512), n(3))
+        self.h15 = C2f(c(512) + c(256), c(256), n(3))
+        self.h16, self.h18 = Conv(c(256), c(256), 3, 2), C2f(c(256) + c(512), c(512), n(3))
+        self.h19, self.h21 = Conv(c(512), c(512), 3, 2), C2f(c(512) + c(1024), c(1024), n(3))
+        self.detect = Detect(nc, (c(256), c(512), c(1024)), nk)
+        self.nc, self.nk = nc, nk
+
+    def forward(self, x):
+        p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
+        p4 = self.b6(self.b5(p3))
+        p5 = self.b9(self.b8(self.b7(p4)))
+        h12 = self.h12(torch.cat((F.interpolate(p5, scale_factor=2.0, mode="nearest"), p4), 1))
+        h15 = self.h15(torch.cat((F.interpolate(h12, scale_factor=2.0, mode="nearest"), p3), 1))
+        h18 = self.h18(torch.cat((self.h16(h15), h12), 1))
+        h21 = self.h21(torch.cat((self.h19(h18), p5), 1))
+        return self.detect([h15, h18, h21])
+
+
+class YOLOv5u(nn.Module):
+    """YOLOv5 backbone/neck (C3 blocks) with the anchor-free head — what `YOLO('yolov5n.pt')`
+    (yolo_multi_model.py:15) resolves to in current Ultralytics."""
+
+    def __init__(self, scale="n", nc=80):
+        super().__init__()
+        d, w, mc = _V8_SCALES[scale]
+        c = lambda x: int(math.ceil(min(x, mc) * w / 8) * 8)
+        n = lambda x: max(round(x * d), 1)
+        self.b0, self.b1, self.b2 = Conv(3, c(64), 6, 2, 2), Conv(c(64), c(128), 3, 2), C3(c(128), c(128), n(3))
+        self.b3, self.b4 = Conv(c(128), c(256), 3, 2), C3(c(256), c(256), n(6))
+        self.b5, self.b6 = Conv(c(256), c(512), 3, 2), C3(c(512), c(512), n(9))
+        self.b7, self.b8, self.b9 = Conv(c(512), c(1024), 3, 2), C3(c(1024), c(1024), n(3)), SPPF(c(1024), c(1024))
+        self.h10, self.h13 = Conv(c(1024), c(512), 1), C3(c(1024), c(512), n(3), False)
+        self.h14, self.h17 = Conv(c(512), c(256), 1), C3(c(512), c(256), n(3), False)
+        self.h18, self.h20 = Conv(c(256), c(256), 3, 2), C3(c(512), c(512), n(3), False)
+        self.h21, self.h23 = Conv(c(512), c(512), 3, 2), C3(c(1024), c(1024), n(3), False)
+        self.detect = Detect(nc, (c(256), c(512), c(1024)))
+        self.nc, self.nk = nc, 0
+
+    def forward(self, x):
+        p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
+        p4 = self.b6(self.b5(p3))
+        p5 = self.h10(self.b9(self.b8(self.b7(p4))))
+        h13 = self.h14(self.h13(torch.cat((F.interpolate(p5, scale_factor=2.0, mode="nearest"), p4), 1)))
+        h17 = self.h17(torch.cat((F.interpolate(h13, scale_factor=2.0, mode="nearest"), p3), 1))
+        h20 = self.h20(torch.cat((self.h18(h17), h13), 1))
+        h23 = self.h23(torch.cat((self.h21(h20), p5), 1))
+        return self.detect([h17, h20, h23])
+
+
+# --------------------------------------------------------------------------------------------------
+# YOLOv7-style detector (ELAN backbone + SPPCSPC neck), anchor-free head for a uniform NMS layout
+# --------------------------------------------------------------------------------------------------
+class ELAN(nn.Module):
+    def __init__(self, c1, c_, c2, depth=4):
+        super().__init__()
+        self.cv1, self.cv2 = Conv(c1, c_, 1), Conv(c1, c_, 1)
+        self.m = nn.ModuleList(Conv(c_, c_, 3) for _ in range(depth))
+        self.out = Conv(c_ * (2 + depth // 2), c2, 1)
+
+    def forward(self, x):
+        y = [self.cv1(x), self.cv2(x)]
+        t = y[-1]
+        for i, m in enumerate(self.m):
+            t = m(t)
+            if i % 2 == 1:
+                y.append(t)
+        return self.out(torch.cat(y, 1))
+
+
+class MP(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.cv1, self.cv2, self.cv3 = Conv(c1, c2 // 2, 1), Conv(c1, c2 // 2, 1), Conv(c2 // 2, c2 // 2, 3, 2)
+
+    def forward(self, x):
+        return torch.cat((self.cv3(self.cv2(x)), self.cv1(F.max_pool2d(x, 2, 2))), 1)
+
+
+class SPPCSPC(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        c_ = c2
+        self.cv1, self.cv2 = Conv(c1, c_, 1), Conv(c1, c_, 1)
+        self.cv3, self.cv4 = Conv(c_, c_, 3), Conv(c_, c_, 1)
+        self.cv5, self.cv6, self.cv7 = Conv(4 * c_, c_, 1), Conv(c_, c_, 3), Conv(2 * c_, c2, 1)
+
+    def forward(self, x):
+        x1 = self.cv4(self.cv3(self.cv1(x)))
+        y1 = self.cv6(self.cv5(torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1)))
+        return self.cv7(torch.cat((y1, self.cv2(x)), 1))
+
+
+class YOLOv7(nn.Module):
+    def __init__(self, nc=80):
+        super().__init__()
+        self.stem = nn.Sequential(Conv(3, 32, 3, 1), Conv(32, 64, 3, 2), Conv(64, 64, 3, 1), Conv(64, 128, 3, 2))
+        self.e1 = ELAN(128, 64, 256)
+        self.mp1, self.e2 = MP(256, 256), ELAN(256, 128, 512)
+        self.mp2, self.e3 = MP(512, 512), ELAN(512, 256, 1024)
+        self.mp3, self.e4 = MP(1024, 1024), ELAN(1024, 256, 1024)
+        self.spp = SPPCSPC(1024, 512)
+        self.l1, self.r1, self.n1 = Conv(512, 256, 1), Conv(1024, 256, 1), ELAN(512, 128, 256)
+        self.l2, self.r2, self.n2 = Conv(256, 128, 1), Conv(512, 128, 1), ELAN(256, 64, 128)
+        self.d1, self.n3 = MP(128, 256), ELAN(512, 128, 256)
+        self.d2, self.n4 = MP(256, 512), ELAN(1024, 256, 512)
+        self.detect = Detect(nc, (128, 256, 512))
+        self.nc, self.nk = nc, 0
+
+    def forward(self, x):
+        c3 = self.e2(self.mp1(self.e1(self.stem(x))))
+        c4 = self.e3(self.mp2(c3))
+        c5 = self.spp(self.e4(self.mp3(c4)))
+        p4 = self.n1(torch.cat((self.r1(c4), F.interpolate(self.l1(c5), scale_factor=2.0, mode="nearest")), 1))
+        p3 = self.n2(torch.cat((self.r2(c3), F.interpolate(self.l2(p4), scale_factor=2.0, mode="nearest")), 1))
+        n4 = self.n3(torch.cat((self.d1(p3), p4), 1))
+        n5 = self.n4(torch.cat((self.d2(n4), c5), 1))
+        return self.detect([p3, n4, n5])
+
+
+# --------------------------------------------------------------------------------------------------
+# OSNet (x0.25: channels 16/64/96/128, 512-d embedding)
+# --------------------------------------------------------------------------------------------------
+class ConvBR(nn.Module):
+    def __init__(self, c1, c2, k, s=1, p=0, g=1, relu=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, p, groups=g, bias=True)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class LightConv3x3(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        self.pw = nn.Conv2d(c1, c2, 1, bias=False)
+        self.dw = nn.Conv2d(c2, c2, 3, 1, 1, groups=c2, bias=True)
+
+    def forward(self, x):
+        return F.relu(self.dw(self.pw(x)), inplace=True)
+
+
+class ChannelGate(nn.Module):
+    def __init__(self, c, reduction=16):
+        super().__init__()
+        self.fc1 = nn.Conv2d(c, max(c // reduction, 1), 1)
+        self.fc2 = nn.Conv2d(max(c // reduction, 1), c, 1)
+
+    def forward(self, x):
+        g = x.mean((2, 3), keepdim=True)
+        return x * torch.sigmoid(self.fc2(F.relu(self.fc1(g), inplace=True)))
+
+
+class OSBlock(nn.Module):
+    def __init__(self, c1, c2):
+        super().__init__()
+        mid = c2 // 4
+        self.conv1 = ConvBR(c1, mid, 1)
+        self.streams = nn.ModuleList(nn.Sequential(*(LightConv3x3(mid, mid) for _ in range(t))) for t in (1, 2, 3, 4))
+        self.gate = ChannelGate(mid)
+        self.conv3 = ConvBR(mid, c2, 1, relu=False)
+        self.down = ConvBR(c1, c2, 1, relu=False) if c1 != c2 else None
+
+    def forward(self, x):
+        idn = x if self.down is None else self.down(x)
+        x1 = self.conv1(x)
+        x2 = sum(self.gate(s(x1)) for s in self.streams)
+        return F.relu(self.conv3(x2) + idn, inplace=True)
+
+
+class OSNet(nn.Module):
+    def __init__(self, channels=(16, 64, 96, 128), feature_dim=512):
+        super().__init__()
+        c = channels
+        self.conv1 = ConvBR(3, c[0], 7, 2, 3)
+        self.conv2 = nn.Sequential(OSBlock(c[0], c[1]), OSBlock(c[1], c[1]), ConvBR(c[1], c[1], 1), nn.AvgPool2d(2, 2))
+        self.conv3 = nn.Sequential(OSBlock(c[1], c[2]), OSBlock(c[2], c[2]), ConvBR(c[2], c[2], 1), nn.AvgPool2d(2, 2))
+        self.conv4 = nn.Sequential(OSBlock(c[2], c[3]), OSBlock(c[3], c[3]))
+        self.conv5 = ConvBR(c[3], c[3], 1)
+        self.fc = nn.Linear(c[3], feature_dim)
+
+    def forward(self, x):
+        x = F.max_pool2d(self.conv1(x), 3, 2, 1)
+        x = self.conv5(self.conv4(self.conv3(self.conv2(x))))
+        return F.relu(self.fc(x.mean((2, 3))))
+
+
+def osnet_x0_25():
+    return OSNet((16, 64, 96, 128), 512)
+
+
+DETECTORS = {
+    "yolov8n": lambda: YOLOv8("n"), "yolov8s": lambda: YOLOv8("s"), "yolov8m": lambda: YOLOv8("m"),
+    "yolov8n-pose": lambda: YOLOv8("n", nc=1, nk=51), "yolo11n-pose": lambda: YOLOv8("n", nc=1, nk=51),
+    "yolov8n-seg": lambda: YOLOv8("n"), "yolo11n": lambda: YOLOv8("n"),
+    "yolov5n": lambda: YOLOv5u("n"), "yolov5s": lambda: YOLOv5u("s"),
+    "yolov7": lambda: YOLOv7(),
+}
+
+
+def build_detector(name: str, seed: int = 0) -> nn.Module:
+    """Seeded random-init detector named like the reference's weight files
+    (yolo_multi_model.py:14-17: 'yolov8n-seg.pt', 'yolov5n.pt', 'yolo11n.pt', 'yolo11n-pose.pt')."""
+    key = name.lower().replace(".pt", "")
+    if key not in DETECTORS:
+        raise ValueError(f"unknown detector '{name}'; known: {sorted(DETECTORS)}")
+    g = torch.random.fork_rng()
+    with g:
+        torch.manual_seed(seed)
+        m = DETECTORS[key]()
+    return m.eval()
+
+
+def build_reid(seed: int = 1) -> nn.Module:
+    with torch.random.fork_rng():
+        torch.manual_seed(seed)
+        m = osnet_x0_25()
+    return m.eval()

@@ -125,8 +125,10 @@ def synth_prediction(dets: np.ndarray, n_anchors: int, n_classes: int, lb_scale:
     """A detector-head-shaped tensor [4+nc, N] (YOLOv8 layout: xywh in letterboxed pixels + class
     scores) whose NMS result is exactly `dets` (in descending-score order): every true box gets
     `dup` overlapping lower-scored duplicates, plus sub-threshold clutter elsewhere.
-    lb_scale / lb_pad map original pixels to letterboxed pixels."""
+    lb_scale / lb_pad map original pixels to letterboxed pixels.
+    Returns (pred, anchor_gt) where anchor_gt[a] = row of `dets` anchor a was drawn from, or -1."""
     n = dets.shape[0]
+    anchor_gt = np.full(n_anchors, -1, dtype=np.int64)
     pred = np.zeros((4 + n_classes, n_anchors), dtype=np.float32)
     # background: tiny scores everywhere
     pred[4:, :] = rng.uniform(0.0, 0.05, (n_classes, n_anchors)).astype(np.float32)
@@ -145,6 +147,7 @@ def synth_prediction(dets: np.ndarray, n_anchors: int, n_classes: int, lb_scale:
         h = (y2 - y1) * lb_scale
         for d in range(dup + 1):
             a = slots[k]; k += 1
+            anchor_gt[a] = i
             if d == 0:
                 pred[0:4, a] = (cx, cy, w, h)
                 pred[4:, a] = 0.01
@@ -157,4 +160,4 @@ def synth_prediction(dets: np.ndarray, n_anchors: int, n_classes: int, lb_scale:
     for _ in range(clutter):
         a = slots[k]; k += 1
         pred[4 + int(rng.integers(0, n_classes)), a] = rng.uniform(0.1, 0.29)
-    return pred
+    return pred, anchor_gt

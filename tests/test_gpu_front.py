@@ -52,7 +52,7 @@ def test_nms_bit_exact_and_recovers_truth(eng, n_ids, wh, nc):
     s = make_stream(3, W, H, n_ids, n_classes=min(nc, 3))
     fr = s.next_frame()
     rng = np.random.default_rng(9)
-    pred = synth_prediction(fr.dets, N, nc, gain, (px, py), rng)
+    pred, _ = synth_prediction(fr.dets, N, nc, gain, (px, py), rng)
     rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, gain, px, py, W, H)
     k = int(count.item())
     rows, keep = rows.cpu().numpy()[:k], keep.cpu().numpy()[:k]
