@@ -111,11 +111,12 @@ class FramePipeline:
     def _track(self):
         self.eng.update_device(self.dets6, self.ndets, self.feats_in, self.img_hw)
 
-    def step(self):
+    def step(self, track: bool = True):
         """Run one frame (all streams).  Asynchronous; results in self.out / self.nout (device)."""
         if self.graph_mode == "none":
             self._step_impl()
-            self._track()
+            if track:
+                self._track()
             return
         if self.graph is None:
             # warm up on a side stream (MIOpen find, allocator), then capture

@@ -1,0 +1,49 @@
+"""Host-side logic of the boundary (no GPU): geometry, result duck types, stream sharding."""
+import numpy as np
+import torch
+
+from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
+from strongsort_yolo_amd.streams import assign_streams
+from strongsort_yolo_amd.yolo import Boxes, Keypoints, Results, YOLO
+
+
+def test_letterbox_geometry_table():
+    # 1280x720 and 1920x1080 -> 640x384; 640x480 -> 640x480
+    for (h, w), (oh, ow, top) in {(720, 1280): (384, 640, 12), (1080, 1920): (384, 640, 12), (480, 640): (480, 640, 0)}.items():
+        g = letterbox_geometry(h, w)
+        assert (g.out_h, g.out_w, g.pad_top, g.pad_left) == (oh, ow, top, 0)
+        gain, px, py = scale_geometry(g, h, w)
+        assert abs(gain - min(oh / h, ow / w)) < 1e-12 and (px, py) == (0.0, float(top))
+
+
+def test_results_duck_type_matches_reference_usage():
+    # the access pattern of /root/reference/yolo_multi_model.py:45-169
+    b = Boxes(torch.tensor([[1., 2., 3., 4.], [5., 6., 7., 8.]]), torch.tensor([0.9, 0.8]), torch.tensor([0., 2.]),
+              torch.tensor([7., 9.]))
+    r = Results(np.zeros((4, 4, 3), np.uint8), {0: "person", 2: "car"}, b, Keypoints(torch.zeros(2, 17, 3)))
+    ids = [int(bbox.id) for predictions in [r] if predictions is not None for bbox in predictions.boxes if bbox.id is not None]
+    assert ids == [7, 9]
+    rows = []
+    for bbox, kp in zip(r.boxes, r.keypoints):
+        assert len(kp.xy.tolist()) == 1 and len(kp.xy.tolist()[0]) == 17
+        for scores, classes, bbox_coords, id_ in zip(bbox.conf, bbox.cls, bbox.xyxy, bbox.id):
+            rows.append((int(id_), r.names[int(classes)], round(float(scores) * 100, 1), [int(v) for v in bbox_coords]))
+    assert rows == [(7, "person", 90.0, [1, 2, 3, 4]), (9, "car", 80.0, [5, 6, 7, 8])]
+    assert r.masks is None and Results(None, {}, None).boxes is None
+
+
+def test_yolo_overrides_and_names():
+    m = YOLO("yolo11n-pose.pt")
+    m.overrides["conf"], m.overrides["iou"], m.overrides["agnostic_nms"], m.overrides["max_det"] = 0.3, 0.4, False, 1000
+    d = m._dcfg()
+    assert (d.conf, d.iou, d.agnostic_nms, d.max_det) == (0.3, 0.4, False, 1000)
+    assert m.names == {0: "person"} and len(YOLO("yolov8n.pt").names) == 80
+    inv = {v: k for k, v in YOLO("yolov5n.pt").names.items()}          # yolo_multi_model.py:23-24
+    assert inv["person"] == 0
+
+
+def test_assign_streams_partitions_everything():
+    for n, w in [(8, 8), (8, 2), (5, 4), (1, 8), (0, 2)]:
+        parts = assign_streams(n, w)
+        assert len(parts) == w and sorted(sum(parts, [])) == list(range(n))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
