@@ -136,6 +136,16 @@ int ss_get_debug(ss_ctx* ctx, int stream, int* counts, float* cos, double* maha,
 /* Gallery of one track (by position in the track list) in natural [count][512] order of slots. */
 int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int cap_rows, int* count);
 
+/* ---- a2 / a5 glue: stateless fused NHWC-half operators around the PyTorch-ROCm convolutions -------
+ * (detector / OSNet forward inside model.track, yolo_multi_model.py:41).  `stream` is a hipStream_t.
+ * act: 0 none, 1 relu, 2 silu, 3 sigmoid.  Tensors are channels-last half. */
+int ss_op_bias_act_f16(void* stream, void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C, int act);
+int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
+                        int N, int H, int W, int C, int act);
+/* OSNet unified aggregation gate: out = sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))), T <= 4 streams. */
+int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
+                       const void* d_w2, const void* d_b2, float* d_means_ws, void* d_out, int N, int HW, int C, int Cr);
+
 /* ---- profiling support ----------------------------------------------------------------------- */
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
  * call, measured with HIP events on the context stream; also returns the launch count. */

@@ -1,0 +1,194 @@
+// ss_ops.hip — small fused NHWC-f16 operators for the detector / OSNet glue (rows a2 / a5).
+//
+// The convolutions themselves stay in PyTorch-ROCm (MIOpen -> MFMA).  What rocprofv3 showed at batch 1
+// (profiles/r01_rocprofv3_kernel_stats_c2_s1.csv) is ~1000 launches per frame, most of them 4-5 us
+// elementwise pieces around the convs: separate bias adds (SubTensorOpWithScalar1d), activations,
+// OSNet's depthwise 3x3s falling to MIOpen's naive_conv, and 8 launches per channel gate.  These
+// stateless kernels fuse those pieces (CDNA rule: fuse elementwise work into as few passes as possible).
+// All tensors are channels-last half: element (n,h,w,c) at ((n*H+h)*W+w)*C+c.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/strongsort_hip.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__device__ inline float act_apply(float v, int act)
+{
+    if (act == 1) return v > 0.f ? v : 0.f;                 // relu
+    if (act == 2) return v / (1.0f + __expf(-v));           // silu
+    if (act == 3) return 1.0f / (1.0f + __expf(-v));        // sigmoid
+    return v;
+}
+
+// x = act(x + bias[c] (+ res)), in place.  C % 8 == 0: 16-byte vectors.
+__global__ __launch_bounds__(256) void k_bias_act8(__half* __restrict__ x, const __half* __restrict__ bias,
+                                                  const __half* __restrict__ res, size_t n_vec, int C8, int act)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+        h8 v = reinterpret_cast<h8*>(x)[i];
+        h8 b = reinterpret_cast<const h8*>(bias)[i % C8];
+        h8 r;
+        if (res) r = reinterpret_cast<const h8*>(res)[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = (float)v[k] + (float)b[k];
+            if (res) f += (float)r[k];
+            v[k] = (_Float16)act_apply(f, act);
+        }
+        reinterpret_cast<h8*>(x)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bias_act1(__half* __restrict__ x, const __half* __restrict__ bias,
+                                                  const __half* __restrict__ res, size_t n, int C, int act)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float f = __half2float(x[i]) + __half2float(bias[i % C]);
+        if (res) f += __half2float(res[i]);
+        x[i] = __float2half(act_apply(f, act));
+    }
+}
+
+// depthwise 3x3, stride 1, pad 1, + bias + relu.  w9 is [9][C] (tap-major).  thread = (pixel, 8 channels).
+__global__ __launch_bounds__(256) void k_dw3x3(const __half* __restrict__ x, const __half* __restrict__ w9,
+                                              const __half* __restrict__ bias, __half* __restrict__ y, int N, int H,
+                                              int W, int C8, int act)
+{
+    const size_t total = (size_t)N * H * W * C8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
+        const int w = (int)(p % W), h = (int)((p / W) % H);
+        const size_t nb = (p / ((size_t)W * H)) * H;
+        float acc[8];
+        {
+            h8 b = reinterpret_cast<const h8*>(bias)[c8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = (float)b[k];
+        }
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int hh = h + dy;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ww = w + dx;
+                if (ww < 0 || ww >= W) continue;
+                h8 v = reinterpret_cast<const h8*>(x)[((nb + hh) * W + ww) * C8 + c8];
+                h8 k9 = reinterpret_cast<const h8*>(w9)[((dy + 1) * 3 + dx + 1) * C8 + c8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)k9[k], acc[k]);
+            }
+        }
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (_Float16)act_apply(acc[k], act);
+        reinterpret_cast<h8*>(y)[i] = o;
+    }
+}
+
+// OSNet unified aggregation gate over T <= 4 streams.
+//   step 1: mean over H*W of every stream -> means[t][n][C] (f32)
+//   step 2: g_t = sigmoid(fc2(relu(fc1(mean_t)))) per sample, out = sum_t x_t * g_t
+struct GatePtrs { const __half* x[4]; };
+
+__global__ __launch_bounds__(256) void k_gate_mean(GatePtrs in, float* __restrict__ means, int N, int HW, int C)
+{
+    __shared__ float red[256];
+    const int t = blockIdx.y, n = blockIdx.x;
+    const __half* x = in.x[t] + (size_t)n * HW * C;
+    // thread handles channel c = tid % C over pixels tid / C, stride 256 / C   (C divides 256 or C <= 256)
+    const int lanes_per_pix = C;
+    const int pix_par = 256 / lanes_per_pix;
+    const int c = threadIdx.x % lanes_per_pix, p0 = threadIdx.x / lanes_per_pix;
+    float s = 0.f;
+    if (p0 < pix_par)
+        for (int p = p0; p < HW; p += pix_par) s += __half2float(x[(size_t)p * C + c]);
+    red[threadIdx.x] = (p0 < pix_par) ? s : 0.f;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float tot = 0.f;
+        for (int q = 0; q < pix_par; ++q) tot += red[q * lanes_per_pix + threadIdx.x];
+        means[((size_t)t * N + n) * C + threadIdx.x] = tot / (float)HW;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const float* __restrict__ means,
+                                                   const __half* __restrict__ w1, const __half* __restrict__ b1,
+                                                   const __half* __restrict__ w2, const __half* __restrict__ b2,
+                                                   __half* __restrict__ out, int N, int HW, int C, int Cr)
+{
+    __shared__ float g[4][256];
+    __shared__ float hid[4][16];
+    const int n = blockIdx.y;
+    if (threadIdx.x < T * Cr) {
+        const int t = threadIdx.x / Cr, r = threadIdx.x % Cr;
+        float a = __half2float(b1[r]);
+        const float* m = means + ((size_t)t * N + n) * C;
+        for (int c = 0; c < C; ++c) a = fmaf(__half2float(w1[r * C + c]), m[c], a);
+        hid[t][r] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * C; i += 256) {
+        const int t = i / C, c = i % C;
+        float a = __half2float(b2[c]);
+        for (int r = 0; r < Cr; ++r) a = fmaf(__half2float(w2[c * Cr + r]), hid[t][r], a);
+        g[t][c] = 1.0f / (1.0f + __expf(-a));
+    }
+    __syncthreads();
+    const int C8 = C / 8;
+    const size_t nvec = (size_t)HW * C8, base = (size_t)n * nvec;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % C8) * 8;
+        float acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int t = 0; t < T; ++t) {
+            h8 v = reinterpret_cast<const h8*>(in.x[t])[base + i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], g[t][c0 + k], acc[k]);
+        }
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (_Float16)acc[k];
+        reinterpret_cast<h8*>(out)[base + i] = o;
+    }
+}
+
+static inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g ? g : 1)); }
+
+extern "C" int ss_op_bias_act_f16(void* stream, void* x, const void* bias, const void* res, long long n_pix, int C, int act)
+{
+    if (!x || !bias || C < 1) return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 8 == 0) {
+        size_t nv = (size_t)n_pix * (C / 8);
+        hipLaunchKernelGGL(k_bias_act8, dim3(grid_for(nv, 256)), dim3(256), 0, st, (__half*)x, (const __half*)bias, (const __half*)res, nv, C / 8, act);
+    } else {
+        size_t n = (size_t)n_pix * C;
+        hipLaunchKernelGGL(k_bias_act1, dim3(grid_for(n, 256)), dim3(256), 0, st, (__half*)x, (const __half*)bias, (const __half*)res, n, C, act);
+    }
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_dwconv3x3_f16(void* stream, const void* x, const void* w9, const void* bias, void* y, int N, int H, int W, int C, int act)
+{
+    if (!x || !w9 || !bias || !y || C % 8) return SS_ERR_INVALID;
+    size_t total = (size_t)N * H * W * (C / 8);
+    hipLaunchKernelGGL(k_dw3x3, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)w9,
+                       (const __half*)bias, (__half*)y, N, H, W, C / 8, act);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, const void* w1, const void* b1, const void* w2,
+                                  const void* b2, float* means_ws, void* out, int N, int HW, int C, int Cr)
+{
+    if (T < 1 || T > 4 || C % 8 || C > 256 || Cr < 1 || Cr > 16) return SS_ERR_INVALID;
+    GatePtrs p;
+    for (int t = 0; t < 4; ++t) p.x[t] = (const __half*)xs[t < T ? t : 0];
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gate_mean, dim3(N, T), dim3(256), 0, st, p, means_ws, N, HW, C);
+    const size_t nvec = (size_t)HW * (C / 8);
+    hipLaunchKernelGGL(k_gate_apply, dim3(grid_for(nvec, 256) > 64 ? 64 : grid_for(nvec, 256), N), dim3(256), 0, st, p, T, means_ws,
+                       (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2, (__half*)out, N, HW, C, Cr);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}

@@ -1,0 +1,65 @@
+"""Fused NHWC-half glue operators (csrc/ss_ops.hip) used by nets.py on the GPU.
+
+Inference only.  Enabled for CUDA half tensors; on CPU (oracle-side baseline, CPU tests) the modules
+in nets.py take their plain torch path instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+ENABLED = True
+ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3}
+
+
+def usable(x: torch.Tensor) -> bool:
+    return ENABLED and x.is_cuda and x.dtype == torch.float16 and x.dim() == 4
+
+
+def _cl(x):
+    return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+
+def _st(x):
+    return C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _ck(rc):
+    if rc != 0:
+        raise _lib.SSError(rc, "fused op failed")
+
+
+def bias_act_(x, bias, act="none", res=None):
+    """x <- act(x + bias[c] (+ res)) in place; x NCHW-shaped, channels-last memory."""
+    x = _cl(x)
+    n, c, h, w = x.shape
+    if res is not None:
+        res = _cl(res)
+    _ck(_lib.load().ss_op_bias_act_f16(_st(x), _p(x), _p(bias), _p(res), n * h * w, c, ACT[act]))
+    return x
+
+
+def dwconv3x3(x, w9, bias, act="relu"):
+    x = _cl(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_dwconv3x3_f16(_st(x), _p(x), _p(w9), _p(bias), _p(y), n, h, w, c, ACT[act]))
+    return y
+
+
+def gate_sum(xs, w1, b1, w2, b2):
+    xs = [_cl(x) for x in xs]
+    n, c, h, w = xs[0].shape
+    out = torch.empty_like(xs[0], memory_format=torch.channels_last)
+    means = torch.empty(len(xs) * n * c, dtype=torch.float32, device=out.device)
+    arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    _ck(_lib.load().ss_op_gate_sum_f16(_st(out), arr, len(xs), _p(w1), _p(b1), _p(w2), _p(b2), _p(means), _p(out),
+                                       n, h * w, c, w1.shape[0]))
+    return out

@@ -17,6 +17,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
+
 
 # --------------------------------------------------------------------------------------------------
 # YOLO building blocks
@@ -28,6 +30,10 @@ class Conv(nn.Module):
         self.act = nn.SiLU(inplace=True) if act else nn.Identity()
 
     def forward(self, x):
+        if fused.usable(x):          # conv without bias (MIOpen) + one fused bias+SiLU pass
+            c = self.conv
+            y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+            return fused.bias_act_(y, c.bias, "silu" if isinstance(self.act, nn.SiLU) else "none")
         return self.act(self.conv(x))
 
 
@@ -268,8 +274,14 @@ class ConvBR(nn.Module):
         self.conv = nn.Conv2d(c1, c2, k, s, p, groups=g, bias=True)
         self.relu = relu
 
-    def forward(self, x):
+    def forward(self, x, res=None):
+        if fused.usable(x):
+            c = self.conv
+            y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+            return fused.bias_act_(y, c.bias, "relu" if self.relu else "none", res)
         x = self.conv(x)
+        if res is not None:
+            x = x + res
         return F.relu(x, inplace=True) if self.relu else x
 
 
@@ -280,6 +292,10 @@ class LightConv3x3(nn.Module):
         self.dw = nn.Conv2d(c2, c2, 3, 1, 1, groups=c2, bias=True)
 
     def forward(self, x):
+        if fused.usable(x):          # 1x1 conv (MIOpen) + fused depthwise 3x3 + bias + ReLU
+            if getattr(self, "_w9", None) is None or self._w9.device != x.device:
+                self._w9 = self.dw.weight.detach().reshape(self.dw.weight.shape[0], 9).t().contiguous()
+            return fused.dwconv3x3(self.pw(x), self._w9, self.dw.bias, "relu")
         return F.relu(self.dw(self.pw(x)), inplace=True)
 
 
@@ -307,6 +323,14 @@ class OSBlock(nn.Module):
     def forward(self, x):
         idn = x if self.down is None else self.down(x)
         x1 = self.conv1(x)
+        if fused.usable(x):          # all four gates + their sum in two launches; bias + residual + ReLU in one
+            g = self.gate
+            cr, c = g.fc1.weight.shape[0], g.fc1.weight.shape[1]
+            x2 = fused.gate_sum([s(x1) for s in self.streams], g.fc1.weight.reshape(cr, c), g.fc1.bias,
+                                g.fc2.weight.reshape(c, cr), g.fc2.bias)
+            c3 = self.conv3.conv
+            y = F.conv2d(x2, c3.weight, None)
+            return fused.bias_act_(y, c3.bias, "relu", idn)
         x2 = sum(self.gate(s(x1)) for s in self.streams)
         return F.relu(self.conv3(x2) + idn, inplace=True)
 
