@@ -19,6 +19,8 @@ The JSON line also carries
                 measured with HIP start/stop events on the kernel's own dispatches inside the timed
                 region; traffic = HBM bytes per launch from the rocprofv3 PMC summary committed
                 under profiles/ (null until that file exists)
+  roofline_batched  the same kernel family at 32 streams per launch (tracker path only), the regime where the
+                HBM roofline is meaningful (one stream moves 6 MB per launch, below a kernel boundary)
   cpu_baseline  the oracle ("port": NumPy/SciPy tracker + C-oracle frame stages + CPU-torch nets)
                 timed on this box's host cores on a bounded sample (rank 0, N=1 only)
   id_match_rate fraction of output rows identical to the exact-order C oracle on the same input
@@ -138,6 +140,51 @@ def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budge
             "tracker_only_frames_per_s": round(1.0 / t_track, 1), "host_cores": ncores}
 
 
+def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, timed=40, device=0):
+    """Association kernel at n_streams streams per launch (tracker path only, detections + features injected on
+    the device): the regime in which the kernel can be compared with the HBM roofline."""
+    import torch
+    from strongsort_yolo_amd.engine import TrackerEngine
+    from strongsort_yolo_amd.synth import make_stream
+    eng = TrackerEngine(cfg, n_streams, device)
+    dev = eng.device
+    dets = torch.zeros(frames, n_streams, 128, 6, device=dev)
+    feats = torch.zeros(frames, n_streams, 128, 512, device=dev)
+    nd = torch.zeros(frames, n_streams, dtype=torch.int32, device=dev)
+    hd, hf, hn = dets.cpu().numpy(), feats.cpu().numpy(), nd.cpu().numpy()
+    for s in range(n_streams):
+        st = make_stream(5000 + s, W, H, n_ids)
+        for k in range(frames):
+            f = st.next_frame()
+            n = len(f.dets)
+            hd[k, s, :n], hf[k, s, :n], hn[k, s] = f.dets, f.feats, n
+    dets.copy_(torch.from_numpy(hd)); feats.copy_(torch.from_numpy(hf)); nd.copy_(torch.from_numpy(hn))
+    hw = torch.tensor([[H, W]] * n_streams, dtype=torch.int32, device=dev)
+    for k in range(frames - timed):
+        eng.update_device(dets[k], nd[k], feats[k], hw)
+    torch.cuda.synchronize()
+    eng.assoc_timing(True)
+    t0 = time.perf_counter()
+    for k in range(frames - timed, frames):
+        eng.update_device(dets[k], nd[k], feats[k], hw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = eng.assoc_timing(False)
+    eng.check_errors()
+    alg = 0.0
+    for s in range(n_streams):
+        t = eng.tracks(s)
+        c = t["state"] == 2
+        Tc, B = int(c.sum()), float(t["gal_count"][c].mean()) if c.any() else 0.0
+        alg += Tc * B * 512 * 4 + float(hn[:, s].mean()) * 512 * 4 + Tc * float(hn[:, s].mean()) * 4 * max(1, int(np.ceil(B / 16)))
+    eng.close()
+    ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"kernel": "k_cosine_stream", "streams_per_launch": n_streams, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
+            "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+            "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n,
+            "tracker_path_frames_per_s": round(n_streams * timed / dt, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +195,7 @@ def main():
     ap.add_argument("--graph", default="front", choices=["front", "all", "none"])
     ap.add_argument("--no-nets", action="store_true", help="skip detector/ReID (tracker-path microbench; not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
     args = ap.parse_args()
 
@@ -215,6 +263,13 @@ def main():
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
     pipe.eng.check_errors()
+    if os.environ.get("SS_TS"):
+        ts = pipe.eng.timestamps()
+        t00 = ts[ts > 0].min() if (ts > 0).any() else 0
+        for b in range(0, 16, 3):
+            for w in (0, 5):
+                row = ts[b, w]; row = row[row > 0]
+                print(f"TS block {b*32} wave {w}:", " ".join(f"{(v - t00) / 100:.2f}" for v in row[:40]), file=sys.stderr)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -270,12 +325,15 @@ def main():
             "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,
         }
+        res["roofline_batched"] = None
+        res["cpu_baseline"] = None
+    pipe.close()
+    if rank == 0:
+        if world == 1 and not args.no_batched:
+            res["roofline_batched"] = batched_association(cfg, device=dev_index)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wls[0], W, H, pipe.geom, gs, nc, cfg, dcfg, detector)
-        else:
-            res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    pipe.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

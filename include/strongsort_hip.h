@@ -142,6 +142,8 @@ int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int ca
 int ss_op_bias_act_f16(void* stream, void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C, int act);
 int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
                         int N, int H, int W, int C, int act);
+/* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */
+int ss_op_maxpool_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C, int k, int stride, int pad);
 /* OSNet unified aggregation gate: out = sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))), T <= 4 streams. */
 int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
                        const void* d_w2, const void* d_b2, float* d_means_ws, void* d_out, int N, int HW, int C, int Cr);
@@ -150,6 +152,9 @@ int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void*
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
  * call, measured with HIP events on the context stream; also returns the launch count. */
 int ss_assoc_timing(ss_ctx* ctx, int enable, float* mean_ms, int* launches);
+/* In-kernel wall-clock stamps (100 MHz) of the throughput association kernel's last launch, recorded when
+ * the environment variable SS_TS=1: [16 sampled workgroups][8 waves][64 stamps].  Profiling aid. */
+int ss_get_timestamps(ss_ctx* ctx, long long* out, int n);
 
 #ifdef __cplusplus
 }

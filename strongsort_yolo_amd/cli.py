@@ -1,0 +1,152 @@
+"""Command line of the reference script, kept: `--source ... --track --count` (yolo_multi_model.py:341-354).
+
+Out of scope by SURVEY §2: drawing, imshow, video encode.  What is kept is the per-stream loop
+(:244-339), the labels file (:34-39, :165-169) and the class-count analytics (:284-305) — the latter as
+an incremental per-id majority-class counter instead of re-reading the whole CSV every frame (SURVEY §8f
+N1).  Frame sources (N3): `synthetic[:N]`, a `.npy` stack [T,H,W,3], or a directory of images (Pillow);
+there is no video decoder in this environment.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from collections import Counter, defaultdict
+from typing import Iterator, Optional
+
+import numpy as np
+
+
+# ---- frame sources (N3) --------------------------------------------------------------------------------
+def frame_source(spec: str, limit: Optional[int] = None) -> Iterator[np.ndarray]:
+    if spec.startswith("synthetic"):
+        from .synth import make_stream
+        n = int(spec.split(":")[1]) if ":" in spec else 100
+        st = make_stream(0, 640, 480, 8)
+        for k in range(n if limit is None else min(n, limit)):
+            yield st.frame_pixels(k).copy()
+    elif spec.endswith(".npy"):
+        arr = np.load(spec, mmap_mode="r")
+        for k in range(len(arr) if limit is None else min(len(arr), limit)):
+            yield np.ascontiguousarray(arr[k])
+    elif os.path.isdir(spec):
+        from PIL import Image
+        names = sorted(f for f in os.listdir(spec) if f.lower().endswith((".jpg", ".jpeg", ".png", ".bmp")))
+        for k, f in enumerate(names):
+            if limit is not None and k >= limit:
+                break
+            yield np.asarray(Image.open(os.path.join(spec, f)).convert("RGB"))[:, :, ::-1].copy()   # BGR like cv2
+    else:
+        raise ValueError(f"cannot open source '{spec}' (synthetic[:N] | stack.npy | image directory)")
+
+
+# ---- labels file + counting (N1) -------------------------------------------------------------------------
+class LabelsWriter:
+    """`frameId cls id conf x1 y1 x2 y2 -1 -1 -1 -1` per tracked box (yolo_multi_model.py:165-169).
+    compat=True reproduces the reference's quirks (frameId always 0, :32; append mode, :39)."""
+
+    def __init__(self, path: str, compat: bool = False):
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        self.f = open(path, "a" if compat else "w")
+        self.compat = compat
+
+    def write(self, frame_id: int, results) -> int:
+        n = 0
+        for r in results:
+            if r is None or r.boxes is None or r.boxes.id is None:
+                continue
+            for bbox in r.boxes:
+                for conf, cls, xyxy, id_ in zip(bbox.conf, bbox.cls, bbox.xyxy, bbox.id):
+                    x1, y1, x2, y2 = (float(v) for v in xyxy)
+                    fid = 0 if self.compat else frame_id
+                    self.f.write(f"{fid} {int(cls)} {int(id_)} {float(conf)} {x1} {y1} {x2} {y2} -1 -1 -1 -1\n")
+                    n += 1
+        self.f.flush()
+        return n
+
+    def close(self):
+        self.f.close()
+
+
+class ClassCounter:
+    """Objects per class = number of track ids whose majority class is that class (yolo_multi_model.py:293-300),
+    maintained incrementally: O(boxes) per frame instead of O(file)."""
+
+    def __init__(self, names):
+        self.names = names
+        self.votes = defaultdict(Counter)
+
+    def update(self, results):
+        for r in results:
+            if r is None or r.boxes is None or r.boxes.id is None:
+                continue
+            for cls, id_ in zip(r.boxes.cls, r.boxes.id):
+                self.votes[int(id_)][int(cls)] += 1
+
+    def counts(self) -> dict:
+        c = Counter()
+        for votes in self.votes.values():
+            top = max(votes.values())
+            c[min(k for k, v in votes.items() if v == top)] += 1     # ties -> lowest class id (pandas mode()[0])
+        return {self.names.get(k, str(k)): v for k, v in sorted(c.items(), key=lambda kv: -kv[1])}
+
+
+# ---- per-stream loop ------------------------------------------------------------------------------------------
+def process_video(args: dict, model=None) -> dict:
+    """One stream (yolo_multi_model.py:244-339).  Returns a summary instead of showing a window."""
+    source, track, count = args["source"], args["track"], args["count"]
+    if model is None:
+        from .yolo import YOLO
+        model = YOLO(args.get("weights", "yolov8n.pt"))
+        model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)      # :18-21
+    name = os.path.splitext(os.path.basename(str(source)))[0] or "stream"
+    writer = LabelsWriter(os.path.join(args.get("outdir", "output"), f"{name}_labels.txt"), args.get("compat", False))
+    counter = ClassCounter(model.names)
+    frames, t0, fps = 0, time.time(), 0.0
+    for frame in frame_source(str(source), args.get("limit")):
+        if track:
+            res = model.track(frame, verbose=False, device=args.get("device", 0), persist=True, tracker="strongsort.yaml")
+            writer.write(frames, res)
+            if count:
+                counter.update(res)
+        else:
+            res = model.predict(frame, verbose=False, device=args.get("device", 0))
+            if count:                                # reference :280-282: counting needs tracking
+                print("[INFO] count works only when objects are tracking.. so use both flags (--track --count)")
+                frames += 1
+                break
+        frames += 1
+        if frames % 10 == 0:                         # reference :321-326 (10-frame window)
+            fps = 10 / max(time.time() - t0, 1e-9)
+            t0 = time.time()
+    writer.close()
+    return {"source": str(source), "frames": frames, "fps": fps, "counts": counter.counts() if count and track else {}}
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--source", nargs="+", type=str, default=["synthetic:30"], help="frame sources")
+    p.add_argument("--track", action="store_true")
+    p.add_argument("--count", action="store_true")
+    p.add_argument("--weights", default="yolov8n.pt")
+    p.add_argument("--limit", type=int, default=None)
+    a = p.parse_args(argv)
+    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "limit": a.limit, "device": i}
+            for i, s in enumerate(a.source)]
+    import torch
+    ngpu = max(torch.cuda.device_count(), 1)
+    for j in jobs:
+        j["device"] %= ngpu                          # stream i -> GPU i mod N (the reference pins device 0, :41)
+    if len(jobs) == 1:
+        out = [process_video(jobs[0])]
+    else:
+        import torch.multiprocessing as mp
+        with mp.get_context("spawn").Pool(processes=len(jobs)) as pool:      # :353-354
+            out = pool.map(process_video, jobs)
+    for o in out:
+        print(o)
+    return out
+
+
+if __name__ == "__main__":
+    main()

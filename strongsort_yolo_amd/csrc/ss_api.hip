@@ -95,7 +95,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->ev_used = 0;
     c->tracks_ub = 0;
     c->fixed_grid = 0;
-    c->cos_grid = 512;           // persistent workgroups (2 per CU)
+    c->cos_grid = 256;           // persistent workgroups: one per CU
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -118,7 +118,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(feat_unit, S * D * SS_F); A(feat_frag, S * SS_NCT * SS_TILE_FLOATS);
     A(tlwh, S * D * 4); A(xyah, S * D * 4); A(chol, S * T * 16); A(ttlwh, S * T * 4);
     A(n_conf, S); A(conf_list, S * T); A(part_min, S * T * SS_NRT * D);
-    A(tiles, 2 * S * T * SS_NRT); A(tile_count, 4);
+    A(tiles, 2 * S * T * SS_NRT); A(tile_count, 4); A(ts, 16 * 8 * 64);
     if (cfg->debug) {
         A(dbg_cos, S * T * D); A(dbg_maha, S * T * D); A(dbg_cost_a, S * T * D); A(dbg_cost_b, S * T * D);
         A(dbg_gated, S * T * D); A(dbg_lists, S * 4 * T); A(dbg_counts, S * 4);
@@ -219,6 +219,7 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
+    if (const char* g = getenv("SS_TS")) dev.ts_enable = atoi(g);
     if (const char* g = getenv("SS_COS_GRID")) dev.cos_grid = atoi(g) > 0 ? atoi(g) : dev.cos_grid;
     ss_launch_frame(dev, c->prm, grid_tracks, c->stream, e0, e1);
     HIPCHK(c, hipGetLastError());
@@ -438,6 +439,14 @@ extern "C" int ss_get_gallery(ss_ctx* c, int s, int track_index, float* rows, in
     for (int b = 0; b < cnt; ++b)
         for (int k = 0; k < SS_F; ++k)
             rows[(size_t)b * SS_F + k] = frag[(size_t)(b / SS_TILE) * SS_TILE_FLOATS + ss_frag_index(b % SS_TILE, k)];
+    return SS_OK;
+}
+
+extern "C" int ss_get_timestamps(ss_ctx* c, long long* out, int n)
+{
+    if (!c || !out || n > 16 * 8 * 64) return SS_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dev.ts, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SS_OK;
 }
 

@@ -73,6 +73,8 @@ struct SSDev {
                                 //   list 0 -> k_cosine_stream (wave per tile, D <= 32), list 1 -> k_cosine_wg
     int* tile_count;            // [2] valid entries per list (re-armed by k_step)
     int stream_mode;            // route D <= 32 tiles to the wave-per-tile kernel (throughput mode)
+    long long* ts;              // [16 blocks][8 waves][64] wall-clock stamps (100 MHz) when ts_enable (profiling aid)
+    int ts_enable;
     // outputs
     float* out_rows;            // [S][MAXT][8]
     int* n_out;                 // [S]

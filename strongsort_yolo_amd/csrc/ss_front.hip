@@ -274,12 +274,25 @@ __global__ __launch_bounds__(64) void k_nms_scan(const float* __restrict__ pred,
                 rw |= __shfl(diag, q);
             }
         }
-        // OR the rows of the kept boxes into the removed words of the later blocks
-        for (int q = 0; q < cnt; ++q) {
-            if (!((keptbits >> q) & 1ull)) continue;
-            const unsigned long long* mr = w.mask + (size_t)(i0 + q) * NMS_WORDS;
-            if (l > ib && l < nw) rem0 |= mr[l];
-            if (l + 64 > ib && l + 64 < nw) rem1 |= mr[l + 64];
+        // OR the rows of the kept boxes into the removed words of the later blocks; four independent row
+        // loads in flight per step (a dependent one-row-per-step chain costs one memory latency per kept box)
+        unsigned long long kb = keptbits;
+        while (kb) {
+            int q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { q[u] = kb ? __builtin_ctzll(kb) : -1; if (kb) kb &= kb - 1; }
+            unsigned long long a0[4], a1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = a1[u] = 0ull;
+                if (q[u] >= 0) {
+                    const unsigned long long* mr = w.mask + (size_t)(i0 + q[u]) * NMS_WORDS;
+                    if (l > ib && l < nw) a0[u] = mr[l];
+                    if (l + 64 > ib && l + 64 < nw) a1[u] = mr[l + 64];
+                }
+            }
+            rem0 |= (a0[0] | a0[1]) | (a0[2] | a0[3]);
+            rem1 |= (a1[0] | a1[1]) | (a1[2] | a1[3]);
         }
     }
     __syncthreads();

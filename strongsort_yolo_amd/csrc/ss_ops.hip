@@ -95,22 +95,59 @@ struct GatePtrs { const __half* x[4]; };
 
 __global__ __launch_bounds__(256) void k_gate_mean(GatePtrs in, float* __restrict__ means, int N, int HW, int C)
 {
-    __shared__ float red[256];
+    // thread = (pixel lane, 8-channel group): 16-byte loads, f32 partial sums, LDS tree over the pixel lanes
+    __shared__ float red[256][8];
     const int t = blockIdx.y, n = blockIdx.x;
-    const __half* x = in.x[t] + (size_t)n * HW * C;
-    // thread handles channel c = tid % C over pixels tid / C, stride 256 / C   (C divides 256 or C <= 256)
-    const int lanes_per_pix = C;
-    const int pix_par = 256 / lanes_per_pix;
-    const int c = threadIdx.x % lanes_per_pix, p0 = threadIdx.x / lanes_per_pix;
-    float s = 0.f;
+    const int C8 = C / 8;
+    const int pix_par = 256 / C8;
+    const int c8 = threadIdx.x % C8, p0 = threadIdx.x / C8;
+    const h8* x = reinterpret_cast<const h8*>(in.x[t] + (size_t)n * HW * C);
+    float s[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (p0 < pix_par)
-        for (int p = p0; p < HW; p += pix_par) s += __half2float(x[(size_t)p * C + c]);
-    red[threadIdx.x] = (p0 < pix_par) ? s : 0.f;
+        for (int p = p0; p < HW; p += pix_par) {
+            h8 v = x[(size_t)p * C8 + c8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = s[k];
     __syncthreads();
     if (threadIdx.x < C) {
+        const int g = threadIdx.x / 8, k = threadIdx.x % 8;
         float tot = 0.f;
-        for (int q = 0; q < pix_par; ++q) tot += red[q * lanes_per_pix + threadIdx.x];
+        for (int q = 0; q < pix_par; ++q) tot += red[q * C8 + g][k];
         means[((size_t)t * N + n) * C + threadIdx.x] = tot / (float)HW;
+    }
+}
+
+// max pooling k x k / stride / pad (-inf padding), NHWC half; thread = (output pixel, 8 channels)
+__global__ __launch_bounds__(256) void k_maxpool(const __half* __restrict__ x, __half* __restrict__ y, int N, int H, int W,
+                                                int C8, int k, int stride, int pad, int OH, int OW)
+{
+    const size_t total = (size_t)N * OH * OW * C8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
+        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH);
+        const size_t n = p / ((size_t)OW * OH);
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+        for (int dy = 0; dy < k; ++dy) {
+            const int hh = oh * stride - pad + dy;
+            if (hh < 0 || hh >= H) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int ww = ow * stride - pad + dx;
+                if (ww < 0 || ww >= W) continue;
+                h8 v = reinterpret_cast<const h8*>(x)[((n * H + hh) * W + ww) * C8 + c8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)v[q]);
+            }
+        }
+        h8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (_Float16)m[q];
+        reinterpret_cast<h8*>(y)[i] = o;
     }
 }
 
@@ -176,6 +213,16 @@ extern "C" int ss_op_dwconv3x3_f16(void* stream, const void* x, const void* w9, 
     size_t total = (size_t)N * H * W * (C / 8);
     hipLaunchKernelGGL(k_dw3x3, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)w9,
                        (const __half*)bias, (__half*)y, N, H, W, C / 8, act);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_maxpool_f16(void* stream, const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad)
+{
+    if (!x || !y || C % 8 || k < 1 || stride < 1) return SS_ERR_INVALID;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    size_t total = (size_t)N * OH * OW * (C / 8);
+    hipLaunchKernelGGL(k_maxpool, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (__half*)y,
+                       N, H, W, C / 8, k, stride, pad, OH, OW);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

@@ -320,8 +320,13 @@ __global__ __launch_bounds__(512) void k_cosine_wg(SSDev dev)
 // stream of 4-KiB segment pieces per wave, prefetched 3 pieces ahead through a 4-deep register ring
 // (ordinary loads, so hipcc's counted vmcnt keeps 3 pieces in flight); the stream's detection operand
 // B (2 x 32 KiB fragment tiles) sits in LDS, shared by the 8 waves of the workgroup.
+#define SS_TS(idx) do { if (dev.ts_enable && blockIdx.x % 32 == 0 && blockIdx.x / 32 < 16 && (threadIdx.x & 63) == 0 && (idx) < 64) \
+        dev.ts[((blockIdx.x / 32) * 8 + (threadIdx.x >> 6)) * 64 + (idx)] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
 {
+    int tsi = 0;
+    SS_TS(tsi++);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
     __syncthreads();
     if (p0 + (int)threadIdx.x < p1) desc[threadIdx.x] = dev.tiles[p0 + threadIdx.x];   // one parallel read, then LDS only
     __syncthreads();
+    SS_TS(tsi++);
     const int4* tiles = desc - p0;                                           // tiles[t] for t in [p0, p1)
     int t0 = p0;
     while (t0 < p1) {
@@ -351,53 +357,67 @@ __global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
             t1 += 64;
         }
         const bool two = D > SS_TILE;
+        // this wave's tiles: t0 + w, t0 + w + 8, ...
+        const int wu = __builtin_amdgcn_readfirstlane(w);
+        const int nmine = (t1 - t0 - wu + 7) / 8;                    // may be <= 0
+        // descriptors live in SGPRs; a tile is addressed as (uniform byte base) + (per-lane offset)
+        auto rd = [&](int t, int& r, int& cw, const char*& base) {
+            const int4 v = tiles[t];
+            const int sl = __builtin_amdgcn_readfirstlane(v.z);
+            r = __builtin_amdgcn_readfirstlane(v.y); cw = __builtin_amdgcn_readfirstlane(v.w);
+            base = reinterpret_cast<const char*>(dev.gallery) +
+                   ((((size_t)s * SS_MAXT + sl) * SS_NRT + ((cw >> 8) & 7)) * SS_TILE_FLOATS) * 4;
+        };
+        // lanes of rows past the gallery count re-read row 0 of the tile (same cache lines, no extra HBM
+        // traffic, no select); those rows are masked to +inf below
+        auto lane_off = [&](int cw) {
+            const bool ok = (l & 15) < (cw & 0xff) - ((cw >> 8) & 7) * SS_TILE;
+            return (unsigned)((ok ? l : (l & ~15)) * 16);
+        };
+        auto ld = [&](const char* base, unsigned voff, int sg, float4 a[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + voff + sg * 4096 + j * 1024);
+        };
+        int r0 = 0, cw0 = 0, r1 = 0, cw1 = 0;
+        const char *base0 = reinterpret_cast<const char*>(dev.gallery), *base1 = base0;
+        unsigned vo0 = 0, vo1 = 0;
+        float4 ra[4][4];                                              // 4-deep ring of segment pieces
+        if (nmine > 0) {
+            // gallery pieces 0..2 of the first tile go on the wire BEFORE the B staging below
+            rd(t0 + wu, r0, cw0, base0);
+            vo0 = lane_off(cw0);
+            ld(base0, vo0, 0, ra[0]); ld(base0, vo0, 1, ra[1]); ld(base0, vo0, 2, ra[2]);
+        }
         // stage B of stream s in LDS
         __syncthreads();
         {
             const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (size_t)s * SS_NCT * SS_TILE_FLOATS);
-            const int n4 = (two ? 2 : 1) * (SS_TILE_FLOATS / 4);
-            for (int i = threadIdx.x; i < n4; i += 512) bl[i] = ff[i];
+            // all loads first, then all LDS writes: one memory latency instead of one per 8 KiB slice
+            float4 tmp[8];
+            const int nu = two ? 8 : 4;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < nu) tmp[u] = ff[threadIdx.x + 512 * u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (u < nu) bl[threadIdx.x + 512 * u] = tmp[u];
         }
         __syncthreads();
-        // this wave's tiles: t0 + w, t0 + w + 8, ...
-        const int wu = __builtin_amdgcn_readfirstlane(w);
-        const int nmine = (t1 - t0 - wu + 7) / 8;                    // may be <= 0
+        SS_TS(tsi++);
         if (nmine > 0) {
-            // descriptors live in SGPRs; a tile is addressed as (uniform byte base) + (per-lane offset)
-            auto rd = [&](int t, int& r, int& cw, const char*& base) {
-                const int4 v = tiles[t];
-                const int sl = __builtin_amdgcn_readfirstlane(v.z);
-                r = __builtin_amdgcn_readfirstlane(v.y); cw = __builtin_amdgcn_readfirstlane(v.w);
-                base = reinterpret_cast<const char*>(dev.gallery) +
-                       ((((size_t)s * SS_MAXT + sl) * SS_NRT + ((cw >> 8) & 7)) * SS_TILE_FLOATS) * 4;
-            };
-            // lanes of rows past the gallery count re-read row 0 of the tile (same cache lines, no extra HBM
-            // traffic, no select); those rows are masked to +inf below
-            auto lane_off = [&](int cw) {
-                const bool ok = (l & 15) < (cw & 0xff) - ((cw >> 8) & 7) * SS_TILE;
-                return (unsigned)((ok ? l : (l & ~15)) * 16);
-            };
-            auto ld = [&](const char* base, unsigned voff, int sg, float4 a[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + voff + sg * 4096 + j * 1024);
-            };
-            int r0, cw0, r1 = 0, cw1 = 0;
-            const char *base0, *base1 = nullptr;
-            rd(t0 + wu, r0, cw0, base0);
-            unsigned vo0 = lane_off(cw0), vo1 = 0;
-            float4 ra[4][4];                                          // 4-deep ring of segment pieces
-            ld(base0, vo0, 0, ra[0]); ld(base0, vo0, 1, ra[1]); ld(base0, vo0, 2, ra[2]);
             const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
             const char* bls1 = bls + (two ? 32768 : 0);          // single column tile: read tile 0 twice (result unused)
             for (int k = 0; k < nmine; ++k) {
                 const bool more = k + 1 < nmine;
+                // the prefetch below is unconditional (static load count -> exact counted vmcnt, no drain at the tile
+                // boundary); the last tile of a wave prefetches its own first pieces again, which nobody reads
                 if (more) { rd(t0 + wu + 8 * (k + 1), r1, cw1, base1); vo1 = lane_off(cw1); }
+                else { base1 = base0; vo1 = vo0; }
                 f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
+                SS_TS(tsi++);
 #pragma unroll
                 for (int sg = 0; sg < 8; ++sg) {
                     // prefetch piece sg+3 (possibly of the next tile) into ring slot (sg+3)%4
                     if (sg + 3 < 8) ld(base0, vo0, sg + 3, ra[(sg + 3) & 3]);
-                    else if (more) ld(base1, vo1, sg + 3 - 8, ra[(sg + 3) & 3]);
+                    else ld(base1, vo1, sg + 3 - 8, ra[(sg + 3) & 3]);
                     const float4* a = ra[sg & 3];
                     f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
@@ -415,7 +435,9 @@ __global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
                         for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
                     }
                     __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
+                    if (sg == 0 || sg == 3) SS_TS(tsi++);
                 }
+                SS_TS(tsi++);
                 // 1 - dot, mask rows past the gallery count, min over the tile's 16 rows
                 const int count = cw0 & 0xff, rt = (cw0 >> 8) & 7;
                 float m0 = INFINITY, m1 = INFINITY;

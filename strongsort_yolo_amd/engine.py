@@ -160,6 +160,11 @@ class TrackerEngine:
         self._ck(self.L.ss_get_gallery(self.ctx, stream, track_index, rows.ctypes.data_as(C.POINTER(C.c_float)), 128, C.byref(cnt)))
         return rows[: cnt.value].copy()
 
+    def timestamps(self):
+        buf = np.zeros(16 * 8 * 64, np.int64)
+        self._ck(self.L.ss_get_timestamps(self.ctx, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size))
+        return buf.reshape(16, 8, 64)
+
     def assoc_timing(self, enable: bool):
         ms, n = C.c_float(), C.c_int()
         self._ck(self.L.ss_assoc_timing(self.ctx, int(enable), C.byref(ms), C.byref(n)))

@@ -63,3 +63,14 @@ def gate_sum(xs, w1, b1, w2, b2):
     _ck(_lib.load().ss_op_gate_sum_f16(_st(out), arr, len(xs), _p(w1), _p(b1), _p(w2), _p(b2), _p(means), _p(out),
                                        n, h * w, c, w1.shape[0]))
     return out
+
+
+def maxpool(x, k, stride, pad):
+    x = _cl(x)
+    n, c, h, w = x.shape
+    if c % 8:
+        return torch.nn.functional.max_pool2d(x, k, stride, pad)
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_maxpool_f16(_st(x), _p(x), _p(y), n, h, w, c, k, stride, pad))
+    return y

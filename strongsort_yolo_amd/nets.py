@@ -83,7 +83,8 @@ class SPPF(nn.Module):
 
     def forward(self, x):
         y = [self.cv1(x)]
-        y.extend(self.m(y[-1]) for _ in range(3))
+        pool = (lambda t: fused.maxpool(t, 5, 1, 2)) if fused.usable(x) else self.m
+        y.extend(pool(y[-1]) for _ in range(3))
         return self.cv2(torch.cat(y, 1))
 
 
@@ -347,7 +348,8 @@ class OSNet(nn.Module):
         self.fc = nn.Linear(c[3], feature_dim)
 
     def forward(self, x):
-        x = F.max_pool2d(self.conv1(x), 3, 2, 1)
+        x = self.conv1(x)
+        x = fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
         x = self.conv5(self.conv4(self.conv3(self.conv2(x))))
         return F.relu(self.fc(x.mean((2, 3))))
 
