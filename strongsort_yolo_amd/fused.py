@@ -74,3 +74,26 @@ def maxpool(x, k, stride, pad):
     y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     _ck(_lib.load().ss_op_maxpool_f16(_st(x), _p(x), _p(y), n, h, w, c, k, stride, pad))
     return y
+
+
+def conv1x1(x, w_t, bias=None):
+    """Pointwise convolution as one GEMM on the NHWC view: [N*H*W, Cin] @ [Cin, Cout] (+ bias in the epilogue).
+    MIOpen's implicit-GEMM kernels for these shapes need a separate zero-fill launch (split-K); a plain GEMM does not."""
+    x = _cl(x)
+    n, c, h, w = x.shape
+    x2 = x.permute(0, 2, 3, 1).reshape(-1, c)
+    y2 = torch.addmm(bias, x2, w_t) if bias is not None else torch.mm(x2, w_t)
+    return y2.view(n, h, w, -1).permute(0, 3, 1, 2)
+
+
+def is_pointwise(conv) -> bool:
+    return conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
+
+
+def weight_t(mod, conv):
+    """[Cin, Cout] contiguous copy of a 1x1 conv weight, cached on the module (inference: weights are static)."""
+    wt = getattr(mod, "_w_t", None)
+    if wt is None or wt.device != conv.weight.device or wt.dtype != conv.weight.dtype:
+        wt = conv.weight.detach().reshape(conv.weight.shape[0], -1).t().contiguous()
+        mod._w_t = wt
+    return wt

@@ -31,7 +31,7 @@ class Conv(nn.Module):
 
     def forward(self, x):
         if fused.usable(x):          # conv without bias (MIOpen) + one fused bias+SiLU pass
-            c = self.conv
+            c = self.conv        # (measured: MIOpen beats a plain GEMM for the detector's batch-1 pointwise convs)
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
             return fused.bias_act_(y, c.bias, "silu" if isinstance(self.act, nn.SiLU) else "none")
         return self.act(self.conv(x))
@@ -278,7 +278,12 @@ class ConvBR(nn.Module):
     def forward(self, x, res=None):
         if fused.usable(x):
             c = self.conv
-            y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+            if fused.is_pointwise(c):
+                if not self.relu and res is None:
+                    return fused.conv1x1(x, fused.weight_t(self, c), c.bias)           # bias in the GEMM epilogue
+                y = fused.conv1x1(x, fused.weight_t(self, c))
+            else:
+                y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
             return fused.bias_act_(y, c.bias, "relu" if self.relu else "none", res)
         x = self.conv(x)
         if res is not None:
@@ -296,7 +301,7 @@ class LightConv3x3(nn.Module):
         if fused.usable(x):          # 1x1 conv (MIOpen) + fused depthwise 3x3 + bias + ReLU
             if getattr(self, "_w9", None) is None or self._w9.device != x.device:
                 self._w9 = self.dw.weight.detach().reshape(self.dw.weight.shape[0], 9).t().contiguous()
-            return fused.dwconv3x3(self.pw(x), self._w9, self.dw.bias, "relu")
+            return fused.dwconv3x3(fused.conv1x1(x, fused.weight_t(self, self.pw)), self._w9, self.dw.bias, "relu")
         return F.relu(self.dw(self.pw(x)), inplace=True)
 
 
@@ -330,7 +335,7 @@ class OSBlock(nn.Module):
             x2 = fused.gate_sum([s(x1) for s in self.streams], g.fc1.weight.reshape(cr, c), g.fc1.bias,
                                 g.fc2.weight.reshape(c, cr), g.fc2.bias)
             c3 = self.conv3.conv
-            y = F.conv2d(x2, c3.weight, None)
+            y = fused.conv1x1(x2, fused.weight_t(self.conv3, c3))
             return fused.bias_act_(y, c3.bias, "relu", idn)
         x2 = sum(self.gate(s(x1)) for s in self.streams)
         return F.relu(self.conv3(x2) + idn, inplace=True)
