@@ -197,13 +197,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
+    ap.add_argument("--overlap", type=int, default=1, help="1: two-stage frame pipeline on two HIP streams (detector of frame k+1 overlaps ReID+tracker of frame k); 0: strictly sequential")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from strongsort_yolo_amd.config import StrongSortConfig, DetectConfig
     from strongsort_yolo_amd.engine import scale_geometry
-    from strongsort_yolo_amd.pipeline import FramePipeline
+    from strongsort_yolo_amd.pipeline import FramePipeline, OverlappedPipeline
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,9 +220,11 @@ def main():
     cfg, dcfg = StrongSortConfig(), DetectConfig()
     S, K, Wm = args.streams, args.steps, args.warmup
     total = PREFILL + Wm + K
-    pipe = FramePipeline(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
-                         det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                         run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32))
+    overlap = bool(args.overlap) and args.graph != "none"
+    PipeCls = OverlappedPipeline if overlap else FramePipeline
+    pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
+                   det_source="synthetic", feat_source="by_anchor", graph=args.graph,
+                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32))
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
     wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
@@ -231,20 +234,39 @@ def main():
     out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
     nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
 
-    def feed(k):
+    def feed(k, b):
         for s, p in enumerate(pools):
-            pipe.frames[s].copy_(p["pixels"][k % p["pixels"].shape[0]])
-            pipe.pred_in[s].copy_(p["preds"][k])
-            pipe.anchor_gt[s].copy_(p["agt"][k])
-            pipe.gt_feats[s].copy_(p["feats"][k])
+            b.frames[s].copy_(p["pixels"][k % p["pixels"].shape[0]])
+            b.pred_in[s].copy_(p["preds"][k])
+            b.anchor_gt[s].copy_(p["agt"][k])
+            b.gt_feats[s].copy_(p["feats"][k])
 
-    def one(k):
-        feed(k)
-        pipe.step()
+    def fetch(k):
         out_host[k].copy_(pipe.out, non_blocking=True)
         nout_host[k].copy_(pipe.nout, non_blocking=True)
 
+    if overlap:
+        pipe.on_result = fetch
+
+        def one(k):
+            b = pipe.begin_frame()
+            with torch.cuda.stream(pipe.sA):
+                feed(k, b)
+            pipe.submit()
+
+        def drain():
+            pipe.flush()
+    else:
+        def one(k):
+            feed(k, pipe)
+            pipe.step()
+            fetch(k)
+
+        def drain():
+            pass
+
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -253,6 +275,7 @@ def main():
         one(k)
     for k in range(PREFILL, PREFILL + Wm):       # W untimed warm-up steps
         one(k)
+    drain()
     torch.cuda.synchronize()
     pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
     barrier()
@@ -320,7 +343,7 @@ def main():
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
             "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
-                       "streams_per_gpu": S, "graph": args.graph, "nets": not args.no_nets, "prefill_frames": PREFILL,
+                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": "2-stage overlap on 2 HIP streams (+1 frame latency)" if overlap else "sequential", "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,

@@ -167,3 +167,162 @@ class FramePipeline:
 def _p(t):
     import ctypes as C
     return C.c_void_p(t.data_ptr())
+
+
+class _Bufs:
+    """One set of per-frame buffers (static addresses, baked into that set's HIP graphs)."""
+
+    def __init__(self, p: "FramePipeline"):
+        dev, S, g = p.dev, p.S, p.geom
+        self.frames = torch.zeros(S, p.H, p.W, 3, dtype=torch.uint8, device=dev)
+        self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
+        self.lb_planar = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev)
+        self.pred_in = torch.zeros(S, 4 + p.nc + p.nk, p.n_anchors, dtype=torch.float32, device=dev)
+        self.dets = torch.zeros(S, MAX_DETS, 6 + p.nk, dtype=torch.float32, device=dev)
+        self.dets6 = self.dets if p.nk == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
+        self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
+        self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
+        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev)
+        self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
+        self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
+
+
+class OverlappedPipeline(FramePipeline):
+    """Two-stage software pipeline over the frames of the same streams, on two HIP streams:
+
+        stream A:  [letterbox -> detector -> NMS -> ReID crops]   of frame k+1
+        stream B:  [OSNet -> feature select -> StrongSORT update] of frame k
+
+    The detector is stateless, so frame k+1's stage A does not depend on the tracker state of frame k; the
+    tracker recurrence stays strictly in frame order on stream B.  Results are identical to FramePipeline
+    (same kernels, same order per stream); throughput approaches max(stage A, stage B) instead of their
+    sum at the price of one frame of latency.  Each stage of each buffer set is one captured HIP graph.
+    """
+
+    def __init__(self, *a, **kw):
+        kw = dict(kw)
+        kw["graph"] = kw.get("graph", "front")
+        if kw["graph"] == "none":
+            raise ValueError("OverlappedPipeline needs graph='front' or 'all'")
+        super().__init__(*a, **kw)
+        self.bufs = [_Bufs(self), _Bufs(self)]
+        self.sA, self.sB = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        self.evA = [torch.cuda.Event(), torch.cuda.Event()]
+        self.evB = [torch.cuda.Event(), torch.cuda.Event()]
+        self.gA, self.gB = [None, None], [None, None]
+        self.k = 0                      # frames submitted
+        self.done = 0                   # frames whose stage B has been enqueued
+        self._captured = False
+
+    # the two stages, parameterised by buffer set -------------------------------------------------------
+    def _stage_a(self, b: _Bufs):
+        e, S, g = self.eng, self.S, self.geom
+        if self.run_nets:
+            for s in range(S):
+                e.letterbox(b.frames[s], g, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb_planar[s])
+            b.lb.copy_(b.lb_planar)
+            pred = self.detector(b.lb)
+            if self.det_source == "detector":
+                b.pred_in.copy_(pred)
+        md = min(self.dcfg.max_det, MAX_DETS)
+        for s in range(S):
+            e._ck(e.L.ss_nms(e.ctx, _p(b.pred_in[s]), self.n_anchors, self.nc, self.nk, self.dcfg.conf, self.dcfg.iou,
+                             int(self.dcfg.agnostic_nms), self.dcfg.max_wh, md, self.gain, self.pad_x, self.pad_y,
+                             float(self.W), float(self.H), _p(b.dets[s]), 6 + self.nk, _p(b.keep[s]), _p(b.ndets[s:s + 1])))
+        if self.nk:
+            b.dets6.copy_(b.dets[:, :, :6])
+        if self.run_nets:
+            for s in range(S):
+                e.crop_norm(b.frames[s], b.dets6[s], self.RB, count=b.ndets[s:s + 1], half=self.half,
+                            out=b.crops[s * self.RB:(s + 1) * self.RB])
+
+    def _stage_b(self, b: _Bufs):
+        S = self.S
+        if self.run_nets:
+            emb = self.reid(b.crops.contiguous(memory_format=torch.channels_last))
+            if self.feat_source == "reid":
+                self.feats_in[:, :self.RB].copy_(emb.view(S, self.RB, FEAT_DIM))
+        if self.feat_source == "by_anchor":
+            idx = b.anchor_gt.gather(1, b.keep.long().clamp_(0, self.n_anchors - 1))
+            torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_in)
+
+    def _track_b(self, b: _Bufs):
+        self.eng.update_device(b.dets6, b.ndets, self.feats_in, self.img_hw)
+
+    def _ss_stream(self, st):
+        import ctypes as C
+        self.eng._ck(self.eng.L.ss_set_hip_stream(self.eng.ctx, C.c_void_p(st.cuda_stream)))
+
+    def _capture(self):
+        cur = torch.cuda.current_stream(self.dev)
+        self.sA.wait_stream(cur); self.sB.wait_stream(cur)
+        for i, b in enumerate(self.bufs):                       # warm-up (MIOpen find, allocator) eagerly, in order
+            with torch.cuda.stream(self.sA):
+                self._ss_stream(self.sA)
+                for _ in range(2):
+                    self._stage_a(b)
+            self.sA.synchronize()
+            with torch.cuda.stream(self.sB):
+                self._ss_stream(self.sB)
+                for _ in range(2):
+                    self._stage_b(b)
+                    self._track_b(b)
+            self.sB.synchronize()
+        for i, b in enumerate(self.bufs):
+            with torch.cuda.stream(self.sA):
+                self._ss_stream(self.sA)
+                self.gA[i] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.gA[i], stream=self.sA):
+                    self._stage_a(b)
+            with torch.cuda.stream(self.sB):
+                self._ss_stream(self.sB)
+                self.gB[i] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.gB[i], stream=self.sB):
+                    self._stage_b(b)
+                    if self.graph_mode == "all":
+                        self._track_b(b)
+        torch.cuda.synchronize(self.dev)
+        self._ss_stream(self.sB)                                 # the tracker lives on stream B from here on
+        self.eng.reset(-1)
+        self._captured = True
+
+    # ---- driver API --------------------------------------------------------------------------------------
+    def begin_frame(self) -> _Bufs:
+        """Buffer set for the next frame.  Fill its inputs inside `with torch.cuda.stream(pipe.sA):`."""
+        if not self._captured:
+            self._capture()
+        i = self.k % 2
+        self.sA.wait_event(self.evB[i])                          # stage B of frame k-2 has released this set
+        return self.bufs[i]
+
+    def _run_b(self, frame_idx: int):
+        i = frame_idx % 2
+        with torch.cuda.stream(self.sB):
+            self.sB.wait_event(self.evA[i])
+            self.gB[i].replay()
+            if self.graph_mode == "front":
+                self._track_b(self.bufs[i])
+            if self.on_result is not None:
+                self.on_result(frame_idx)                        # e.g. enqueue the D2H copy of self.out on stream B
+            self.evB[i].record(self.sB)
+        self.done = frame_idx + 1
+
+    on_result = None
+
+    def submit(self):
+        """Launch stage A of the frame just filled, and stage B of the previous frame."""
+        i = self.k % 2
+        with torch.cuda.stream(self.sA):
+            self.gA[i].replay()
+            self.evA[i].record(self.sA)
+        if self.k >= 1 and self.done < self.k:
+            self._run_b(self.k - 1)
+        self.k += 1
+
+    def flush(self):
+        """Stage B of the last submitted frame; afterwards every result has been enqueued on stream B."""
+        if self.k > self.done:
+            self._run_b(self.k - 1)
+
+    def step(self, track: bool = True):
+        raise RuntimeError("use begin_frame()/submit()/flush() on an OverlappedPipeline")
