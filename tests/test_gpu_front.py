@@ -116,3 +116,22 @@ def test_crop_norm_bit_exact(eng, wh, n):
     got = eng.crop_norm(torch.from_numpy(img).to(eng.device), dt, len(dets)).cpu().numpy()
     ref = cexact.crop_norm(img, dets)
     assert bits_equal(got, ref)
+
+
+def test_nms_carries_extra_channels(eng):
+    """pose heads: 51 keypoint channels ride along with the kept anchors (n_extra)."""
+    dcfg = DetectConfig()
+    N, nc, ne = 1344, 1, 51
+    rng = np.random.default_rng(3)
+    pred = np.zeros((4 + nc + ne, N), np.float32)
+    pred[0] = rng.uniform(0, 320, N); pred[1] = rng.uniform(0, 256, N)
+    pred[2] = rng.uniform(10, 60, N); pred[3] = rng.uniform(10, 60, N)
+    pred[4] = rng.uniform(0, 1, N)
+    pred[5:] = rng.standard_normal((ne, N))
+    rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 1.0, 0.0, 0.0, 320, 256, n_extra=ne)
+    k = int(count.item())
+    rows, keep = rows.cpu().numpy()[:k], keep.cpu().numpy()[:k]
+    rkeep, rrows = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, False, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+    assert k > 10 and np.array_equal(keep, rkeep)
+    assert bits_equal(rows[:, :6], cexact.scale_boxes(rrows, 1.0, 0.0, 0.0, 320, 256))
+    assert bits_equal(rows[:, 6:], np.ascontiguousarray(pred[5:, keep].T))
