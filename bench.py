@@ -197,7 +197,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
-    ap.add_argument("--overlap", type=int, default=1, help="1: two-stage frame pipeline on two HIP streams (detector of frame k+1 overlaps ReID+tracker of frame k); 0: strictly sequential")
+    ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
 
     import torch
@@ -220,11 +220,11 @@ def main():
     cfg, dcfg = StrongSortConfig(), DetectConfig()
     S, K, Wm = args.streams, args.steps, args.warmup
     total = PREFILL + Wm + K
-    overlap = bool(args.overlap) and args.graph != "none"
+    overlap = args.overlap > 1 and args.graph != "none" and not args.no_nets
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32))
+                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap} if overlap else {}))
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
     wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
@@ -343,7 +343,7 @@ def main():
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
             "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
-                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": "2-stage overlap on 2 HIP streams (+1 frame latency)" if overlap else "sequential", "nets": not args.no_nets, "prefill_frames": PREFILL,
+                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" if overlap else "sequential", "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,

@@ -72,10 +72,14 @@ class TrackerEngine:
 
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
+            torch.cuda.synchronize(self.device)          # nothing of ours may still be in flight on any stream
             self.L.ss_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():           # interpreter teardown: the HIP runtime may already be gone
+            return
         try:
             self.close()
         except Exception:

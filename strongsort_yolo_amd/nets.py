@@ -154,15 +154,21 @@ class YOLOv8(nn.Module):
         self.detect = Detect(nc, (c(256), c(512), c(1024)), nk)
         self.nc, self.nk = nc, nk
 
-    def forward(self, x):
+    def forward_backbone(self, x):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
         p4 = self.b6(self.b5(p3))
         p5 = self.b9(self.b8(self.b7(p4)))
+        return p3, p4, p5
+
+    def forward_head(self, p3, p4, p5):
         h12 = self.h12(torch.cat((F.interpolate(p5, scale_factor=2.0, mode="nearest"), p4), 1))
         h15 = self.h15(torch.cat((F.interpolate(h12, scale_factor=2.0, mode="nearest"), p3), 1))
         h18 = self.h18(torch.cat((self.h16(h15), h12), 1))
         h21 = self.h21(torch.cat((self.h19(h18), p5), 1))
         return self.detect([h15, h18, h21])
+
+    def forward(self, x):
+        return self.forward_head(*self.forward_backbone(x))
 
 
 class YOLOv5u(nn.Module):
@@ -352,11 +358,19 @@ class OSNet(nn.Module):
         self.conv5 = ConvBR(c[3], c[3], 1)
         self.fc = nn.Linear(c[3], feature_dim)
 
-    def forward(self, x):
+    def forward_a(self, x):
         x = self.conv1(x)
         x = fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
-        x = self.conv5(self.conv4(self.conv3(self.conv2(x))))
+        return self.conv3[0](self.conv2(x))                     # through the first block of conv3 (~half the launches)
+
+    def forward_b(self, x):
+        for m in list(self.conv3)[1:]:
+            x = m(x)
+        x = self.conv5(self.conv4(x))
         return F.relu(self.fc(x.mean((2, 3))))
+
+    def forward(self, x):
+        return self.forward_b(self.forward_a(x))
 
 
 def osnet_x0_25():

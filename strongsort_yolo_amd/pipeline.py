@@ -160,7 +160,10 @@ class FramePipeline:
         return [d[s, :n[s]].copy() for s in range(self.S)]
 
     def close(self):
+        torch.cuda.synchronize(self.dev)
         self.graph = None
+        if hasattr(self, "graphs"):
+            self.graphs = None                           # captured graphs reference the context's buffers: drop them first
         self.eng.close()
 
 
@@ -188,46 +191,87 @@ class _Bufs:
 
 
 class OverlappedPipeline(FramePipeline):
-    """Two-stage software pipeline over the frames of the same streams, on two HIP streams:
+    """Software pipeline over the frames of the same streams: stage j of frame k-j runs concurrently with the
+    other stages on its own HIP stream,
 
-        stream A:  [letterbox -> detector]                                        of frame k+1
-        stream B:  [NMS -> ReID crops -> OSNet -> feature select -> StrongSORT update] of frame k
+        stage 0  letterbox -> detector backbone                                frame k
+        stage 1  detector neck + head (-> head tensor)                         frame k-1
+        stage 2  NMS -> ReID crops -> OSNet (first half)                       frame k-2
+        stage 3  OSNet (second half) -> feature select -> StrongSORT update    frame k-3
 
-    The detector is stateless, so frame k+1's stage A does not depend on the tracker state of frame k; the
-    tracker recurrence stays strictly in frame order on stream B.  Results are identical to FramePipeline
-    (same kernels, same order per stream); throughput approaches max(stage A, stage B) instead of their
-    sum at the price of one frame of latency.  Each stage of each buffer set is one captured HIP graph.
+    (stages 0/1 and 2/3 merge when the network has no split entry points, or with `n_stages=2`).  The
+    detector and OSNet are stateless, so only the last stage carries the tracker recurrence, and it sees the
+    frames strictly in order.  Results are identical to FramePipeline (same kernels, same order per frame);
+    a frame still takes the sum of the stage times to come out, but throughput approaches the longest stage
+    because the GPU is otherwise idle between the ~4 us launches of these batch-1 networks.  Every stage of
+    every buffer set is one captured HIP graph; buffer sets = stages.  Measured at configs[1] on MI355X: 1 stage
+    427, 2 stages 761, 4 stages 659 frames/s (four concurrent launch chains contend in the dispatcher), so the
+    default is 2: [letterbox, detector] | [NMS, crops, OSNet, select, tracker].
     """
 
-    def __init__(self, *a, **kw):
+    def __init__(self, *a, n_stages: int = 2, **kw):
         kw = dict(kw)
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
             raise ValueError("OverlappedPipeline needs graph='front' or 'all'")
         super().__init__(*a, **kw)
-        self.bufs = [_Bufs(self), _Bufs(self)]
-        self.sA, self.sB = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-        self.evA = [torch.cuda.Event(), torch.cuda.Event()]
-        self.evB = [torch.cuda.Event(), torch.cuda.Event()]
-        self.gA, self.gB = [None, None], [None, None]
-        self.k = 0                      # frames submitted
-        self.done = 0                   # frames whose stage B has been enqueued
+        split_det = self.run_nets and n_stages >= 4 and hasattr(self.detector, "forward_backbone")
+        split_reid = self.run_nets and n_stages >= 4 and hasattr(self.reid, "forward_a")
+        st = []
+        if split_det:
+            st += [self._s_backbone, self._s_head]
+        else:
+            st += [self._s_detector]
+        if split_reid:
+            st += [self._s_nms_crop_reid_a, self._s_reid_b_select]
+        else:
+            st += [self._s_nms_crop_reid_select]
+        self.stages = st
+        self.n = len(st)
+        self.bufs = [_Bufs(self) for _ in range(self.n)]
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)]
+        self.ev = [[torch.cuda.Event() for _ in range(self.n)] for _ in range(self.n)]    # ev[stage][set]
+        self.graphs = [[None] * self.n for _ in range(self.n)]                            # graphs[stage][set]
+        self.sA, self.sB = self.streams[0], self.streams[-1]       # input stream / tracker + result stream
+        self.k = 0                          # frames submitted
+        self.stage_done = [0] * self.n      # frames enqueued per stage
         self._captured = False
 
-    # the two stages, parameterised by buffer set -------------------------------------------------------
-    def _stage_a(self, b: _Bufs):
-        """letterbox -> detector (the longest stage: ~240 launches for yolov8n)"""
-        e, S, g = self.eng, self.S, self.geom
+    # ---- stage bodies (b = the frame's buffer set) -------------------------------------------------------
+    def _letterbox(self, b):
+        e = self.eng
+        for s in range(self.S):
+            e.letterbox(b.frames[s], self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb_planar[s])
+        b.lb.copy_(b.lb_planar)
+
+    @staticmethod
+    def _keep(b, name, tensors):
+        """Stage outputs that cross a graph boundary live in per-set static buffers."""
+        cur = getattr(b, name, None)
+        if cur is None:
+            cur = [torch.empty_like(t) for t in tensors]
+            setattr(b, name, cur)
+        for d, t in zip(cur, tensors):
+            d.copy_(t)
+
+    def _s_backbone(self, b):
         if self.run_nets:
-            for s in range(S):
-                e.letterbox(b.frames[s], g, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb_planar[s])
-            b.lb.copy_(b.lb_planar)
+            self._letterbox(b)
+            self._keep(b, "pyr", self.detector.forward_backbone(b.lb))
+
+    def _s_head(self, b):
+        pred = self.detector.forward_head(*b.pyr)
+        if self.det_source == "detector":
+            b.pred_in.copy_(pred)
+
+    def _s_detector(self, b):
+        if self.run_nets:
+            self._letterbox(b)
             pred = self.detector(b.lb)
             if self.det_source == "detector":
                 b.pred_in.copy_(pred)
 
-    def _stage_b(self, b: _Bufs):
-        """NMS -> ReID crops -> OSNet -> feature select (the tracker kernels follow on the same stream)"""
+    def _nms_crop(self, b):
         e, S = self.eng, self.S
         md = min(self.dcfg.max_det, MAX_DETS)
         for s in range(S):
@@ -240,12 +284,25 @@ class OverlappedPipeline(FramePipeline):
             for s in range(S):
                 e.crop_norm(b.frames[s], b.dets6[s], self.RB, count=b.ndets[s:s + 1], half=self.half,
                             out=b.crops[s * self.RB:(s + 1) * self.RB])
-            emb = self.reid(b.crops.contiguous(memory_format=torch.channels_last))
-            if self.feat_source == "reid":
-                self.feats_in[:, :self.RB].copy_(emb.view(S, self.RB, FEAT_DIM))
+
+    def _select(self, b, emb):
+        if emb is not None and self.feat_source == "reid":
+            self.feats_in[:, :self.RB].copy_(emb.view(self.S, self.RB, FEAT_DIM))
         if self.feat_source == "by_anchor":
             idx = b.anchor_gt.gather(1, b.keep.long().clamp_(0, self.n_anchors - 1))
             torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_in)
+
+    def _s_nms_crop_reid_a(self, b):
+        self._nms_crop(b)
+        self._keep(b, "mid", [self.reid.forward_a(b.crops.contiguous(memory_format=torch.channels_last))])
+
+    def _s_reid_b_select(self, b):
+        self._select(b, self.reid.forward_b(b.mid[0]))
+
+    def _s_nms_crop_reid_select(self, b):
+        self._nms_crop(b)
+        emb = self.reid(b.crops.contiguous(memory_format=torch.channels_last)) if self.run_nets else None
+        self._select(b, emb)
 
     def _track_b(self, b: _Bufs):
         self.eng.update_device(b.dets6, b.ndets, self.feats_in, self.img_hw)
@@ -256,74 +313,73 @@ class OverlappedPipeline(FramePipeline):
 
     def _capture(self):
         cur = torch.cuda.current_stream(self.dev)
-        self.sA.wait_stream(cur); self.sB.wait_stream(cur)
-        for i, b in enumerate(self.bufs):                       # warm-up (MIOpen find, allocator) eagerly, in order
-            with torch.cuda.stream(self.sA):
-                self._ss_stream(self.sA)
-                for _ in range(2):
-                    self._stage_a(b)
-            self.sA.synchronize()
-            with torch.cuda.stream(self.sB):
-                self._ss_stream(self.sB)
-                for _ in range(2):
-                    self._stage_b(b)
-                    self._track_b(b)
-            self.sB.synchronize()
+        for st in self.streams:
+            st.wait_stream(cur)
+        last = self.n - 1
+        for i, b in enumerate(self.bufs):                       # eager warm-up in stage order (MIOpen find, allocator)
+            for j, fn in enumerate(self.stages):
+                with torch.cuda.stream(self.streams[j]):
+                    self._ss_stream(self.streams[j])
+                    for _ in range(2):
+                        fn(b)
+                        if j == last:
+                            self._track_b(b)
+                self.streams[j].synchronize()
         for i, b in enumerate(self.bufs):
-            with torch.cuda.stream(self.sA):
-                self._ss_stream(self.sA)
-                self.gA[i] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.gA[i], stream=self.sA):
-                    self._stage_a(b)
-            with torch.cuda.stream(self.sB):
-                self._ss_stream(self.sB)
-                self.gB[i] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.gB[i], stream=self.sB):
-                    self._stage_b(b)
-                    if self.graph_mode == "all":
-                        self._track_b(b)
+            for j, fn in enumerate(self.stages):
+                with torch.cuda.stream(self.streams[j]):
+                    self._ss_stream(self.streams[j])
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[j]):
+                        fn(b)
+                        if j == last and self.graph_mode == "all":
+                            self._track_b(b)
+                    self.graphs[j][i] = g
         torch.cuda.synchronize(self.dev)
-        self._ss_stream(self.sB)                                 # the tracker lives on stream B from here on
+        self._ss_stream(self.sB)                                 # the tracker lives on the last stage's stream
         self.eng.reset(-1)
         self._captured = True
 
     # ---- driver API --------------------------------------------------------------------------------------
+    on_result = None
+
     def begin_frame(self) -> _Bufs:
         """Buffer set for the next frame.  Fill its inputs inside `with torch.cuda.stream(pipe.sA):`."""
         if not self._captured:
             self._capture()
-        i = self.k % 2
-        self.sA.wait_event(self.evB[i])                          # stage B of frame k-2 has released this set
+        i = self.k % self.n
+        self.sA.wait_event(self.ev[self.n - 1][i])               # the frame that used this set has left the last stage
         return self.bufs[i]
 
-    def _run_b(self, frame_idx: int):
-        i = frame_idx % 2
-        with torch.cuda.stream(self.sB):
-            self.sB.wait_event(self.evA[i])
-            self.gB[i].replay()
-            if self.graph_mode == "front":
-                self._track_b(self.bufs[i])
-            if self.on_result is not None:
-                self.on_result(frame_idx)                        # e.g. enqueue the D2H copy of self.out on stream B
-            self.evB[i].record(self.sB)
-        self.done = frame_idx + 1
-
-    on_result = None
+    def _run_stage(self, j: int, frame_idx: int):
+        i = frame_idx % self.n
+        st = self.streams[j]
+        with torch.cuda.stream(st):
+            if j > 0:
+                st.wait_event(self.ev[j - 1][i])
+            self.graphs[j][i].replay()
+            if j == self.n - 1:
+                if self.graph_mode == "front":
+                    self._track_b(self.bufs[i])
+                if self.on_result is not None:
+                    self.on_result(frame_idx)                    # e.g. enqueue the D2H copy of self.out on this stream
+            self.ev[j][i].record(st)
+        self.stage_done[j] = frame_idx + 1
 
     def submit(self):
-        """Launch stage A of the frame just filled, and stage B of the previous frame."""
-        i = self.k % 2
-        with torch.cuda.stream(self.sA):
-            self.gA[i].replay()
-            self.evA[i].record(self.sA)
-        if self.k >= 1 and self.done < self.k:
-            self._run_b(self.k - 1)
+        """Stage 0 of the frame just filled, and stage j of frame k-j for every j that has one."""
+        k = self.k
+        for j in range(self.n):
+            f = k - j
+            if f >= 0 and self.stage_done[j] == f:
+                self._run_stage(j, f)
         self.k += 1
 
     def flush(self):
-        """Stage B of the last submitted frame; afterwards every result has been enqueued on stream B."""
-        if self.k > self.done:
-            self._run_b(self.k - 1)
+        """Push every submitted frame through the remaining stages (results are then enqueued on stream sB)."""
+        for j in range(1, self.n):
+            while self.stage_done[j] < self.stage_done[j - 1]:
+                self._run_stage(j, self.stage_done[j])
 
     def step(self, track: bool = True):
         raise RuntimeError("use begin_frame()/submit()/flush() on an OverlappedPipeline")

@@ -59,10 +59,12 @@ def test_sequential_pipeline_equals_oracle(graph):
     pipe.close()
 
 
-@pytest.mark.parametrize("graph", ["front", "all"])
-def test_overlapped_pipeline_equals_oracle(graph):
+@pytest.mark.parametrize("graph,n_stages", [("front", 4), ("all", 4), ("front", 2)])
+def test_overlapped_pipeline_equals_oracle(graph, n_stages):
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
-    pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64)
+    pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64,
+                              n_stages=n_stages)
+    assert pipe.n == n_stages
     gs, items = _workload(pipe)
     ref = _oracle(gs, items, pipe.nc)
     got = {}
