@@ -118,3 +118,35 @@ def test_capacity_error_is_loud():
     with pytest.raises(SSError):
         eng.update_host(np.zeros((129, 6), np.float32), np.zeros((129, 512), np.float32), (480, 640))
     eng.close()
+
+
+def test_golden_tracker_vector_through_the_c_abi():
+    """tests/golden/tracker_6ids_24frames.npz (inputs + oracle outputs) replayed on the GPU."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracker_6ids_24frames.npz"))
+    eng = engine(StrongSortConfig())
+    H, W = z["hw"]
+    for k in range(len(z["counts"])):
+        n = int(z["counts"][k])
+        got = eng.update_host(z["dets"][k, :n], z["feats"][k, :n], (H, W))
+        ref = z["rows"][k, : int(z["nrows"][k])]
+        assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), f"frame {k}"
+        dbg = eng.debug(0)
+        assert bits_equal(dbg["cost_a"], z["cost_a"][k][: dbg["n_conf"], : dbg["n_dets"]])
+    t = eng.tracks(0)
+    assert np.array_equal(t["track_id"], z["final_ids"]) and t["next_id"] == int(z["next_id"])
+    assert bits_equal(t["mean"], z["final_mean"]) and bits_equal(t["cov"], z["final_cov"])
+    eng.close()
+
+
+def test_near_capacity_stream():
+    """110 identities at 1920x1080: 110 x 110 = 12,100 cost entries (LDS cap 14,336), 7 detection column tiles."""
+    cfg = StrongSortConfig()
+    eng, orc = engine(cfg, debug=False), OracleStrongSort(cfg, "c")
+    sg, so = make_stream(44, 1920, 1080, 110), make_stream(44, 1920, 1080, 110)
+    for k in range(8):
+        fg, fo = sg.next_frame(), so.next_frame()
+        got, ref = eng.update_host(fg.dets, fg.feats, (1080, 1920)), orc.update(fo.dets, fo.feats, (1080, 1920))
+        assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), f"frame {k}"
+    assert len(orc.tracks) >= 100
+    eng.close()
