@@ -6,6 +6,7 @@ libstrongsort_hip.so (csrc/).  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import sys as _sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -77,10 +78,9 @@ class TrackerEngine:
             self.ctx = C.c_void_p()
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():           # interpreter teardown: the HIP runtime may already be gone
-            return
-        try:
+        try:                                             # interpreter teardown: the HIP runtime may already be gone
+            if _sys is None or _sys.is_finalizing():
+                return
             self.close()
         except Exception:
             pass

@@ -116,7 +116,7 @@ class YOLO:
         classes = self.overrides.get("classes")
         kpts = None
         if pipe.nk:
-            k = dets[:, 6:].reshape(n, -1, 3).clone()
+            k = dets[:, 6:].reshape(n, pipe.nk // 3, 3).clone()
             k[..., 0] = (k[..., 0] - pipe.pad_x) / pipe.gain
             k[..., 1] = (k[..., 1] - pipe.pad_y) / pipe.gain
             kpts = k

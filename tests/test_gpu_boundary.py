@@ -36,9 +36,10 @@ def test_strongsort_update_with_reid_net_runs_and_is_deterministic():
     assert outs[0].shape[1] == 8 and np.array_equal(outs[0], outs[1])
 
 
-def test_yolo_track_and_predict_contract():
+@pytest.mark.parametrize("weights", ["yolov8n.pt", "yolo11n-pose.pt"])
+def test_yolo_track_and_predict_contract(weights):
     from strongsort_yolo_amd.yolo import YOLO
-    model = YOLO("yolov8n.pt")
+    model = YOLO(weights)
     model.overrides.update(conf=0.9, iou=0.4, agnostic_nms=False, max_det=50)    # random-init head: keep it sparse
     img = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
     res = model.predict(img, verbose=False, device=0)
@@ -46,6 +47,11 @@ def test_yolo_track_and_predict_contract():
     for _ in range(3):
         res = model.track(img, verbose=False, device=0, persist=True, tracker="botsort.yaml")
     r = res[0]
+    if "pose" in weights and r.keypoints is not None:
+        assert len(r.keypoints) == len(r.boxes)
+        for bbox, kp in zip(r.boxes, r.keypoints):               # yolo_multi_model.py:58-62
+            pts = kp.xy.tolist()
+            assert len(pts) == 1 and len(pts[0]) == 17 and len(pts[0][0]) == 2
     if r.boxes.id is None:                 # nothing confirmed: the reference skips such frames (yolo_multi_model.py:54)
         assert len(r.boxes) == 0
         return

@@ -88,3 +88,32 @@ def test_overlapped_pipeline_equals_oracle(graph, n_stages):
         g = out_host[k, : int(n_host[k])].numpy()
         assert g.shape == ref[k].shape and g.tobytes() == ref[k].tobytes(), f"{graph}: frame {k}"
     pipe.close()
+
+
+def test_two_streams_in_one_pipeline_equal_their_oracles():
+    """S = 2 streams batched in one context / one set of launches (streams are independent)."""
+    from strongsort_yolo_amd.pipeline import FramePipeline
+    pipe = FramePipeline("yolov8n", 2, (H, W), graph="front", det_source="synthetic", feat_source="by_anchor", track_grid=64)
+    gs = scale_geometry(pipe.geom, H, W)
+    dcfg = DetectConfig()
+    streams = [make_stream(50 + s, W, H, N_IDS + 2 * s) for s in range(2)]
+    rngs = [np.random.default_rng(50 + s) for s in range(2)]
+    orcs = [OracleStrongSort(StrongSortConfig(), "c") for _ in range(2)]
+    for k in range(10):
+        refs = []
+        for s in range(2):
+            fr = streams[s].next_frame()
+            pred, agt = synth_prediction(fr.dets, pipe.n_anchors, pipe.nc, gs[0], (gs[1], gs[2]), rngs[s])
+            feats = np.zeros((128, 512), np.float32); feats[:len(fr.feats)] = fr.feats
+            pipe.frames[s].copy_(torch.from_numpy(streams[s].frame_pixels(k)).to(pipe.dev))
+            pipe.pred_in[s].copy_(torch.from_numpy(pred).to(pipe.dev))
+            pipe.anchor_gt[s].copy_(torch.from_numpy(agt).to(pipe.dev))
+            pipe.gt_feats[s].copy_(torch.from_numpy(feats).to(pipe.dev))
+            keep, r = cexact.nms(pred, pipe.nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 128)
+            r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W, H)
+            refs.append(orcs[s].update(r, feats[np.maximum(agt[keep], 0)], (H, W)))
+        pipe.step()
+        got = pipe.results()
+        for s in range(2):
+            assert got[s].shape == refs[s].shape and got[s].tobytes() == refs[s].tobytes(), f"stream {s} frame {k}"
+    pipe.close()
