@@ -209,12 +209,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("SS_BENCH_BACKEND", "nccl")            # "gloo" + SS_BENCH_SINGLE_DEVICE=1: control-flow test on one GPU
+    one_dev = os.environ.get("SS_BENCH_SINGLE_DEVICE") == "1"
+    dev_index = 0 if (world == 1 or one_dev) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev_index = local_rank if world > 1 else 0
-    torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     detector, W, H, n_ids, rb = PRESETS[args.preset]
     cfg, dcfg = StrongSortConfig(), DetectConfig()
@@ -293,7 +297,7 @@ def main():
             for w in (0, 5):
                 row = ts[b, w]; row = row[row > 0]
                 print(f"TS block {b*32} wave {w}:", " ".join(f"{(v - t00) / 100:.2f}" for v in row[:40]), file=sys.stderr)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
