@@ -179,8 +179,15 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, 
         alg += Tc * B * 512 * 4 + float(hn[:, s].mean()) * 512 * 4 + Tc * float(hn[:, s].mean()) * 4 * max(1, int(np.ceil(B / 16)))
     eng.close()
     ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_assoc.json")
+    if os.path.exists(pmc) and n_streams == 32:
+        try:
+            traffic = json.load(open(pmc)).get("c2_b32", {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
     return {"kernel": "k_cosine_stream", "streams_per_launch": n_streams, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
-            "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg),
+            "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg),
             "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n,
             "tracker_path_frames_per_s": round(n_streams * timed / dt, 1)}
 
