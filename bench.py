@@ -300,6 +300,8 @@ def main():
     if os.environ.get("SS_TS"):
         ts = pipe.eng.timestamps()
         t00 = ts[ts > 0].min() if (ts > 0).any() else 0
+        st = ts[15, 7, :7]
+        print("TS k_step (us from start): " + " ".join(f"{(v - st[0]) / 100:.2f}" for v in st), file=sys.stderr)
         for b in range(0, 16, 3):
             for w in (0, 5):
                 row = ts[b, w]; row = row[row > 0]

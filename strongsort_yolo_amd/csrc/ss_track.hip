@@ -481,9 +481,124 @@ struct LsapLds {
     unsigned char *SR, *SC;                      // [256] each
 };
 
+// ---- wave-64 reductions on the DPP path (gfx9 row shifts + row broadcasts: an inclusive scan whose lane 63 holds
+// the reduction; ~6 VALU steps instead of 6 LDS-crossbar shuffles) ----------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v, unsigned long long identity)
+{
+    const int lo = __builtin_amdgcn_update_dpp((int)(identity & 0xffffffffu), (int)(v & 0xffffffffu), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(identity >> 32), (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long m)
+{
+    const unsigned long long ID = ~0ull;
+    unsigned long long o;
+    o = dpp_u64<0x111, 0xf>(m, ID); m = o < m ? o : m;          // row_shr:1
+    o = dpp_u64<0x112, 0xf>(m, ID); m = o < m ? o : m;          // row_shr:2
+    o = dpp_u64<0x114, 0xf>(m, ID); m = o < m ? o : m;          // row_shr:4
+    o = dpp_u64<0x118, 0xf>(m, ID); m = o < m ? o : m;          // row_shr:8
+    o = dpp_u64<0x142, 0xa>(m, ID); m = o < m ? o : m;          // row_bcast:15 -> rows 1,3
+    o = dpp_u64<0x143, 0xc>(m, ID); m = o < m ? o : m;          // row_bcast:31 -> rows 2,3
+    const int lo = __builtin_amdgcn_readlane((int)(m & 0xffffffffu), 63), hi = __builtin_amdgcn_readlane((int)(m >> 32), 63);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_i32(int p)
+{
+    const int ID = MAX ? (int)0x80000000 : 0x7fffffff;
+    int o;
+#define SS_STEP(CTRL, RM) o = __builtin_amdgcn_update_dpp(ID, p, CTRL, RM, 0xf, false); p = MAX ? max(p, o) : min(p, o)
+    SS_STEP(0x111, 0xf); SS_STEP(0x112, 0xf); SS_STEP(0x114, 0xf); SS_STEP(0x118, 0xf); SS_STEP(0x142, 0xa); SS_STEP(0x143, 0xc);
+#undef SS_STEP
+    return __builtin_amdgcn_readlane(p, 63);
+}
+
+// ---- register-resident form for nr <= nc <= 64 (the common case: <= 64 tracks x <= 64 detections) --------
+// lane j owns column j (v, shortest path cost, path, row4col, position in SciPy's `remaining` list), lane i owns
+// row i (u, col4row).  One LDS read (the cost entry) per scan step; the arg-min is a 64-bit unsigned wave-min of an
+// order-preserving image of the double, ties resolved with ballots by scan position exactly as the sequential code
+// does (last unassigned column among the minima, else the first minimum).
+__device__ __forceinline__ unsigned long long ss_f64_key(double v)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v + 0.0);      // +0.0: -0 and +0 share a key
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ inline int lsap_wave_small(int nr, int nc, const double* cost, const LsapLds& L)
+{
+    const int l = threadIdx.x & 63;
+    double u = 0.0, v = 0.0;
+    int c4r = -1, r4c = -1, path = -1;
+    const unsigned long long KINF = ss_f64_key(INFINITY);
+    for (int cur = 0; cur < nr; ++cur) {
+        int pos = nc - 1 - l;
+        bool active = l < nc, scj = false, sr = false;
+        double sp = INFINITY, minVal = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        while (sink == -1) {
+            if (l == i) sr = true;
+            const double ui = __longlong_as_double(__builtin_amdgcn_readlane((int)(__double_as_longlong(u) & 0xffffffff), i) & 0xffffffffll |
+                                                   ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(u) >> 32), i) << 32));
+            if (active) {
+                const double r = minVal + cost[i * nc + l] - ui - v;
+                if (r < sp) { path = i; sp = r; }
+            }
+            const unsigned long long key = active ? ss_f64_key(sp) : ~0ull;
+            const unsigned long long m = wave_min_u64(key);
+            if (m >= KINF) return -1;                                              // infeasible (or nothing active)
+            const unsigned long long tied = __ballot(active && key == m);
+            int w;
+            if (__popcll(tied) == 1) w = __builtin_ctzll(tied);
+            else {
+                const unsigned long long tu = __ballot(active && key == m && r4c == -1);
+                const bool wantmax = tu != 0ull;
+                const bool insel = active && key == m && (!wantmax || r4c == -1);
+                const int p0 = insel ? pos : (wantmax ? -1 : 0x3fffffff);
+                const int p = wantmax ? wave_minmax_i32<true>(p0) : wave_minmax_i32<false>(p0);
+                w = __builtin_ctzll(__ballot(insel && pos == p));
+            }
+            w = __builtin_amdgcn_readfirstlane(w);
+            {
+                const long long bits = __double_as_longlong(sp);
+                minVal = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(bits >> 32), w) << 32) |
+                                              ((long long)__builtin_amdgcn_readlane((int)(bits & 0xffffffff), w) & 0xffffffffll));
+            }
+            const int rj = __builtin_amdgcn_readlane(r4c, w);
+            const int pj = __builtin_amdgcn_readlane(pos, w);
+            if (rj == -1) sink = w; else i = rj;
+            --num_remaining;
+            if (active && l != w && pos == num_remaining) pos = pj;               // remaining[index] = remaining[--n]
+            if (l == w) { active = false; scj = true; }
+        }
+        // dual variables
+        const int src = c4r >= 0 ? c4r : 0;
+        const double spc = __shfl(sp, src);
+        if (l == cur) u += minVal;
+        else if (sr) u += minVal - spc;
+        if (scj) v -= minVal - sp;
+        // augment along the path (uniform walk; every step is a pair of readlanes)
+        int j = sink;
+        for (;;) {
+            const int r = __builtin_amdgcn_readlane(path, j);
+            if (l == j) r4c = r;
+            const int t = __builtin_amdgcn_readlane(c4r, r);
+            if (l == r) c4r = j;
+            j = t;
+            if (r == cur) break;
+        }
+    }
+    if (l < nr) L.col4row[l] = c4r;
+    SS_WAVE_SYNC();
+    return 0;
+}
+
 // cost: [nr][nc] (nr <= nc <= 256) in LDS or global.  Result col4row[0..nr).  Returns 0 / -1.
 __device__ inline int lsap_wave(int nr, int nc, const double* cost, const LsapLds& L)
 {
+    if (nc <= 64) return lsap_wave_small(nr, nc, cost, L);
     const int l = threadIdx.x & 63;
     for (int j = l; j < nc; j += 64) { L.v[j] = 0.0; L.path[j] = -1; L.row4col[j] = -1; }
     for (int i = l; i < nr; i += 64) { L.u[i] = 0.0; L.col4row[i] = -1; }
@@ -608,8 +723,11 @@ __device__ inline void gallery_append_wave(float* gal_track, int b, const float*
     frag_write_row(reinterpret_cast<float4*>(gal_track + (size_t)(b / SS_TILE) * SS_TILE_FLOATS), b % SS_TILE, src, false);
 }
 
+#define SS_TS_STEP(idx) do { if (dev.ts_enable && blockIdx.x == 0 && threadIdx.x == 0) dev.ts[(15 * 8 + 7) * 64 + (idx)] = wall_clock64(); } while (0)
+
 __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
 {
+    SS_TS_STEP(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* p = smem;
     double* cost = (double*)p; p += (size_t)SS_COST_CAP * 8;
@@ -667,12 +785,14 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
                 }
             }
             __syncthreads();
+            SS_TS_STEP(1);
             if (wave == 0) {
                 int rc = lsap_wave(nr, nc, cost, L);
                 if (rc) { if (tid == 0) dev.err[s] = SS_ERR_INFEASIBLE; }
                 else for (int i = tid; i < nr; i += 64) { if (tr) asg[L.col4row[i]] = i; else asg[i] = L.col4row[i]; }
             }
             __syncthreads();
+            SS_TS_STEP(2);
             if (tid < nC) {
                 int d = asg[tid];
                 if (d >= 0) {
@@ -687,6 +807,7 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
     __syncthreads();
 
     // ---------------- stage B: IoU association ----------------------------------------------
+    SS_TS_STEP(3);
     int pos, nU, nC1, nCols;
     const int isU = (tid < nT) && (mystate != SS_CONFIRMED);
     block_scan256(isU, wtot, pos, nU);
@@ -742,6 +863,7 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
     __syncthreads();
 
     // ---------------- stage C: matched / missed tracks ---------------------------------------
+    SS_TS_STEP(4);
     int alive = 0;
     if (tid < nT) {
         const size_t g = sb + myslot;
@@ -831,6 +953,7 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
     __syncthreads();
 
     // ---------------- stage D: gallery append (every confirmed track) + output rows -----------
+    SS_TS_STEP(5);
     for (int k = wave; k < nSurv; k += 4) {
         const size_t g = sb + neworder[k];
         if (dev.state[g] != SS_CONFIRMED) continue;
@@ -862,7 +985,8 @@ __global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
         o[7] = (float)dev.det_idx[g];
     }
     if (tid == 0) dev.n_out[s] = nOut;
-    if (tid == 0 && s == 0) { dev.tile_count[0] = 0; dev.tile_count[1] = 0; }          // re-arm the association work list for the next frame
+    if (tid == 0 && s == 0) { dev.tile_count[0] = 0; dev.tile_count[1] = 0; }
+    SS_TS_STEP(6);          // re-arm the association work list for the next frame
 }
 
 // =================================================================================================
