@@ -97,9 +97,9 @@ int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const 
 int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, const float* h_feats,
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
 
-/* Fix the association kernel's track grid (>0) instead of the host's running upper bound (0).
- * Needed before capturing ss_track_update into a HIP graph; the device raises SS_ERR_CAPACITY if a
- * stream ever holds more confirmed tracks than the fixed grid. */
+/* Kept for callers of earlier builds: the association kernels are now persistent over device-built work
+ * lists, so no launch dimension depends on the track count and ss_track_update can be captured into a HIP
+ * graph without this call.  Accepts 0..SS_MAX_TRACKS and has no effect. */
 int ss_set_track_grid(ss_ctx* ctx, int max_confirmed_tracks);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */

@@ -202,11 +202,10 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
     SSDev dev = c->dev;
     dev.dets = d_dets; dev.n_dets = d_ndets; dev.feats_raw = d_feats; dev.img_hw = (int*)d_img_hw;
     dev.out_rows = d_out; dev.n_out = d_nout;
-    // grid upper bound on confirmed tracks: no host sync; grows by at most MAXD per frame and is
-    // refreshed whenever the host reads the table (ss_track_update_host / ss_get_tracks).
-    c->tracks_ub = c->tracks_ub + SS_MAXD > SS_MAXT ? SS_MAXT : c->tracks_ub + SS_MAXD;
-    const int grid_tracks = c->fixed_grid > 0 ? c->fixed_grid : (c->tracks_ub < 1 ? 1 : c->tracks_ub);
-    dev.grid_tracks = grid_tracks;
+    // The association kernels are persistent over device-built work lists (k_pre), so no launch dimension depends
+    // on the number of live tracks: nothing here needs a host round trip, and the same launch sequence can be
+    // captured into a HIP graph as is.
+    dev.grid_tracks = SS_MAXT;
     dev.cos_grid = c->cos_grid;
     dev.stream_mode = c->dev.S >= 4 ? 1 : 0;                // throughput form once enough streams share the launch
     if (const char* g = getenv("SS_STREAM_MODE")) dev.stream_mode = atoi(g);
@@ -221,7 +220,7 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
     }
     if (const char* g = getenv("SS_TS")) dev.ts_enable = atoi(g);
     if (const char* g = getenv("SS_COS_GRID")) dev.cos_grid = atoi(g) > 0 ? atoi(g) : dev.cos_grid;
-    ss_launch_frame(dev, c->prm, grid_tracks, c->stream, e0, e1);
+    ss_launch_frame(dev, c->prm, SS_MAXT, c->stream, e0, e1);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }
