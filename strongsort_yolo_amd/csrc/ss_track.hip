@@ -595,10 +595,144 @@ __device__ inline int lsap_wave_small(int nr, int nc, const double* cost, const 
     return 0;
 }
 
+// ---- register-resident form for 64 < nc <= 64*Q: lane l owns columns l, l+64, ... and rows l, l+64, ... -----------
+// Same algorithm and tie rule as lsap_wave_small; indexed accesses use a uniform (lane, q) split and statically
+// unrolled selects so that the per-column arrays stay in registers.
+template <int Q> __device__ __forceinline__ double rl_f64(const double (&a)[Q], int idx)
+{
+    const int ln = idx & 63, qi = idx >> 6;
+    double out = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (q == qi) {
+            const long long b = __double_as_longlong(a[q]);
+            out = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), ln) << 32) |
+                                       ((long long)__builtin_amdgcn_readlane((int)(b & 0xffffffff), ln) & 0xffffffffll));
+        }
+    return out;
+}
+template <int Q> __device__ __forceinline__ int rl_i32(const int (&a)[Q], int idx)
+{
+    const int ln = idx & 63, qi = idx >> 6;
+    int out = 0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) if (q == qi) out = __builtin_amdgcn_readlane(a[q], ln);
+    return out;
+}
+
+template <int Q>
+__device__ inline int lsap_wave_regs(int nr, int nc, const double* cost, const LsapLds& L)
+{
+    const int l = threadIdx.x & 63;
+    double u[Q], v[Q], sp[Q];
+    int c4r[Q], r4c[Q], path[Q], pos[Q];
+    bool active[Q], scj[Q], sr[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { u[q] = 0.0; v[q] = 0.0; c4r[q] = -1; r4c[q] = -1; path[q] = -1; }
+    const unsigned long long KINF = ss_f64_key(INFINITY);
+    for (int cur = 0; cur < nr; ++cur) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int j = l + 64 * q;
+            pos[q] = nc - 1 - j; active[q] = j < nc; scj[q] = false; sr[q] = false; sp[q] = INFINITY;
+        }
+        double minVal = 0.0;
+        int num_remaining = nc, sink = -1, i = cur;
+        while (sink == -1) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (l + 64 * q == i) sr[q] = true;
+            const double ui = rl_f64<Q>(u, i);
+            unsigned long long key[Q], kmin = ~0ull;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (active[q]) {
+                    const double r = minVal + cost[i * nc + l + 64 * q] - ui - v[q];
+                    if (r < sp[q]) { path[q] = i; sp[q] = r; }
+                }
+                key[q] = active[q] ? ss_f64_key(sp[q]) : ~0ull;
+                kmin = key[q] < kmin ? key[q] : kmin;
+            }
+            const unsigned long long m = wave_min_u64(kmin);
+            if (m >= KINF) return -1;
+            unsigned long long tied[Q];
+            int ntied = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { tied[q] = __ballot(active[q] && key[q] == m); ntied += __popcll(tied[q]); }
+            int w = 0;
+            if (ntied == 1) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) if (tied[q]) w = 64 * q + __builtin_ctzll(tied[q]);
+            } else {
+                bool wantmax = false;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wantmax = wantmax || __ballot(active[q] && key[q] == m && r4c[q] == -1) != 0ull;
+                int p0 = wantmax ? -1 : 0x3fffffff;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const bool insel = active[q] && key[q] == m && (!wantmax || r4c[q] == -1);
+                    if (insel) p0 = wantmax ? max(p0, pos[q]) : min(p0, pos[q]);
+                }
+                const int pbest = wantmax ? wave_minmax_i32<true>(p0) : wave_minmax_i32<false>(p0);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const bool insel = active[q] && key[q] == m && (!wantmax || r4c[q] == -1);
+                    const unsigned long long b = __ballot(insel && pos[q] == pbest);
+                    if (b) w = 64 * q + __builtin_ctzll(b);
+                }
+            }
+            w = __builtin_amdgcn_readfirstlane(w);
+            minVal = rl_f64<Q>(sp, w);
+            const int rj = rl_i32<Q>(r4c, w);
+            const int pj = rl_i32<Q>(pos, w);
+            if (rj == -1) sink = w; else i = rj;
+            --num_remaining;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int j = l + 64 * q;
+                if (active[q] && j != w && pos[q] == num_remaining) pos[q] = pj;
+                if (j == w) { active[q] = false; scj[q] = true; }
+            }
+        }
+        // dual variables: u[r] += minVal - sp[col4row[r]] (r in SR, r != cur); v[j] -= minVal - sp[j] (j in SC)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int c = c4r[q] >= 0 ? c4r[q] : 0;
+            double spc = 0.0;
+#pragma unroll
+            for (int qq = 0; qq < Q; ++qq) {
+                const double t = __shfl(sp[qq], c & 63);
+                if ((c >> 6) == qq) spc = t;
+            }
+            if (l + 64 * q == cur) u[q] += minVal;
+            else if (sr[q]) u[q] += minVal - spc;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) if (scj[q]) v[q] -= minVal - sp[q];
+        // augment
+        int j = sink;
+        for (;;) {
+            const int r = rl_i32<Q>(path, j);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (l + 64 * q == j) r4c[q] = r;
+            const int t = rl_i32<Q>(c4r, r);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (l + 64 * q == r) c4r[q] = j;
+            j = t;
+            if (r == cur) break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) if (l + 64 * q < nr) L.col4row[l + 64 * q] = c4r[q];
+    SS_WAVE_SYNC();
+    return 0;
+}
+
 // cost: [nr][nc] (nr <= nc <= 256) in LDS or global.  Result col4row[0..nr).  Returns 0 / -1.
 __device__ inline int lsap_wave(int nr, int nc, const double* cost, const LsapLds& L)
 {
     if (nc <= 64) return lsap_wave_small(nr, nc, cost, L);
+    if (nc <= 128) return lsap_wave_regs<2>(nr, nc, cost, L);
+    if (nc <= 256) return lsap_wave_regs<4>(nr, nc, cost, L);
     const int l = threadIdx.x & 63;
     for (int j = l; j < nc; j += 64) { L.v[j] = 0.0; L.path[j] = -1; L.row4col[j] = -1; }
     for (int i = l; i < nr; i += 64) { L.u[i] = 0.0; L.col4row[i] = -1; }
