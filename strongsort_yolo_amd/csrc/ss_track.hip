@@ -733,67 +733,7 @@ __device__ inline int lsap_wave(int nr, int nc, const double* cost, const LsapLd
     if (nc <= 64) return lsap_wave_small(nr, nc, cost, L);
     if (nc <= 128) return lsap_wave_regs<2>(nr, nc, cost, L);
     if (nc <= 256) return lsap_wave_regs<4>(nr, nc, cost, L);
-    const int l = threadIdx.x & 63;
-    for (int j = l; j < nc; j += 64) { L.v[j] = 0.0; L.path[j] = -1; L.row4col[j] = -1; }
-    for (int i = l; i < nr; i += 64) { L.u[i] = 0.0; L.col4row[i] = -1; }
-    SS_WAVE_SYNC();
-    for (int cur = 0; cur < nr; ++cur) {
-        for (int it = l; it < nc; it += 64) { L.remaining[it] = nc - it - 1; L.sp[it] = INFINITY; L.SC[it] = 0; }
-        for (int i = l; i < nr; i += 64) L.SR[i] = 0;
-        SS_WAVE_SYNC();
-        double minVal = 0.0;
-        int num_remaining = nc, sink = -1, i = cur;
-        while (sink == -1) {
-            if (l == 0) L.SR[i] = 1;
-            const double ui = L.u[i];
-            const double* crow = cost + (size_t)i * nc;
-            double bval = INFINITY;
-            int bscore = -1, bit = -1;
-            for (int it = l; it < num_remaining; it += 64) {
-                int j = L.remaining[it];
-                double r = minVal + crow[j] - ui - L.v[j];
-                double spj = L.sp[j];
-                if (r < spj) { L.path[j] = i; L.sp[j] = r; spj = r; }
-                int score = (L.row4col[j] == -1) ? (1024 + it) : (1023 - it);
-                if (spj < bval || (spj == bval && score > bscore)) { bval = spj; bscore = score; bit = it; }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                double oval = __shfl_xor(bval, off);
-                int oscore = __shfl_xor(bscore, off);
-                int oit = __shfl_xor(bit, off);
-                if (oval < bval || (oval == bval && oscore > bscore)) { bval = oval; bscore = oscore; bit = oit; }
-            }
-            minVal = bval;
-            if (!(minVal < INFINITY)) return -1;       // infeasible
-            SS_WAVE_SYNC();
-            int j = L.remaining[bit];
-            int rj = L.row4col[j];
-            if (rj == -1) sink = j; else i = rj;
-            --num_remaining;
-            if (l == 0) { L.SC[j] = 1; L.remaining[bit] = L.remaining[num_remaining]; }
-            SS_WAVE_SYNC();
-        }
-        // dual updates
-        if (l == 0) L.u[cur] += minVal;
-        for (int r = l; r < nr; r += 64)
-            if (L.SR[r] && r != cur) L.u[r] += minVal - L.sp[L.col4row[r]];
-        for (int j = l; j < nc; j += 64)
-            if (L.SC[j]) L.v[j] -= minVal - L.sp[j];
-        SS_WAVE_SYNC();
-        // augment
-        if (l == 0) {
-            int j = sink;
-            for (;;) {
-                int r = L.path[j];
-                L.row4col[j] = r;
-                int t = L.col4row[r]; L.col4row[r] = j; j = t;
-                if (r == cur) break;
-            }
-        }
-        SS_WAVE_SYNC();
-    }
-    return 0;
+    return -1;                       // callers cap both dimensions at 256 (SS_MAX_TRACKS)
 }
 
 __device__ inline LsapLds carve_lsap(char*& p)
