@@ -9,6 +9,12 @@ Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synt
 (~30 det/frame), 1 stream per GPU.  Streams are independent, so N GPUs = N x the work ("weak"); no
 data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
 
+Throughput structure (all of it result-preserving — every frame runs every stage, rows are bit-identical to the
+oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 4)
+consecutive frames of a stream at a time, the tracker consumes them one by one in frame order; stage A of
+group k+1 overlaps stage B of group k on a second HIP stream (`--overlap`).  `--frame-batch 1 --overlap 0` is
+the strictly frame-at-a-time pipeline (profiles/ keeps both lines).
+
 Synthetic data (no weights / decoder offline): the detector and OSNet are seeded random-init nets
 of the published shapes and run on every frame for load; the detections the tracker sees come from
 the HIP NMS applied to a synthetic head tensor that encodes the stream's ground-truth boxes, and
@@ -204,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
+    ap.add_argument("--frame-batch", type=int, default=4, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
 
@@ -235,7 +242,8 @@ def main():
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap} if overlap else {}))
+                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch} if overlap else {}))
+    FB = args.frame_batch if overlap else 1
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
     wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
@@ -245,33 +253,39 @@ def main():
     out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
     nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
 
-    def feed(k, b):
+    def feed(k, b, f=0):
         for s, p in enumerate(pools):
-            b.frames[s].copy_(p["pixels"][k % p["pixels"].shape[0]])
-            b.pred_in[s].copy_(p["preds"][k])
-            b.anchor_gt[s].copy_(p["agt"][k])
-            b.gt_feats[s].copy_(p["feats"][k])
-
-    def fetch(k):
-        out_host[k].copy_(pipe.out, non_blocking=True)
-        nout_host[k].copy_(pipe.nout, non_blocking=True)
+            v = f * S + s                                   # virtual stream of frame f of the group
+            b.frames[v].copy_(p["pixels"][k % p["pixels"].shape[0]])
+            b.pred_in[v].copy_(p["preds"][k])
+            b.anchor_gt[v].copy_(p["agt"][k])
+            b.gt_feats[v].copy_(p["feats"][k])
 
     if overlap:
+        def fetch(k, f):
+            out_host[k].copy_(pipe.outs[f], non_blocking=True)
+            nout_host[k].copy_(pipe.nouts[f], non_blocking=True)
+
         pipe.on_result = fetch
 
-        def one(k):
-            b = pipe.begin_frame()
-            with torch.cuda.stream(pipe.sA):
-                feed(k, b)
-            pipe.submit()
+        def run(k0, k1):
+            for g0 in range(k0, k1, FB):
+                n = min(FB, k1 - g0)
+                b = pipe.begin_frame()
+                with torch.cuda.stream(pipe.sA):
+                    for f in range(n):
+                        feed(g0 + f, b, f)
+                pipe.submit(n)
 
         def drain():
             pipe.flush()
     else:
-        def one(k):
-            feed(k, pipe)
-            pipe.step()
-            fetch(k)
+        def run(k0, k1):
+            for k in range(k0, k1):
+                feed(k, pipe)
+                pipe.step()
+                out_host[k].copy_(pipe.out, non_blocking=True)
+                nout_host[k].copy_(pipe.nout, non_blocking=True)
 
         def drain():
             pass
@@ -282,17 +296,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(PREFILL):                     # untimed: galleries reach nn_budget rows
-        one(k)
-    for k in range(PREFILL, PREFILL + Wm):       # W untimed warm-up steps
-        one(k)
+    run(0, PREFILL)                              # untimed: galleries reach nn_budget rows
+    run(PREFILL, PREFILL + Wm)                   # W untimed warm-up steps
     drain()
     torch.cuda.synchronize()
     pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
     barrier()
     t0 = time.perf_counter()
-    for k in range(PREFILL + Wm, total):         # exactly K timed steps
-        one(k)
+    run(PREFILL + Wm, total)                     # exactly K timed steps (frames)
     barrier()
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
@@ -356,7 +367,7 @@ def main():
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
             "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
-                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" if overlap else "sequential", "nets": not args.no_nets, "prefill_frames": PREFILL,
+                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,

@@ -176,7 +176,7 @@ class _Bufs:
     """One set of per-frame buffers (static addresses, baked into that set's HIP graphs)."""
 
     def __init__(self, p: "FramePipeline"):
-        dev, S, g = p.dev, p.S, p.geom
+        dev, S, g = p.dev, getattr(p, "Sv", p.S), p.geom
         self.frames = torch.zeros(S, p.H, p.W, 3, dtype=torch.uint8, device=dev)
         self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.lb_planar = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev)
@@ -209,12 +209,23 @@ class OverlappedPipeline(FramePipeline):
     default is 2: [letterbox, detector] | [NMS, crops, OSNet, select, tracker].
     """
 
-    def __init__(self, *a, n_stages: int = 2, **kw):
+    def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, **kw):
         kw = dict(kw)
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
             raise ValueError("OverlappedPipeline needs graph='front' or 'all'")
         super().__init__(*a, **kw)
+        # frame batching: F consecutive frames of every stream travel through the stateless stages together as
+        # S*F "virtual streams" (index f*S + s); the tracker then consumes them one frame at a time, in order.
+        self.F = int(frame_batch)
+        if self.F < 1:
+            raise ValueError("frame_batch >= 1")
+        if self.F > 1:
+            self.graph_mode = "front"       # the per-frame tracker calls stay eager (partial last groups)
+        self.Sv = self.S * self.F
+        self.feats_v = torch.zeros(self.Sv, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=self.dev)
+        self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
+        self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
         split_det = self.run_nets and n_stages >= 4 and hasattr(self.detector, "forward_backbone")
         split_reid = self.run_nets and n_stages >= 4 and hasattr(self.reid, "forward_a")
         st = []
@@ -233,14 +244,17 @@ class OverlappedPipeline(FramePipeline):
         self.ev = [[torch.cuda.Event() for _ in range(self.n)] for _ in range(self.n)]    # ev[stage][set]
         self.graphs = [[None] * self.n for _ in range(self.n)]                            # graphs[stage][set]
         self.sA, self.sB = self.streams[0], self.streams[-1]       # input stream / tracker + result stream
-        self.k = 0                          # frames submitted
-        self.stage_done = [0] * self.n      # frames enqueued per stage
+        self.k = 0                          # groups (of frame_batch frames) submitted
+        self.stage_done = [0] * self.n      # groups enqueued per stage
+        self.valid = [self.F] * self.n      # real frames in the group occupying each buffer set
+        self.base = [0] * self.n            # frame index of the first frame of that group
+        self.frames_in = 0
         self._captured = False
 
     # ---- stage bodies (b = the frame's buffer set) -------------------------------------------------------
     def _letterbox(self, b):
         e = self.eng
-        for s in range(self.S):
+        for s in range(self.Sv):
             e.letterbox(b.frames[s], self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb_planar[s])
         b.lb.copy_(b.lb_planar)
 
@@ -272,7 +286,7 @@ class OverlappedPipeline(FramePipeline):
                 b.pred_in.copy_(pred)
 
     def _nms_crop(self, b):
-        e, S = self.eng, self.S
+        e, S = self.eng, self.Sv
         md = min(self.dcfg.max_det, MAX_DETS)
         for s in range(S):
             e._ck(e.L.ss_nms(e.ctx, _p(b.pred_in[s]), self.n_anchors, self.nc, self.nk, self.dcfg.conf, self.dcfg.iou,
@@ -287,10 +301,10 @@ class OverlappedPipeline(FramePipeline):
 
     def _select(self, b, emb):
         if emb is not None and self.feat_source == "reid":
-            self.feats_in[:, :self.RB].copy_(emb.view(self.S, self.RB, FEAT_DIM))
+            self.feats_v[:, :self.RB].copy_(emb.view(self.Sv, self.RB, FEAT_DIM))
         if self.feat_source == "by_anchor":
             idx = b.anchor_gt.gather(1, b.keep.long().clamp_(0, self.n_anchors - 1))
-            torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_in)
+            torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_v)
 
     def _s_nms_crop_reid_a(self, b):
         self._nms_crop(b)
@@ -304,8 +318,16 @@ class OverlappedPipeline(FramePipeline):
         emb = self.reid(b.crops.contiguous(memory_format=torch.channels_last)) if self.run_nets else None
         self._select(b, emb)
 
-    def _track_b(self, b: _Bufs):
-        self.eng.update_device(b.dets6, b.ndets, self.feats_in, self.img_hw)
+    def _track_b(self, b: _Bufs, n_valid: int = None, group: int = None):
+        """Tracker update of the group's frames, one frame at a time in order (frame f = virtual streams f*S..);
+        `group` = index of the group's first frame (None while warming up / capturing: no callbacks)."""
+        e, S = self.eng, self.S
+        for f in range(self.F if n_valid is None else n_valid):
+            sl = slice(f * S, (f + 1) * S)
+            e._ck(e.L.ss_track_update(e.ctx, _p(b.dets6[sl]), _p(b.ndets[sl]), _p(self.feats_v[sl]), _p(self.img_hw),
+                                      _p(self.outs[f]), _p(self.nouts[f])))
+            if group is not None and self.on_result is not None:
+                self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
 
     def _ss_stream(self, st):
         import ctypes as C
@@ -360,15 +382,20 @@ class OverlappedPipeline(FramePipeline):
             self.graphs[j][i].replay()
             if j == self.n - 1:
                 if self.graph_mode == "front":
-                    self._track_b(self.bufs[i])
-                if self.on_result is not None:
-                    self.on_result(frame_idx)                    # e.g. enqueue the D2H copy of self.out on this stream
+                    self._track_b(self.bufs[i], self.valid[i], self.base[i])
+                elif self.on_result is not None:
+                    self.on_result(self.base[i], 0)              # graph == "all" implies frame_batch == 1
             self.ev[j][i].record(st)
         self.stage_done[j] = frame_idx + 1
 
-    def submit(self):
-        """Stage 0 of the frame just filled, and stage j of frame k-j for every j that has one."""
+    def submit(self, n_valid: int = None):
+        """Stage 0 of the group of frames just filled (n_valid <= frame_batch of them are real), and stage j of
+        group k-j for every j that has one."""
         k = self.k
+        nv = self.F if n_valid is None else int(n_valid)
+        self.valid[k % self.n] = nv
+        self.base[k % self.n] = self.frames_in                 # index of the group's first frame (partial groups allowed)
+        self.frames_in += nv
         for j in range(self.n):
             f = k - j
             if f >= 0 and self.stage_done[j] == f:

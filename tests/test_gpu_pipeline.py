@@ -59,34 +59,40 @@ def test_sequential_pipeline_equals_oracle(graph):
     pipe.close()
 
 
-@pytest.mark.parametrize("graph,n_stages", [("front", 4), ("all", 4), ("front", 2)])
-def test_overlapped_pipeline_equals_oracle(graph, n_stages):
+@pytest.mark.parametrize("graph,n_stages,fb", [("front", 4, 1), ("all", 2, 1), ("front", 2, 1), ("front", 2, 3)])
+def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb):
+    """fb = 3 with 14 frames: groups of 3,3,3,3 and a partial group of 2."""
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
     pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64,
-                              n_stages=n_stages)
+                              n_stages=n_stages, frame_batch=fb)
     assert pipe.n == n_stages
     gs, items = _workload(pipe)
     ref = _oracle(gs, items, pipe.nc)
-    got = {}
     out_host = torch.empty(FRAMES, 256, 8).pin_memory()
     n_host = torch.empty(FRAMES, dtype=torch.int32).pin_memory()
 
-    def fetch(idx):
-        out_host[idx].copy_(pipe.out[0], non_blocking=True)
-        n_host[idx].copy_(pipe.nout[0], non_blocking=True)
+    def fetch(idx, f):
+        out_host[idx].copy_(pipe.outs[f][0], non_blocking=True)
+        n_host[idx].copy_(pipe.nouts[f][0], non_blocking=True)
 
     pipe.on_result = fetch
-    for k, it in enumerate(items):
+    for g0 in range(0, FRAMES, fb):
+        n = min(fb, FRAMES - g0)
         b = pipe.begin_frame()
         with torch.cuda.stream(pipe.sA):
-            _fill(b, it, pipe.dev)
-        pipe.submit()
+            for f in range(n):
+                img, pred, agt, feats = items[g0 + f]
+                b.frames[f].copy_(torch.from_numpy(img).to(pipe.dev))
+                b.pred_in[f].copy_(torch.from_numpy(pred).to(pipe.dev))
+                b.anchor_gt[f].copy_(torch.from_numpy(agt).to(pipe.dev))
+                b.gt_feats[f].copy_(torch.from_numpy(feats).to(pipe.dev))
+        pipe.submit(n)
     pipe.flush()
     torch.cuda.synchronize()
     pipe.eng.check_errors()
     for k in range(FRAMES):
         g = out_host[k, : int(n_host[k])].numpy()
-        assert g.shape == ref[k].shape and g.tobytes() == ref[k].tobytes(), f"{graph}: frame {k}"
+        assert g.shape == ref[k].shape and g.tobytes() == ref[k].tobytes(), f"{graph} fb={fb}: frame {k}"
     pipe.close()
 
 
