@@ -62,11 +62,19 @@ int  ss_reset(ss_ctx* ctx, int stream);                  /* stream < 0: all stre
 int  ss_synchronize(ss_ctx* ctx);
 
 /* ---- a1  letterbox / preprocess  (inside model.track/.predict, yolo_multi_model.py:41,:173) ---
- * BGR u8 [h][w][3] (row_stride bytes) -> RGB planar [3][out_h][out_w], /255, pad 114.
- * dst_f16 != 0 writes IEEE half, else float. */
+ * BGR u8 [h][w][3] (row_stride bytes) -> RGB [3][out_h][out_w], /255, pad 114.
+ * dst_flags: bit 0 (SS_DST_F16) writes IEEE half, else float; bit 1 (SS_DST_HWC) writes
+ * channels-last [out_h][out_w][3] (what the NHWC convolutions read) instead of three planes. */
+#define SS_DST_F16 1
+#define SS_DST_HWC 2
 int ss_letterbox(ss_ctx* ctx, const uint8_t* d_src, int h, int w, int row_stride, void* d_dst,
-                 int dst_f16, int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left,
+                 int dst_flags, int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left,
                  int pad_value);
+/* Same for `batch` equally sized images in one launch (the streams of a rank, or consecutive frames of a
+ * stream): image b at d_src + b*src_batch_stride bytes, output b at d_dst + b*3*out_h*out_w elements. */
+int ss_letterbox_batch(ss_ctx* ctx, const uint8_t* d_src, int batch, long long src_batch_stride, int h,
+                       int w, int row_stride, void* d_dst, int dst_flags, int out_h, int out_w, int new_h,
+                       int new_w, int pad_top, int pad_left, int pad_value);
 
 /* ---- a3  NMS  (inside model.track/.predict; thresholds = yolo_multi_model.py:18-21) -----------
  * d_pred: YOLOv8 head layout [(4+nc+n_extra)][n_anchors] float (xywh, class scores, extra rows).
@@ -75,13 +83,29 @@ int ss_letterbox(ss_ctx* ctx, const uint8_t* d_src, int h, int w, int row_stride
 int ss_nms(ss_ctx* ctx, const float* d_pred, int n_anchors, int nc, int n_extra, float conf_thres,
            float iou_thres, int agnostic, float max_wh, int max_det, float gain, float pad_x,
            float pad_y, float w0, float h0, float* d_rows, int row_stride, int* d_keep, int* d_count);
+/* `batch` images in one set of launches.  Image b: predictions at d_pred + b*pred_batch_stride floats,
+ * geometry d_geom[b] = {gain, pad_x, pad_y, w0, h0} (device floats, so images of different sizes can share
+ * a batch), rows at d_rows + b*rows_batch_stride floats, anchors at d_keep + b*keep_batch_stride, count
+ * d_count[b].  The first call with a larger batch than any before grows the context's workspace and must
+ * not be inside a HIP-graph capture.  More than 8192 candidates above conf_thres in an image leave that
+ * image's count 0 and raise SS_ERR_CAPACITY at the next ss_check_errors (same for ss_nms). */
+int ss_nms_batch(ss_ctx* ctx, const float* d_pred, int batch, long long pred_batch_stride, int n_anchors,
+                 int nc, int n_extra, float conf_thres, float iou_thres, int agnostic, float max_wh,
+                 int max_det, const float* d_geom, float* d_rows, int row_stride,
+                 long long rows_batch_stride, int* d_keep, long long keep_batch_stride, int* d_count);
 
 /* ---- a4  ReID crop-extract  (StrongSORT._get_features, inside model.track) ---------------------
  * For each detection row (x1,y1,x2,y2,... ; det_stride floats) crop + bilinear to 256x128,
- * /255, ImageNet mean/std, RGB planar [n][3][256][128].  n from *d_count when d_count != NULL. */
+ * /255, ImageNet mean/std, RGB [n][3][256][128] (out_flags as ss_letterbox's dst_flags: SS_DST_F16,
+ * SS_DST_HWC for [n][256][128][3]).  Rows >= *d_count are left untouched when d_count != NULL. */
 int ss_crop_norm(ss_ctx* ctx, const uint8_t* d_frame, int h, int w, int row_stride,
                  const float* d_dets, int det_stride, int n, const int* d_count, void* d_out,
-                 int out_f16);
+                 int out_flags);
+/* `batch` frames in one launch: frame b at d_frames + b*frame_batch_stride bytes, its detections at
+ * d_dets + b*dets_batch_stride floats, its count d_counts[b] (NULL: n each), output [batch][n][3][256][128]. */
+int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long long frame_batch_stride,
+                       int h, int w, int row_stride, const float* d_dets, int det_stride,
+                       long long dets_batch_stride, int n, const int* d_counts, void* d_out, int out_flags);
 
 /* ---- a6..a10  tracker update  (tracker.update inside model.track, yolo_multi_model.py:41) -----
  * One frame for EVERY stream of the context in one batch of launches:

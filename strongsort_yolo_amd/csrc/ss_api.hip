@@ -20,11 +20,12 @@ void ss_launch_assoc(const float*, const int*, int, const float*, int, const dou
 void ss_launch_iou(const double*, int, const double*, int, double, double*, hipStream_t);
 void ss_launch_lsap(const double*, int, int, int*, double*, int*, hipStream_t);
 int  ss_front_init();
-void ss_launch_letterbox(const uint8_t*, int, int, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
-int  ss_launch_nms(const float*, int, int, int, float, float, int, float, int, float, float, float, float,
-                   float, float*, int, int*, int*, void* ws, size_t ws_bytes, hipStream_t);
+void ss_launch_letterbox(const uint8_t*, int, long long, int, int, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
+int  ss_launch_nms(const float*, int, long long, int, int, int, float, float, int, float, int, float, float, float, float,
+                   float, const float*, float*, int, long long, int*, long long, int*, void*, size_t, hipStream_t);
+int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
-void ss_launch_crop(const uint8_t*, int, int, int, const float*, int, int, const int*, void*, int, hipStream_t);
+void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t);
 extern "C" void ss_step_kernel_attr();
 
 static std::string g_last_error;
@@ -44,8 +45,9 @@ struct ss_ctx {
     float *kat_featfrag, *kat_partmin;
     double* kat_lsap_t;
     int* kat_err;
-    void* nms_ws;
+    void* nms_ws;               // nms_units workspace units (grown on demand outside graph capture)
     size_t nms_ws_bytes;
+    int nms_units;
     int tracks_ub;              // host upper bound of live tracks per stream (grid sizing)
     int fixed_grid;             // >0: use this grid instead (graph capture)
     int cos_grid;               // persistent workgroups of the association kernel
@@ -135,6 +137,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     if (rc == SS_OK) rc = dalloc(c, &c->kat_lsap_t, (size_t)256 * 256);
     if (rc == SS_OK) rc = dalloc(c, &c->kat_err, 4);
     c->nms_ws_bytes = ss_nms_workspace_bytes();
+    c->nms_units = 1;
     if (rc == SS_OK) { char* w; rc = dalloc(c, &w, c->nms_ws_bytes); c->nms_ws = w; }
     if (rc == SS_OK) { ss_step_kernel_attr(); if (ss_front_init() != 0) rc = fail(c, SS_ERR_HIP, "kernel attribute setup failed"); }
     if (rc == SS_OK) { hipError_t e2 = hipStreamSynchronize(c->stream); if (e2 != hipSuccess) rc = fail(c, SS_ERR_HIP, hipGetErrorString(e2)); }
@@ -188,6 +191,8 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, hipMemsetAsync(d.tile_count, 0, 16, c->stream));
+    if (stream < 0)
+        for (int u = 0; u < c->nms_units; ++u) HIPCHK(c, hipMemsetAsync(ss_nms_error_flag(c->nms_ws, u), 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tracks_ub = 0;
     return SS_OK;
@@ -275,6 +280,11 @@ extern "C" int ss_check_errors(ss_ctx* c)
     c->tracks_ub = ub;
     for (size_t s = 0; s < e.size(); ++s)
         if (e[s]) return fail(c, e[s], "device error flag on stream " + std::to_string(s));
+    for (int u = 0; u < c->nms_units; ++u) {                 // NMS candidate overflow (flag stays set until ss_reset)
+        int f = 0;
+        HIPCHK(c, hipMemcpy(&f, ss_nms_error_flag(c->nms_ws, u), 4, hipMemcpyDeviceToHost));
+        if (f) return fail(c, f, "ss_nms: more than 8192 candidates above conf_thres (image " + std::to_string(u) + " of the batch)");
+    }
     return SS_OK;
 }
 
@@ -331,11 +341,54 @@ extern "C" int ss_lsap(ss_ctx* c, const double* cost, int nr, int nc, int* r2c)
 }
 
 // ---- front end ----------------------------------------------------------------------------------------
-extern "C" int ss_letterbox(ss_ctx* c, const uint8_t* src, int h, int w, int stride, void* dst, int f16,
+extern "C" int ss_letterbox_batch(ss_ctx* c, const uint8_t* src, int batch, long long src_batch_stride, int h, int w,
+                                  int stride, void* dst, int dst_flags, int out_h, int out_w, int new_h, int new_w,
+                                  int pad_top, int pad_left, int pad_value)
+{
+    if (!c || !src || !dst || new_h < 1 || new_w < 1 || batch < 0 || batch > 65535 || out_h > 65535)
+        return fail(c, SS_ERR_INVALID, "ss_letterbox: bad argument");
+    ss_launch_letterbox(src, batch, src_batch_stride, h, w, stride, dst, dst_flags, out_h, out_w, new_h, new_w, pad_top,
+                        pad_left, pad_value, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_letterbox(ss_ctx* c, const uint8_t* src, int h, int w, int stride, void* dst, int dst_flags,
                             int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left, int pad_value)
 {
-    if (!c || !src || !dst || new_h < 1 || new_w < 1) return fail(c, SS_ERR_INVALID, "ss_letterbox: bad argument");
-    ss_launch_letterbox(src, h, w, stride, dst, f16, out_h, out_w, new_h, new_w, pad_top, pad_left, pad_value, c->stream);
+    return ss_letterbox_batch(c, src, 1, 0, h, w, stride, dst, dst_flags, out_h, out_w, new_h, new_w, pad_top, pad_left,
+                              pad_value);
+}
+
+// workspace for `batch` images; growing it allocates, which a stream capture does not allow
+static int nms_reserve(ss_ctx* c, int batch)
+{
+    if (batch <= c->nms_units) return SS_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (c->stream) HIPCHK(c, hipStreamIsCapturing(c->stream, &cs));
+    if (cs != hipStreamCaptureStatusNone)
+        return fail(c, SS_ERR_INVALID, "ss_nms_batch: first call with this batch size must not be inside a graph capture");
+    char* w = nullptr;
+    int rc = dalloc(c, &w, c->nms_ws_bytes * (size_t)batch);
+    if (rc) return rc;
+    c->nms_ws = w;               // the smaller workspace stays owned by the context until ss_destroy
+    c->nms_units = batch;
+    return SS_OK;
+}
+
+extern "C" int ss_nms_batch(ss_ctx* c, const float* pred, int batch, long long pred_batch_stride, int n_anchors, int nc,
+                            int n_extra, float conf_thres, float iou_thres, int agnostic, float max_wh, int max_det,
+                            const float* d_geom, float* rows, int row_stride, long long rows_batch_stride, int* keep,
+                            long long keep_batch_stride, int* count)
+{
+    if (!c || !pred || !d_geom || !rows || !keep || !count || row_stride < 6 + n_extra || batch < 0 || batch > 65535)
+        return fail(c, SS_ERR_INVALID, "ss_nms_batch: bad argument");
+    int rc = nms_reserve(c, batch);
+    if (rc) return rc;
+    rc = ss_launch_nms(pred, batch, pred_batch_stride, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh,
+                       max_det, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, d_geom, rows, row_stride, rows_batch_stride, keep,
+                       keep_batch_stride, count, c->nms_ws, c->nms_ws_bytes * (size_t)c->nms_units, c->stream);
+    if (rc) return fail(c, rc, "ss_nms_batch: anchors exceed the workspace (n_anchors <= 32768)");
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }
@@ -346,20 +399,30 @@ extern "C" int ss_nms(ss_ctx* c, const float* pred, int n_anchors, int nc, int n
 {
     if (!c || !pred || !rows || !keep || !count || row_stride < 6 + n_extra)
         return fail(c, SS_ERR_INVALID, "ss_nms: bad argument");
-    int rc = ss_launch_nms(pred, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh, max_det, gain,
-                           pad_x, pad_y, w0, h0, rows, row_stride, keep, count, c->nms_ws, c->nms_ws_bytes, c->stream);
+    int rc = ss_launch_nms(pred, 1, 0, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh, max_det, gain,
+                           pad_x, pad_y, w0, h0, nullptr, rows, row_stride, 0, keep, 0, count, c->nms_ws,
+                           c->nms_ws_bytes * (size_t)c->nms_units, c->stream);
     if (rc) return fail(c, rc, "ss_nms: anchors exceed the workspace (n_anchors <= 32768)");
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }
 
-extern "C" int ss_crop_norm(ss_ctx* c, const uint8_t* frame, int h, int w, int stride, const float* dets,
-                            int det_stride, int n, const int* d_count, void* out, int f16)
+extern "C" int ss_crop_norm_batch(ss_ctx* c, const uint8_t* frames, int batch, long long frame_batch_stride, int h,
+                                  int w, int stride, const float* dets, int det_stride, long long dets_batch_stride,
+                                  int n, const int* d_counts, void* out, int out_flags)
 {
-    if (!c || !frame || !dets || !out) return fail(c, SS_ERR_INVALID, "ss_crop_norm: null argument");
-    ss_launch_crop(frame, h, w, stride, dets, det_stride, n, d_count, out, f16, c->stream);
+    if (!c || !frames || !dets || !out || batch < 0 || n < 0 || (long long)batch * n > 65535)
+        return fail(c, SS_ERR_INVALID, "ss_crop_norm: bad argument (batch * n <= 65535)");
+    ss_launch_crop(frames, batch, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_counts, out,
+                   out_flags, c->stream);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
+}
+
+extern "C" int ss_crop_norm(ss_ctx* c, const uint8_t* frame, int h, int w, int stride, const float* dets,
+                            int det_stride, int n, const int* d_count, void* out, int out_flags)
+{
+    return ss_crop_norm_batch(c, frame, 1, 0, h, w, stride, dets, det_stride, 0, n, d_count, out, out_flags);
 }
 
 // ---- inspection ----------------------------------------------------------------------------------------

@@ -33,19 +33,25 @@ template <> __device__ inline __half ss_cvt<__half>(float v) { return __float2ha
 // =================================================================================================
 // a1 letterbox: one thread per output pixel column pair; writes 3 planes
 // =================================================================================================
-template <typename T>
-__global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ src, int H, int W, int stride,
-                                                   T* __restrict__ dst, int out_h, int out_w, int new_h,
-                                                   int new_w, int pad_top, int pad_left, float padv)
+// blockIdx.z = image of the batch; HWC != 0 writes [out_h][out_w][3] (channels-last) instead of 3 planes
+template <typename T, int HWC>
+__global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ src, long long src_batch_stride,
+                                                   int H, int W, int stride, T* __restrict__ dst, int out_h,
+                                                   int out_w, int new_h, int new_w, int pad_top, int pad_left,
+                                                   float padv)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= out_w) return;
-    const size_t plane = (size_t)out_h * out_w, o = (size_t)y * out_w + x;
+    const size_t plane = (size_t)out_h * out_w;
+    src += (size_t)blockIdx.z * src_batch_stride;
+    dst += (size_t)blockIdx.z * 3 * plane;
+    const size_t o = HWC ? ((size_t)y * out_w + x) * 3 : (size_t)y * out_w + x;
+    const size_t cs = HWC ? 1 : plane;
     const int ry = y - pad_top, rx = x - pad_left;
     if (ry < 0 || ry >= new_h || rx < 0 || rx >= new_w) {
         T p = ss_cvt<T>(padv);
-        dst[o] = p; dst[plane + o] = p; dst[2 * plane + o] = p;
+        dst[o] = p; dst[cs + o] = p; dst[2 * cs + o] = p;
         return;
     }
     const float sx = (float)W / (float)new_w, sy = (float)H / (float)new_h;
@@ -58,33 +64,46 @@ __global__ __launch_bounds__(256) void k_letterbox(const uint8_t* __restrict__ s
     for (int c = 0; c < 3; ++c) {
         const int sc = 2 - c;
         float p00 = r0[x0 * 3 + sc], p01 = r0[x1 * 3 + sc], p10 = r1[x0 * 3 + sc], p11 = r1[x1 * 3 + sc];
-        dst[c * plane + o] = ss_cvt<T>(ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f);
+        dst[c * cs + o] = ss_cvt<T>(ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f);
     }
 }
 
-void ss_launch_letterbox(const uint8_t* src, int h, int w, int stride, void* dst, int f16, int out_h, int out_w,
-                         int new_h, int new_w, int pad_top, int pad_left, int pad_value, hipStream_t st)
+// flags: bit 0 = half output, bit 1 = channels-last output
+void ss_launch_letterbox(const uint8_t* src, int batch, long long src_batch_stride, int h, int w, int stride, void* dst,
+                         int flags, int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left,
+                         int pad_value, hipStream_t st)
 {
-    dim3 grid((out_w + 255) / 256, out_h), block(256);
+    if (batch <= 0) return;
+    dim3 grid((out_w + 255) / 256, out_h, batch), block(256);
     float padv = (float)pad_value / 255.0f;
-    if (f16) hipLaunchKernelGGL(k_letterbox<__half>, grid, block, 0, st, src, h, w, stride, (__half*)dst, out_h, out_w, new_h, new_w, pad_top, pad_left, padv);
-    else     hipLaunchKernelGGL(k_letterbox<float>, grid, block, 0, st, src, h, w, stride, (float*)dst, out_h, out_w, new_h, new_w, pad_top, pad_left, padv);
+#define SS_LB(T, L) hipLaunchKernelGGL((k_letterbox<T, L>), grid, block, 0, st, src, src_batch_stride, h, w, stride, \
+                                       (T*)dst, out_h, out_w, new_h, new_w, pad_top, pad_left, padv)
+    switch (flags & 3) {
+    case 0: SS_LB(float, 0); break;
+    case 1: SS_LB(__half, 0); break;
+    case 2: SS_LB(float, 1); break;
+    default: SS_LB(__half, 1); break;
+    }
+#undef SS_LB
 }
 
 // =================================================================================================
 // a4 ReID crop: grid (x tiles, out rows, dets); one thread per output pixel
 // =================================================================================================
-template <typename T>
-__global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, int H, int W, int stride,
-                                              const float* __restrict__ dets, int det_stride, int n,
-                                              const int* __restrict__ d_count, T* __restrict__ dst)
+// blockIdx.z = image * n + detection; HWC != 0 writes [256][128][3] per crop (channels-last)
+template <typename T, int HWC>
+__global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, long long src_batch_stride, int H, int W,
+                                              int stride, const float* __restrict__ dets, int det_stride,
+                                              long long dets_batch_stride, int n, const int* __restrict__ d_count,
+                                              T* __restrict__ dst)
 {
     const int out_w = 128, out_h = 256;
-    const int d = blockIdx.z;
-    const int cnt = d_count ? *d_count : n;
+    const int img = blockIdx.z / n, d = blockIdx.z - img * n;
+    const int cnt = d_count ? d_count[img] : n;
     if (d >= cnt) return;
+    src += (size_t)img * src_batch_stride;
     const int x = threadIdx.x, y = blockIdx.y;
-    const float* b = dets + (size_t)d * det_stride;
+    const float* b = dets + (size_t)img * dets_batch_stride + (size_t)d * det_stride;
     int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];
     if (x1 < 0) x1 = 0; if (y1 < 0) y1 = 0;
     if (x2 > W - 1) x2 = W - 1; if (y2 > H - 1) y2 = H - 1;
@@ -99,24 +118,34 @@ __global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, i
     const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride;
     const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
     const size_t plane = (size_t)out_h * out_w;
-    T* o = dst + (size_t)d * 3 * plane + (size_t)y * out_w + x;
+    T* o = dst + (size_t)blockIdx.z * 3 * plane + (HWC ? ((size_t)y * out_w + x) * 3 : (size_t)y * out_w + x);
+    const size_t cs = HWC ? 1 : plane;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int sc = 2 - c;
         float p00 = r0[(x1 + xx0) * 3 + sc], p01 = r0[(x1 + xx1) * 3 + sc];
         float p10 = r1[(x1 + xx0) * 3 + sc], p11 = r1[(x1 + xx1) * 3 + sc];
         float q = ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f;
-        o[c * plane] = ss_cvt<T>((q - mean[c]) / sd[c]);
+        o[c * cs] = ss_cvt<T>((q - mean[c]) / sd[c]);
     }
 }
 
-void ss_launch_crop(const uint8_t* frame, int h, int w, int stride, const float* dets, int det_stride, int n,
-                    const int* d_count, void* out, int f16, hipStream_t st)
+// flags: bit 0 = half output, bit 1 = channels-last output
+void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_stride, int h, int w, int stride,
+                    const float* dets, int det_stride, long long dets_batch_stride, int n, const int* d_count,
+                    void* out, int flags, hipStream_t st)
 {
-    if (n <= 0) return;
-    dim3 grid(1, 256, n), block(128);
-    if (f16) hipLaunchKernelGGL(k_crop<__half>, grid, block, 0, st, frame, h, w, stride, dets, det_stride, n, d_count, (__half*)out);
-    else     hipLaunchKernelGGL(k_crop<float>, grid, block, 0, st, frame, h, w, stride, dets, det_stride, n, d_count, (float*)out);
+    if (n <= 0 || batch <= 0) return;
+    dim3 grid(1, 256, n * batch), block(128);
+#define SS_CR(T, L) hipLaunchKernelGGL((k_crop<T, L>), grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, \
+                                       det_stride, dets_batch_stride, n, d_count, (T*)out)
+    switch (flags & 3) {
+    case 0: SS_CR(float, 0); break;
+    case 1: SS_CR(__half, 0); break;
+    case 2: SS_CR(float, 1); break;
+    default: SS_CR(__half, 1); break;
+    }
+#undef SS_CR
 }
 
 // =================================================================================================
@@ -141,7 +170,7 @@ size_t ss_nms_workspace_bytes()
            (size_t)NMS_MAX_CAND * 4 + (size_t)NMS_MAX_CAND * NMS_WORDS * 8 + 64;
 }
 
-static NmsWs carve_nms(void* ws)
+__host__ __device__ inline NmsWs carve_nms(void* ws)
 {
     NmsWs w; char* p = (char*)ws;
     w.keys = (unsigned long long*)p; p += (size_t)NMS_MAX_ANCHORS * 8;
@@ -153,10 +182,20 @@ static NmsWs carve_nms(void* ws)
     return w;
 }
 
+// Batched launch: every kernel takes the image index from its grid and finds that image's prediction
+// tensor and workspace unit by stride.
+struct NmsBatch {
+    const float* pred; long long pred_stride;     // floats between images
+    char* ws; long long ws_stride;                // bytes between workspace units
+};
+__device__ inline NmsWs nms_unit(const NmsBatch& nb, int img) { return carve_nms(nb.ws + (size_t)img * nb.ws_stride); }
+
 // candidate filter: best class per anchor, score > conf.  key = (~score_bits, anchor): ascending
 // key order == descending score, ties by ascending anchor (stable order of the oracle's sort).
-__global__ __launch_bounds__(512) void k_nms_filter(const float* __restrict__ pred, int N, int nc, float conf, NmsWs w)
+__global__ __launch_bounds__(512) void k_nms_filter(NmsBatch nb, int N, int nc, float conf)
 {
+    const float* __restrict__ pred = nb.pred + (size_t)blockIdx.y * nb.pred_stride;
+    const NmsWs w = nms_unit(nb, blockIdx.y);
     // 64 anchors per block; wave g scans classes g, g+8, ... (coalesced over anchors), LDS combine
     __shared__ float sbest[8][64];
     __shared__ int scls[8][64];
@@ -184,12 +223,18 @@ __global__ __launch_bounds__(512) void k_nms_filter(const float* __restrict__ pr
 }
 
 // single-block bitonic sort of the candidate keys in LDS, then offset boxes / areas in sorted order
-__global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ pred, int N, int agnostic, float max_wh, NmsWs w)
+__global__ __launch_bounds__(1024) void k_nms_sort(NmsBatch nb, int N, int agnostic, float max_wh)
 {
+    const float* __restrict__ pred = nb.pred + (size_t)blockIdx.x * nb.pred_stride;
+    const NmsWs w = nms_unit(nb, blockIdx.x);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long* k = (unsigned long long*)smem;
     int n = w.counters[0];
-    if (n > NMS_MAX_CAND) { if (threadIdx.x == 0) { w.counters[1] = SS_ERR_CAPACITY; } n = 0; }
+    __syncthreads();
+    if (n > NMS_MAX_CAND) {       // too many candidates: flag it and make the mask / scan kernels see an empty image
+        if (threadIdx.x == 0) { w.counters[1] = SS_ERR_CAPACITY; w.counters[0] = 0; }
+        n = 0;
+    }
     int np = 1; while (np < n) np <<= 1;
     for (int i = threadIdx.x; i < np; i += 1024) k[i] = i < n ? w.keys[i] : ~0ull;
     __syncthreads();
@@ -217,8 +262,9 @@ __global__ __launch_bounds__(1024) void k_nms_sort(const float* __restrict__ pre
 }
 
 // suppression bit matrix: mask[i][jb] bit t set when j = jb*64+t > i and IoU(i,j) > thr
-__global__ __launch_bounds__(64) void k_nms_mask(float iou_thres, NmsWs w)
+__global__ __launch_bounds__(64) void k_nms_mask(NmsBatch nb, float iou_thres)
 {
+    const NmsWs w = nms_unit(nb, blockIdx.z);
     __shared__ float sb[64 * 4];
     __shared__ float sa[64];
     const int n = min(w.counters[0], NMS_MAX_CAND);
@@ -246,11 +292,18 @@ __global__ __launch_bounds__(64) void k_nms_mask(float iou_thres, NmsWs w)
 }
 
 // greedy scan (one wave) + output rows in original-image pixels
-__global__ __launch_bounds__(64) void k_nms_scan(const float* __restrict__ pred, int N, int nc, int n_extra,
-                                                 int max_det, float gain, float pad_x, float pad_y, float w0,
-                                                 float h0, float* __restrict__ rows, int row_stride,
-                                                 int* __restrict__ keep, int* __restrict__ count, NmsWs w)
+// geom != NULL: per-image [gain, pad_x, pad_y, w0, h0] on the device (images of different sizes in one batch)
+__global__ __launch_bounds__(64) void k_nms_scan(NmsBatch nb, int N, int nc, int n_extra, int max_det, float gain,
+                                                 float pad_x, float pad_y, float w0, float h0,
+                                                 const float* __restrict__ geom, float* __restrict__ rows,
+                                                 int row_stride, long long rows_batch_stride, int* __restrict__ keep,
+                                                 long long keep_batch_stride, int* __restrict__ count)
 {
+    const int img = blockIdx.x;
+    const float* __restrict__ pred = nb.pred + (size_t)img * nb.pred_stride;
+    const NmsWs w = nms_unit(nb, img);
+    rows += (size_t)img * rows_batch_stride; keep += (size_t)img * keep_batch_stride; count += img;
+    if (geom) { const float* g = geom + img * 5; gain = g[0]; pad_x = g[1]; pad_y = g[2]; w0 = g[3]; h0 = g[4]; }
     __shared__ int kept_sorted[1024];
     const int n = min(w.counters[0], NMS_MAX_CAND);
     const int l = threadIdx.x;
@@ -321,19 +374,24 @@ int ss_front_init()
     return e == hipSuccess ? 0 : 1;
 }
 
-int ss_launch_nms(const float* pred, int N, int nc, int n_extra, float conf, float iou, int agnostic, float max_wh,
-                  int max_det, float gain, float pad_x, float pad_y, float w0, float h0, float* rows, int row_stride,
-                  int* keep, int* count, void* ws, size_t ws_bytes, hipStream_t st)
+// error flags (counters[1]) of the first `units` workspace units, for ss_check_errors
+int* ss_nms_error_flag(void* ws, int unit) { return carve_nms((char*)ws + (size_t)unit * ss_nms_workspace_bytes()).counters + 1; }
+
+int ss_launch_nms(const float* pred, int batch, long long pred_stride, int N, int nc, int n_extra, float conf, float iou,
+                  int agnostic, float max_wh, int max_det, float gain, float pad_x, float pad_y, float w0, float h0,
+                  const float* geom, float* rows, int row_stride, long long rows_batch_stride, int* keep,
+                  long long keep_batch_stride, int* count, void* ws, size_t ws_bytes, hipStream_t st)
 {
-    if (N > NMS_MAX_ANCHORS || ws_bytes < ss_nms_workspace_bytes()) return SS_ERR_CAPACITY;
-    NmsWs w = carve_nms(ws);
+    if (batch <= 0) return 0;
+    if (N > NMS_MAX_ANCHORS || ws_bytes < ss_nms_workspace_bytes() * (size_t)batch) return SS_ERR_CAPACITY;
+    NmsBatch nb{ pred, pred_stride, (char*)ws, (long long)ss_nms_workspace_bytes() };
     // the candidate counter is re-armed by k_nms_scan itself (no memset node: graph-capture safe)
-    hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64), dim3(512), 0, st, pred, N, nc, conf, w);
-    hipLaunchKernelGGL(k_nms_sort, dim3(1), dim3(1024), NMS_MAX_CAND * 8, st, pred, N, agnostic, max_wh, w);
+    hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64, batch), dim3(512), 0, st, nb, N, nc, conf);
+    hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(1024), NMS_MAX_CAND * 8, st, nb, N, agnostic, max_wh);
     // mask grid sized for the worst case the filter could produce; blocks beyond n exit at once
     const int nbmax = (min(N, NMS_MAX_CAND) + 63) / 64;
-    hipLaunchKernelGGL(k_nms_mask, dim3(nbmax, nbmax), dim3(64), 0, st, iou, w);
-    hipLaunchKernelGGL(k_nms_scan, dim3(1), dim3(64), 0, st, pred, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
-                       rows, row_stride, keep, count, w);
+    hipLaunchKernelGGL(k_nms_mask, dim3(nbmax, nbmax, batch), dim3(64), 0, st, nb, iou);
+    hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), 0, st, nb, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
+                       geom, rows, row_stride, rows_batch_stride, keep, keep_batch_stride, count);
     return 0;
 }

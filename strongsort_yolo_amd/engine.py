@@ -252,6 +252,47 @@ class TrackerEngine:
                                      g.out_w, g.new_h, g.new_w, g.pad_top, g.pad_left, pad_value))
         return out
 
+    def letterbox_batch(self, frames: torch.Tensor, g: LetterboxGeom, half: bool = False, pad_value: int = 114,
+                        out=None, channels_last: bool = False):
+        """frames: uint8 [B,H,W,3] BGR on the device -> [B,3,out_h,out_w] float/half in one launch;
+        channels_last=True writes the NHWC memory format the convolutions read (no permute copy afterwards)."""
+        B, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        if out is None:
+            out = torch.empty(B, 3, g.out_h, g.out_w, dtype=torch.float16 if half else torch.float32, device=self.device,
+                              memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        flags = (_lib.DST_F16 if half else 0) | (_lib.DST_HWC if channels_last else 0)
+        self._ck(self.L.ss_letterbox_batch(self.ctx, _ptr(frames), B, frames.stride(0), H, W, frames.stride(1), _ptr(out),
+                                           flags, g.out_h, g.out_w, g.new_h, g.new_w, g.pad_top, g.pad_left, pad_value))
+        return out
+
+    def nms_batch(self, pred: torch.Tensor, nc: int, dcfg: DetectConfig, geom: torch.Tensor, n_extra: int = 0,
+                  rows=None, keep=None, count=None, max_det: int | None = None):
+        """pred: [B,(4+nc+n_extra),N] float32; geom: [B,5] float32 rows (gain, pad_x, pad_y, w0, h0), both on the
+        device.  One set of launches for the whole batch."""
+        B, N = pred.shape[0], pred.shape[2]
+        md = min(dcfg.max_det, 1024) if max_det is None else max_det
+        stride = 6 + n_extra
+        if rows is None:
+            rows = torch.zeros(B, md, stride, dtype=torch.float32, device=self.device)
+            keep = torch.zeros(B, md, dtype=torch.int32, device=self.device)
+            count = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self._ck(self.L.ss_nms_batch(self.ctx, _ptr(pred), B, pred.stride(0), N, nc, n_extra, dcfg.conf, dcfg.iou,
+                                     int(dcfg.agnostic_nms), dcfg.max_wh, md, _ptr(geom), _ptr(rows), rows.stride(1),
+                                     rows.stride(0), _ptr(keep), keep.stride(0), _ptr(count)))
+        return rows, keep, count
+
+    def crop_norm_batch(self, frames: torch.Tensor, dets: torch.Tensor, n: int, counts=None, half: bool = False,
+                        out=None, channels_last: bool = False):
+        """frames uint8 [B,H,W,3], dets [B,cap,>=4] float32, counts [B] int32 -> crops [B*n,3,256,128]."""
+        B, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        if out is None:
+            out = torch.empty(B * n, 3, 256, 128, dtype=torch.float16 if half else torch.float32, device=self.device,
+                              memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+        flags = (_lib.DST_F16 if half else 0) | (_lib.DST_HWC if channels_last else 0)
+        self._ck(self.L.ss_crop_norm_batch(self.ctx, _ptr(frames), B, frames.stride(0), H, W, frames.stride(1), _ptr(dets),
+                                           dets.stride(1), dets.stride(0), n, _ptr(counts), _ptr(out), flags))
+        return out
+
     def nms(self, pred: torch.Tensor, nc: int, dcfg: DetectConfig, gain: float, pad_x: float, pad_y: float,
             w0: int, h0: int, n_extra: int = 0, rows=None, keep=None, count=None):
         """pred: [(4+nc+n_extra), N] float32 on the device."""

@@ -16,10 +16,12 @@ CSRC = os.path.join(_HERE, "csrc")
 
 SS_OK, SS_ERR_INVALID, SS_ERR_CAPACITY, SS_ERR_HIP, SS_ERR_INFEASIBLE = 0, -1, -2, -3, -4
 MAX_TRACKS, MAX_DETS, FEAT_DIM, OUT_COLS = 256, 128, 512, 8
+DST_F16, DST_HWC = 1, 2
 
 EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
-    "ss_letterbox", "ss_nms", "ss_crop_norm", "ss_track_update", "ss_track_update_host",
+    "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_crop_norm", "ss_crop_norm_batch",
+    "ss_track_update", "ss_track_update_host",
     "ss_check_errors", "ss_set_track_grid", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
     "ss_get_gallery", "ss_assoc_timing", "ss_get_timestamps", "ss_op_bias_act_f16", "ss_op_dwconv3x3_f16", "ss_op_gate_sum_f16", "ss_op_maxpool_f16",
@@ -77,6 +79,10 @@ def load():
     L.ss_letterbox.argtypes = [vp, u8, i, i, i, vp, i, i, i, i, i, i, i, i]
     L.ss_nms.argtypes = [vp, fp, i, i, i, f, f, i, f, i, f, f, f, f, f, fp, i, ip, ip]
     L.ss_crop_norm.argtypes = [vp, u8, i, i, i, fp, i, i, ip, vp, i]
+    ll = C.c_longlong
+    L.ss_letterbox_batch.argtypes = [vp, u8, i, ll, i, i, i, vp, i, i, i, i, i, i, i, i]
+    L.ss_nms_batch.argtypes = [vp, fp, i, ll, i, i, i, f, f, i, f, i, fp, fp, i, ll, ip, ll, ip]
+    L.ss_crop_norm_batch.argtypes = [vp, u8, i, ll, i, i, i, fp, i, ll, i, ip, vp, i]
     L.ss_track_update.argtypes = [vp, fp, ip, fp, ip, fp, ip]
     hf, hi = C.POINTER(C.c_float), C.POINTER(C.c_int)
     L.ss_track_update_host.argtypes = [vp, i, hf, i, hf, i, i, hf, i, hi]

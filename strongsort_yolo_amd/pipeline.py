@@ -64,13 +64,14 @@ class FramePipeline:
         # ---- static buffers (addresses are baked into the graph) ----
         self.frames = torch.zeros(S, self.H, self.W, 3, dtype=torch.uint8, device=dev)
         self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
-        self.lb_planar = torch.zeros(S, 3, g.out_h, g.out_w, dtype=self.dtype, device=dev)
+        self.geom_dev = torch.tensor([[self.gain, self.pad_x, self.pad_y, float(self.W), float(self.H)]] * S,
+                                     dtype=torch.float32, device=dev)      # per-image scale_boxes geometry for ss_nms_batch
         self.pred_in = torch.zeros(S, 4 + self.nc + self.nk, self.n_anchors, dtype=torch.float32, device=dev)
         self.dets = torch.zeros(S, MAX_DETS, 6 + self.nk, dtype=torch.float32, device=dev)
         self.dets6 = self.dets if self.nk == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
         self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.dtype, device=dev)
+        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.feats_in = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.img_hw = torch.tensor([[self.H, self.W]] * S, dtype=torch.int32, device=dev)
         self.out, self.nout = self.eng.out, self.eng.nout
@@ -81,27 +82,22 @@ class FramePipeline:
 
     # ---- one frame for every stream, from the static buffers ----------------------------------------
     def _step_impl(self):
+        # every frame-side stage is ONE launch (set) over all S streams, written straight in the NHWC layout the
+        # convolutions read
         e, S, g = self.eng, self.S, self.geom
         if self.run_nets:
-            for s in range(S):
-                e.letterbox(self.frames[s], g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb_planar[s])
-            self.lb.copy_(self.lb_planar)                       # planar -> channels_last for MIOpen
+            e.letterbox_batch(self.frames, g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb, channels_last=True)
             pred = self.detector(self.lb)                       # [S, 4+nc+nk, A]
             if self.det_source == "detector":
                 self.pred_in.copy_(pred)
-        md = min(self.dcfg.max_det, MAX_DETS)
-        for s in range(S):
-            self.eng._ck(e.L.ss_nms(e.ctx, _p(self.pred_in[s]), self.n_anchors, self.nc, self.nk, self.dcfg.conf,
-                                    self.dcfg.iou, int(self.dcfg.agnostic_nms), self.dcfg.max_wh, md, self.gain,
-                                    self.pad_x, self.pad_y, float(self.W), float(self.H), _p(self.dets[s]),
-                                    6 + self.nk, _p(self.keep[s]), _p(self.ndets[s:s + 1])))
+        e.nms_batch(self.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=self.dets, keep=self.keep,
+                    count=self.ndets, max_det=min(self.dcfg.max_det, MAX_DETS))
         if self.nk:
             self.dets6.copy_(self.dets[:, :, :6])
         if self.run_nets:
-            for s in range(S):
-                e.crop_norm(self.frames[s], self.dets6[s], self.RB, count=self.ndets[s:s + 1], half=self.half,
-                            out=self.crops[s * self.RB:(s + 1) * self.RB])
-            emb = self.reid(self.crops.contiguous(memory_format=torch.channels_last))     # [S*RB, 512]
+            e.crop_norm_batch(self.frames, self.dets6, self.RB, counts=self.ndets, half=self.half, out=self.crops,
+                              channels_last=True)
+            emb = self.reid(self.crops)                         # [S*RB, 512]
             if self.feat_source == "reid":
                 self.feats_in[:, :self.RB].copy_(emb.view(S, self.RB, FEAT_DIM))
         if self.feat_source == "by_anchor":
@@ -179,13 +175,12 @@ class _Bufs:
         dev, S, g = p.dev, getattr(p, "Sv", p.S), p.geom
         self.frames = torch.zeros(S, p.H, p.W, 3, dtype=torch.uint8, device=dev)
         self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
-        self.lb_planar = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev)
         self.pred_in = torch.zeros(S, 4 + p.nc + p.nk, p.n_anchors, dtype=torch.float32, device=dev)
         self.dets = torch.zeros(S, MAX_DETS, 6 + p.nk, dtype=torch.float32, device=dev)
         self.dets6 = self.dets if p.nk == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
         self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev)
+        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
 
@@ -223,6 +218,7 @@ class OverlappedPipeline(FramePipeline):
         if self.F > 1:
             self.graph_mode = "front"       # the per-frame tracker calls stay eager (partial last groups)
         self.Sv = self.S * self.F
+        self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
         self.feats_v = torch.zeros(self.Sv, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=self.dev)
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
@@ -253,10 +249,8 @@ class OverlappedPipeline(FramePipeline):
 
     # ---- stage bodies (b = the frame's buffer set) -------------------------------------------------------
     def _letterbox(self, b):
-        e = self.eng
-        for s in range(self.Sv):
-            e.letterbox(b.frames[s], self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb_planar[s])
-        b.lb.copy_(b.lb_planar)
+        self.eng.letterbox_batch(b.frames, self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb,
+                                 channels_last=True)
 
     @staticmethod
     def _keep(b, name, tensors):
@@ -286,18 +280,13 @@ class OverlappedPipeline(FramePipeline):
                 b.pred_in.copy_(pred)
 
     def _nms_crop(self, b):
-        e, S = self.eng, self.Sv
-        md = min(self.dcfg.max_det, MAX_DETS)
-        for s in range(S):
-            e._ck(e.L.ss_nms(e.ctx, _p(b.pred_in[s]), self.n_anchors, self.nc, self.nk, self.dcfg.conf, self.dcfg.iou,
-                             int(self.dcfg.agnostic_nms), self.dcfg.max_wh, md, self.gain, self.pad_x, self.pad_y,
-                             float(self.W), float(self.H), _p(b.dets[s]), 6 + self.nk, _p(b.keep[s]), _p(b.ndets[s:s + 1])))
+        e = self.eng                       # one launch set over all S*F virtual streams
+        e.nms_batch(b.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=b.dets, keep=b.keep,
+                    count=b.ndets, max_det=min(self.dcfg.max_det, MAX_DETS))
         if self.nk:
             b.dets6.copy_(b.dets[:, :, :6])
         if self.run_nets:
-            for s in range(S):
-                e.crop_norm(b.frames[s], b.dets6[s], self.RB, count=b.ndets[s:s + 1], half=self.half,
-                            out=b.crops[s * self.RB:(s + 1) * self.RB])
+            e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.half, out=b.crops, channels_last=True)
 
     def _select(self, b, emb):
         if emb is not None and self.feat_source == "reid":
@@ -308,14 +297,14 @@ class OverlappedPipeline(FramePipeline):
 
     def _s_nms_crop_reid_a(self, b):
         self._nms_crop(b)
-        self._keep(b, "mid", [self.reid.forward_a(b.crops.contiguous(memory_format=torch.channels_last))])
+        self._keep(b, "mid", [self.reid.forward_a(b.crops)])
 
     def _s_reid_b_select(self, b):
         self._select(b, self.reid.forward_b(b.mid[0]))
 
     def _s_nms_crop_reid_select(self, b):
         self._nms_crop(b)
-        emb = self.reid(b.crops.contiguous(memory_format=torch.channels_last)) if self.run_nets else None
+        emb = self.reid(b.crops) if self.run_nets else None
         self._select(b, emb)
 
     def _track_b(self, b: _Bufs, n_valid: int = None, group: int = None):

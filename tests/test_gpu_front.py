@@ -135,3 +135,108 @@ def test_nms_carries_extra_channels(eng):
     assert k > 10 and np.array_equal(keep, rkeep)
     assert bits_equal(rows[:, :6], cexact.scale_boxes(rrows, 1.0, 0.0, 0.0, 320, 256))
     assert bits_equal(rows[:, 6:], np.ascontiguousarray(pred[5:, keep].T))
+
+
+# ---- batched launches (one per stage over all streams / frames of a group) -----------------------------
+@pytest.mark.parametrize("half,hwc", [(False, False), (True, False), (False, True), (True, True)])
+def test_letterbox_batch_bit_exact(eng, half, hwc):
+    W, H, B = 1280, 720, 5
+    rng = np.random.default_rng(11)
+    imgs = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    g = letterbox_geometry(H, W)
+    out = eng.letterbox_batch(torch.from_numpy(imgs).to(eng.device), g, half=half, channels_last=hwc)
+    assert out.shape == (B, 3, g.out_h, g.out_w)
+    assert out.is_contiguous(memory_format=torch.channels_last if hwc else torch.contiguous_format)
+    got = out.cpu().numpy()                                  # logical NCHW view either way
+    for b in range(B):
+        ref = cexact.letterbox(imgs[b], g.out_h, g.out_w, g.new_h, g.new_w, g.pad_top, g.pad_left)
+        assert bits_equal(got[b], ref.astype(np.float16) if half else ref)
+
+
+def test_nms_batch_bit_exact_mixed_geometry(eng):
+    """Images of one batch carry their own scale_boxes geometry; one of them is empty, one is dense."""
+    dcfg = DetectConfig()
+    nc, N = 80, 5040
+    rng = np.random.default_rng(21)
+    sizes = [(1280, 720), (1920, 1080), (1280, 720), (1280, 720), (1920, 1080), (1280, 720)]
+    preds, geoms = [], []
+    for b, (W, H) in enumerate(sizes):
+        g = letterbox_geometry(H, W)
+        gain, px, py = scale_geometry(g, H, W)
+        if b == 2:                                           # nothing above threshold
+            pred = rng.uniform(0, 0.2, (4 + nc, N)).astype(np.float32)
+        elif b == 3:                                         # dense random field: hundreds of survivors
+            pred = np.zeros((4 + nc, N), np.float32)
+            pred[0] = rng.uniform(0, 640, N); pred[1] = rng.uniform(0, 384, N)
+            pred[2] = rng.uniform(10, 80, N); pred[3] = rng.uniform(10, 80, N)
+            pred[4:6] = rng.uniform(0, 1, (2, N))
+        else:
+            fr = make_stream(30 + b, W, H, 20 + 15 * b, n_classes=3).next_frame()
+            pred, _ = synth_prediction(fr.dets, N, nc, gain, (px, py), rng)
+        preds.append(pred); geoms.append([gain, px, py, float(W), float(H)])
+    P = torch.from_numpy(np.stack(preds)).to(eng.device)
+    G = torch.tensor(geoms, dtype=torch.float32, device=eng.device)
+    rows, keep, count = eng.nms_batch(P, nc, dcfg, G)
+    rows, keep, count = rows.cpu().numpy(), keep.cpu().numpy(), count.cpu().numpy()
+    for b, (W, H) in enumerate(sizes):
+        rkeep, rrows = cexact.nms(preds[b], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+        rrows = cexact.scale_boxes(rrows, geoms[b][0], geoms[b][1], geoms[b][2], W, H)
+        k = int(count[b])
+        assert k == len(rkeep), b
+        assert np.array_equal(keep[b, :k], rkeep)
+        assert bits_equal(rows[b, :k], rrows)
+    assert count[2] == 0 and count[3] > 100
+    # the same batch again (counters re-armed in-kernel) and a smaller batch on the grown workspace
+    rows2, keep2, count2 = eng.nms_batch(P, nc, dcfg, G)
+    assert np.array_equal(count2.cpu().numpy(), count) and bits_equal(rows2.cpu().numpy(), rows)
+    r1, k1, c1 = eng.nms_batch(P[4:5], nc, dcfg, G[4:5])
+    assert int(c1[0]) == count[4] and bits_equal(r1.cpu().numpy()[0], rows[4])
+    # and the single-image entry point agrees with its row of the batch
+    r0, k0, c0 = eng.nms(P[1], nc, dcfg, geoms[1][0], geoms[1][1], geoms[1][2], 1920, 1080)
+    assert int(c0.item()) == count[1] and bits_equal(r0.cpu().numpy()[:count[1]], rows[1, :count[1]])
+    eng.check_errors()
+
+
+def test_nms_candidate_overflow_is_reported(eng):
+    """More than 8192 candidates above conf: the image yields no rows and ss_check_errors raises CAPACITY
+    (the reference's max_nms=30000 truncation is out of the supported range and must not pass silently)."""
+    from strongsort_yolo_amd.lib import SSError, SS_ERR_CAPACITY
+    dcfg = DetectConfig()
+    nc, N = 2, 21504
+    rng = np.random.default_rng(5)
+    pred = np.zeros((4 + nc, N), np.float32)
+    pred[0] = rng.uniform(0, 640, N); pred[1] = rng.uniform(0, 640, N); pred[2:4] = 20.0
+    pred[4] = rng.uniform(0.5, 1.0, N)
+    _, _, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 1.0, 0.0, 0.0, 640, 640)
+    assert int(count.item()) == 0
+    with pytest.raises(SSError) as ei:
+        eng.check_errors()
+    assert ei.value.code == SS_ERR_CAPACITY
+    eng.reset(-1)
+    eng.check_errors()
+
+
+@pytest.mark.parametrize("half,hwc", [(False, False), (True, True)])
+def test_crop_norm_batch_bit_exact(eng, half, hwc):
+    W, H, B, n = 1280, 720, 3, 16
+    imgs, dets, counts = [], np.zeros((B, 32, 6), np.float32), []
+    for b in range(B):
+        s = make_stream(40 + b, W, H, 6 + 5 * b)
+        fr = s.next_frame()
+        imgs.append(s.frame_pixels(0))
+        k = min(len(fr.dets), n)
+        dets[b, :k] = fr.dets[:k]
+        counts.append(k)
+    dets[0, 0, :4] = [-5.0, -3.0, 20.5, 30.2]
+    dets[1, 1, :4] = [W - 10.0, H - 12.0, W + 50.0, H + 50.0]
+    out = torch.full((B * n, 3, 256, 128), 7.0, dtype=torch.float16 if half else torch.float32, device=eng.device)
+    if hwc:
+        out = out.contiguous(memory_format=torch.channels_last)
+    eng.crop_norm_batch(torch.from_numpy(np.stack(imgs)).to(eng.device), torch.from_numpy(dets).to(eng.device), n,
+                        counts=torch.tensor(counts, dtype=torch.int32, device=eng.device), half=half, out=out,
+                        channels_last=hwc)
+    got = out.cpu().numpy().reshape(B, n, 3, 256, 128)
+    for b in range(B):
+        ref = cexact.crop_norm(imgs[b], dets[b, :counts[b]])
+        assert bits_equal(got[b, :counts[b]], ref.astype(np.float16) if half else ref)
+        assert np.all(got[b, counts[b]:] == 7.0)             # rows past the count stay untouched
