@@ -10,10 +10,12 @@ Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synt
 data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
 
 Throughput structure (all of it result-preserving — every frame runs every stage, rows are bit-identical to the
-oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 4)
-consecutive frames of a stream at a time, the tracker consumes them one by one in frame order; stage A of
-group k+1 overlaps stage B of group k on a second HIP stream (`--overlap`).  `--frame-batch 1 --overlap 0` is
-the strictly frame-at-a-time pipeline (profiles/ keeps both lines).
+oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 8)
+consecutive frames of a stream at a time — a decoded video file or a capture queue supplies them; it costs
+frame_batch frame periods of latency on a live camera — and the tracker consumes them one by one in frame
+order; stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
+stage B of group k (rest of OSNet, feature select, tracker) on a second HIP stream (`--overlap`).
+`--frame-batch 1 --overlap 0` is the strictly frame-at-a-time pipeline (profiles/ keeps these lines too).
 
 Synthetic data (no weights / decoder offline): the detector and OSNet are seeded random-init nets
 of the published shapes and run on every frame for load; the detections the tracker sees come from
@@ -210,7 +212,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
-    ap.add_argument("--frame-batch", type=int, default=4, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
+    ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
+    ap.add_argument("--frame-batch", type=int, default=8, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
 
@@ -242,7 +245,7 @@ def main():
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch} if overlap else {}))
+                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split} if overlap else {}))
     FB = args.frame_batch if overlap else 1
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors

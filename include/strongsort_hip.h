@@ -166,6 +166,10 @@ int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int ca
 int ss_op_bias_act_f16(void* stream, void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C, int act);
 int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
                         int N, int H, int W, int C, int act);
+/* OSNet LightConv3x3 in one pass: y = relu(dw3x3(pw1x1(x)) + bias); w1 [C][C] (out, in), w9 [9][C], C in
+ * {16,24,32}, W % 8 == 0, 18*(W+2)*C*2 <= 65536 (the band lives in LDS; SS_ERR_INVALID otherwise). */
+int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
+                        void* d_y, int N, int H, int W, int C);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */
 int ss_op_maxpool_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C, int k, int stride, int pad);
 /* OSNet unified aggregation gate: out = sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))), T <= 4 streams. */

@@ -88,6 +88,110 @@ __global__ __launch_bounds__(256) void k_dw3x3(const __half* __restrict__ x, con
     }
 }
 
+// OSNet "LightConv3x3" in one pass: y = relu(dw3x3(pw1x1(x)) + bias), C in {16, 24, 32}.
+//
+// The two-launch form (GEMM, then k_dw3x3) writes and re-reads the C-channel intermediate through HBM and
+// spends a hipBLASLt launch on a [pixels x C] x [C x C] product whose K is 16..32.  Here a workgroup owns a
+// TH-row band of one image: phase 1 computes the pointwise product for the band plus one halo row each side
+// on the matrix cores (v_mfma_f32_16x16x16_f16: M = output channel, N = 16 pixels, K = input channel; the
+// weights are the A operand and stay in registers) and parks it as f16 in LDS with a zero pad column each
+// side; phase 2 is the depthwise 3x3 + bias + ReLU out of LDS (thread = pixel x 8 channels, tap weights in
+// registers, same fmaf order as k_dw3x3).  HBM traffic = read x once (+2/TH halo) + write y once.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define LC_TH 16
+
+template <int C>
+__global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x, const __half* __restrict__ w1,
+                                                  const __half* __restrict__ w9, const __half* __restrict__ bias,
+                                                  __half* __restrict__ y, int H, int W, int bands)
+{
+    constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH;
+    extern __shared__ __attribute__((aligned(16))) char lc_smem[];
+    _Float16* T = (_Float16*)lc_smem;                       // [(TH+2)][W+2][C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x / bands, y0 = (blockIdx.x - img * bands) * TH;
+    const int WP = W + 2;
+    const h4 z4 = { 0, 0, 0, 0 };
+
+    for (int i = tid; i < (TH + 2) * 2 * C8; i += 256) {    // zero pad columns 0 and W+1
+        const int c8 = i % C8, rc = i / C8, r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
+        h8 z = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        *reinterpret_cast<h8*>(T + ((size_t)(r * WP + col) * C + c8 * 8)) = z;
+    }
+
+    // ---- phase 1: pointwise product on the matrix cores ----
+    const int q = lane >> 4, n = lane & 15;
+    h4 a[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int oc = mt * 16 + n, ic0 = ks * 16 + 4 * q;
+            a[mt][ks] = (oc < C && ic0 < C) ? *reinterpret_cast<const h4*>(w1 + (size_t)oc * C + ic0) : z4;
+        }
+    const __half* xi = x + (size_t)img * H * W * C;
+    const int NT = (TH + 2) * W / 16;
+    auto load_b = [&](int t, h4 (&b)[KS]) {
+        const int p = t * 16 + n, r = p / W, c = p - r * W, gr = y0 - 1 + r;
+        const bool ok = t < NT && gr >= 0 && gr < H;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ic0 = ks * 16 + 4 * q;
+            b[ks] = (ok && ic0 < C) ? *reinterpret_cast<const h4*>(xi + ((size_t)gr * W + c) * C + ic0) : z4;
+        }
+    };
+    h4 bcur[KS], bnext[KS];
+    load_b(wave, bcur);
+    for (int t = wave; t < NT; t += 4) {
+        load_b(t + 4, bnext);                               // next tile's pixels in flight during this tile's MFMAs
+        const int p = t * 16 + n, r = p / W, c = p - r * W;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f4 d = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt][ks], bcur[ks], d, 0, 0, 0);
+            const int oc0 = mt * 16 + 4 * q;
+            if (oc0 < C) {
+                h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
+                *reinterpret_cast<h4*>(T + ((size_t)(r * WP + c + 1) * C + oc0)) = o;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
+    }
+    __syncthreads();
+
+    // ---- phase 2: depthwise 3x3 + bias + ReLU out of LDS ----
+    constexpr int PXPAR = 256 / C8;
+    const int c8 = tid % C8, ps = tid / C8;
+    if (ps >= PXPAR) return;
+    h8 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9)[k * C8 + c8];
+    const h8 bb = reinterpret_cast<const h8*>(bias)[c8];
+    const int npx = TH * W;
+    for (int p = ps; p < npx; p += PXPAR) {
+        const int py = p / W, px = p - py * W, gy = y0 + py;
+        if (gy >= H) break;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = (float)bb[k];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const h8 v = *reinterpret_cast<const h8*>(T + ((size_t)((py + ky) * WP + px + kx) * C + c8 * 8));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)wk[ky * 3 + kx][k], acc[k]);
+            }
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] > 0.f ? acc[k] : 0.f);
+        reinterpret_cast<h8*>(y)[(((size_t)img * H + gy) * W + px) * C8 + c8] = o;
+    }
+}
+
 // OSNet unified aggregation gate over T <= 4 streams.
 //   step 1: mean over H*W of every stream -> means[t][n][C] (f32)
 //   step 2: g_t = sigmoid(fc2(relu(fc1(mean_t)))) per sample, out = sum_t x_t * g_t
@@ -213,6 +317,25 @@ extern "C" int ss_op_dwconv3x3_f16(void* stream, const void* x, const void* w9, 
     size_t total = (size_t)N * H * W * (C / 8);
     hipLaunchKernelGGL(k_dw3x3, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)w9,
                        (const __half*)bias, (__half*)y, N, H, W, C / 8, act);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_lightconv_f16(void* stream, const void* x, const void* w1, const void* w9, const void* bias, void* y,
+                                   int N, int H, int W, int C)
+{
+    if (!x || !w1 || !w9 || !bias || !y || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
+    const size_t lds = (size_t)(LC_TH + 2) * (W + 2) * C * 2;
+    if (lds > 65536) return SS_ERR_INVALID;
+    const int bands = (H + LC_TH - 1) / LC_TH;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((size_t)N * bands)), block(256);
+#define SS_LC(CC) hipLaunchKernelGGL(k_lightconv<CC>, grid, block, lds, st, (const __half*)x, (const __half*)w1, \
+                                     (const __half*)w9, (const __half*)bias, (__half*)y, H, W, bands)
+    if (C == 16) SS_LC(16);
+    else if (C == 24) SS_LC(24);
+    else if (C == 32) SS_LC(32);
+    else return SS_ERR_INVALID;
+#undef SS_LC
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

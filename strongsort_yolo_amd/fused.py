@@ -54,6 +54,23 @@ def dwconv3x3(x, w9, bias, act="relu"):
     return y
 
 
+LIGHTCONV = True            # fused pointwise + depthwise path of OSNet's LightConv3x3 (off: GEMM + dwconv3x3)
+
+
+def lightconv_ok(x) -> bool:
+    n, c, h, w = x.shape
+    return LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 18 * (w + 2) * c * 2 <= 65536
+
+
+def lightconv(x, w1, w9, bias):
+    """relu(dw3x3(pw1x1(x)) + bias) in one launch.  w1 [C,C] (out, in) of the pointwise conv, w9 [9,C] tap-major."""
+    x = _cl(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_lightconv_f16(_st(x), _p(x), _p(w1), _p(w9), _p(bias), _p(y), n, h, w, c))
+    return y
+
+
 def gate_sum(xs, w1, b1, w2, b2):
     xs = [_cl(x) for x in xs]
     n, c, h, w = xs[0].shape

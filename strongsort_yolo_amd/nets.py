@@ -307,6 +307,9 @@ class LightConv3x3(nn.Module):
         if fused.usable(x):          # 1x1 conv (MIOpen) + fused depthwise 3x3 + bias + ReLU
             if getattr(self, "_w9", None) is None or self._w9.device != x.device:
                 self._w9 = self.dw.weight.detach().reshape(self.dw.weight.shape[0], 9).t().contiguous()
+                self._w1 = self.pw.weight.detach().reshape(self.pw.weight.shape[0], -1).contiguous()
+            if self._w1.shape[0] == self._w1.shape[1] and fused.lightconv_ok(x):      # one pass: MFMA pointwise -> LDS -> depthwise
+                return fused.lightconv(x, self._w1, self._w9, self.dw.bias)
             return fused.dwconv3x3(fused.conv1x1(x, fused.weight_t(self, self.pw)), self._w9, self.dw.bias, "relu")
         return F.relu(self.dw(self.pw(x)), inplace=True)
 
@@ -358,19 +361,38 @@ class OSNet(nn.Module):
         self.conv5 = ConvBR(c[3], c[3], 1)
         self.fc = nn.Linear(c[3], feature_dim)
 
-    def forward_a(self, x):
-        x = self.conv1(x)
-        x = fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
-        return self.conv3[0](self.conv2(x))                     # through the first block of conv3 (~half the launches)
+    N_PARTS = 10
 
-    def forward_b(self, x):
-        for m in list(self.conv3)[1:]:
-            x = m(x)
-        x = self.conv5(self.conv4(x))
+    def _part(self, k, x):
+        """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages."""
+        if k == 0:
+            x = self.conv1(x)
+            return fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
+        if k in (1, 2):
+            return self.conv2[k - 1](x)
+        if k == 3:
+            return self.conv2[3](self.conv2[2](x))
+        if k in (4, 5):
+            return self.conv3[k - 4](x)
+        if k == 6:
+            return self.conv3[3](self.conv3[2](x))
+        if k in (7, 8):
+            return self.conv4[k - 7](x)
+        return self.conv5(x)
+
+    def forward_a(self, x, upto: int = 5):
+        """Parts [0, upto): the default runs through the first block of conv3 (~half the launches)."""
+        for k in range(upto):
+            x = self._part(k, x)
+        return x
+
+    def forward_b(self, x, start: int = 5):
+        for k in range(start, self.N_PARTS):
+            x = self._part(k, x)
         return F.relu(self.fc(x.mean((2, 3))))
 
     def forward(self, x):
-        return self.forward_b(self.forward_a(x))
+        return self.forward_b(self.forward_a(x, 0), 0)
 
 
 def osnet_x0_25():

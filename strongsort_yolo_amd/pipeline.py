@@ -201,10 +201,12 @@ class OverlappedPipeline(FramePipeline):
     because the GPU is otherwise idle between the ~4 us launches of these batch-1 networks.  Every stage of
     every buffer set is one captured HIP graph; buffer sets = stages.  Measured at configs[1] on MI355X: 1 stage
     427, 2 stages 761, 4 stages 659 frames/s (four concurrent launch chains contend in the dispatcher), so the
-    default is 2: [letterbox, detector] | [NMS, crops, OSNet, select, tracker].
+    default is 2: [letterbox, detector] | [NMS, crops, OSNet, select, tracker]; `reid_split=k` moves the cut to
+    after part k of the ReID backbone ([letterbox, detector, NMS, crops, OSNet parts <k] | [rest, tracker]) so
+    the two streams carry equal work when frames are batched.
     """
 
-    def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, **kw):
+    def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None, **kw):
         kw = dict(kw)
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
@@ -224,12 +226,23 @@ class OverlappedPipeline(FramePipeline):
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
         split_det = self.run_nets and n_stages >= 4 and hasattr(self.detector, "forward_backbone")
         split_reid = self.run_nets and n_stages >= 4 and hasattr(self.reid, "forward_a")
+        # two stages can also be cut INSIDE the ReID network to balance them: stage 0 = letterbox, detector, NMS,
+        # crops and OSNet parts [0, reid_split); stage 1 = the remaining parts, feature select and the tracker
+        self.reid_split = None
+        if reid_split is not None and n_stages == 2:
+            self.reid_split = int(reid_split) if (self.run_nets and hasattr(self.reid, "N_PARTS")) else 0
+            if not 0 <= self.reid_split <= getattr(self.reid, "N_PARTS", 0):
+                raise ValueError("reid_split out of range")
         st = []
-        if split_det:
+        if self.reid_split is not None:
+            st += [self._s_front_split, self._s_back_split]
+        elif split_det:
             st += [self._s_backbone, self._s_head]
         else:
             st += [self._s_detector]
-        if split_reid:
+        if self.reid_split is not None:
+            pass
+        elif split_reid:
             st += [self._s_nms_crop_reid_a, self._s_reid_b_select]
         else:
             st += [self._s_nms_crop_reid_select]
@@ -305,6 +318,18 @@ class OverlappedPipeline(FramePipeline):
     def _s_nms_crop_reid_select(self, b):
         self._nms_crop(b)
         emb = self.reid(b.crops) if self.run_nets else None
+        self._select(b, emb)
+
+    def _s_front_split(self, b):
+        self._s_detector(b)
+        self._nms_crop(b)
+        if self.run_nets and self.reid_split > 0:
+            self._keep(b, "mid", [self.reid.forward_a(b.crops, self.reid_split)])
+
+    def _s_back_split(self, b):
+        emb = None
+        if self.run_nets:
+            emb = self.reid.forward_b(b.mid[0] if self.reid_split > 0 else b.crops, self.reid_split)
         self._select(b, emb)
 
     def _track_b(self, b: _Bufs, n_valid: int = None, group: int = None):
