@@ -264,6 +264,21 @@ def main():
             b.anchor_gt[v].copy_(p["agt"][k])
             b.gt_feats[v].copy_(p["feats"][k])
 
+    def feed_group(g0, n, b):
+        """Frames g0..g0+n-1 of every stream into the group's buffers: one device copy per input tensor per stream
+        (stands for the decoder writing its frames into the batch buffer)."""
+        for s, p in enumerate(pools):
+            npix = p["pixels"].shape[0]
+            k0 = g0 % npix
+            if k0 + n <= npix:
+                b.frames.view(FB, S, *b.frames.shape[1:])[:n, s].copy_(p["pixels"][k0:k0 + n])
+            else:
+                for f in range(n):
+                    b.frames[f * S + s].copy_(p["pixels"][(g0 + f) % npix])
+            b.pred_in.view(FB, S, *b.pred_in.shape[1:])[:n, s].copy_(p["preds"][g0:g0 + n])
+            b.anchor_gt.view(FB, S, *b.anchor_gt.shape[1:])[:n, s].copy_(p["agt"][g0:g0 + n])
+            b.gt_feats.view(FB, S, *b.gt_feats.shape[1:])[:n, s].copy_(p["feats"][g0:g0 + n])
+
     if overlap:
         def fetch(k, f):
             out_host[k].copy_(pipe.outs[f], non_blocking=True)
@@ -276,8 +291,7 @@ def main():
                 n = min(FB, k1 - g0)
                 b = pipe.begin_frame()
                 with torch.cuda.stream(pipe.sA):
-                    for f in range(n):
-                        feed(g0 + f, b, f)
+                    feed_group(g0, n, b)
                 pipe.submit(n)
 
         def drain():

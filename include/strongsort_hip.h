@@ -164,6 +164,17 @@ int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int ca
  * (detector / OSNet forward inside model.track, yolo_multi_model.py:41).  `stream` is a hipStream_t.
  * act: 0 none, 1 relu, 2 silu, 3 sigmoid.  Tensors are channels-last half. */
 int ss_op_bias_act_f16(void* stream, void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C, int act);
+/* Epilogue with placement (C2f blocks): d_out[pix*out_ld + c] = act(x + bias)[c] (+ res after the activation when
+ * res_after), d_out pointing at a channel slice of a wider NHWC tensor (pitch out_ld elements); channels
+ * [c0, c0+cn) are also written densely to d_out2 when it is not NULL.  C, out_ld, c0, cn multiples of 8. */
+int ss_op_bias_act_place_f16(void* stream, const void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C,
+                             int act, int res_after, void* d_out, int out_ld, void* d_out2, int c0, int cn);
+/* YOLOv8 anchor-free head decode: per level l<3 the branch outputs d_box[l] [B][H][W][64] and d_cls[l] [B][H][W][nc]
+ * (NHWC half, final 1x1 conv without bias; the biases are added here) -> d_pred [B][4+nc][A] float (xywh in input
+ * pixels, class sigmoid), A = sum H[l]*W[l] — the tensor ss_nms reads.  H, W, strides are host int[3]. */
+int ss_op_v8_decode_f16(void* stream, const void* const* d_box, const void* const* d_cls, const void* const* d_box_bias,
+                        const void* const* d_cls_bias, const int* H, const int* W, const int* strides, int B, int nc,
+                        float* d_pred);
 int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
                         int N, int H, int W, int C, int act);
 /* OSNet LightConv3x3 in one pass: y = relu(dw3x3(pw1x1(x)) + bias); w1 [C][C] (out, in), w9 [9][C], C in

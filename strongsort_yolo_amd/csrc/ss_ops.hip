@@ -88,6 +88,90 @@ __global__ __launch_bounds__(256) void k_dw3x3(const __half* __restrict__ x, con
     }
 }
 
+// Epilogue with placement: out[pix][0..C) = act(x + bias) (+ res after the activation when res_after), where `out`
+// is a channel slice of a wider NHWC tensor (row pitch out_ld elements) — a C2f block's concat buffer — and
+// channels [c0, c0+cn) are optionally mirrored into a second, dense tensor (the half the next bottleneck
+// convolves).  Replaces chunk().contiguous(), the shortcut add and torch.cat's per-input copies.
+__global__ __launch_bounds__(256) void k_bias_act_place(const __half* __restrict__ x, const __half* __restrict__ bias,
+                                                       const __half* __restrict__ res, size_t n_vec, int C8, int act,
+                                                       int res_after, __half* __restrict__ out, int out_ld8,
+                                                       __half* __restrict__ out2, int c0_8, int cn_8)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t pix = i / C8;
+        const int c8 = (int)(i - pix * C8);
+        h8 v = reinterpret_cast<const h8*>(x)[i];
+        const h8 b = reinterpret_cast<const h8*>(bias)[c8];
+        h8 r;
+        if (res) r = reinterpret_cast<const h8*>(res)[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float f = (float)v[k] + (float)b[k];
+            if (res && !res_after) f += (float)r[k];
+            f = act_apply(f, act);
+            if (res && res_after) f = (float)(_Float16)f + (float)r[k];      // the unfused form rounds the activation first
+            v[k] = (_Float16)f;
+        }
+        reinterpret_cast<h8*>(out)[pix * out_ld8 + c8] = v;
+        if (out2 && c8 >= c0_8 && c8 < c0_8 + cn_8) reinterpret_cast<h8*>(out2)[pix * cn_8 + (c8 - c0_8)] = v;
+    }
+}
+
+// YOLOv8 anchor-free head decode in one pass (DFL softmax expectation, dist2bbox, stride scale, class sigmoid,
+// level concat): reads the six branch outputs of the three levels (NHWC half, final 1x1 conv WITHOUT its bias —
+// added here) and writes pred [B][4+nc][A] float, the layout ss_nms reads.  thread = one anchor of one image.
+struct V8Levels {
+    const __half* box[3]; const __half* cls[3];             // [B][H][W][64], [B][H][W][nc]
+    const __half* box_bias[3]; const __half* cls_bias[3];
+    int H[3], W[3], stride[3];
+};
+
+__global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, int A, float* __restrict__ pred)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= A) return;
+    int l = 0, a0 = 0;
+    while (l < 2 && a >= a0 + L.H[l] * L.W[l]) { a0 += L.H[l] * L.W[l]; ++l; }
+    const int p = a - a0, hw = L.H[l] * L.W[l];
+    const int py = p / L.W[l], px = p - py * L.W[l];
+    const h8* bx = reinterpret_cast<const h8*>(L.box[l] + ((size_t)b * hw + p) * 64);
+    const h8* bb = reinterpret_cast<const h8*>(L.box_bias[l]);
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16], m = -INFINITY;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const h8 t = bx[s * 2 + h], tb = bb[s * 2 + h];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[h * 8 + k] = (float)t[k] + (float)tb[k]; m = fmaxf(m, v[h * 8 + k]); }
+        }
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float e = __expf(v[k] - m); se += e; sw += e * (float)k; }
+        d[s] = sw / se;
+    }
+    const float ax = (float)px + 0.5f, ay = (float)py + 0.5f, st = (float)L.stride[l];
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    float* o = pred + (size_t)b * (4 + nc) * A + a;
+    o[0] = (x1 + x2) * 0.5f * st; o[(size_t)A] = (y1 + y2) * 0.5f * st;
+    o[(size_t)2 * A] = (x2 - x1) * st; o[(size_t)3 * A] = (y2 - y1) * st;
+    const __half* cl = L.cls[l] + ((size_t)b * hw + p) * nc;
+    const __half* cb = L.cls_bias[l];
+    if (nc % 8 == 0) {
+        for (int k8 = 0; k8 < nc / 8; ++k8) {
+            const h8 t = reinterpret_cast<const h8*>(cl)[k8], tb = reinterpret_cast<const h8*>(cb)[k8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[(size_t)(4 + k8 * 8 + k) * A] = 1.0f / (1.0f + __expf(-((float)t[k] + (float)tb[k])));
+        }
+        return;
+    }
+    for (int k = 0; k < nc; ++k) {
+        const float z = __half2float(cl[k]) + __half2float(cb[k]);
+        o[(size_t)(4 + k) * A] = 1.0f / (1.0f + __expf(-z));
+    }
+}
+
 // OSNet "LightConv3x3" in one pass: y = relu(dw3x3(pw1x1(x)) + bias), C in {16, 24, 32}.
 //
 // The two-launch form (GEMM, then k_dw3x3) writes and re-reads the C-channel intermediate through HBM and
@@ -317,6 +401,35 @@ extern "C" int ss_op_dwconv3x3_f16(void* stream, const void* x, const void* w9, 
     size_t total = (size_t)N * H * W * (C / 8);
     hipLaunchKernelGGL(k_dw3x3, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)w9,
                        (const __half*)bias, (__half*)y, N, H, W, C / 8, act);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_bias_act_place_f16(void* stream, const void* x, const void* bias, const void* res, long long n_pix, int C,
+                                        int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn)
+{
+    if (!x || !bias || !out || C < 8 || C % 8 || out_ld % 8 || out_ld < C || c0 % 8 || cn % 8 || (out2 && (cn < 8 || c0 + cn > C)))
+        return SS_ERR_INVALID;
+    const size_t nv = (size_t)n_pix * (C / 8);
+    hipLaunchKernelGGL(k_bias_act_place, dim3(grid_for(nv, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x,
+                       (const __half*)bias, (const __half*)res, nv, C / 8, act, res_after, (__half*)out, out_ld / 8,
+                       (__half*)out2, c0 / 8, cn / 8);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const void* const* cls, const void* const* box_bias,
+                                   const void* const* cls_bias, const int* H, const int* W, const int* strides, int B, int nc,
+                                   float* pred)
+{
+    if (!box || !cls || !box_bias || !cls_bias || !H || !W || !strides || !pred || B < 1 || B > 65535 || nc < 1) return SS_ERR_INVALID;
+    V8Levels L;
+    int A = 0;
+    for (int l = 0; l < 3; ++l) {
+        L.box[l] = (const __half*)box[l]; L.cls[l] = (const __half*)cls[l];
+        L.box_bias[l] = (const __half*)box_bias[l]; L.cls_bias[l] = (const __half*)cls_bias[l];
+        L.H[l] = H[l]; L.W[l] = W[l]; L.stride[l] = strides[l];
+        A += H[l] * W[l];
+    }
+    hipLaunchKernelGGL(k_v8_decode, dim3((A + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, L, B, nc, A, pred);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

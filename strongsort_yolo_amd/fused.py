@@ -46,6 +46,36 @@ def bias_act_(x, bias, act="none", res=None):
     return x
 
 
+def bias_act_place(y, bias, act, out, c_off, res=None, res_after=False, out2=None, c0=0):
+    """out[:, c_off:c_off+C] = act(y + bias) (+ res after the activation), `out` a wider channels-last tensor (a
+    concat buffer); channels [c0, c0+out2.C) are mirrored into the dense tensor `out2`.  One launch."""
+    y = _cl(y)
+    n, c, h, w = y.shape
+    if res is not None:
+        res = _cl(res)
+    ct = out.shape[1]
+    dst = C.c_void_p(out.data_ptr() + 2 * c_off)
+    _ck(_lib.load().ss_op_bias_act_place_f16(_st(y), _p(y), _p(bias), _p(res), n * h * w, c, ACT[act], int(res_after), dst, ct,
+                                             _p(out2), c0, 0 if out2 is None else out2.shape[1]))
+
+
+def place_ok(c: int, ctot: int) -> bool:
+    return c % 8 == 0 and ctot % 8 == 0
+
+
+def v8_decode(boxes, clss, box_bias, cls_bias, strides, nc):
+    """DFL + dist2bbox + sigmoid + level concat of the anchor-free head in one launch -> [B, 4+nc, A] float32."""
+    boxes, clss = [_cl(t) for t in boxes], [_cl(t) for t in clss]
+    B = boxes[0].shape[0]
+    H = (C.c_int * 3)(*[t.shape[2] for t in boxes]); W = (C.c_int * 3)(*[t.shape[3] for t in boxes])
+    A = sum(t.shape[2] * t.shape[3] for t in boxes)
+    pred = torch.empty(B, 4 + nc, A, dtype=torch.float32, device=boxes[0].device)
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    _ck(_lib.load().ss_op_v8_decode_f16(_st(pred), arr(boxes), arr(clss), arr(box_bias), arr(cls_bias), H, W,
+                                        (C.c_int * 3)(*strides), B, nc, _p(pred)))
+    return pred
+
+
 def dwconv3x3(x, w9, bias, act="relu"):
     x = _cl(x)
     n, c, h, w = x.shape

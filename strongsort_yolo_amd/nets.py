@@ -57,10 +57,31 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, e=1.0) for _ in range(n))
 
     def forward(self, x):
+        if fused.usable(x) and fused.place_ok(self.c, (2 + len(self.m)) * self.c) and all(type(m) is Bottleneck for m in self.m):
+            return self._forward_placed(x)
         y = list(self.cv1(x).chunk(2, 1))
         for m in self.m:
             y.append(m(y[-1]))
         return self.cv2(torch.cat(y, 1))
+
+    def _forward_placed(self, x):
+        """Same arithmetic, no chunk / add / cat launches: every producer's bias+SiLU epilogue writes straight into
+        its channel slice of the concat buffer (and a dense copy of the half the next 3x3 conv reads)."""
+        c, n = self.c, len(self.m)
+        B, _, H, W = x.shape
+        cat = torch.empty((B, (2 + n) * c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dense = lambda: torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        cv = self.cv1.conv
+        cur = dense()
+        fused.bias_act_place(F.conv2d(x, cv.weight, None, cv.stride, cv.padding), cv.bias, "silu", cat, 0, out2=cur, c0=c)
+        for i, m in enumerate(self.m):
+            cv = m.cv2.conv
+            t = F.conv2d(m.cv1(cur), cv.weight, None, cv.stride, cv.padding)
+            nxt = dense() if i + 1 < n else None
+            fused.bias_act_place(t, cv.bias, "silu", cat, (2 + i) * c, res=cur if m.add else None, res_after=True,
+                                 out2=nxt, c0=0)
+            cur = nxt
+        return self.cv2(cat)
 
 
 class C3(nn.Module):
@@ -117,6 +138,11 @@ class Detect(nn.Module):
 
     def forward(self, feats):
         B = feats[0].shape[0]
+        if fused.usable(feats[0]) and self.nk == 0:          # six branch tensors -> [B,4+nc,A] float in one launch
+            last = lambda seq, f: F.conv2d(seq[1](seq[0](f)), seq[2].weight)
+            return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)],
+                                   [last(self.cv3[i], f) for i, f in enumerate(feats)],
+                                   [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3], self.strides, self.nc)
         box = torch.cat([self.cv2[i](f).view(B, 64, -1) for i, f in enumerate(feats)], 2)
         cls = torch.cat([self.cv3[i](f).view(B, self.nc, -1) for i, f in enumerate(feats)], 2)
         if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:

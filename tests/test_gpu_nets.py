@@ -45,3 +45,53 @@ def test_lightconv_matches_pointwise_plus_depthwise(shape):
     # one half-ulp flip of an intermediate can move an output by ~|w| * ulp(mid); outputs themselves are half
     assert err <= 2e-2 * (ref.abs().max().item() + 1e-6), err
     assert (got != ref).float().mean().item() < 0.02       # and nearly every element is bit-identical
+
+
+def test_bias_act_place_matches_torch():
+    """Placement epilogue of the C2f blocks: slice of a wider NHWC buffer + dense mirror + post-activation shortcut."""
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, C, H, W, CT = 3, 32, 9, 13, 96
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float16)
+    y = mk(B, C, H, W).contiguous(memory_format=torch.channels_last)
+    res = mk(B, C, H, W).contiguous(memory_format=torch.channels_last)
+    bias = mk(C)
+    cat = torch.full((B, CT, H, W), 5.0, dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+    out2 = torch.empty((B, 16, H, W), dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+    fused.bias_act_place(y, bias, "silu", cat, 40, res=res, res_after=True, out2=out2, c0=16)
+    ref = (F.silu(y.float() + bias.float().view(1, C, 1, 1)).half().float() + res.float()).half()
+    assert torch.equal(cat[:, 40:72], ref) or (cat[:, 40:72].float() - ref.float()).abs().max().item() <= 2e-3
+    assert torch.equal(out2, cat[:, 56:72])
+    assert (cat[:, :40] == 5.0).all() and (cat[:, 72:] == 5.0).all()      # neighbours of the slice untouched
+    cat2 = torch.zeros_like(cat)
+    fused.bias_act_place(y, bias, "silu", cat2, 0)
+    ref2 = F.silu(y.float() + bias.float().view(1, C, 1, 1)).half()
+    assert (cat2[:, :C].float() - ref2.float()).abs().max().item() <= 2e-3 and (cat2[:, C:] == 0).all()
+
+
+def test_v8_decode_matches_float_reference():
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, nc, sizes, strides = 3, 80, [(12, 20), (6, 10), (3, 5)], (8, 16, 32)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float16)
+    boxes = [(2 * mk(B, 64, h, w)).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    clss = [(2 * mk(B, nc, h, w)).contiguous(memory_format=torch.channels_last) for h, w in sizes]
+    bb, cb = [mk(64) for _ in sizes], [mk(nc) for _ in sizes]
+    got = fused.v8_decode(boxes, clss, bb, cb, strides, nc)
+    A = sum(h * w for h, w in sizes)
+    assert got.shape == (B, 4 + nc, A) and got.dtype == torch.float32
+    box = torch.cat([(t.float() + b.float().view(1, -1, 1, 1)).reshape(B, 64, -1) for t, b in zip(boxes, bb)], 2)
+    cls = torch.cat([(t.float() + b.float().view(1, -1, 1, 1)).reshape(B, nc, -1) for t, b in zip(clss, cb)], 2)
+    pts, st = [], []
+    for (h, w), s in zip(sizes, strides):
+        yy, xx = torch.meshgrid(torch.arange(h, device=dev) + 0.5, torch.arange(w, device=dev) + 0.5, indexing="ij")
+        pts.append(torch.stack((xx, yy), 0).view(2, -1)); st.append(torch.full((1, h * w), float(s), device=dev))
+    anchors, st = torch.cat(pts, 1).unsqueeze(0), torch.cat(st, 1).unsqueeze(0)
+    d = (box.view(B, 4, 16, A).softmax(2) * torch.arange(16, device=dev, dtype=torch.float32).view(1, 1, 16, 1)).sum(2)
+    x1y1, x2y2 = anchors - d[:, :2], anchors + d[:, 2:]
+    ref = torch.cat((torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st, cls.sigmoid()), 1)
+    assert (got - ref).abs().max().item() <= 1e-3 * 32 * 16         # __expf-level error on coordinates up to stride*16
+    assert (got[:, 4:] - ref[:, 4:]).abs().max().item() <= 1e-5
