@@ -321,6 +321,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(PREFILL + Wm, total)                     # exactly K timed steps (frames)
+    t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (the GPU may still be working)
     barrier()
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
@@ -386,7 +387,7 @@ def main():
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
-            "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
+            "host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,
         }
         res["roofline_batched"] = None

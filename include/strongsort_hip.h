@@ -169,6 +169,12 @@ int ss_op_bias_act_f16(void* stream, void* d_x, const void* d_bias, const void* 
  * [c0, c0+cn) are also written densely to d_out2 when it is not NULL.  C, out_ld, c0, cn multiples of 8. */
 int ss_op_bias_act_place_f16(void* stream, const void* d_x, const void* d_bias, const void* d_res, long long n_pix, int C,
                              int act, int res_after, void* d_out, int out_ld, void* d_out2, int c0, int cn);
+/* 1x1 convolution + bias + activation (+ shortcut) in one MFMA kernel: d_out[pix*out_ld + n] =
+ * act(sum_k x[pix][k] w[n][k] + bias[n] (+ res[pix][n] before, or after when res_after, the activation)); x [M][K],
+ * w [N][K], res [M][N] dense NHWC half; placement arguments as ss_op_bias_act_place_f16 (multiples of 4 here).
+ * K % 8 == 0, N % 8 == 0. */
+int ss_op_pointwise_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, long long M,
+                        int K, int N, int act, int res_after, void* d_out, int out_ld, void* d_out2, int c0, int cn);
 /* YOLOv8 anchor-free head decode: per level l<3 the branch outputs d_box[l] [B][H][W][64] and d_cls[l] [B][H][W][nc]
  * (NHWC half, final 1x1 conv without bias; the biases are added here) -> d_pred [B][4+nc][A] float (xywh in input
  * pixels, class sigmoid), A = sum H[l]*W[l] — the tensor ss_nms reads.  H, W, strides are host int[3]. */

@@ -12,6 +12,8 @@
 #include "../../include/strongsort_hip.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ inline float act_apply(float v, int act)
 {
@@ -172,6 +174,97 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
     }
 }
 
+// Pointwise (1x1) convolution + bias + activation (+ shortcut) with placement, on the matrix cores:
+//   out[pix][n] = act(sum_k x[pix][k] * w[n][k] + bias[n])        x NHWC half [M][K], w [N][K] half
+// MIOpen runs these as zero-fill + implicit GEMM + our bias/activation pass (3 launches, ~20 us at the
+// detector's sizes); hipBLASLt needs a separate activation pass and is 2-4x off the HBM roofline for K,N <= 64.
+// Workgroup = 4 waves x PT pixel tiles of 16 = BM pixels x BN output channels.  Output channel = MFMA M
+// (weights = A operand, staged per 64-wide K chunk in LDS), pixel = MFMA N (B operand straight from global).
+// v_mfma_f32_16x16x16_f16 sums over k whatever the k <-> (lane group, element) assignment is, as long as A and
+// B use the same one: lane group q takes k = 8q..8q+7 of a 32-wide chunk, elements 0-3 for the first MFMA and
+// 4-7 for the second, so both operands are single 16-byte loads.  K % 8 == 0, N % 8 == 0.
+template <int BN, int PT>
+__global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const __half* __restrict__ w,
+                                           const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
+                                           int N, int act, int res_after, __half* __restrict__ out, int out_ld,
+                                           __half* __restrict__ out2, int c0, int cn)
+{
+    constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT;
+    __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int n0 = blockIdx.y * BN;
+    const size_t px0 = (size_t)blockIdx.x * BM + wave * (16 * PT);
+    f4 acc[MT][PT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+
+    for (int kc = 0; kc < K; kc += KC) {
+        __syncthreads();                                    // previous chunk's reads are done
+        for (int i = tid; i < BN * (KC / 8); i += 256) {    // stage W[n0..n0+BN)[kc..kc+KC) (zero beyond N, K)
+            const int r = i / (KC / 8), c8 = i - r * (KC / 8);
+            const int oc = n0 + r, k = kc + c8 * 8;
+            const h8 v = (oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
+            *reinterpret_cast<h8*>(Ws + r * PITCH + c8 * 8) = v;
+        }
+        h8 b[KC / 32][PT];                                  // this chunk's pixels: in flight across the barrier
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const size_t px = px0 + pt * 16 + n;
+                const int k = kc + ks * 32 + 8 * q;
+                b[ks][pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KC / 32; ++ks) {
+            if (kc + ks * 32 >= K) break;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 a = *reinterpret_cast<const h8*>(Ws + (mt * 16 + n) * PITCH + ks * 32 + 8 * q);
+                const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const h8 bv = b[ks][pt];
+                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: lane (q, n) holds channels oc0..oc0+3 of pixel n of each tile
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const size_t px = px0 + pt * 16 + n;
+        if (px >= (size_t)M) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oc0 = n0 + mt * 16 + 4 * q;
+            if (oc0 >= N) continue;
+            const h4 bb = *reinterpret_cast<const h4*>(bias + oc0);
+            h4 r = { 0, 0, 0, 0 };
+            if (res) r = *reinterpret_cast<const h4*>(res + px * N + oc0);
+            h4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // the unfused form rounds the convolution to half before the bias pass
+                float f = (float)(_Float16)acc[mt][pt][j] + (float)bb[j];
+                if (res && !res_after) f += (float)r[j];
+                f = act_apply(f, act);
+                if (res && res_after) f = (float)(_Float16)f + (float)r[j];
+                o[j] = (_Float16)f;
+            }
+            *reinterpret_cast<h4*>(out + px * out_ld + oc0) = o;
+            if (out2 && oc0 >= c0 && oc0 < c0 + cn) *reinterpret_cast<h4*>(out2 + px * cn + (oc0 - c0)) = o;
+        }
+    }
+}
+
 // OSNet "LightConv3x3" in one pass: y = relu(dw3x3(pw1x1(x)) + bias), C in {16, 24, 32}.
 //
 // The two-launch form (GEMM, then k_dw3x3) writes and re-reads the C-channel intermediate through HBM and
@@ -181,8 +274,6 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
 // weights are the A operand and stay in registers) and parks it as f16 in LDS with a zero pad column each
 // side; phase 2 is the depthwise 3x3 + bias + ReLU out of LDS (thread = pixel x 8 channels, tap weights in
 // registers, same fmaf order as k_dw3x3).  HBM traffic = read x once (+2/TH halo) + write y once.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 #define LC_TH 16
 
 template <int C>
@@ -430,6 +521,25 @@ extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const v
         A += H[l] * W[l];
     }
     hipLaunchKernelGGL(k_v8_decode, dim3((A + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, L, B, nc, A, pred);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_pointwise_f16(void* stream, const void* x, const void* w, const void* bias, const void* res, long long M,
+                                   int K, int N, int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn)
+{
+    if (!x || !w || !bias || !out || M < 1 || M > 0x7fffffffLL || K < 8 || K % 8 || N < 8 || N % 8 || out_ld % 4 || out_ld < N ||
+        c0 % 4 || cn % 4 || (out2 && (cn < 4 || c0 + cn > N)))
+        return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+#define SS_PW(BN, PT)                                                                                                   \
+    hipLaunchKernelGGL((k_pw<BN, PT>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
+                       (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act,     \
+                       res_after, (__half*)out, out_ld, (__half*)out2, c0, cn)
+    const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
+    if (N <= 32) { if (big) SS_PW(32, 2); else SS_PW(32, 1); }
+    else if (N <= 64 || !big) { if (big) SS_PW(64, 2); else SS_PW(64, 1); }
+    else SS_PW(128, 2);
+#undef SS_PW
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

@@ -59,6 +59,40 @@ def bias_act_place(y, bias, act, out, c_off, res=None, res_after=False, out2=Non
                                              _p(out2), c0, 0 if out2 is None else out2.shape[1]))
 
 
+POINTWISE = True            # own MFMA kernel for 1x1 convolutions (off: MIOpen / hipBLASLt + separate epilogue)
+
+
+def pointwise_ok(conv) -> bool:
+    return POINTWISE and is_pointwise(conv) and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.bias is not None
+
+
+def weight_nk(mod, conv):
+    """[Cout, Cin] view of a 1x1 conv weight (already the layout k_pw stages), cached on the module."""
+    w = getattr(mod, "_w_nk", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        w = conv.weight.detach().reshape(conv.weight.shape[0], -1).contiguous()
+        mod._w_nk = w
+    return w
+
+
+def pointwise(x, w_nk, bias, act="none", res=None, res_after=False, out=None, c_off=0, out2=None, c0=0):
+    """act(conv1x1(x) + bias) (+ res, before or after the activation) in ONE launch; optionally written into the
+    channel slice [c_off, c_off+N) of a wider channels-last tensor `out`, with channels [c0, c0+out2.C) mirrored
+    into the dense tensor `out2` (C2f blocks)."""
+    x = _cl(x)
+    b, k, h, w = x.shape
+    n = w_nk.shape[0]
+    if res is not None:
+        res = _cl(res)
+    ret = out
+    if out is None:
+        ret = out = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    dst = C.c_void_p(out.data_ptr() + 2 * c_off)
+    _ck(_lib.load().ss_op_pointwise_f16(_st(x), _p(x), _p(w_nk), _p(bias), _p(res), b * h * w, k, n, ACT[act], int(res_after),
+                                        dst, out.shape[1], _p(out2), c0, 0 if out2 is None else out2.shape[1]))
+    return ret
+
+
 def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 

@@ -30,10 +30,14 @@ class Conv(nn.Module):
         self.act = nn.SiLU(inplace=True) if act else nn.Identity()
 
     def forward(self, x):
-        if fused.usable(x):          # conv without bias (MIOpen) + one fused bias+SiLU pass
-            c = self.conv        # (measured: MIOpen beats a plain GEMM for the detector's batch-1 pointwise convs)
+        if fused.usable(x):
+            c = self.conv
+            act = "silu" if isinstance(self.act, nn.SiLU) else "none"
+            if fused.pointwise_ok(c):        # 1x1: own MFMA kernel, bias + SiLU in its epilogue (one launch)
+                return fused.pointwise(x, fused.weight_nk(self, c), c.bias, act)
+            # k x k: conv without bias (MIOpen) + one fused bias+SiLU pass
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
-            return fused.bias_act_(y, c.bias, "silu" if isinstance(self.act, nn.SiLU) else "none")
+            return fused.bias_act_(y, c.bias, act)
         return self.act(self.conv(x))
 
 
@@ -73,7 +77,10 @@ class C2f(nn.Module):
         dense = lambda: torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         cv = self.cv1.conv
         cur = dense()
-        fused.bias_act_place(F.conv2d(x, cv.weight, None, cv.stride, cv.padding), cv.bias, "silu", cat, 0, out2=cur, c0=c)
+        if fused.pointwise_ok(cv):
+            fused.pointwise(x, fused.weight_nk(self.cv1, cv), cv.bias, "silu", out=cat, c_off=0, out2=cur, c0=c)
+        else:
+            fused.bias_act_place(F.conv2d(x, cv.weight, None, cv.stride, cv.padding), cv.bias, "silu", cat, 0, out2=cur, c0=c)
         for i, m in enumerate(self.m):
             cv = m.cv2.conv
             t = F.conv2d(m.cv1(cur), cv.weight, None, cv.stride, cv.padding)
@@ -139,10 +146,18 @@ class Detect(nn.Module):
     def forward(self, feats):
         B = feats[0].shape[0]
         if fused.usable(feats[0]) and self.nk == 0:          # six branch tensors -> [B,4+nc,A] float in one launch
-            last = lambda seq, f: F.conv2d(seq[1](seq[0](f)), seq[2].weight)
+            if all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
+                # final 1x1 of every branch on the pointwise kernel (bias in its epilogue; the decode adds zeros)
+                last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)
+                z = getattr(self, "_zeros", None)
+                if z is None or z.device != feats[0].device:
+                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
+                bb, cb = [z] * 3, [z] * 3
+            else:
+                last = lambda seq, f: F.conv2d(seq[1](seq[0](f)), seq[2].weight)
+                bb, cb = [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3]
             return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)],
-                                   [last(self.cv3[i], f) for i, f in enumerate(feats)],
-                                   [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3], self.strides, self.nc)
+                                   [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, self.strides, self.nc)
         box = torch.cat([self.cv2[i](f).view(B, 64, -1) for i, f in enumerate(feats)], 2)
         cls = torch.cat([self.cv3[i](f).view(B, self.nc, -1) for i, f in enumerate(feats)], 2)
         if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:
@@ -310,6 +325,8 @@ class ConvBR(nn.Module):
     def forward(self, x, res=None):
         if fused.usable(x):
             c = self.conv
+            if fused.pointwise_ok(c):        # one MFMA launch: bias (+ shortcut) + ReLU in the epilogue
+                return fused.pointwise(x, fused.weight_nk(self, c), c.bias, "relu" if self.relu else "none", res=res)
             if fused.is_pointwise(c):
                 if not self.relu and res is None:
                     return fused.conv1x1(x, fused.weight_t(self, c), c.bias)           # bias in the GEMM epilogue
@@ -370,6 +387,8 @@ class OSBlock(nn.Module):
             x2 = fused.gate_sum([s(x1) for s in self.streams], g.fc1.weight.reshape(cr, c), g.fc1.bias,
                                 g.fc2.weight.reshape(c, cr), g.fc2.bias)
             c3 = self.conv3.conv
+            if fused.pointwise_ok(c3):
+                return fused.pointwise(x2, fused.weight_nk(self.conv3, c3), c3.bias, "relu", res=idn)
             y = fused.conv1x1(x2, fused.weight_t(self.conv3, c3))
             return fused.bias_act_(y, c3.bias, "relu", idn)
         x2 = sum(self.gate(s(x1)) for s in self.streams)

@@ -95,3 +95,36 @@ def test_v8_decode_matches_float_reference():
     ref = torch.cat((torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st, cls.sigmoid()), 1)
     assert (got - ref).abs().max().item() <= 1e-3 * 32 * 16         # __expf-level error on coordinates up to stride*16
     assert (got[:, 4:] - ref[:, 4:]).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("M_hw,K,N,act", [((8, 48, 80), 64, 32, "silu"), ((2, 12, 20), 384, 128, "silu"), ((64, 64, 32), 16, 64, "relu"),
+                                          ((3, 7, 9), 24, 96, "none"), ((5, 16, 8), 128, 128, "relu"), ((1, 5, 5), 512, 256, "silu"),
+                                          ((40, 64, 32), 16, 16, "relu"), ((2, 3, 5), 8, 8, "sigmoid")])
+def test_pointwise_matches_conv_bias_act(M_hw, K, N, act):
+    """MFMA 1x1 conv kernel vs conv2d (fp32 accumulate, rounded to half as the library conv writes it) + bias + act,
+    with and without the shortcut (before / after the activation), over every tile configuration and ragged M."""
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    B, H, W = M_hw
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(K * 1000 + N)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float16)
+    x = mk(B, K, H, W).contiguous(memory_format=torch.channels_last)
+    w = (mk(N, K).float() / K ** 0.5).half()
+    bias, res = mk(N), mk(B, N, H, W).contiguous(memory_format=torch.channels_last)
+    f = {"silu": F.silu, "relu": F.relu, "none": lambda t: t, "sigmoid": torch.sigmoid}[act]
+    conv = F.conv2d(x.float(), w.float().view(N, K, 1, 1)).half().float() + bias.float().view(1, N, 1, 1)
+    tol = lambda ref: 4e-3 * (ref.abs().max().item() + 1.0)
+    got = fused.pointwise(x, w, bias, act)
+    assert got.shape == (B, N, H, W) and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - f(conv)).abs().max().item() <= tol(f(conv))
+    got = fused.pointwise(x, w, bias, act, res=res)
+    assert (got.float() - f(conv + res.float())).abs().max().item() <= tol(f(conv + res.float()))
+    got = fused.pointwise(x, w, bias, act, res=res, res_after=True)
+    assert (got.float() - (f(conv).half().float() + res.float())).abs().max().item() <= tol(f(conv) + res.float())
+    if N % 16 == 0:                                          # placement into a wider buffer + dense mirror of the upper half
+        cat = torch.full((B, N + 24, H, W), 3.0, dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+        out2 = torch.empty((B, N // 2, H, W), dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+        fused.pointwise(x, w, bias, act, out=cat, c_off=8, out2=out2, c0=N // 2)
+        assert torch.equal(cat[:, 8:8 + N], fused.pointwise(x, w, bias, act))
+        assert torch.equal(out2, cat[:, 8 + N // 2:8 + N]) and (cat[:, :8] == 3.0).all() and (cat[:, 8 + N:] == 3.0).all()
