@@ -280,15 +280,20 @@ def main():
             b.gt_feats.view(FB, S, *b.gt_feats.shape[1:])[:n, s].copy_(p["feats"][g0:g0 + n])
 
     if overlap:
+        seg_last = set()                                    # frame indices that end a (possibly partial) group
+
         def fetch(k, f):
-            out_host[k].copy_(pipe.outs[f], non_blocking=True)
-            nout_host[k].copy_(pipe.nouts[f], non_blocking=True)
+            # results of a whole group leave in two device-to-host copies once its last frame is tracked
+            if f == FB - 1 or k in seg_last:
+                out_host[k - f:k + 1].copy_(pipe.outs[:f + 1], non_blocking=True)
+                nout_host[k - f:k + 1].copy_(pipe.nouts[:f + 1], non_blocking=True)
 
         pipe.on_result = fetch
 
         def run(k0, k1):
             for g0 in range(k0, k1, FB):
                 n = min(FB, k1 - g0)
+                seg_last.add(g0 + n - 1)
                 b = pipe.begin_frame()
                 with torch.cuda.stream(pipe.sA):
                     feed_group(g0, n, b)

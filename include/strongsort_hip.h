@@ -187,6 +187,16 @@ int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]
  * {16,24,32}, W % 8 == 0, 18*(W+2)*C*2 <= 65536 (the band lives in LDS; SS_ERR_INVALID otherwise). */
 int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                         void* d_y, int N, int H, int W, int C);
+/* The four LightConv3x3 chains of an OSNet block (1..4 layers deep, same input) in one launch, intermediates in LDS:
+ * d_w1 [10][C][C], d_w9 [10][9][C], d_bias [10][C] = the layers of the 1-, 2-, 3-, 4-deep chain in that order;
+ * d_ys[4] the chain outputs [N][H][W][C]; d_psum [4][N][ceil(H/16)][C] float = per-band channel sums of each output
+ * (for ss_op_gate_apply_f16).  C in {16,24,32}, W % 8 == 0, 24*(2W+2)*C*2 <= 65536. */
+int ss_op_osnet_streams_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
+                            void* const* d_ys, float* d_psum, int N, int H, int W, int C);
+/* Aggregation gate with the channel means given as `parts` partial sums per (stream, image) times `scale`. */
+int ss_op_gate_apply_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
+                         const void* d_w2, const void* d_b2, const float* d_sums, int parts, float scale, void* d_out,
+                         int N, int HW, int C, int Cr);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */
 int ss_op_maxpool_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C, int k, int stride, int pad);
 /* OSNet unified aggregation gate: out = sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))), T <= 4 streams. */

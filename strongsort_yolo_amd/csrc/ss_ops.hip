@@ -367,6 +367,137 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
     }
 }
 
+// The four LightConv3x3 chains of an OSNet block (1, 2, 3 and 4 layers deep, all reading the same x1) in one launch.
+// blockIdx.y = chain; a workgroup takes a TH-row band of one image with a halo of t rows each side and runs its t
+// layers back to back out of LDS: layer l's pointwise product (matrix cores) goes to P, its depthwise+bias+ReLU
+// reads P and writes the next layer's input X (LDS) or, for the last layer, the chain's output in HBM.  The valid
+// rows shrink by one per layer and side (halo recompute factor (TH+t+1)/TH); rows outside the image are forced to
+// zero after every layer, as the per-layer zero padding requires.  Per chain the intermediates never touch HBM:
+// traffic = x1 band (+halo) in, y_t out, instead of t x (in + out).  The last layer also leaves the band's channel
+// sums (psum), so the aggregation gate needs no separate mean pass.  Arithmetic per layer is k_lightconv's, bit for bit.
+struct StreamOut { __half* y[4]; };
+#define OS_TMAX 4
+
+template <int C>
+__global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict__ x, const __half* __restrict__ w1,
+                                                      const __half* __restrict__ w9, const __half* __restrict__ bias,
+                                                      StreamOut out, float* __restrict__ psum, int N, int H, int W,
+                                                      int bands)
+{
+    constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH, PXPAR = 256 / C8;
+    extern __shared__ __attribute__((aligned(16))) char lc_smem[];
+    const int WP = W + 2;
+    _Float16* P = (_Float16*)lc_smem;                                        // [TH+2*TMAX][W+2][C]
+    _Float16* X = P + (size_t)(TH + 2 * OS_TMAX) * WP * C;                   // [TH+2*TMAX][W][C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15;
+    const int t = blockIdx.y + 1, lbase = (t * (t - 1)) / 2;
+    const int img = blockIdx.x / bands, band = blockIdx.x - img * bands, y0 = band * TH;
+    const int R = TH + 2 * t;                                                // local row i <-> image row y0 - t + i
+    const h4 z4 = { 0, 0, 0, 0 };
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int i = tid; i < R * 2 * C8; i += 256) {                            // zero pad columns of P
+        const int c8 = i % C8, rc = i / C8, r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
+        *reinterpret_cast<h8*>(P + ((size_t)(r * WP + col) * C + c8 * 8)) = z8;
+    }
+    const __half* xi = x + (size_t)img * H * W * C;
+    const int c8 = tid % C8, ps = tid / C8;
+    float s8[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+
+    for (int l = 1; l <= t; ++l) {
+        const int Lw = lbase + l - 1;
+        // ---- pointwise product of local rows [l-1, R-l] ----
+        h4 a[MT][KS];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int oc = mt * 16 + n16, ic0 = ks * 16 + 4 * q;
+                a[mt][ks] = (oc < C && ic0 < C) ? *reinterpret_cast<const h4*>(w1 + ((size_t)Lw * C + oc) * C + ic0) : z4;
+            }
+        const int rlo = l - 1, NT = (R - 2 * l + 2) * W / 16;
+        auto load_b = [&](int ti, h4 (&b)[KS]) {
+            const int p = ti * 16 + n16, rr = p / W, c = p - rr * W, r = rlo + rr, gr = y0 - t + r;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ic0 = ks * 16 + 4 * q;
+                if (l == 1) {
+                    const bool ok = ti < NT && gr >= 0 && gr < H && ic0 < C;
+                    b[ks] = ok ? *reinterpret_cast<const h4*>(xi + ((size_t)gr * W + c) * C + ic0) : z4;
+                } else {
+                    b[ks] = (ti < NT && ic0 < C) ? *reinterpret_cast<const h4*>(X + ((size_t)r * W + c) * C + ic0) : z4;
+                }
+            }
+        };
+        h4 bcur[KS], bnext[KS];
+        load_b(wave, bcur);
+        for (int ti = wave; ti < NT; ti += 4) {
+            load_b(ti + 4, bnext);
+            const int p = ti * 16 + n16, rr = p / W, c = p - rr * W, r = rlo + rr;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f4 d = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt][ks], bcur[ks], d, 0, 0, 0);
+                const int oc0 = mt * 16 + 4 * q;
+                if (oc0 < C) {
+                    h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
+                    *reinterpret_cast<h4*>(P + ((size_t)(r * WP + c + 1) * C + oc0)) = o;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
+        }
+        __syncthreads();
+
+        // ---- depthwise 3x3 + bias + ReLU of local rows [l, R-l-1] ----
+        if (ps < PXPAR) {
+            h8 wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9 + (size_t)Lw * 9 * C)[k * C8 + c8];
+            const h8 bb = reinterpret_cast<const h8*>(bias + (size_t)Lw * C)[c8];
+            const int npx = (R - 2 * l) * W;
+            for (int p = ps; p < npx; p += PXPAR) {
+                const int pr = p / W, px = p - pr * W, py = pr + l, gr = y0 - t + py;
+                const bool inside = gr >= 0 && gr < H;
+                float acc[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = (float)bb[k];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const h8 v = *reinterpret_cast<const h8*>(P + ((size_t)((py - 1 + ky) * WP + px + kx) * C + c8 * 8));
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)wk[ky * 3 + kx][k], acc[k]);
+                    }
+                h8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] > 0.f ? acc[k] : 0.f);
+                if (l < t) {
+                    *reinterpret_cast<h8*>(X + ((size_t)(py * W + px) * C + c8 * 8)) = inside ? o : z8;
+                } else if (inside) {
+                    reinterpret_cast<h8*>(out.y[t - 1])[(((size_t)img * H + gr) * W + px) * C8 + c8] = o;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s8[k] += (float)o[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // band's channel sums of the chain output, fixed order (deterministic)
+    float* red = reinterpret_cast<float*>(lc_smem);                          // [256][8]
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[tid * 8 + k] = ps < PXPAR ? s8[k] : 0.f;
+    __syncthreads();
+    if (tid < C) {
+        const int cg = tid >> 3, k = tid & 7;
+        float a = 0.f;
+        for (int j = 0; j < PXPAR; ++j) a += red[(j * C8 + cg) * 8 + k];
+        psum[(((size_t)(t - 1) * N + img) * bands + band) * C + tid] = a;
+    }
+}
+
 // OSNet unified aggregation gate over T <= 4 streams.
 //   step 1: mean over H*W of every stream -> means[t][n][C] (f32)
 //   step 2: g_t = sigmoid(fc2(relu(fc1(mean_t)))) per sample, out = sum_t x_t * g_t
@@ -430,18 +561,28 @@ __global__ __launch_bounds__(256) void k_maxpool(const __half* __restrict__ x, _
     }
 }
 
-__global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const float* __restrict__ means,
-                                                   const __half* __restrict__ w1, const __half* __restrict__ b1,
-                                                   const __half* __restrict__ w2, const __half* __restrict__ b2,
-                                                   __half* __restrict__ out, int N, int HW, int C, int Cr)
+// means[t][n][parts][C]: `parts` partial sums per (stream, image), scaled by `scale` (parts = 1, scale = 1: plain means)
+__global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const float* __restrict__ means, int parts,
+                                                   float scale, const __half* __restrict__ w1,
+                                                   const __half* __restrict__ b1, const __half* __restrict__ w2,
+                                                   const __half* __restrict__ b2, __half* __restrict__ out, int N, int HW,
+                                                   int C, int Cr)
 {
     __shared__ float g[4][256];
     __shared__ float hid[4][16];
     const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < T * C; i += 256) {          // g doubles as the mean buffer until the gates are known
+        const int t = i / C, c = i % C;
+        const float* m = means + (((size_t)t * N + n) * parts) * C + c;
+        float a = 0.f;
+        for (int p = 0; p < parts; ++p) a += m[(size_t)p * C];
+        g[t][c] = a * scale;
+    }
+    __syncthreads();
     if (threadIdx.x < T * Cr) {
         const int t = threadIdx.x / Cr, r = threadIdx.x % Cr;
         float a = __half2float(b1[r]);
-        const float* m = means + ((size_t)t * N + n) * C;
+        const float* m = g[t];
         for (int c = 0; c < C; ++c) a = fmaf(__half2float(w1[r * C + c]), m[c], a);
         hid[t][r] = a > 0.f ? a : 0.f;
     }
@@ -581,7 +722,43 @@ extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, co
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gate_mean, dim3(N, T), dim3(256), 0, st, p, means_ws, N, HW, C);
     const size_t nvec = (size_t)HW * (C / 8);
-    hipLaunchKernelGGL(k_gate_apply, dim3(grid_for(nvec, 256) > 64 ? 64 : grid_for(nvec, 256), N), dim3(256), 0, st, p, T, means_ws,
+    hipLaunchKernelGGL(k_gate_apply, dim3(grid_for(nvec, 256) > 64 ? 64 : grid_for(nvec, 256), N), dim3(256), 0, st, p, T, means_ws, 1, 1.0f,
                        (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2, (__half*)out, N, HW, C, Cr);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* w1, const void* w9, const void* bias,
+                                       void* const* ys, float* psum, int N, int H, int W, int C)
+{
+    if (!x || !w1 || !w9 || !bias || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
+    const size_t lds = (size_t)(LC_TH + 2 * OS_TMAX) * (2 * W + 2) * C * 2;
+    if (lds > 65536) return SS_ERR_INVALID;
+    const int bands = (H + LC_TH - 1) / LC_TH;
+    StreamOut o;
+    for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((size_t)N * bands), 4), block(256);
+#define SS_OS(CC) hipLaunchKernelGGL(k_osnet_streams<CC>, grid, block, lds, st, (const __half*)x, (const __half*)w1, \
+                                     (const __half*)w9, (const __half*)bias, o, psum, N, H, W, bands)
+    if (C == 16) SS_OS(16);
+    else if (C == 24) SS_OS(24);
+    else if (C == 32) SS_OS(32);
+    else return SS_ERR_INVALID;
+#undef SS_OS
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+// aggregation gate from precomputed partial channel sums (ss_op_osnet_streams_f16's psum): parts per (stream, image)
+extern "C" int ss_op_gate_apply_f16(void* stream, const void* const* xs, int T, const void* w1, const void* b1, const void* w2,
+                                    const void* b2, const float* sums, int parts, float scale, void* out, int N, int HW, int C,
+                                    int Cr)
+{
+    if (T < 1 || T > 4 || C % 8 || C > 256 || Cr < 1 || Cr > 16 || parts < 1 || !sums || !out) return SS_ERR_INVALID;
+    GatePtrs p;
+    for (int t = 0; t < 4; ++t) p.x[t] = (const __half*)xs[t < T ? t : 0];
+    const size_t nvec = (size_t)HW * (C / 8);
+    hipLaunchKernelGGL(k_gate_apply, dim3(grid_for(nvec, 256) > 64 ? 64 : grid_for(nvec, 256), N), dim3(256), 0, (hipStream_t)stream,
+                       p, T, sums, parts, scale, (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2,
+                       (__half*)out, N, HW, C, Cr);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -135,6 +135,37 @@ def lightconv(x, w1, w9, bias):
     return y
 
 
+STREAMS = True              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)
+
+
+def streams_ok(x) -> bool:
+    n, c, h, w = x.shape
+    return STREAMS and LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 24 * (2 * w + 2) * c * 2 <= 65536
+
+
+def osnet_streams(x, w1, w9, bias):
+    """x [N,C,H,W] channels-last half; w1 [10,C,C], w9 [10,9,C], bias [10,C]: the layers of the 1-, 2-, 3- and 4-deep
+    chains in that order.  Returns the four chain outputs and the per-band channel sums psum [4,N,bands,C] (float)."""
+    x = _cl(x)
+    n, c, h, w = x.shape
+    bands = (h + 15) // 16
+    ys = [torch.empty_like(x, memory_format=torch.channels_last) for _ in range(4)]
+    psum = torch.empty(4, n, bands, c, dtype=torch.float32, device=x.device)
+    arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
+    _ck(_lib.load().ss_op_osnet_streams_f16(_st(x), _p(x), _p(w1), _p(w9), _p(bias), arr, _p(psum), n, h, w, c))
+    return ys, psum
+
+
+def gate_apply(xs, psum, w1, b1, w2, b2):
+    """sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))) with the means taken from partial sums psum [T,N,parts,C]."""
+    n, c, h, w = xs[0].shape
+    out = torch.empty_like(xs[0], memory_format=torch.channels_last)
+    arr = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    _ck(_lib.load().ss_op_gate_apply_f16(_st(out), arr, len(xs), _p(w1), _p(b1), _p(w2), _p(b2), _p(psum), psum.shape[2],
+                                         1.0 / (h * w), _p(out), n, h * w, c, w1.shape[0]))
+    return out
+
+
 def gate_sum(xs, w1, b1, w2, b2):
     xs = [_cl(x) for x in xs]
     n, c, h, w = xs[0].shape

@@ -384,8 +384,18 @@ class OSBlock(nn.Module):
         if fused.usable(x):          # all four gates + their sum in two launches; bias + residual + ReLU in one
             g = self.gate
             cr, c = g.fc1.weight.shape[0], g.fc1.weight.shape[1]
-            x2 = fused.gate_sum([s(x1) for s in self.streams], g.fc1.weight.reshape(cr, c), g.fc1.bias,
-                                g.fc2.weight.reshape(c, cr), g.fc2.bias)
+            gw = (g.fc1.weight.reshape(cr, c), g.fc1.bias, g.fc2.weight.reshape(c, cr), g.fc2.bias)
+            if fused.streams_ok(x1):     # the ten LightConv layers of the four chains in one launch + gate from its sums
+                sw = getattr(self, "_sw", None)
+                if sw is None or sw[0].device != x1.device:
+                    layers = [m for st in self.streams for m in st]
+                    sw = self._sw = (torch.stack([m.pw.weight.detach().reshape(c, c) for m in layers]).contiguous(),
+                                     torch.stack([m.dw.weight.detach().reshape(c, 9).t() for m in layers]).contiguous(),
+                                     torch.stack([m.dw.bias.detach() for m in layers]).contiguous())
+                ys, psum = fused.osnet_streams(x1, *sw)
+                x2 = fused.gate_apply(ys, psum, *gw)
+            else:
+                x2 = fused.gate_sum([s(x1) for s in self.streams], *gw)
             c3 = self.conv3.conv
             if fused.pointwise_ok(c3):
                 return fused.pointwise(x2, fused.weight_nk(self.conv3, c3), c3.bias, "relu", res=idn)

@@ -324,7 +324,9 @@ class OverlappedPipeline(FramePipeline):
         self._s_detector(b)
         self._nms_crop(b)
         if self.run_nets and self.reid_split > 0:
-            self._keep(b, "mid", [self.reid.forward_a(b.crops, self.reid_split)])
+            # no copy across the stage boundary: the tensor lives in this graph's private pool, keeps its address over
+            # replays, and the next stage's graph (captured after this one, for the same buffer set) reads it there
+            b.mid = [self.reid.forward_a(b.crops, self.reid_split)]
 
     def _s_back_split(self, b):
         emb = None

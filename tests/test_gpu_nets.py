@@ -128,3 +128,35 @@ def test_pointwise_matches_conv_bias_act(M_hw, K, N, act):
         fused.pointwise(x, w, bias, act, out=cat, c_off=8, out2=out2, c0=N // 2)
         assert torch.equal(cat[:, 8:8 + N], fused.pointwise(x, w, bias, act))
         assert torch.equal(out2, cat[:, 8 + N // 2:8 + N]) and (cat[:, :8] == 3.0).all() and (cat[:, 8 + N:] == 3.0).all()
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 64, 32), (2, 24, 32, 16), (4, 32, 16, 8), (2, 16, 40, 24), (1, 32, 5, 8)])
+def test_osnet_streams_equal_layerwise_chains(shape):
+    """Chain-fused kernel (intermediates in LDS, shrinking halo) vs the same ten layers run one launch each: outputs
+    bit-identical (same arithmetic per layer), band sums equal the float sum of the outputs; then the gate built on
+    those sums vs the two-pass gate."""
+    from strongsort_yolo_amd import fused
+    n, c, h, w = shape
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(c * 7 + h)
+    x = torch.randn(n, c, h, w, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(10, c, c, generator=g) / c ** 0.5).to(dev, torch.float16)
+    w9 = (torch.randn(10, 9, c, generator=g) / 3).to(dev, torch.float16)
+    b = (torch.randn(10, c, generator=g) / 2).to(dev, torch.float16)
+    assert fused.streams_ok(x)
+    ys, psum = fused.osnet_streams(x, w1, w9, b)
+    L, ref = 0, []
+    for t in range(1, 5):
+        cur = x
+        for _ in range(t):
+            cur = fused.lightconv(cur, w1[L], w9[L], b[L]); L += 1
+        ref.append(cur)
+    for t in range(4):
+        assert torch.equal(ys[t], ref[t]), t
+        tot = ref[t].float().sum((2, 3))                                     # [n, c]
+        assert (psum[t].sum(1) - tot).abs().max().item() <= 1e-3 * (tot.abs().max().item() + 1.0)
+    cr = max(c // 16, 1)
+    gw = [(torch.randn(cr, c, generator=g) / c ** 0.5).to(dev, torch.float16), torch.randn(cr, generator=g).to(dev, torch.float16),
+          torch.randn(c, cr, generator=g).to(dev, torch.float16), torch.randn(c, generator=g).to(dev, torch.float16)]
+    a, r = fused.gate_apply(ys, psum, *gw), fused.gate_sum(ref, *gw)
+    assert (a.float() - r.float()).abs().max().item() <= 2e-3 * (r.float().abs().max().item() + 1.0)
