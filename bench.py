@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
+    ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
     ap.add_argument("--frame-batch", type=int, default=8, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
@@ -245,7 +246,7 @@ def main():
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split} if overlap else {}))
+                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream} if overlap else {}))
     FB = args.frame_batch if overlap else 1
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
@@ -390,7 +391,7 @@ def main():
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
             "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
-                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
+                       "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,

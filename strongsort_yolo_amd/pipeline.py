@@ -183,6 +183,7 @@ class _Bufs:
         self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
+        self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads
 
 
 class OverlappedPipeline(FramePipeline):
@@ -206,7 +207,8 @@ class OverlappedPipeline(FramePipeline):
     the two streams carry equal work when frames are batched.
     """
 
-    def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None, **kw):
+    def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
+                 tracker_stream: bool = False, **kw):
         kw = dict(kw)
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
@@ -221,7 +223,6 @@ class OverlappedPipeline(FramePipeline):
             self.graph_mode = "front"       # the per-frame tracker calls stay eager (partial last groups)
         self.Sv = self.S * self.F
         self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
-        self.feats_v = torch.zeros(self.Sv, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=self.dev)
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
         split_det = self.run_nets and n_stages >= 4 and hasattr(self.detector, "forward_backbone")
@@ -248,15 +249,24 @@ class OverlappedPipeline(FramePipeline):
             st += [self._s_nms_crop_reid_select]
         self.stages = st
         self.n = len(st)
-        self.bufs = [_Bufs(self) for _ in range(self.n)]
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)]
-        self.ev = [[torch.cuda.Event() for _ in range(self.n)] for _ in range(self.n)]    # ev[stage][set]
-        self.graphs = [[None] * self.n for _ in range(self.n)]                            # graphs[stage][set]
-        self.sA, self.sB = self.streams[0], self.streams[-1]       # input stream / tracker + result stream
+        # tracker_stream=True gives the tracker (one-workgroup kernels, ~70 us a frame) a stream of its own next to the
+        # last stage of the following group, with one more buffer set so that stage 0 does not wait for it.  Measured
+        # at configs[1], same box, frame batch 8: 3110 frames/s with it vs 3280 without — a third concurrent launch
+        # chain costs more in the dispatcher than the queue stall it removes (same finding as the 4-stage split) — so
+        # it is off by default.
+        self.sT = torch.cuda.Stream(self.dev) if (tracker_stream and self.graph_mode == "front") else None
+        self.nb = self.n + (1 if self.sT is not None else 0)                              # buffer sets
+        self.bufs = [_Bufs(self) for _ in range(self.nb)]
+        self.ev = [[torch.cuda.Event() for _ in range(self.nb)] for _ in range(self.n)]   # ev[stage][set]
+        self.ev_graph = [torch.cuda.Event() for _ in range(self.nb)]                      # last stage's graph done (tracker may start)
+        self.graphs = [[None] * self.nb for _ in range(self.n)]                           # graphs[stage][set]
+        self.sA = self.streams[0]                                  # input stream
+        self.sB = self.sT if self.sT is not None else self.streams[-1]                    # tracker + result stream
         self.k = 0                          # groups (of frame_batch frames) submitted
         self.stage_done = [0] * self.n      # groups enqueued per stage
-        self.valid = [self.F] * self.n      # real frames in the group occupying each buffer set
-        self.base = [0] * self.n            # frame index of the first frame of that group
+        self.valid = [self.F] * self.nb     # real frames in the group occupying each buffer set
+        self.base = [0] * self.nb           # frame index of the first frame of that group
         self.frames_in = 0
         self._captured = False
 
@@ -303,10 +313,10 @@ class OverlappedPipeline(FramePipeline):
 
     def _select(self, b, emb):
         if emb is not None and self.feat_source == "reid":
-            self.feats_v[:, :self.RB].copy_(emb.view(self.Sv, self.RB, FEAT_DIM))
+            b.feats_v[:, :self.RB].copy_(emb.view(self.Sv, self.RB, FEAT_DIM))
         if self.feat_source == "by_anchor":
             idx = b.anchor_gt.gather(1, b.keep.long().clamp_(0, self.n_anchors - 1))
-            torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_v)
+            torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=b.feats_v)
 
     def _s_nms_crop_reid_a(self, b):
         self._nms_crop(b)
@@ -340,7 +350,7 @@ class OverlappedPipeline(FramePipeline):
         e, S = self.eng, self.S
         for f in range(self.F if n_valid is None else n_valid):
             sl = slice(f * S, (f + 1) * S)
-            e._ck(e.L.ss_track_update(e.ctx, _p(b.dets6[sl]), _p(b.ndets[sl]), _p(self.feats_v[sl]), _p(self.img_hw),
+            e._ck(e.L.ss_track_update(e.ctx, _p(b.dets6[sl]), _p(b.ndets[sl]), _p(b.feats_v[sl]), _p(self.img_hw),
                                       _p(self.outs[f]), _p(self.nouts[f])))
             if group is not None and self.on_result is not None:
                 self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
@@ -385,23 +395,30 @@ class OverlappedPipeline(FramePipeline):
         """Buffer set for the next frame.  Fill its inputs inside `with torch.cuda.stream(pipe.sA):`."""
         if not self._captured:
             self._capture()
-        i = self.k % self.n
-        self.sA.wait_event(self.ev[self.n - 1][i])               # the frame that used this set has left the last stage
+        i = self.k % self.nb
+        self.sA.wait_event(self.ev[self.n - 1][i])               # the group that used this set has left the tracker
         return self.bufs[i]
 
     def _run_stage(self, j: int, frame_idx: int):
-        i = frame_idx % self.n
+        i = frame_idx % self.nb
         st = self.streams[j]
         with torch.cuda.stream(st):
             if j > 0:
                 st.wait_event(self.ev[j - 1][i])
             self.graphs[j][i].replay()
-            if j == self.n - 1:
-                if self.graph_mode == "front":
+            if j == self.n - 1 and self.sT is not None:          # tracker of this group on its own stream
+                self.ev_graph[i].record(st)
+                with torch.cuda.stream(self.sT):
+                    self.sT.wait_event(self.ev_graph[i])
                     self._track_b(self.bufs[i], self.valid[i], self.base[i])
-                elif self.on_result is not None:
-                    self.on_result(self.base[i], 0)              # graph == "all" implies frame_batch == 1
-            self.ev[j][i].record(st)
+                    self.ev[j][i].record(self.sT)
+            else:
+                if j == self.n - 1:
+                    if self.graph_mode == "front":
+                        self._track_b(self.bufs[i], self.valid[i], self.base[i])
+                    elif self.on_result is not None:
+                        self.on_result(self.base[i], 0)          # graph == "all" implies frame_batch == 1
+                self.ev[j][i].record(st)
         self.stage_done[j] = frame_idx + 1
 
     def submit(self, n_valid: int = None):
@@ -409,8 +426,8 @@ class OverlappedPipeline(FramePipeline):
         group k-j for every j that has one."""
         k = self.k
         nv = self.F if n_valid is None else int(n_valid)
-        self.valid[k % self.n] = nv
-        self.base[k % self.n] = self.frames_in                 # index of the group's first frame (partial groups allowed)
+        self.valid[k % self.nb] = nv
+        self.base[k % self.nb] = self.frames_in                 # index of the group's first frame (partial groups allowed)
         self.frames_in += nv
         for j in range(self.n):
             f = k - j

@@ -59,13 +59,17 @@ def test_sequential_pipeline_equals_oracle(graph):
     pipe.close()
 
 
-@pytest.mark.parametrize("graph,n_stages,fb", [("front", 4, 1), ("all", 2, 1), ("front", 2, 1), ("front", 2, 3)])
-def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb):
-    """fb = 3 with 14 frames: groups of 3,3,3,3 and a partial group of 2."""
+@pytest.mark.parametrize("graph,n_stages,fb,kw", [("front", 4, 1, {}), ("all", 2, 1, {}), ("front", 2, 1, {}), ("front", 2, 3, {}),
+                                                  ("front", 2, 3, {"reid_split": 2}), ("front", 2, 2, {"reid_split": 0}),
+                                                  ("front", 2, 2, {"reid_split": 1, "tracker_stream": True})])
+def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb, kw):
+    """fb = 3 with 14 frames: groups of 3,3,3,3 and a partial group of 2.  kw: stage cut inside the ReID backbone,
+    tracker on the last stage's stream (default) or on its own stream with three buffer sets."""
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
     pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64,
-                              n_stages=n_stages, frame_batch=fb)
+                              n_stages=n_stages, frame_batch=fb, **kw)
     assert pipe.n == n_stages
+    assert (pipe.sT is not None) == (graph == "front" and kw.get("tracker_stream", False))
     gs, items = _workload(pipe)
     ref = _oracle(gs, items, pipe.nc)
     out_host = torch.empty(FRAMES, 256, 8).pin_memory()
