@@ -175,6 +175,12 @@ int ss_op_bias_act_place_f16(void* stream, const void* d_x, const void* d_bias, 
  * K % 8 == 0, N % 8 == 0. */
 int ss_op_pointwise_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, long long M,
                         int K, int N, int act, int res_after, void* d_out, int out_ld, void* d_out2, int c0, int cn);
+/* 3x3 / pad 1 / stride 1|2 convolution + bias + activation (+ shortcut) as an implicit GEMM on the same kernel:
+ * x [B][H][W][Cin], w [N][3][3][Cin], output [B][OH][OW][N] with OH = (H-1)/stride+1; epilogue and placement
+ * arguments as ss_op_pointwise_f16.  Cin % 8 == 0, N % 8 == 0. */
+int ss_op_conv3x3_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, int B, int H,
+                      int W, int Cin, int N, int conv_stride, int act, int res_after, void* d_out, int out_ld,
+                      void* d_out2, int c0, int cn);
 /* YOLOv8 anchor-free head decode: per level l<3 the branch outputs d_box[l] [B][H][W][64] and d_cls[l] [B][H][W][nc]
  * (NHWC half, final 1x1 conv without bias; the biases are added here) -> d_pred [B][4+nc][A] float (xywh in input
  * pixels, class sigmoid), A = sum H[l]*W[l] — the tensor ss_nms reads.  H, W, strides are host int[3]. */

@@ -183,11 +183,17 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
 // v_mfma_f32_16x16x16_f16 sums over k whatever the k <-> (lane group, element) assignment is, as long as A and
 // B use the same one: lane group q takes k = 8q..8q+7 of a 32-wide chunk, elements 0-3 for the first MFMA and
 // 4-7 for the second, so both operands are single 16-byte loads.  K % 8 == 0, N % 8 == 0.
-template <int BN, int PT>
+//
+// CONV3: the same kernel as an implicit GEMM for 3x3 / pad 1 / stride 1|2 convolutions: K = 9*Cin with k = tap*Cin + c
+// (weights [N][3][3][Cin]), and a lane's eight k's — always inside one tap because Cin % 8 == 0 — come from the
+// input pixel shifted by that tap (zeros outside the image).  Replaces MIOpen's zero-fill + igemm + our epilogue pass.
+struct ConvGeom { int H, W, Cin, OH, OW, stride; };
+
+template <int BN, int PT, bool CONV3>
 __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const __half* __restrict__ w,
                                            const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
                                            int N, int act, int res_after, __half* __restrict__ out, int out_ld,
-                                           __half* __restrict__ out2, int c0, int cn)
+                                           __half* __restrict__ out2, int c0, int cn, ConvGeom g)
 {
     constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT;
     __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
@@ -200,24 +206,59 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
     const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-
-    for (int kc = 0; kc < K; kc += KC) {
-        __syncthreads();                                    // previous chunk's reads are done
-        for (int i = tid; i < BN * (KC / 8); i += 256) {    // stage W[n0..n0+BN)[kc..kc+KC) (zero beyond N, K)
-            const int r = i / (KC / 8), c8 = i - r * (KC / 8);
-            const int oc = n0 + r, k = kc + c8 * 8;
-            const h8 v = (oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
-            *reinterpret_cast<h8*>(Ws + r * PITCH + c8 * 8) = v;
+    // CONV3: image base and top-left input coordinate of this lane's output pixel(s)
+    size_t ibase[PT];
+    int iy0[PT], ix0[PT];
+    if (CONV3) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const size_t px = px0 + pt * 16 + n;
+            const int ohw = g.OH * g.OW;
+            const int bimg = (int)(px / ohw), rem = (int)(px - (size_t)bimg * ohw), oy = rem / g.OW, ox = rem - oy * g.OW;
+            ibase[pt] = (size_t)bimg * g.H * g.W;
+            iy0[pt] = oy * g.stride - 1; ix0[pt] = ox * g.stride - 1;
         }
-        h8 b[KC / 32][PT];                                  // this chunk's pixels: in flight across the barrier
+    }
+
+    // software pipeline over 64-wide K chunks: chunk kc+64's weights (to registers) and pixels are requested before
+    // chunk kc's MFMAs, so global latency hides behind the matrix work of the previous chunk
+    constexpr int WV = (BN * (KC / 8) + 255) / 256;         // weight vectors staged per thread and chunk
+    auto load_w = [&](int kc, h8 (&wr)[WV]) {
+#pragma unroll
+        for (int j = 0; j < WV; ++j) {
+            const int i = tid + j * 256, r = i / (KC / 8), c8 = i - r * (KC / 8);
+            const int oc = n0 + r, k = kc + c8 * 8;
+            wr[j] = (i < BN * (KC / 8) && oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
+        }
+    };
+    auto load_b = [&](int kc, h8 (&b)[KC / 32][PT]) {
 #pragma unroll
         for (int ks = 0; ks < KC / 32; ++ks)
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
                 const size_t px = px0 + pt * 16 + n;
                 const int k = kc + ks * 32 + 8 * q;
-                b[ks][pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
+                if (!CONV3) {
+                    b[ks][pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
+                } else {
+                    const int tap = k / g.Cin, c = k - tap * g.Cin, dy = tap / 3, dx = tap - dy * 3;
+                    const int iy = iy0[pt] + dy, ix = ix0[pt] + dx;
+                    const bool ok = px < (size_t)M && k < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                    b[ks][pt] = ok ? *reinterpret_cast<const h8*>(x + (ibase[pt] + (size_t)iy * g.W + ix) * g.Cin + c) : z8;
+                }
             }
+    };
+    h8 wr[WV], wn[WV], b[KC / 32][PT], bn[KC / 32][PT];
+    load_w(0, wr);
+    load_b(0, b);
+    for (int kc = 0; kc < K; kc += KC) {
+        __syncthreads();                                    // previous chunk's LDS reads are done
+#pragma unroll
+        for (int j = 0; j < WV; ++j) {
+            const int i = tid + j * 256, r = i / (KC / 8), c8 = i - r * (KC / 8);
+            if (i < BN * (KC / 8)) *reinterpret_cast<h8*>(Ws + r * PITCH + c8 * 8) = wr[j];
+        }
+        if (kc + KC < K) { load_w(kc + KC, wn); load_b(kc + KC, bn); }
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < KC / 32; ++ks) {
@@ -234,6 +275,14 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
                     acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
                 }
             }
+        }
+        if (kc + KC < K) {
+#pragma unroll
+            for (int j = 0; j < WV; ++j) wr[j] = wn[j];
+#pragma unroll
+            for (int ks = 0; ks < KC / 32; ++ks)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) b[ks][pt] = bn[ks][pt];
         }
     }
 
@@ -665,23 +714,43 @@ extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const v
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
+static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, const void* bias, const void* res, long long M, int K,
+                     int N, int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn, ConvGeom g)
+{
+#define SS_PW(BN, PT, CV)                                                                                               \
+    hipLaunchKernelGGL((k_pw<BN, PT, CV>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
+                       (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act,     \
+                       res_after, (__half*)out, out_ld, (__half*)out2, c0, cn, g)
+#define SS_PW2(BN, PT) do { if (conv3) SS_PW(BN, PT, true); else SS_PW(BN, PT, false); } while (0)
+    const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
+    if (N <= 32) { if (big) SS_PW2(32, 2); else SS_PW2(32, 1); }
+    else if (N <= 64 || !big) { if (big) SS_PW2(64, 2); else SS_PW2(64, 1); }
+    else SS_PW2(128, 2);
+#undef SS_PW2
+#undef SS_PW
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
 extern "C" int ss_op_pointwise_f16(void* stream, const void* x, const void* w, const void* bias, const void* res, long long M,
                                    int K, int N, int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn)
 {
     if (!x || !w || !bias || !out || M < 1 || M > 0x7fffffffLL || K < 8 || K % 8 || N < 8 || N % 8 || out_ld % 4 || out_ld < N ||
         c0 % 4 || cn % 4 || (out2 && (cn < 4 || c0 + cn > N)))
         return SS_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-#define SS_PW(BN, PT)                                                                                                   \
-    hipLaunchKernelGGL((k_pw<BN, PT>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
-                       (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act,     \
-                       res_after, (__half*)out, out_ld, (__half*)out2, c0, cn)
-    const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
-    if (N <= 32) { if (big) SS_PW(32, 2); else SS_PW(32, 1); }
-    else if (N <= 64 || !big) { if (big) SS_PW(64, 2); else SS_PW(64, 1); }
-    else SS_PW(128, 2);
-#undef SS_PW
-    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+    return launch_pw((hipStream_t)stream, false, x, w, bias, res, M, K, N, act, res_after, out, out_ld, out2, c0, cn, ConvGeom{});
+}
+
+extern "C" int ss_op_conv3x3_f16(void* stream, const void* x, const void* w, const void* bias, const void* res, int B, int H, int W,
+                                 int Cin, int N, int conv_stride, int act, int res_after, void* out, int out_ld, void* out2, int c0,
+                                 int cn)
+{
+    if (!x || !w || !bias || !out || B < 1 || H < 1 || W < 1 || Cin < 8 || Cin % 8 || N < 8 || N % 8 || (conv_stride != 1 && conv_stride != 2) ||
+        out_ld % 4 || out_ld < N || c0 % 4 || cn % 4 || (out2 && (cn < 4 || c0 + cn > N)))
+        return SS_ERR_INVALID;
+    ConvGeom g{ H, W, Cin, (H - 1) / conv_stride + 1, (W - 1) / conv_stride + 1, conv_stride };
+    const long long M = (long long)B * g.OH * g.OW;
+    if (M > 0x7fffffffLL) return SS_ERR_INVALID;
+    return launch_pw((hipStream_t)stream, true, x, w, bias, res, M, 9 * Cin, N, act, res_after, out, out_ld, out2, c0, cn, g);
 }
 
 extern "C" int ss_op_lightconv_f16(void* stream, const void* x, const void* w1, const void* w9, const void* bias, void* y,

@@ -11,7 +11,15 @@ import torch
 
 from . import lib as _lib
 
+import os as _os
+
 ENABLED = True
+
+
+def _flag(name: str) -> bool:
+    """A/B switches for measurements: SS_FUSED_<NAME>=0 falls back to the library convolution + separate epilogue."""
+    return _os.environ.get("SS_FUSED_" + name, "1") != "0"
+
 ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3}
 
 
@@ -59,7 +67,7 @@ def bias_act_place(y, bias, act, out, c_off, res=None, res_after=False, out2=Non
                                              _p(out2), c0, 0 if out2 is None else out2.shape[1]))
 
 
-POINTWISE = True            # own MFMA kernel for 1x1 convolutions (off: MIOpen / hipBLASLt + separate epilogue)
+POINTWISE = _flag("POINTWISE")            # own MFMA kernel for 1x1 convolutions (off: MIOpen / hipBLASLt + separate epilogue)
 
 
 def pointwise_ok(conv) -> bool:
@@ -93,6 +101,41 @@ def pointwise(x, w_nk, bias, act="none", res=None, res_after=False, out=None, c_
     return ret
 
 
+CONV3X3 = _flag("CONV3X3")              # own implicit-GEMM kernel for 3x3 convolutions (off: MIOpen + separate epilogue)
+
+
+def conv3x3_ok(conv) -> bool:
+    return (CONV3X3 and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.stride in ((1, 1), (2, 2)) and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
+            and conv.bias is not None)
+
+
+def weight_n9k(mod, conv):
+    """[Cout, 3*3*Cin] (tap-major, channel-minor) copy of a 3x3 conv weight, cached on the module."""
+    w = getattr(mod, "_w_n9k", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        w = conv.weight.detach().permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).contiguous()
+        mod._w_n9k = w
+    return w
+
+
+def conv3x3(x, w_n9k, bias, stride=1, act="none", res=None, res_after=False, out=None, c_off=0, out2=None, c0=0):
+    """act(conv3x3(x, pad 1, stride 1|2) + bias) (+ res) in one launch; placement arguments as `pointwise`."""
+    x = _cl(x)
+    b, k, h, w = x.shape
+    n = w_n9k.shape[0]
+    oh, ow = (h - 1) // stride + 1, (w - 1) // stride + 1
+    if res is not None:
+        res = _cl(res)
+    ret = out
+    if out is None:
+        ret = out = torch.empty((b, n, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    dst = C.c_void_p(out.data_ptr() + 2 * c_off)
+    _ck(_lib.load().ss_op_conv3x3_f16(_st(x), _p(x), _p(w_n9k), _p(bias), _p(res), b, h, w, k, n, stride, ACT[act], int(res_after),
+                                      dst, out.shape[1], _p(out2), c0, 0 if out2 is None else out2.shape[1]))
+    return ret
+
+
 def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 
@@ -118,7 +161,7 @@ def dwconv3x3(x, w9, bias, act="relu"):
     return y
 
 
-LIGHTCONV = True            # fused pointwise + depthwise path of OSNet's LightConv3x3 (off: GEMM + dwconv3x3)
+LIGHTCONV = _flag("LIGHTCONV")            # fused pointwise + depthwise path of OSNet's LightConv3x3 (off: GEMM + dwconv3x3)
 
 
 def lightconv_ok(x) -> bool:
@@ -135,7 +178,7 @@ def lightconv(x, w1, w9, bias):
     return y
 
 
-STREAMS = True              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)
+STREAMS = _flag("STREAMS")              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)
 
 
 def streams_ok(x) -> bool:

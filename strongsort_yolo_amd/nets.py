@@ -35,6 +35,8 @@ class Conv(nn.Module):
             act = "silu" if isinstance(self.act, nn.SiLU) else "none"
             if fused.pointwise_ok(c):        # 1x1: own MFMA kernel, bias + SiLU in its epilogue (one launch)
                 return fused.pointwise(x, fused.weight_nk(self, c), c.bias, act)
+            if fused.conv3x3_ok(c):          # 3x3: the same kernel as an implicit GEMM
+                return fused.conv3x3(x, fused.weight_n9k(self, c), c.bias, c.stride[0], act)
             # k x k: conv without bias (MIOpen) + one fused bias+SiLU pass
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
             return fused.bias_act_(y, c.bias, act)
@@ -83,10 +85,14 @@ class C2f(nn.Module):
             fused.bias_act_place(F.conv2d(x, cv.weight, None, cv.stride, cv.padding), cv.bias, "silu", cat, 0, out2=cur, c0=c)
         for i, m in enumerate(self.m):
             cv = m.cv2.conv
-            t = F.conv2d(m.cv1(cur), cv.weight, None, cv.stride, cv.padding)
             nxt = dense() if i + 1 < n else None
-            fused.bias_act_place(t, cv.bias, "silu", cat, (2 + i) * c, res=cur if m.add else None, res_after=True,
-                                 out2=nxt, c0=0)
+            if fused.conv3x3_ok(cv):         # conv + bias + SiLU + shortcut + placement in one launch
+                fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, cv.stride[0], "silu", res=cur if m.add else None,
+                              res_after=True, out=cat, c_off=(2 + i) * c, out2=nxt, c0=0)
+            else:
+                t = F.conv2d(m.cv1(cur), cv.weight, None, cv.stride, cv.padding)
+                fused.bias_act_place(t, cv.bias, "silu", cat, (2 + i) * c, res=cur if m.add else None, res_after=True,
+                                     out2=nxt, c0=0)
             cur = nxt
         return self.cv2(cat)
 

@@ -5,7 +5,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,shape", [("yolov8n", (1, 3, 384, 640)), ("osnet", (8, 3, 256, 128)), ("yolov8n-pose", (2, 3, 128, 160))])
+@pytest.mark.parametrize("name,shape", [("yolov8n", (1, 3, 384, 640)), ("osnet", (8, 3, 256, 128)), ("yolov8n-pose", (2, 3, 128, 160)),
+                                        ("yolov8s", (2, 3, 192, 320)), ("yolov5n", (2, 3, 128, 160)), ("yolov7", (1, 3, 192, 320))])
 def test_fused_ops_match_torch_modules(name, shape):
     from strongsort_yolo_amd import fused, nets
     dev = torch.device("cuda", 0)
@@ -160,3 +161,36 @@ def test_osnet_streams_equal_layerwise_chains(shape):
           torch.randn(c, cr, generator=g).to(dev, torch.float16), torch.randn(c, generator=g).to(dev, torch.float16)]
     a, r = fused.gate_apply(ys, psum, *gw), fused.gate_sum(ref, *gw)
     assert (a.float() - r.float()).abs().max().item() <= 2e-3 * (r.float().abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("shape,N,stride,act", [((2, 16, 48, 80), 16, 1, "silu"), ((8, 16, 96, 160), 32, 2, "silu"), ((2, 64, 24, 40), 64, 1, "silu"),
+                                                ((3, 128, 12, 20), 128, 1, "relu"), ((1, 32, 7, 9), 64, 2, "none"), ((2, 64, 13, 11), 256, 2, "silu"),
+                                                ((1, 8, 5, 5), 8, 1, "sigmoid"), ((4, 24, 17, 16), 40, 1, "silu")])
+def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
+    """Implicit-GEMM 3x3 kernel vs conv2d (pad 1) + bias + act, shortcut before/after, placement; odd sizes and stride 2."""
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    B, K, H, W = shape
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(K * 100 + N + stride)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float16)
+    x = mk(B, K, H, W).contiguous(memory_format=torch.channels_last)
+    w = (mk(N, K, 3, 3).float() / (9 * K) ** 0.5).half()
+    w9 = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous()
+    bias = mk(N)
+    f = {"silu": F.silu, "relu": F.relu, "none": lambda t: t, "sigmoid": torch.sigmoid}[act]
+    conv = F.conv2d(x.float(), w.float(), None, stride, 1).half().float() + bias.float().view(1, N, 1, 1)
+    OH, OW = conv.shape[2:]
+    res = mk(B, N, OH, OW).contiguous(memory_format=torch.channels_last)
+    tol = lambda ref: 4e-3 * (ref.abs().max().item() + 1.0)
+    got = fused.conv3x3(x, w9, bias, stride, act)
+    assert got.shape == (B, N, OH, OW) and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - f(conv)).abs().max().item() <= tol(f(conv))
+    got = fused.conv3x3(x, w9, bias, stride, act, res=res, res_after=True)
+    assert (got.float() - (f(conv).half().float() + res.float())).abs().max().item() <= tol(f(conv) + res.float())
+    if N % 16 == 0:
+        cat = torch.full((B, N + 16, OH, OW), 3.0, dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+        out2 = torch.empty((B, N, OH, OW), dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+        fused.conv3x3(x, w9, bias, stride, act, out=cat, c_off=16, out2=out2, c0=0)
+        assert torch.equal(cat[:, 16:], fused.conv3x3(x, w9, bias, stride, act)) and torch.equal(out2, cat[:, 16:])
+        assert (cat[:, :16] == 3.0).all()
