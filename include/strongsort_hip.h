@@ -193,6 +193,11 @@ int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]
  * {16,24,32}, W % 8 == 0, 18*(W+2)*C*2 <= 65536 (the band lives in LDS; SS_ERR_INVALID otherwise). */
 int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                         void* d_y, int N, int H, int W, int C);
+/* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
+ * half -> [N][H/4][32][16]; d_w_prep [16][7][24] = per (out channel, ky) the taps 3*kx+ch, zero-padded.  W == 128,
+ * H % 16 == 0. */
+int ss_op_osnet_stem_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int N, int H,
+                         int W);
 /* The four LightConv3x3 chains of an OSNet block (1..4 layers deep, same input) in one launch, intermediates in LDS:
  * d_w1 [10][C][C], d_w9 [10][9][C], d_bias [10][C] = the layers of the 1-, 2-, 3-, 4-deep chain in that order;
  * d_ys[4] the chain outputs [N][H][W][C]; d_psum [4][N][ceil(H/16)][C] float = per-band channel sums of each output

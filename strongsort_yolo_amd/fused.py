@@ -178,6 +178,33 @@ def lightconv(x, w1, w9, bias):
     return y
 
 
+STEM = _flag("STEM")                    # OSNet conv1 7x7/2 + bias + ReLU + max pool 3x3/2 in one launch
+
+
+def stem_ok(x, conv) -> bool:
+    n, c, h, w = x.shape
+    return (STEM and c == 3 and w == 128 and h % 16 == 0 and conv.kernel_size == (7, 7) and conv.stride == (2, 2)
+            and conv.padding == (3, 3) and conv.out_channels == 16 and conv.groups == 1 and conv.bias is not None)
+
+
+def stem_weight(mod, conv):
+    """[16][7][24]: per (out channel, ky) the 21 (kx, ch) taps in the order they lie in an NHWC input row, zero-padded."""
+    w = getattr(mod, "_w_stem", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        w = torch.zeros(16, 7, 24, dtype=conv.weight.dtype, device=conv.weight.device)
+        w[:, :, :21] = conv.weight.detach().permute(0, 2, 3, 1).reshape(16, 7, 21)
+        mod._w_stem = w
+    return w
+
+
+def osnet_stem(x, w_prep, bias):
+    x = _cl(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, 16, h // 4, w // 4), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_osnet_stem_f16(_st(x), _p(x), _p(w_prep), _p(bias), _p(y), n, h, w))
+    return y
+
+
 STREAMS = _flag("STREAMS")              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)
 
 

@@ -427,6 +427,8 @@ class OSNet(nn.Module):
     def _part(self, k, x):
         """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages."""
         if k == 0:
+            if fused.usable(x) and fused.stem_ok(x, self.conv1.conv) and self.conv1.relu:      # conv + bias + ReLU + pool, one launch
+                return fused.osnet_stem(x, fused.stem_weight(self.conv1, self.conv1.conv), self.conv1.conv.bias)
             x = self.conv1(x)
             return fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
         if k in (1, 2):

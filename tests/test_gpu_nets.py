@@ -194,3 +194,21 @@ def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
         fused.conv3x3(x, w9, bias, stride, act, out=cat, c_off=16, out2=out2, c0=0)
         assert torch.equal(cat[:, 16:], fused.conv3x3(x, w9, bias, stride, act)) and torch.equal(out2, cat[:, 16:])
         assert (cat[:, :16] == 3.0).all()
+
+
+@pytest.mark.parametrize("N,H", [(3, 256), (2, 64), (1, 16)])
+def test_osnet_stem_matches_conv_relu_pool(N, H):
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(H)
+    x = torch.randn(N, 3, H, 128, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(3, 16, 7, 2, 3).to(dev, torch.float16)
+    assert fused.stem_ok(x, conv)
+    holder = torch.nn.Module()
+    got = fused.osnet_stem(x, fused.stem_weight(holder, conv), conv.bias)
+    c = F.conv2d(x.float(), conv.weight.float(), None, 2, 3).half().float() + conv.bias.float().view(1, 16, 1, 1)
+    ref = F.max_pool2d(F.relu(c).half().float(), 3, 2, 1)
+    assert got.shape == ref.shape == (N, 16, H // 4, 32)
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * (ref.abs().max().item() + 1.0)
+    assert (got.float() != ref).float().mean().item() < 0.02
