@@ -208,6 +208,8 @@ int ss_op_osnet_streams_f16(void* stream, const void* d_x, const void* d_w1, con
 int ss_op_gate_apply_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
                          const void* d_w2, const void* d_b2, const float* d_sums, int parts, float scale, void* d_out,
                          int N, int HW, int C, int Cr);
+/* 2x2 / stride 2 average pooling, NHWC half (H, W even; C % 8 == 0). */
+int ss_op_avgpool2_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */
 int ss_op_maxpool_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C, int k, int stride, int pad);
 /* OSNet unified aggregation gate: out = sum_t x_t * sigmoid(fc2(relu(fc1(mean_hw(x_t))))), T <= 4 streams. */

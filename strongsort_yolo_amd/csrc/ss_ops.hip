@@ -9,6 +9,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/strongsort_hip.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -189,7 +190,10 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
 // input pixel shifted by that tap (zeros outside the image).  Replaces MIOpen's zero-fill + igemm + our epilogue pass.
 struct ConvGeom { int H, W, Cin, OH, OW, stride; };
 
-template <int BN, int PT, bool CONV3>
+// VEC_EPI: the accumulators (4 channels x 1 pixel per lane and tile) are transposed through a per-wave LDS tile so the
+// epilogue reads the shortcut and writes the output as 16-byte vectors, 128 contiguous bytes per 8 lanes, instead
+// of 8-byte pieces of 32-byte segments.
+template <int BN, int PT, bool CONV3, bool VEC_EPI>
 __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const __half* __restrict__ w,
                                            const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
                                            int N, int act, int res_after, __half* __restrict__ out, int out_ld,
@@ -286,6 +290,43 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
         }
     }
 
+    if (VEC_EPI) {
+        constexpr int EP = BN + 8;                                           // tile pitch (halfs)
+        __shared__ __attribute__((aligned(16))) _Float16 Et[4 * PT * 16 * EP];
+        _Float16* tile = Et + wave * (PT * 16 * EP);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
+                *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;     // conv rounded to half, as unfused
+            }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int CG = BN / 8;                                           // 8-channel groups per row
+#pragma unroll
+        for (int it = 0; it < PT * 16 * CG / 64; ++it) {
+            const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+            const size_t px = px0 + row;
+            const int oc = n0 + cg * 8;
+            if (px >= (size_t)M || oc >= N) continue;
+            const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+            const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
+            h8 r = z8;
+            if (res) r = *reinterpret_cast<const h8*>(res + px * N + oc);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j] + (float)bb[j];
+                if (res && !res_after) f += (float)r[j];
+                f = act_apply(f, act);
+                if (res && res_after) f = (float)(_Float16)f + (float)r[j];
+                o[j] = (_Float16)f;
+            }
+            *reinterpret_cast<h8*>(out + px * out_ld + oc) = o;
+            if (out2 && oc >= c0 && oc < c0 + cn) *reinterpret_cast<h8*>(out2 + px * cn + (oc - c0)) = o;
+        }
+        return;
+    }
     // epilogue: lane (q, n) holds channels oc0..oc0+3 of pixel n of each tile
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
@@ -638,6 +679,27 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
     }
 }
 
+// 2x2 / stride 2 average pooling (OSNet's stage transitions): thread = (output pixel, 8 channels), fp32 sum in the
+// library's order ((a00 + a01) + a10) + a11, / 4.  (torch's NHWC kernel runs at 1.1 TB/s on these shapes.)
+__global__ __launch_bounds__(256) void k_avgpool2(const __half* __restrict__ x, __half* __restrict__ y, int N, int H, int W, int C8)
+{
+    const int OH = H / 2, OW = W / 2;
+    const size_t total = (size_t)N * OH * OW * C8;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
+        const int ow = (int)(p % OW), oh = (int)((p / OW) % OH);
+        const size_t nimg = p / ((size_t)OW * OH);
+        const h8* r0 = reinterpret_cast<const h8*>(x) + ((nimg * H + 2 * oh) * W + 2 * ow) * C8 + c8;
+        const h8* r1 = r0 + (size_t)W * C8;
+        const h8 a = r0[0], b = r0[C8], c = r1[0], d = r1[C8];
+        h8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (_Float16)(((((float)a[k] + (float)b[k]) + (float)c[k]) + (float)d[k]) / 4.0f);
+        reinterpret_cast<h8*>(y)[i] = o;
+    }
+}
+
 // OSNet unified aggregation gate over T <= 4 streams.
 //   step 1: mean over H*W of every stream -> means[t][n][C] (f32)
 //   step 2: g_t = sigmoid(fc2(relu(fc1(mean_t)))) per sample, out = sum_t x_t * g_t
@@ -808,11 +870,19 @@ extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const v
 static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, const void* bias, const void* res, long long M, int K,
                      int N, int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn, ConvGeom g)
 {
-#define SS_PW(BN, PT, CV)                                                                                               \
-    hipLaunchKernelGGL((k_pw<BN, PT, CV>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
+    // vector epilogue needs 16-byte aligned rows and slices; SS_PW_EPILOGUE=0 forces the 8-byte form (A/B switch)
+    static const bool vec_allowed = [] { const char* e = getenv("SS_PW_EPILOGUE"); return !(e && e[0] == '0'); }();
+    const bool vec = vec_allowed && out_ld % 8 == 0 && c0 % 8 == 0 && cn % 8 == 0 && ((uintptr_t)out % 16) == 0 &&
+                     (!out2 || ((uintptr_t)out2 % 16) == 0) && (!res || ((uintptr_t)res % 16) == 0);
+#define SS_PW(BN, PT, CV, VE)                                                                                           \
+    hipLaunchKernelGGL((k_pw<BN, PT, CV, VE>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
                        (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act,     \
                        res_after, (__half*)out, out_ld, (__half*)out2, c0, cn, g)
-#define SS_PW2(BN, PT) do { if (conv3) SS_PW(BN, PT, true); else SS_PW(BN, PT, false); } while (0)
+#define SS_PW2(BN, PT)                                                                                                  \
+    do {                                                                                                                \
+        if (conv3) { if (vec) SS_PW(BN, PT, true, true); else SS_PW(BN, PT, true, false); }                             \
+        else { if (vec) SS_PW(BN, PT, false, true); else SS_PW(BN, PT, false, false); }                                 \
+    } while (0)
     const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
     if (N <= 32) { if (big) SS_PW2(32, 2); else SS_PW2(32, 1); }
     else if (N <= 64 || !big) { if (big) SS_PW2(64, 2); else SS_PW2(64, 1); }
@@ -929,5 +999,13 @@ extern "C" int ss_op_gate_apply_f16(void* stream, const void* const* xs, int T, 
     hipLaunchKernelGGL(k_gate_apply, dim3(grid_for(nvec, 256) > 64 ? 64 : grid_for(nvec, 256), N), dim3(256), 0, (hipStream_t)stream,
                        p, T, sums, parts, scale, (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2,
                        (__half*)out, N, HW, C, Cr);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_avgpool2_f16(void* stream, const void* x, void* y, int N, int H, int W, int C)
+{
+    if (!x || !y || C % 8 || H < 2 || W < 2 || H % 2 || W % 2) return SS_ERR_INVALID;
+    size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(k_avgpool2, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (__half*)y, N, H, W, C / 8);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -258,6 +258,17 @@ def maxpool(x, k, stride, pad):
     return y
 
 
+def avgpool2(x):
+    """2x2 / stride 2 average pooling on a channels-last half tensor (even H, W; C % 8 == 0), else torch's."""
+    x = _cl(x)
+    n, c, h, w = x.shape
+    if c % 8 or h % 2 or w % 2:
+        return torch.nn.functional.avg_pool2d(x, 2, 2)
+    y = torch.empty((n, c, h // 2, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_avgpool2_f16(_st(x), _p(x), _p(y), n, h, w, c))
+    return y
+
+
 def conv1x1(x, w_t, bias=None):
     """Pointwise convolution as one GEMM on the NHWC view: [N*H*W, Cin] @ [Cin, Cout] (+ bias in the epilogue).
     MIOpen's implicit-GEMM kernels for these shapes need a separate zero-fill launch (split-K); a plain GEMM does not."""

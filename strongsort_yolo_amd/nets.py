@@ -434,11 +434,13 @@ class OSNet(nn.Module):
         if k in (1, 2):
             return self.conv2[k - 1](x)
         if k == 3:
-            return self.conv2[3](self.conv2[2](x))
+            t = self.conv2[2](x)
+            return fused.avgpool2(t) if fused.usable(t) else self.conv2[3](t)
         if k in (4, 5):
             return self.conv3[k - 4](x)
         if k == 6:
-            return self.conv3[3](self.conv3[2](x))
+            t = self.conv3[2](x)
+            return fused.avgpool2(t) if fused.usable(t) else self.conv3[3](t)
         if k in (7, 8):
             return self.conv4[k - 7](x)
         return self.conv5(x)

@@ -212,3 +212,15 @@ def test_osnet_stem_matches_conv_relu_pool(N, H):
     assert got.shape == ref.shape == (N, 16, H // 4, 32)
     assert (got.float() - ref).abs().max().item() <= 4e-3 * (ref.abs().max().item() + 1.0)
     assert (got.float() != ref).float().mean().item() < 0.02
+
+
+def test_avgpool2_equals_torch():
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for shape in [(3, 64, 64, 32), (2, 96, 32, 16), (1, 8, 2, 2)]:
+        x = torch.randn(*shape, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+        got, ref = fused.avgpool2(x), F.avg_pool2d(x, 2, 2)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got.float() - ref.float()).abs().max().item() <= 1e-3 * (ref.float().abs().max().item() + 1e-6)
