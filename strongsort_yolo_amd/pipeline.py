@@ -249,7 +249,10 @@ class OverlappedPipeline(FramePipeline):
             st += [self._s_nms_crop_reid_select]
         self.stages = st
         self.n = len(st)
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)]
+        # the last stage carries the tracker's short dependent launches: SS_TRACK_PRIORITY=1 gives its stream high priority
+        import os as _os
+        hi = _os.environ.get("SS_TRACK_PRIORITY", "0") == "1"
+        self.streams = [torch.cuda.Stream(self.dev, priority=(-1 if (hi and j == self.n - 1) else 0)) for j in range(self.n)]
         # tracker_stream=True gives the tracker (one-workgroup kernels, ~70 us a frame) a stream of its own next to the
         # last stage of the following group, with one more buffer set so that stage 0 does not wait for it.  Measured
         # at configs[1], same box, frame batch 8: 3110 frames/s with it vs 3280 without — a third concurrent launch
