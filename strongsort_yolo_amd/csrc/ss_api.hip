@@ -48,8 +48,6 @@ struct ss_ctx {
     void* nms_ws;               // nms_units workspace units (grown on demand outside graph capture)
     size_t nms_ws_bytes;
     int nms_units;
-    int tracks_ub;              // host upper bound of live tracks per stream (grid sizing)
-    int fixed_grid;             // >0: use this grid instead (graph capture)
     int cos_grid;               // persistent workgroups of the association kernel
     // association-kernel timing
     bool timing;
@@ -95,8 +93,6 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->stream = nullptr;
     c->timing = false;
     c->ev_used = 0;
-    c->tracks_ub = 0;
-    c->fixed_grid = 0;
     c->cos_grid = 256;           // persistent workgroups: one per CU
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
@@ -194,7 +190,6 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
     if (stream < 0)
         for (int u = 0; u < c->nms_units; ++u) HIPCHK(c, hipMemsetAsync(ss_nms_error_flag(c->nms_ws, u), 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->tracks_ub = 0;
     return SS_OK;
 }
 
@@ -248,12 +243,10 @@ extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, 
     HIPCHK(c, hipMemcpyAsync(c->d_imghw, hw, 8, hipMemcpyHostToDevice, c->stream));
     int rc = ss_track_update(c, c->d_dets, c->d_ndets, c->d_feats, c->d_imghw, c->d_out, c->d_nout);
     if (rc) return rc;
-    int cnt[2] = { 0, 0 }, nt = 0, err = 0;
+    int cnt[2] = { 0, 0 }, err = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt[0], c->d_nout, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&nt, c->dev.n_tracks, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&err, c->dev.err, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->tracks_ub = nt;
     if (err) return fail(c, err, err == SS_ERR_CAPACITY ? "tracker capacity exceeded on device" : "assignment infeasible on device");
     *n_out = cnt[0];
     if (cnt[0] > cap_rows) return fail(c, SS_ERR_CAPACITY, "ss_track_update_host: output buffer too small");
@@ -264,20 +257,15 @@ extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, 
 extern "C" int ss_set_track_grid(ss_ctx* c, int n)
 {
     if (!c || n < 0 || n > SS_MAXT) return fail(c, SS_ERR_INVALID, "ss_set_track_grid: 0 <= n <= 256");
-    c->fixed_grid = n;
-    return SS_OK;
+    return SS_OK;                // no launch dimension depends on the track count any more (see the header)
 }
 
 extern "C" int ss_check_errors(ss_ctx* c)
 {
     if (!c) return SS_ERR_INVALID;
-    std::vector<int> e(c->dev.S), nt(c->dev.S);
+    std::vector<int> e(c->dev.S);
     HIPCHK(c, hipMemcpyAsync(e.data(), c->dev.err, e.size() * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(nt.data(), c->dev.n_tracks, nt.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int ub = 0;
-    for (int v : nt) ub = v > ub ? v : ub;
-    c->tracks_ub = ub;
     for (size_t s = 0; s < e.size(); ++s)
         if (e[s]) return fail(c, e[s], "device error flag on stream " + std::to_string(s));
     for (int u = 0; u < c->nms_units; ++u) {                 // NMS candidate overflow (flag stays set until ss_reset)
@@ -438,7 +426,6 @@ extern "C" int ss_get_tracks(ss_ctx* c, int s, int cap, int* n_tracks, int* next
     HIPCHK(c, hipMemcpy(&nid, d.next_id + s, 4, hipMemcpyDeviceToHost));
     if (n_tracks) *n_tracks = nt;
     if (next_id) *next_id = nid;
-    c->tracks_ub = c->dev.S == 1 ? nt : c->tracks_ub;
     if (nt > cap) return fail(c, SS_ERR_CAPACITY, "ss_get_tracks: cap too small");
     const size_t T = SS_MAXT, sb = (size_t)s * T;
     std::vector<int> order(T), tmp(T);

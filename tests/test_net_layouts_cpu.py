@@ -1,0 +1,112 @@
+"""CPU restatements of the index arithmetic the network-side HIP kernels rely on (csrc/ss_ops.hip), checked against
+torch's own operators in fp32.  They pin the host-side weight layouts (`fused.weight_nk`, `weight_n9k`, `stem_weight`,
+the stacked LightConv weights of an OSNet block) and the kernels' addressing schemes independent of a GPU; the GPU
+tests (`tests/test_gpu_nets.py`) then check the kernels themselves."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from strongsort_yolo_amd import fused, nets
+
+
+def test_weight_n9k_is_the_implicit_gemm_operand():
+    """k_pw<…,CONV3>: out[p][n] = sum_k W[n][k] * X[p][k] with k = tap*Cin + c and tap = 3*dy + dx, input pixel
+    (stride*oy - 1 + dy, stride*ox - 1 + dx), zeros outside."""
+    torch.manual_seed(0)
+    for cin, cout, stride, hw in [(8, 16, 1, (5, 7)), (16, 8, 2, (6, 9)), (24, 40, 2, (7, 7))]:
+        conv = torch.nn.Conv2d(cin, cout, 3, stride, 1)
+        assert fused.conv3x3_ok(conv)
+        w = fused.weight_n9k(torch.nn.Module(), conv)
+        assert w.shape == (cout, 9 * cin)
+        x = torch.randn(2, cin, *hw)
+        H, W = hw
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+        xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1)                       # [B, H+2, W+2, Cin], padded index = index + 1
+        cols = torch.empty(2, OH, OW, 9 * cin)
+        for tap in range(9):
+            dy, dx = divmod(tap, 3)
+            cols[..., tap * cin:(tap + 1) * cin] = xp[:, dy:dy + stride * (OH - 1) + 1:stride, dx:dx + stride * (OW - 1) + 1:stride]
+        got = (cols.reshape(-1, 9 * cin) @ w.t()).reshape(2, OH, OW, cout).permute(0, 3, 1, 2)
+        ref = F.conv2d(x, conv.weight, None, stride, 1)
+        assert got.shape == ref.shape and torch.allclose(got, ref, atol=1e-5)
+
+
+def test_weight_nk_and_the_permuted_k_assignment():
+    """k_pw feeds the MFMA with lane group q holding k = 8q..8q+7 of a 32-wide chunk (elements 0-3 to the first
+    16x16x16 instruction, 4-7 to the second): any k <-> slot assignment used for BOTH operands leaves the dot
+    product unchanged.  Restated with an explicit permutation."""
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(32, 16, 1)
+    assert fused.pointwise_ok(conv)
+    w = fused.weight_nk(torch.nn.Module(), conv)                             # [N, K]
+    x = torch.randn(10, 32)
+    slot = np.array([[8 * q + j for q in range(4) for j in range(4)], [8 * q + 4 + j for q in range(4) for j in range(4)]])
+    assert sorted(slot.reshape(-1).tolist()) == list(range(32))              # the two instructions cover every k once
+    acc = sum(x[:, slot[i]] @ w[:, slot[i]].t() for i in range(2))
+    assert torch.allclose(acc, F.conv2d(x.view(10, 32, 1, 1), conv.weight).view(10, 16), atol=1e-5)
+
+
+def test_stem_weight_and_flat_row_windows():
+    """k_osnet_stem keeps each NHWC input row as a flat array of halfs with 9 halfs (3 pixels) of zero margin in front;
+    the 21 taps (kx, ch) of conv column c on row ky are then the contiguous window starting at 6c, multiplied with the
+    weights laid out [oc][ky][3*kx+ch] (padded to 24; the 3 extra window elements meet zero weights)."""
+    torch.manual_seed(2)
+    conv = torch.nn.Conv2d(3, 16, 7, 2, 3)
+    wp = fused.stem_weight(torch.nn.Module(), conv)
+    assert wp.shape == (16, 7, 24) and (wp[:, :, 21:] == 0).all()
+    H = 16
+    x = torch.randn(1, 3, H, 128)
+    assert fused.stem_ok(x, conv)
+    rows = torch.zeros(H + 6, 404)                                           # 3 zero rows above and below, margins zero
+    rows[3:H + 3, 9:9 + 384] = x[0].permute(1, 2, 0).reshape(H, 384)
+    out = torch.empty(16, H // 2, 64)
+    for r in range(H // 2):
+        for c in range(64):
+            win = torch.stack([rows[2 * r + ky, 6 * c:6 * c + 24] for ky in range(7)])      # [7, 24]
+            out[:, r, c] = (wp * win).sum((1, 2))
+    ref = F.conv2d(x, conv.weight, None, 2, 3)[0]
+    assert torch.allclose(out, ref, atol=1e-4)
+    # ReLU outputs are >= 0, so a 0 in a padded pooling position never changes the maximum (the kernel's pad value)
+    a = F.relu(ref + conv.bias.view(16, 1, 1))
+    pooled_zero_pad = F.max_pool2d(F.pad(a, (1, 1, 1, 1), value=0.0), 3, 2, 0)
+    assert torch.equal(pooled_zero_pad, F.max_pool2d(a, 3, 2, 1))
+
+
+def test_osnet_block_layer_order_matches_the_chain_kernel():
+    """k_osnet_streams takes the ten LightConv layers as [chain1: 1 layer][chain2: 2][chain3: 3][chain4: 4]; chain t
+    starts at index t(t-1)/2.  The module order `for st in streams for m in st` must be that order."""
+    blk = nets.OSBlock(16, 64)
+    layers = [m for st in blk.streams for m in st]
+    assert len(layers) == 10 and [len(st) for st in blk.streams] == [1, 2, 3, 4]
+    for t in range(1, 5):
+        base = t * (t - 1) // 2
+        assert all(layers[base + l] is blk.streams[t - 1][l] for l in range(t))
+
+
+def test_chain_halo_rows_shrink_one_per_layer():
+    """Row bookkeeping of k_osnet_streams: band of TH rows, chain depth t, local row i <-> image row y0 - t + i; layer
+    l computes the pointwise product on local rows [l-1, R-l] and the depthwise output on [l, R-l-1] (R = TH + 2t), so
+    the last layer yields exactly the band.  Checked by propagating 'valid row' sets through real 3x3 dependencies."""
+    TH = 16
+    for t in range(1, 5):
+        R = TH + 2 * t
+        have = set(range(R))                                                 # input rows present in LDS / global
+        for l in range(1, t + 1):
+            pw = set(range(l - 1, R - l + 1))
+            assert pw <= have                                                # pointwise needs only rows we hold
+            dw = set(range(l, R - l))
+            assert all({r - 1, r, r + 1} <= pw for r in dw)                  # 3x3 reads inside the pointwise rows
+            have = dw
+        assert have == set(range(t, TH + t))                                 # = the band
+
+
+def test_avgpool_and_place_guards():
+    conv = torch.nn.Conv2d(12, 16, 1)                                        # Cin % 8 != 0 -> library path
+    assert not fused.pointwise_ok(conv)
+    assert not fused.conv3x3_ok(torch.nn.Conv2d(16, 16, 3, 1, 0))            # pad 0
+    assert not fused.conv3x3_ok(torch.nn.Conv2d(16, 16, 3, 1, 1, groups=16))
+    assert fused.place_ok(16, 48) and not fused.place_ok(12, 36)
+    x = torch.zeros(1, 16, 64, 32)
+    assert fused.lightconv_ok(x) and fused.streams_ok(x)
+    assert not fused.streams_ok(torch.zeros(1, 16, 64, 100))                 # W % 8 != 0
+    assert not fused.streams_ok(torch.zeros(1, 32, 64, 64))                  # LDS budget
