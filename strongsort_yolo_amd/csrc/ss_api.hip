@@ -140,7 +140,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     if (rc != SS_OK) { std::string m = c->err; ss_destroy(c); g_last_error = m; return rc; }
     // next_id starts at 1
     std::vector<int> ones(S, 1);
-    hipMemcpy(d.next_id, ones.data(), S * sizeof(int), hipMemcpyHostToDevice);
+    hipError_t e3 = hipMemcpy(d.next_id, ones.data(), S * sizeof(int), hipMemcpyHostToDevice);
+    if (e3 != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("ss_create: ") + hipGetErrorString(e3)); ss_destroy(c); return r; }
     *out = c;
     return SS_OK;
 }
@@ -148,10 +149,11 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
 extern "C" void ss_destroy(ss_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipDeviceSynchronize();
-    for (auto& e : c->ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (void* p : c->allocs) hipFree(p);
+    // teardown: nothing useful can be done with an error here
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
 

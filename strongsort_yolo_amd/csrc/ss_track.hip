@@ -1168,9 +1168,10 @@ size_t ss_cosine_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 512 * 16; }
 
 extern "C" void ss_step_kernel_attr()
 {
-    hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_step_lds_bytes());
-    hipFuncSetAttribute((const void*)k_lsap_kat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_lsap_lds_bytes());
-    hipFuncSetAttribute((const void*)k_cosine_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_cosine_lds_bytes());
+    // a failure here surfaces as a launch error on first use (checked with hipGetLastError after every launch)
+    (void)hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_step_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_lsap_kat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_lsap_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_cosine_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_cosine_lds_bytes());
 }
 
 void ss_launch_frame(const SSDev& dev, const SSParams& prm, int grid_tracks, hipStream_t st,
