@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One "step" = one frame of every stream owned by the rank through the whole hot path
-(letterbox -> detector -> NMS -> ReID crops -> OSNet -> StrongSORT update), inputs resident in HBM.
+One "step" = one batch of `frames_per_step` consecutive frames (default 4 frame-batch groups of 8 = 32 frames) of
+every stream owned by the rank through the whole hot path (letterbox -> detector -> NMS -> ReID crops -> OSNet ->
+StrongSORT update), inputs resident in HBM; `value` = frames/s = world * streams * steps * frames_per_step / time.
+With `--gpus N` and no WORLD_SIZE in the environment the script starts its N ranks itself (torch.distributed.run,
+one process per GPU, RCCL); under an external launcher it uses the ranks it is given.
 Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synthetic, 30 identities
 (~30 det/frame), 1 stream per GPU.  Streams are independent, so N GPUs = N x the work ("weak"); no
 data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
@@ -49,8 +52,25 @@ PRESETS = {
     "c2": ("yolov8n", 1280, 720, 30, 32),      # BASELINE.json configs[1] (the metric's configuration)
     "c3": ("yolov8s", 1280, 720, 30, 32),      # configs[2] per GPU
     "c4": ("yolov7", 1920, 1080, 100, 128),    # configs[3] crowded scene
+    "c5": ("yolov8n-pose", 1280, 720, 30, 32), # configs[4] per GPU: pose head, keypoints carried by det_idx
 }
-PREFILL = 103      # frames before any timing so galleries hold nn_budget rows
+CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}
+PREFILL = 104      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init)
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
+    127.0.0.1), exactly the command form the driver uses for N > 1."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def make_workload(seed, W, H, n_ids, n_frames, geom_scale, nc, n_anchors):
@@ -88,8 +108,11 @@ def oracle_rows(wl, n_frames, W, H, geom_scale, nc, cfg, dcfg):
     return rows
 
 
-def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budget_s=22.0):
-    """Reference-style CPU path on the host cores, bounded sample.  kind = "port"."""
+def cpu_baseline(W, H, n_ids, geom, geom_scale, nc, n_anchors, cfg, dcfg, detector_name, budget_s=22.0,
+                 n_track=40, n_full=60):
+    """Reference-style CPU path on the host cores, bounded sample.  kind = "port".  Builds its own workload
+    (PREFILL warm-up frames + n_track tracker-only frames + up to n_full full-pipeline frames), so the sample does
+    not depend on --steps."""
     import torch
     from oracle import cexact
     from oracle.strongsort_np import OracleStrongSort
@@ -99,6 +122,7 @@ def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budge
     except Exception:                                     # pragma: no cover
         threadpool_limits = None
     gain, px, py = geom_scale
+    wl = make_workload(777, W, H, n_ids, PREFILL + n_track + n_full, geom_scale, nc, n_anchors)
     ncores = os.cpu_count() or 1
     nthr = min(ncores, 32)
     torch.set_num_threads(nthr)
@@ -115,22 +139,18 @@ def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budge
         f = wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
         return r, f
 
-    k = 0
     for k in range(PREFILL):                               # untimed: fill the galleries
         r, f = track_only(k)
         orc.update(r, f, (H, W))
-    # tracker-only timing
-    t0 = time.perf_counter(); n_t = 0
-    while n_t < 40 and k + 1 < len(wl["preds"]):
-        k += 1
+    k = PREFILL
+    t0 = time.perf_counter(); n_t = 0                      # tracker-only timing
+    while n_t < n_track:
         r, f = track_only(k)
-        orc.update(r, f, (H, W)); n_t += 1
-    t_track = (time.perf_counter() - t0) / max(n_t, 1)
-    # full pipeline timing
-    t0 = time.perf_counter(); n_f = 0
+        orc.update(r, f, (H, W)); n_t += 1; k += 1
+    t_track = (time.perf_counter() - t0) / n_t
+    t0 = time.perf_counter(); n_f = 0                      # full pipeline timing
     with torch.no_grad():
-        while time.perf_counter() - t0 < budget_s and n_f < 60 and k + 1 < len(wl["preds"]):
-            k += 1
+        while n_f < n_full and (n_f == 0 or time.perf_counter() - t0 < budget_s):
             img = wl["pixels"][k % len(wl["pixels"])]
             lb = cexact.letterbox(img, geom.out_h, geom.out_w, geom.new_h, geom.new_w, geom.pad_top, geom.pad_left)
             det(torch.from_numpy(lb)[None])                                    # random-init: output unused
@@ -138,14 +158,15 @@ def cpu_baseline(wl, W, H, geom, geom_scale, nc, cfg, dcfg, detector_name, budge
             crops = cexact.crop_norm(img, r)
             if len(crops):
                 reid(torch.from_numpy(crops))
-            orc.update(r, f, (H, W)); n_f += 1
+            orc.update(r, f, (H, W)); n_f += 1; k += 1
     t_full = (time.perf_counter() - t0) / max(n_f, 1)
     if ctx:
         ctx.__exit__(None, None, None)
-    return {"value": round(1.0 / t_full, 2), "unit": "frames/s", "cores": nthr, "kind": "port",
-            "sample": f"{n_f} frames of the same stream after {PREFILL} untimed warm-up frames: C-oracle letterbox/NMS/crop, "
+    return {"value": round(1.0 / t_full, 2) if n_f > 0 else None, "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"{n_f} frames of one synthetic stream after {PREFILL} untimed warm-up frames: C-oracle letterbox/NMS/crop, "
                       f"CPU-torch fp32 {detector_name}+OSNet-x0.25 ({nthr} threads), NumPy/SciPy StrongSORT update (1 BLAS thread)",
-            "tracker_only_frames_per_s": round(1.0 / t_track, 1), "host_cores": ncores}
+            "sample_frames": n_f, "tracker_only_frames_per_s": round(1.0 / t_track, 1), "tracker_only_frames": n_t,
+            "host_cores": ncores}
 
 
 def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, timed=40, device=0):
@@ -168,17 +189,37 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, 
             hd[k, s, :n], hf[k, s, :n], hn[k, s] = f.dets, f.feats, n
     dets.copy_(torch.from_numpy(hd)); feats.copy_(torch.from_numpy(hf)); nd.copy_(torch.from_numpy(hn))
     hw = torch.tensor([[H, W]] * n_streams, dtype=torch.int32, device=dev)
+    rows_all = torch.zeros(frames, n_streams, 256, 8, device=dev)
+    nrows_all = torch.zeros(frames, n_streams, dtype=torch.int32, device=dev)
+
+    def step(k):
+        out, nout = eng.update_device(dets[k], nd[k], feats[k], hw)
+        rows_all[k].copy_(out); nrows_all[k].copy_(nout)
+
     for k in range(frames - timed):
-        eng.update_device(dets[k], nd[k], feats[k], hw)
+        step(k)
     torch.cuda.synchronize()
     eng.assoc_timing(True)
     t0 = time.perf_counter()
     for k in range(frames - timed, frames):
-        eng.update_device(dets[k], nd[k], feats[k], hw)
+        step(k)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, n = eng.assoc_timing(False)
     eng.check_errors()
+    # parity of the batched launches: first and last stream against the exact-order oracle, every frame
+    from oracle.strongsort_np import OracleStrongSort
+    hr, hnr = rows_all.cpu().numpy(), nrows_all.cpu().numpy()
+    tot = same = 0
+    for s in sorted({0, n_streams - 1}):
+        orc = OracleStrongSort(cfg, "c")
+        for k in range(frames):
+            nk = int(hn[k, s])
+            ref = orc.update(hd[k, s, :nk], hf[k, s, :nk], (H, W))
+            got = hr[k, s, :hnr[k, s]]
+            tot += max(len(ref), len(got))
+            if got.shape == ref.shape:
+                same += int((got == ref).all(axis=1).sum())
     alg = 0.0
     for s in range(n_streams):
         t = eng.tracks(s)
@@ -197,14 +238,17 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, 
     return {"kernel": "k_cosine_stream", "streams_per_launch": n_streams, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
             "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg),
             "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n,
-            "tracker_path_frames_per_s": round(n_streams * timed / dt, 1)}
+            "tracker_path_frames_per_s": round(n_streams * timed / dt, 1),
+            "batched_id_match_rate": round(same / max(tot, 1), 6), "rows_checked": tot}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30, help="timed steps; one step = --groups-per-step frame-batch groups of every stream")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--groups-per-step", type=int, default=4, help="frame-batch groups per step (frames_per_step = this x --frame-batch)")
+    ap.add_argument("--dist-check", action="store_true", help="only start the ranks, run the barrier / max-over-ranks exchange and print n_gpus (no GPU work)")
     ap.add_argument("--streams", type=int, default=1, help="streams per GPU (configs[1] = 1)")
     ap.add_argument("--preset", default="c2", choices=sorted(PRESETS))
     ap.add_argument("--graph", default="front", choices=["front", "all", "none"])
@@ -217,6 +261,8 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=8, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -230,24 +276,41 @@ def main():
     backend = os.environ.get("SS_BENCH_BACKEND", "nccl")            # "gloo" + SS_BENCH_SINGLE_DEVICE=1: control-flow test on one GPU
     one_dev = os.environ.get("SS_BENCH_SINGLE_DEVICE") == "1"
     dev_index = 0 if (world == 1 or one_dev) else local_rank
-    torch.cuda.set_device(dev_index)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    if not args.dist_check:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+    if args.dist_check:
+        t = torch.tensor([1.0 + rank], dtype=torch.float64, device=torch.device("cuda", dev_index) if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"dist_check": True, "n_gpus": world, "max_over_ranks": float(t.item()), "backend": backend if world > 1 else None}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     detector, W, H, n_ids, rb = PRESETS[args.preset]
     cfg, dcfg = StrongSortConfig(), DetectConfig()
-    S, K, Wm = args.streams, args.steps, args.warmup
-    total = PREFILL + Wm + K
     overlap = args.overlap > 1 and args.graph != "none" and not args.no_nets
+    FB = args.frame_batch if overlap else 1
+    FPS = FB * args.groups_per_step                     # frames of a stream per step
+    S, K, Wm = args.streams, args.steps, args.warmup
+    KF, WF = K * FPS, Wm * FPS                          # timed / warm-up frames per stream
+    total = PREFILL + WF + KF
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, track_grid=min(256, 2 * n_ids + 32), **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream} if overlap else {}))
-    FB = args.frame_batch if overlap else 1
+                   run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream} if overlap else {}))
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
     wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
@@ -320,13 +383,13 @@ def main():
         torch.cuda.synchronize()
 
     run(0, PREFILL)                              # untimed: galleries reach nn_budget rows
-    run(PREFILL, PREFILL + Wm)                   # W untimed warm-up steps
+    run(PREFILL, PREFILL + WF)                   # W untimed warm-up steps
     drain()
     torch.cuda.synchronize()
     pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
     barrier()
     t0 = time.perf_counter()
-    run(PREFILL + Wm, total)                     # exactly K timed steps (frames)
+    run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
     t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (the GPU may still be working)
     barrier()
     dt = time.perf_counter() - t0
@@ -398,15 +461,15 @@ def main():
                 same += int(eq.sum())
                 exact_frames += int(got.tobytes() == r.tobytes())
         res = {
-            "metric": "tracked frames/sec (whole node), 1280x720@30det" if args.preset != "c4" else "tracked frames/sec (whole node), 1920x1080@100det",
-            "value": round(world * S * K / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": f"tracked frames/sec (whole node), {W}x{H}@{n_ids}det",
+            "value": round(world * S * KF / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "frames_per_step": FPS, "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
-            "config": {"workload": f"configs[{ {'c2': 1, 'c3': 2, 'c4': 3}[args.preset] }]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
+            "config": {"workload": f"configs[{CONFIG_INDEX[args.preset]}]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
-            "host_enqueue_ms_per_step": round(t_enq / K * 1e3, 4), "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
+            "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "id_match_rate": round(same / max(tot, 1), 6), "frames_bit_exact": f"{exact_frames}/{nchk}",
             "roofline": roofline,
         }
         res["roofline_batched"] = None
@@ -416,7 +479,7 @@ def main():
         if world == 1 and not args.no_batched:
             res["roofline_batched"] = batched_association(cfg, device=dev_index)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wls[0], W, H, pipe.geom, gs, nc, cfg, dcfg, detector)
+            res["cpu_baseline"] = cpu_baseline(W, H, n_ids, pipe.geom, gs, nc, A, cfg, dcfg, detector)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -121,10 +121,11 @@ int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const 
 int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, const float* h_feats,
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
 
-/* Kept for callers of earlier builds: the association kernels are now persistent over device-built work
- * lists, so no launch dimension depends on the track count and ss_track_update can be captured into a HIP
- * graph without this call.  Accepts 0..SS_MAX_TRACKS and has no effect. */
-int ss_set_track_grid(ss_ctx* ctx, int max_confirmed_tracks);
+/* Tuning / profiling switches of a context (host state, read at the next ss_track_update):
+ *   "stream_mode"  -1 (default): wave-per-tile association kernel from 4 streams per context up; 0 / 1 force it
+ *   "cos_grid"     persistent workgroups of the association kernel (default 256 = one per CU)
+ *   "timestamps"   1: record in-kernel wall-clock stamps for ss_get_timestamps */
+int ss_set_option(ss_ctx* ctx, const char* name, int value);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
 int ss_check_errors(ss_ctx* ctx);

@@ -95,7 +95,7 @@ float so_sumsq(const float* v, int F)
 void so_normalize(const float* in, float* out, int F)
 {
     float n = sqrtf(so_sumsq(in, F));
-    for (int k = 0; k < F; ++k) out[k] = in[k] / n;
+    for (int k = 0; k < F; ++k) out[k] = n > 0.0f ? in[k] / n : 0.0f;      /* an all-zero row stays zero (D-17), no NaN */
 }
 
 /* E7  EMA feature update + renormalise (StrongSORT Track.update, D-05). */

@@ -49,7 +49,8 @@ class NumpyNumerics:
     # appearance
     def normalize(self, v):
         v = np.asarray(v, dtype=np.float32)
-        return (v / np.linalg.norm(v)).astype(np.float32)
+        n = np.linalg.norm(v)
+        return (v / n).astype(np.float32) if n > 0 else np.zeros_like(v)
 
     def cosine_min(self, gallery, feats):
         d = np.float32(1.0) - gallery @ feats.T          # [B, D] sgemm

@@ -57,9 +57,9 @@ class LabelsWriter:
                 continue
             for bbox in r.boxes:
                 for conf, cls, xyxy, id_ in zip(bbox.conf, bbox.cls, bbox.xyxy, bbox.id):
-                    x1, y1, x2, y2 = (float(v) for v in xyxy)
+                    x1, y1, x2, y2 = (int(v) for v in xyxy)                 # reference :166 int() box corners
                     fid = 0 if self.compat else frame_id
-                    self.f.write(f"{fid} {int(cls)} {int(id_)} {float(conf)} {x1} {y1} {x2} {y2} -1 -1 -1 -1\n")
+                    self.f.write(f"{fid} {int(cls)} {int(id_)} {round(float(conf), 3)} {x1} {y1} {x2} {y2} -1 -1 -1 -1\n")
                     n += 1
         self.f.flush()
         return n
@@ -97,7 +97,7 @@ def process_video(args: dict, model=None) -> dict:
     source, track, count = args["source"], args["track"], args["count"]
     if model is None:
         from .yolo import YOLO
-        model = YOLO(args.get("weights", "yolov8n.pt"))
+        model = YOLO(args.get("weights", "yolov8n.pt"), random_init_ok=args.get("random_init", False))
         model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)      # :18-21
     name = os.path.splitext(os.path.basename(str(source)))[0] or "stream"
     writer = LabelsWriter(os.path.join(args.get("outdir", "output"), f"{name}_labels.txt"), args.get("compat", False))
@@ -130,8 +130,9 @@ def main(argv=None):
     p.add_argument("--count", action="store_true")
     p.add_argument("--weights", default="yolov8n.pt")
     p.add_argument("--limit", type=int, default=None)
+    p.add_argument("--random-init", action="store_true", help="run seeded random-init networks when the weights file is missing")
     a = p.parse_args(argv)
-    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "limit": a.limit, "device": i}
+    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "limit": a.limit, "device": i, "random_init": a.random_init}
             for i, s in enumerate(a.source)]
     import torch
     ngpu = max(torch.cuda.device_count(), 1)

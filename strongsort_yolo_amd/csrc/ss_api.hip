@@ -49,6 +49,8 @@ struct ss_ctx {
     size_t nms_ws_bytes;
     int nms_units;
     int cos_grid;               // persistent workgroups of the association kernel
+    int stream_mode;            // -1: throughput association form from 4 streams up; 0 / 1: forced (ss_set_option)
+    int ts_enable;              // in-kernel timeline stamps (profiling aid)
     // association-kernel timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -94,6 +96,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->timing = false;
     c->ev_used = 0;
     c->cos_grid = 256;           // persistent workgroups: one per CU
+    c->stream_mode = -1;
+    c->ts_enable = 0;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -209,8 +213,8 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
     // captured into a HIP graph as is.
     dev.grid_tracks = SS_MAXT;
     dev.cos_grid = c->cos_grid;
-    dev.stream_mode = c->dev.S >= 4 ? 1 : 0;                // throughput form once enough streams share the launch
-    if (const char* g = getenv("SS_STREAM_MODE")) dev.stream_mode = atoi(g);
+    dev.stream_mode = c->stream_mode >= 0 ? c->stream_mode : (c->dev.S >= 4 ? 1 : 0);   // throughput form once enough streams share the launch
+    dev.ts_enable = c->ts_enable;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -220,8 +224,6 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
-    if (const char* g = getenv("SS_TS")) dev.ts_enable = atoi(g);
-    if (const char* g = getenv("SS_COS_GRID")) dev.cos_grid = atoi(g) > 0 ? atoi(g) : dev.cos_grid;
     ss_launch_frame(dev, c->prm, SS_MAXT, c->stream, e0, e1);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
@@ -256,10 +258,15 @@ extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, 
     return SS_OK;
 }
 
-extern "C" int ss_set_track_grid(ss_ctx* c, int n)
+extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
 {
-    if (!c || n < 0 || n > SS_MAXT) return fail(c, SS_ERR_INVALID, "ss_set_track_grid: 0 <= n <= 256");
-    return SS_OK;                // no launch dimension depends on the track count any more (see the header)
+    if (!c || !name) return fail(c, SS_ERR_INVALID, "ss_set_option: null argument");
+    const std::string n(name);
+    if (n == "stream_mode") { if (value < -1 || value > 1) return fail(c, SS_ERR_INVALID, "stream_mode: -1 (auto), 0, 1"); c->stream_mode = value; }
+    else if (n == "cos_grid") { if (value < 1 || value > 4096) return fail(c, SS_ERR_INVALID, "cos_grid: 1..4096"); c->cos_grid = value; }
+    else if (n == "timestamps") c->ts_enable = value != 0;
+    else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
+    return SS_OK;
 }
 
 extern "C" int ss_check_errors(ss_ctx* c)

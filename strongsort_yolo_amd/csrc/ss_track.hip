@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
         float n = sqrtf(ss_wave_sumsq_reduce(a));
         float* unit = dev.feat_unit + ((size_t)s * SS_MAXD + d) * SS_F;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { float u = v[j] / n; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }
+        for (int j = 0; j < 8; ++j) { float u = n > 0.0f ? v[j] / n : 0.0f; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }   // all-zero row stays zero (D-17)
         SS_WAVE_SYNC();
         frag_write_row(frag, jj, rowbuf[w], false);
         if (l == 0) {
@@ -788,7 +788,7 @@ __device__ inline void ema_wave(const float* smooth_in, const float* feat, float
     }
     float n = sqrtf(ss_wave_sumsq_reduce(acc));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[l + 64 * j] = v[j] / n;
+    for (int j = 0; j < 8; ++j) out[l + 64 * j] = n > 0.0f ? v[j] / n : 0.0f;
 }
 
 // append row-major unit row `src` (global) as gallery row b of a track (fragment-major tiles)
@@ -1075,7 +1075,7 @@ __global__ void k_kat_normalize(const float* raw, int n, float* unit)
     for (int j = 0; j < 8; ++j) { v[j] = raw[(size_t)w * SS_F + l + 64 * j]; a = fmaf(v[j], v[j], a); }
     float nn = sqrtf(ss_wave_sumsq_reduce(a));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) unit[(size_t)w * SS_F + l + 64 * j] = v[j] / nn;
+    for (int j = 0; j < 8; ++j) unit[(size_t)w * SS_F + l + 64 * j] = nn > 0.0f ? v[j] / nn : 0.0f;
 }
 
 __global__ void k_kat_ema(const float* smooth, const float* feat, int n, float a, float b, float* out)

@@ -94,8 +94,9 @@ class TrackerEngine:
     def reset(self, stream: int = -1):
         self._ck(self.L.ss_reset(self.ctx, stream))
 
-    def set_track_grid(self, n: int):
-        self._ck(self.L.ss_set_track_grid(self.ctx, n))
+    def set_option(self, name: str, value: int):
+        """stream_mode (-1 auto / 0 / 1), cos_grid, timestamps — see include/strongsort_hip.h."""
+        self._ck(self.L.ss_set_option(self.ctx, name.encode(), int(value)))
 
     def check_errors(self):
         self._ck(self.L.ss_check_errors(self.ctx))

@@ -22,7 +22,7 @@ EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
     "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_crop_norm", "ss_crop_norm_batch",
     "ss_track_update", "ss_track_update_host",
-    "ss_check_errors", "ss_set_track_grid", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
+    "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
     "ss_get_gallery", "ss_assoc_timing", "ss_get_timestamps", "ss_op_bias_act_f16", "ss_op_bias_act_place_f16", "ss_op_pointwise_f16", "ss_op_conv3x3_f16", "ss_op_v8_decode_f16", "ss_op_dwconv3x3_f16", "ss_op_lightconv_f16", "ss_op_osnet_stem_f16", "ss_op_osnet_streams_f16", "ss_op_gate_apply_f16", "ss_op_gate_sum_f16", "ss_op_avgpool2_f16", "ss_op_maxpool_f16",
 ]
@@ -87,7 +87,7 @@ def load():
     hf, hi = C.POINTER(C.c_float), C.POINTER(C.c_int)
     L.ss_track_update_host.argtypes = [vp, i, hf, i, hf, i, i, hf, i, hi]
     L.ss_check_errors.argtypes = [vp]
-    L.ss_set_track_grid.argtypes = [vp, i]
+    L.ss_set_option.argtypes = [vp, C.c_char_p, i]
     L.ss_feat_normalize.argtypes = [vp, fp, i, fp]
     L.ss_ema.argtypes = [vp, fp, fp, i, fp]
     L.ss_kf_predict.argtypes = [vp, dp, dp, i]

@@ -1,10 +1,12 @@
 """Detector and ReID backbones (rows a2 / a5 of SURVEY.md §8a) as plain PyTorch modules.
 
-These are the dense-conv part of the path: on MI355X they run through PyTorch-ROCm (MIOpen /
-hipBLASLt -> MFMA) and are *not* hand-written HIP (north_star: "PyTorch-ROCm for the YOLOv5/7/8
-detector and OSNet-x0.25 ReID backbones").  No weights exist offline, so they are
-seeded random-init networks of the published architectures; their job is to load the GPU with the
-real layer shapes.  Conv+BN pairs are built in their fused inference form (conv with bias).
+These are the dense-conv part of the path (north_star: "PyTorch-ROCm for the YOLOv5/7/8 detector and
+OSNet-x0.25 ReID backbones").  The modules are plain PyTorch; on half channels-last CUDA tensors their 1x1 / 3x3
+convolutions, the OSNet stem and LightConv chains and the v8 head decode dispatch to the hand-written gfx950
+kernels of csrc/ss_ops.hip (through fused.py), everything else (and the CPU / fp32 path used as the oracle-side
+baseline) to PyTorch-ROCm's libraries.  No weights exist offline, so they are seeded random-init
+networks of the published architectures; their job is to load the GPU with the real layer shapes.  Conv+BN
+pairs are built in their fused inference form (conv with bias).
 
 They stand behind `YOLO(weights)` (/root/reference/yolo_multi_model.py:14-17) and the forward pass
 inside model.track / model.predict (:41, :173).
@@ -175,7 +177,10 @@ class Detect(nn.Module):
         x1y1, x2y2 = anchors - lt, anchors + rb
         out = [torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides, cls.sigmoid()]
         if self.nk:
-            out.append(torch.cat([self.cv4[i](f).view(B, self.nk, -1) for i, f in enumerate(feats)], 2))
+            # keypoint decode (Ultralytics Pose.kpts_decode): xy = (2 k + anchor - 0.5) * stride, visibility = sigmoid
+            k = torch.cat([self.cv4[i](f).view(B, self.nk, -1) for i, f in enumerate(feats)], 2).view(B, self.nk // 3, 3, -1)
+            xy = (k[:, :, :2] * 2.0 + (anchors - 0.5).unsqueeze(1)) * strides.unsqueeze(1)
+            out.append(torch.cat((xy, k[:, :, 2:].sigmoid()), 2).view(B, self.nk, -1))
         return torch.cat(out, 1)
 
 
@@ -484,6 +489,31 @@ def build_detector(name: str, seed: int = 0) -> nn.Module:
         torch.manual_seed(seed)
         m = DETECTORS[key]()
     return m.eval()
+
+
+def load_weights(module: nn.Module, path, what: str, random_init_ok: bool = False) -> bool:
+    """Load a plain state_dict (or {'state_dict': ...} / {'model': state_dict}) into `module`.  A missing file is an
+    error unless random-init weights were asked for explicitly (`random_init_ok`, or SS_RANDOM_INIT=1 in the
+    environment — the only mode available offline): a tracker that silently runs on random weights
+    returns plausible-looking garbage.  Pickled module checkpoints (Ultralytics `{'model': nn.Module}`) are refused:
+    `torch.load(weights_only=True)` never executes checkpoint code."""
+    import os
+    import warnings
+    if not path or not os.path.isfile(path):
+        if random_init_ok or os.environ.get("SS_RANDOM_INIT") == "1":
+            warnings.warn(f"{what}: no weights file ({path!r}); running on SEEDED RANDOM-INIT weights — outputs are "
+                          f"synthetic-load only", RuntimeWarning, stacklevel=3)
+            return False
+        raise FileNotFoundError(f"{what}: weights file {path!r} not found (pass random_init_ok=True / --random-init or set "
+                                f"SS_RANDOM_INIT=1 to run the seeded random-init network of the same architecture)")
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    for key in ("state_dict", "model"):
+        if isinstance(ck, dict) and isinstance(ck.get(key), dict):
+            ck = ck[key]
+    if not isinstance(ck, dict) or not all(isinstance(v, torch.Tensor) for v in ck.values()):
+        raise ValueError(f"{what}: {path} is not a plain state_dict; export one with torch.save(model.state_dict(), ...)")
+    module.load_state_dict(ck, strict=True)
+    return True
 
 
 def build_reid(seed: int = 1) -> nn.Module:

@@ -37,19 +37,19 @@ class FramePipeline:
     def __init__(self, detector: str = "yolov8n", n_streams: int = 1, frame_hw=(720, 1280), device: int = 0,
                  half: bool = True, reid_batch: int = 32, cfg: Optional[StrongSortConfig] = None,
                  dcfg: Optional[DetectConfig] = None, det_source: str = "detector", feat_source: str = "reid",
-                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0,
-                 track_grid: int = MAX_TRACKS):
+                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0):
         self.cfg, self.dcfg = cfg or StrongSortConfig(), dcfg or DetectConfig()
         self.S, (self.H, self.W) = n_streams, frame_hw
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
         dev = self.dev = self.eng.device
-        if graph == "all":
-            self.eng.set_track_grid(track_grid)
         self.half, self.dtype = half, torch.float16 if half else torch.float32
         self.det_source, self.feat_source, self.run_nets = det_source, feat_source, run_nets
         self.RB = reid_batch
         if reid_batch > MAX_DETS:
             raise ValueError("reid_batch <= 128")
+        # Only the first reid_batch detections of a frame are cropped and embedded: with OSNet features feeding the
+        # tracker, NMS keeps at most that many (highest scores first), so no detection reaches it without a feature.
+        self.max_det = min(self.dcfg.max_det, MAX_DETS, reid_batch if (feat_source == "reid" and run_nets) else MAX_DETS)
         self.geom = letterbox_geometry(self.H, self.W, self.dcfg.imgsz, self.dcfg.stride)
         self.gain, self.pad_x, self.pad_y = scale_geometry(self.geom, self.H, self.W)
         self.detector = self.reid = None
@@ -91,7 +91,7 @@ class FramePipeline:
             if self.det_source == "detector":
                 self.pred_in.copy_(pred)
         e.nms_batch(self.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=self.dets, keep=self.keep,
-                    count=self.ndets, max_det=min(self.dcfg.max_det, MAX_DETS))
+                    count=self.ndets, max_det=self.max_det)
         if self.nk:
             self.dets6.copy_(self.dets[:, :, :6])
         if self.run_nets:
@@ -308,7 +308,7 @@ class OverlappedPipeline(FramePipeline):
     def _nms_crop(self, b):
         e = self.eng                       # one launch set over all S*F virtual streams
         e.nms_batch(b.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=b.dets, keep=b.keep,
-                    count=b.ndets, max_det=min(self.dcfg.max_det, MAX_DETS))
+                    count=b.ndets, max_det=self.max_det)
         if self.nk:
             b.dets6.copy_(b.dets[:, :, :6])
         if self.run_nets:

@@ -27,15 +27,15 @@ class StrongSORT:
 
     def __init__(self, model_weights: Optional[str] = None, device: int = 0, fp16: bool = True,
                  max_dist: float = 0.2, max_iou_distance: float = 0.7, max_age: int = 30, n_init: int = 3,
-                 nn_budget: int = 100, mc_lambda: float = 0.995, ema_alpha: float = 0.9, reid_seed: int = 1):
+                 nn_budget: int = 100, mc_lambda: float = 0.995, ema_alpha: float = 0.9, reid_seed: int = 1,
+                 random_init_ok: bool = False):
         self.cfg = StrongSortConfig(max_dist=max_dist, max_iou_distance=max_iou_distance, max_age=max_age,
                                     n_init=n_init, nn_budget=nn_budget, mc_lambda=mc_lambda, ema_alpha=ema_alpha)
         self.eng = TrackerEngine(self.cfg, 1, device)
         self.dev = self.eng.device
         self.dtype = torch.float16 if fp16 else torch.float32
         self.reid = nets.build_reid(reid_seed)
-        if model_weights:
-            self.reid.load_state_dict(torch.load(model_weights, map_location="cpu"))
+        nets.load_weights(self.reid, model_weights, "OSNet-x0.25 ReID", random_init_ok)
         self.reid = self.reid.to(self.dev, self.dtype).to(memory_format=torch.channels_last)
         self._dets = torch.zeros(1, MAX_DETS, 6, dtype=torch.float32, device=self.dev)
         self._feats = torch.zeros(1, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=self.dev)
@@ -44,6 +44,7 @@ class StrongSORT:
 
     @torch.no_grad()
     def update(self, dets, frame, features=None) -> np.ndarray:
+        self.eng.use_current_stream()                    # launch on the caller's current torch stream
         dets = torch.as_tensor(dets, dtype=torch.float32).reshape(-1, 6)
         n = dets.shape[0]
         if n > MAX_DETS:

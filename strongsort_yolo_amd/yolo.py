@@ -76,8 +76,9 @@ class Results:
 
 
 class YOLO:
-    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0):
+    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False):
         self.weights = weights
+        self.random_init_ok = random_init_ok
         self.arch = os.path.basename(weights).replace(".pt", "")
         self.overrides = {"conf": 0.25, "iou": 0.7, "agnostic_nms": False, "max_det": 300}
         self.seed = seed
@@ -100,8 +101,8 @@ class YOLO:
             self._pipe = FramePipeline(self.arch, 1, shape, device=int(device or 0), reid_batch=128, cfg=StrongSortConfig(),
                                        dcfg=self._dcfg(), det_source="detector", feat_source="reid", graph="none",
                                        seed=self.seed)
-            if os.path.isfile(self.weights):
-                self._pipe.detector.load_state_dict(torch.load(self.weights, map_location="cpu"))
+            from . import nets
+            nets.load_weights(self._pipe.detector, self.weights, f"detector {self.arch}", self.random_init_ok)
             self._shape = shape
         self._pipe.dcfg = self._dcfg()
         return self._pipe

@@ -8,6 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("SS_RANDOM_INIT", "1")          # no weights exist offline: tests run the seeded random-init networks
 
 
 def pytest_configure(config):

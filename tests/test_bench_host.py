@@ -30,7 +30,7 @@ def test_workload_and_oracle_replay():
     assert wl["preds"].shape == (8, 84, A) and wl["agt"].shape == (8, A) and wl["pixels"].dtype == np.uint8
     rows = b.oracle_rows(wl, 8, W, H, gs, 80, StrongSortConfig(), DetectConfig())
     assert len(rows) == 8 and rows[-1].shape[1] == 8 and len(rows[-1]) > 0        # confirmed tracks by frame 3
-    assert set(b.PRESETS) >= {"c2", "c3", "c4"} and b.PREFILL >= 103
+    assert set(b.PRESETS) >= {"c2", "c3", "c4", "c5"} and b.PREFILL >= 103 and b.PREFILL % 8 == 0
 
 
 @settings(max_examples=15, deadline=None)
@@ -52,3 +52,24 @@ def test_tracker_invariants(seed, n_ids):
         assert all(tr.state in (1, 2) for tr in t.tracks)                           # deleted tracks are gone
         assert [tr.track_id for tr in t.tracks] == sorted(tr.track_id for tr in t.tracks)
         assert (rows[:, 0] >= 0).all() and (rows[:, 2] <= 639).all() and (rows[:, 3] <= 479).all()
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher in the environment must come back with n_gpus == 2
+    (--gpus was parsed and ignored).  gloo + --dist-check: rendezvous, barrier and the max-over-ranks
+    exchange only, no GPU work."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SS_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-check"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["dist_check"] is True and res["n_gpus"] == 2 and res["max_over_ranks"] == 2.0
+    # under an external launcher the ranks it provides are used as they are
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1

@@ -48,7 +48,7 @@ def _fill(b, item, dev):
 @pytest.mark.parametrize("graph", ["none", "front", "all"])
 def test_sequential_pipeline_equals_oracle(graph):
     from strongsort_yolo_amd.pipeline import FramePipeline
-    pipe = FramePipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64)
+    pipe = FramePipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor")
     gs, items = _workload(pipe)
     ref = _oracle(gs, items, pipe.nc)
     for k, it in enumerate(items):
@@ -66,7 +66,7 @@ def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb, kw):
     """fb = 3 with 14 frames: groups of 3,3,3,3 and a partial group of 2.  kw: stage cut inside the ReID backbone,
     tracker on the last stage's stream (default) or on its own stream with three buffer sets."""
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
-    pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor", track_grid=64,
+    pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor",
                               n_stages=n_stages, frame_batch=fb, **kw)
     assert pipe.n == n_stages
     assert (pipe.sT is not None) == (graph == "front" and kw.get("tracker_stream", False))
@@ -103,7 +103,7 @@ def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb, kw):
 def test_two_streams_in_one_pipeline_equal_their_oracles():
     """S = 2 streams batched in one context / one set of launches (streams are independent)."""
     from strongsort_yolo_amd.pipeline import FramePipeline
-    pipe = FramePipeline("yolov8n", 2, (H, W), graph="front", det_source="synthetic", feat_source="by_anchor", track_grid=64)
+    pipe = FramePipeline("yolov8n", 2, (H, W), graph="front", det_source="synthetic", feat_source="by_anchor")
     gs = scale_geometry(pipe.geom, H, W)
     dcfg = DetectConfig()
     streams = [make_stream(50 + s, W, H, N_IDS + 2 * s) for s in range(2)]

@@ -40,7 +40,7 @@ def _compare_table(eng, orc, s=0):
     assert bits_equal(t["smooth"], o["smooth"])
 
 
-@pytest.mark.parametrize("n_ids,wh,frames,seed", [(30, (1280, 720), 150, 0), (100, (1920, 1080), 40, 1), (8, (640, 480), 60, 2)])
+@pytest.mark.parametrize("n_ids,wh,frames,seed", [(30, (1280, 720), 150, 0), (100, (1920, 1080), 112, 1), (8, (640, 480), 60, 2)])
 def test_stream_parity(n_ids, wh, frames, seed):
     W, H = wh
     cfg = StrongSortConfig()
@@ -81,35 +81,64 @@ def test_births_deaths_and_empty_frames():
     eng.close()
 
 
-def test_multi_stream_batch_equals_single_streams():
-    """S streams in one context (one batch of launches) == each stream run alone."""
+def _run_multi_stream(S, ids_of, frames, mode=-1, mute=(), late=()):
+    """S streams in one context (one batch of launches per frame) against S single-stream oracles, every frame, with
+    the stage intermediates of every stream (rows a8-a10 in the batched launch shapes).  `mute` streams
+    never see a detection, `late` streams see their first detection two frames before the end (tentative tracks only)."""
     import torch
     cfg = StrongSortConfig()
-    S, W, H = 3, 1280, 720
-    eng = engine(cfg, n_streams=S, debug=False)
+    W, H = 1280, 720
+    eng = engine(cfg, n_streams=S, debug=True)
+    eng.set_option("stream_mode", mode)
     orcs = [OracleStrongSort(cfg, "c") for _ in range(S)]
-    streams = [make_stream(10 + s, W, H, 20 + 5 * s) for s in range(S)]
-    streams_o = [make_stream(10 + s, W, H, 20 + 5 * s) for s in range(S)]
+    streams = [make_stream(10 + s, W, H, ids_of(s)) for s in range(S)]
     dev = eng.device
-    dets = torch.zeros(S, 128, 6, device=dev)
-    feats = torch.zeros(S, 128, 512, device=dev)
-    nd = torch.zeros(S, dtype=torch.int32, device=dev)
     hw = torch.tensor([[H, W]] * S, dtype=torch.int32, device=dev)
-    for k in range(40):
+    seen_conf = [0] * S
+    for k in range(frames):
+        hd, hf, hn = np.zeros((S, 128, 6), np.float32), np.zeros((S, 128, 512), np.float32), np.zeros(S, np.int32)
         ref = []
         for s in range(S):
-            f, fo = streams[s].next_frame(), streams_o[s].next_frame()
+            f = streams[s].next_frame()
             n = len(f.dets)
-            dets[s, :n] = torch.from_numpy(f.dets).to(dev)
-            feats[s, :n] = torch.from_numpy(f.feats).to(dev)
-            nd[s] = n
-            ref.append(orcs[s].update(fo.dets, fo.feats, (H, W)))
-        out, nout = eng.update_device(dets, nd, feats, hw)
+            if s in mute or (s in late and k < frames - 2):
+                n = 0
+            hd[s, :n], hf[s, :n], hn[s] = f.dets[:n], f.feats[:n], n
+            ref.append(orcs[s].update(f.dets[:n], f.feats[:n], (H, W)))
+        out, nout = eng.update_device(torch.from_numpy(hd).to(dev), torch.from_numpy(hn).to(dev),
+                                      torch.from_numpy(hf).to(dev), hw)
         eng.check_errors()
         out, nout = out.cpu().numpy(), nout.cpu().numpy()
         for s in range(S):
-            assert bits_equal(out[s, :nout[s]], ref[s]), f"stream {s} frame {k}"
+            _compare_frame(eng, orcs[s], out[s, :nout[s]], ref[s], k, s)
+            seen_conf[s] = max(seen_conf[s], len(orcs[s].last["confirmed"]))
+    for s in range(S):
+        _compare_table(eng, orcs[s], s)
     eng.close()
+    return seen_conf
+
+
+def test_multi_stream_batch_equals_single_streams():
+    """latency form (S < 4)"""
+    _run_multi_stream(3, lambda s: 20 + 5 * s, 40)
+
+
+@pytest.mark.parametrize("S,frames", [(4, 112), (8, 30), (32, 22)])
+def test_throughput_association_form(S, frames):
+    """The wave-per-tile association kernel (selected from 4 streams per context up; the form behind bench.py's
+    roofline_batched): detections per stream <= 16, 17..32 and > 32 (the latter leave through the workgroup-per-tile
+    kernel in the same frame), galleries of 1, 15, 16, 17 ... rows while they fill (100 rows at S = 4), a stream that
+    never sees a detection and one without a confirmed track."""
+    ids = [10, 24, 40, 30]
+    conf = _run_multi_stream(S, lambda s: ids[s % 4], frames, mute=(S - 1,), late=(S - 2,) if S > 4 else ())
+    assert conf[0] > 0 and conf[1] > 16 and conf[2] > 32 and conf[S - 1] == 0
+    if S > 4:
+        assert conf[S - 2] == 0
+
+
+@pytest.mark.parametrize("S", [1, 2])
+def test_throughput_form_forced_on_small_contexts(S):
+    _run_multi_stream(S, lambda s: 28 + 4 * s, 24, mode=1)
 
 
 def test_capacity_error_is_loud():

@@ -47,3 +47,52 @@ def test_assign_streams_partitions_everything():
         parts = assign_streams(n, w)
         assert len(parts) == w and sorted(sum(parts, [])) == list(range(n))
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_weights_policy_is_loud(tmp_path, monkeypatch):
+    """a missing weights file must not silently become a random-init network; checkpoints are loaded
+    with weights_only=True and must be plain state_dicts."""
+    import pytest
+    from strongsort_yolo_amd import nets
+    m = nets.build_reid(1)
+    monkeypatch.delenv("SS_RANDOM_INIT", raising=False)
+    with pytest.raises(FileNotFoundError):
+        nets.load_weights(m, str(tmp_path / "osnet_x0_25.pt"), "reid")
+    with pytest.warns(RuntimeWarning):
+        assert nets.load_weights(m, None, "reid", random_init_ok=True) is False
+    sd = {k: v + 1 for k, v in m.state_dict().items()}
+    torch.save({"state_dict": sd}, tmp_path / "w.pt")
+    assert nets.load_weights(m, str(tmp_path / "w.pt"), "reid") is True
+    assert torch.equal(m.fc.bias, sd["fc.bias"])
+    torch.save({"model": nets.build_reid(2)}, tmp_path / "pickled.pt")           # Ultralytics-style module checkpoint
+    with pytest.raises(Exception):
+        nets.load_weights(m, str(tmp_path / "pickled.pt"), "reid")
+
+
+def test_pose_head_decodes_keypoints_like_ultralytics():
+    """xy = (2 k + anchor - 0.5) * stride, visibility = sigmoid (Ultralytics Pose.kpts_decode); ADVICE r1."""
+    from strongsort_yolo_amd import nets
+    det = nets.build_detector("yolov8n-pose", 0).float()
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        feats = None
+
+        def grab(mod, inp):
+            nonlocal feats
+            feats = inp[0]
+        h = det.detect.register_forward_pre_hook(grab)
+        out = det(x)
+        h.remove()
+        raw = torch.cat([det.detect.cv4[i](f).view(1, 51, -1) for i, f in enumerate(feats)], 2).view(1, 17, 3, -1)
+    A = out.shape[2]
+    assert out.shape == (1, 4 + 1 + 51, A) and A == sum((64 // s) * (96 // s) for s in (8, 16, 32))
+    k = out[0, 5:].view(17, 3, A)
+    a, col = 0, []
+    for s in (8, 16, 32):
+        hh, ww = 64 // s, 96 // s
+        gy, gx = torch.meshgrid(torch.arange(hh), torch.arange(ww), indexing="ij")
+        col.append(torch.stack((gx.reshape(-1), gy.reshape(-1), torch.full((hh * ww,), s))).float())
+    g = torch.cat(col, 1)                                                       # [3, A]: grid x, grid y, stride
+    assert torch.allclose(k[:, 0], (raw[0, :, 0] * 2 + g[0]) * g[2], atol=1e-5)
+    assert torch.allclose(k[:, 1], (raw[0, :, 1] * 2 + g[1]) * g[2], atol=1e-5)
+    assert torch.allclose(k[:, 2], raw[0, :, 2].sigmoid(), atol=1e-6)
