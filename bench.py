@@ -387,6 +387,7 @@ def main():
     drain()
     torch.cuda.synchronize()
     pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
+    pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
     barrier()
     t0 = time.perf_counter()
     run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
@@ -394,16 +395,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
+    assoc_ik_us, assoc_ik_n = pipe.eng.assoc_inkernel_timing(False)
     pipe.eng.check_errors()
-    if os.environ.get("SS_TS"):
-        ts = pipe.eng.timestamps()
-        t00 = ts[ts > 0].min() if (ts > 0).any() else 0
-        st = ts[15, 7, :7]
-        print("TS k_step (us from start): " + " ".join(f"{(v - st[0]) / 100:.2f}" for v in st), file=sys.stderr)
-        for b in range(0, 16, 3):
-            for w in (0, 5):
-                row = ts[b, w]; row = row[row > 0]
-                print(f"TS block {b*32} wave {w}:", " ".join(f"{(v - t00) / 100:.2f}" for v in row[:40]), file=sys.stderr)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -108,12 +108,19 @@ int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long lon
                        long long dets_batch_stride, int n, const int* d_counts, void* d_out, int out_flags);
 
 /* ---- a6..a10  tracker update  (tracker.update inside model.track, yolo_multi_model.py:41) -----
- * One frame for EVERY stream of the context in one batch of launches:
- *   d_dets   [n_streams][SS_MAX_DETS][6]   x1,y1,x2,y2,conf,cls (original pixels, float)
- *   d_ndets  [n_streams]                   detections per stream (device ints)
- *   d_feats  [n_streams][SS_MAX_DETS][512] raw ReID embeddings (normalised on device)
- *   d_img_hw [n_streams][2]                frame height, width (device ints; output clipping)
- * Results stay on the device: d_out [n_streams][SS_MAX_TRACKS][8], d_nout [n_streams]. */
+ * A GROUP of n_frames (1..16) consecutive frames for EVERY stream of the context in one batch of launches; the
+ * frames are associated strictly in order (frame f sees the tracks, galleries and ids left by frame f-1), so the
+ * rows are identical to n_frames single-frame calls — what the group buys is that the galleries are read from HBM
+ * once per group instead of once per frame (the association kernel handles the detections of all frames at once).
+ *   d_dets   [n_frames][n_streams][SS_MAX_DETS][6]   x1,y1,x2,y2,conf,cls (original pixels, float)
+ *   d_ndets  [n_frames][n_streams]                   detections per frame and stream (device ints)
+ *   d_feats  [n_frames][n_streams][SS_MAX_DETS][512] raw ReID embeddings (normalised on device)
+ *   d_img_hw [n_streams][2]                          frame height, width (device ints; output clipping)
+ * Results stay on the device: d_out [n_frames][n_streams][SS_MAX_TRACKS][8], d_nout [n_frames][n_streams].
+ * After a device-side error (ss_check_errors != SS_OK) the affected stream's state is undefined: ss_reset it. */
+int ss_track_update_group(ss_ctx* ctx, int n_frames, const float* d_dets, const int* d_ndets, const float* d_feats,
+                          const int* d_img_hw, float* d_out, int* d_nout);
+/* One frame: ss_track_update_group with n_frames = 1. */
 int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const float* d_feats,
                     const int* d_img_hw, float* d_out, int* d_nout);
 
@@ -121,10 +128,8 @@ int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const 
 int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, const float* h_feats,
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
 
-/* Tuning / profiling switches of a context (host state, read at the next ss_track_update):
- *   "stream_mode"  -1 (default): wave-per-tile association kernel from 4 streams per context up; 0 / 1 force it
- *   "cos_grid"     persistent workgroups of the association kernel (default 256 = one per CU)
- *   "timestamps"   1: record in-kernel wall-clock stamps for ss_get_timestamps */
+/* Tuning switches of a context (host state, read at the next tracker call):
+ *   "cos_grid"     persistent workgroups of the association kernel (default 512 = two per CU) */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
@@ -154,9 +159,9 @@ int ss_lsap(ss_ctx* ctx, const double* d_cost, int nr, int nc, int* d_row_to_col
 int ss_get_tracks(ss_ctx* ctx, int stream, int cap, int* n_tracks, int* next_id, int* track_id,
                   int* state, int* hits, int* age, int* tsu, int* class_id, float* conf,
                   double* mean, double* cov, float* smooth, int* gal_count);
-/* Stage intermediates of the last frame (ctx created with debug != 0).
+/* Stage intermediates of frame `frame` of the last group (ctx created with debug != 0).
  * counts[4] = n_conf, n_cand, n_cols_b, n_dets; matrices are [SS_MAX_TRACKS][SS_MAX_DETS] strided. */
-int ss_get_debug(ss_ctx* ctx, int stream, int* counts, float* cos, double* maha, uint8_t* gated,
+int ss_get_debug(ss_ctx* ctx, int stream, int frame, int* counts, float* cos, double* maha, uint8_t* gated,
                  double* cost_a, double* cost_b, int* lists /* [4][SS_MAX_TRACKS] */);
 /* Gallery of one track (by position in the track list) in natural [count][512] order of slots. */
 int ss_get_gallery(ss_ctx* ctx, int stream, int track_index, float* rows, int cap_rows, int* count);
@@ -221,9 +226,10 @@ int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void*
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
  * call, measured with HIP events on the context stream; also returns the launch count. */
 int ss_assoc_timing(ss_ctx* ctx, int enable, float* mean_ms, int* launches);
-/* In-kernel wall-clock stamps (100 MHz) of the throughput association kernel's last launch, recorded when
- * the environment variable SS_TS=1: [16 sampled workgroups][8 waves][64 stamps].  Profiling aid. */
-int ss_get_timestamps(ss_ctx* ctx, long long* out, int n);
+/* The same kernel timed from inside: first workgroup start -> last workgroup end (100 MHz wall clock, written by the
+ * kernel itself), i.e. without the time a dispatch waits for compute units behind other streams' kernels.  Returns
+ * the mean over the launches since the last call (microseconds) and re-arms / disarms the stamps. */
+int ss_assoc_inkernel_timing(ss_ctx* ctx, int enable, double* mean_us, int* launches);
 
 #ifdef __cplusplus
 }

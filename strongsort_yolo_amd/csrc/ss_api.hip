@@ -8,9 +8,8 @@
 #include "ss_common.h"
 
 // launchers implemented in ss_track.hip / ss_front.hip
-size_t ss_step_lds_bytes();
 size_t ss_lsap_lds_bytes();
-void ss_launch_frame(const SSDev&, const SSParams&, int, hipStream_t, hipEvent_t, hipEvent_t);
+void ss_launch_group(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t);
 void ss_launch_normalize(const float*, int, float*, hipStream_t);
 void ss_launch_ema(const float*, const float*, int, float, float, float*, hipStream_t);
 void ss_launch_kf(int, double*, double*, const double*, const double*, int, double, double, hipStream_t);
@@ -49,8 +48,7 @@ struct ss_ctx {
     size_t nms_ws_bytes;
     int nms_units;
     int cos_grid;               // persistent workgroups of the association kernel
-    int stream_mode;            // -1: throughput association form from 4 streams up; 0 / 1: forced (ss_set_option)
-    int ts_enable;              // in-kernel timeline stamps (profiling aid)
+    bool inkernel;              // in-kernel timing of the association kernel armed
     // association-kernel timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -95,9 +93,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->stream = nullptr;
     c->timing = false;
     c->ev_used = 0;
-    c->cos_grid = 256;           // persistent workgroups: one per CU
-    c->stream_mode = -1;
-    c->ts_enable = 0;
+    c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
+    c->inkernel = false;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -110,6 +107,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     SSDev& d = c->dev;
     memset(&d, 0, sizeof d);
     d.S = (int)S;
+    d.budget = cfg->nn_budget;
     int rc = SS_OK;
 #define A(field, n) if (rc == SS_OK) rc = dalloc(c, &d.field, (n))
     A(n_tracks, S); A(next_id, S); A(frame, S); A(err, S); A(order, S * T);
@@ -117,13 +115,15 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(class_id, S * T); A(det_idx, S * T); A(gal_count, S * T); A(gal_head, S * T); A(conf, S * T);
     A(mean, S * T * 8); A(cov, S * T * 64); A(smooth, S * T * SS_F);
     A(gallery, S * T * SS_NRT * SS_TILE_FLOATS);
-    A(feat_unit, S * D * SS_F); A(feat_frag, S * SS_NCT * SS_TILE_FLOATS);
-    A(tlwh, S * D * 4); A(xyah, S * D * 4); A(chol, S * T * 16); A(ttlwh, S * T * 4);
-    A(n_conf, S); A(conf_list, S * T); A(part_min, S * T * SS_NRT * D);
-    A(tiles, 2 * S * T * SS_NRT); A(tile_count, 4); A(ts, 16 * 8 * 64);
+    const size_t FM = SS_FMAX;
+    A(feat_unit, FM * S * D * SS_F); A(feat_frag, FM * S * SS_NCT * SS_TILE_FLOATS);
+    A(tlwh, FM * S * D * 4); A(xyah, FM * S * D * 4);
+    A(M, S * T * FM * D); A(tl, S * SS_TLMAX); A(n_tl, S); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
+    A(items, S * SS_PLMAX * (SS_TLMAX / SS_CHUNK)); A(n_items, 4);
+    A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4);
     if (cfg->debug) {
-        A(dbg_cos, S * T * D); A(dbg_maha, S * T * D); A(dbg_cost_a, S * T * D); A(dbg_cost_b, S * T * D);
-        A(dbg_gated, S * T * D); A(dbg_lists, S * 4 * T); A(dbg_counts, S * 4);
+        A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);
+        A(dbg_gated, FM * S * T * D); A(dbg_lists, FM * S * 4 * T); A(dbg_counts, FM * S * 4);
     }
 #undef A
     if (rc == SS_OK) rc = dalloc(c, &c->d_dets, S * D * 6);
@@ -192,7 +192,7 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
         HIPCHK(c, hipMemcpyAsync(d.next_id + s, &one, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(d.tile_count, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(d.n_items, 0, 16, c->stream));
     if (stream < 0)
         for (int u = 0; u < c->nms_units; ++u) HIPCHK(c, hipMemsetAsync(ss_nms_error_flag(c->nms_ws, u), 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -200,21 +200,22 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
 }
 
 // ---- tracker -----------------------------------------------------------------------------------
-extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndets, const float* d_feats,
-                               const int* d_img_hw, float* d_out, int* d_nout)
+extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_dets, const int* d_ndets, const float* d_feats,
+                                     const int* d_img_hw, float* d_out, int* d_nout)
 {
     if (!c || !d_dets || !d_ndets || !d_feats || !d_img_hw || !d_out || !d_nout)
-        return fail(c, SS_ERR_INVALID, "ss_track_update: null argument");
+        return fail(c, SS_ERR_INVALID, "ss_track_update_group: null argument");
+    if (n_frames < 1 || n_frames > SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_track_update_group: 1 <= n_frames <= 16");
+    // a gallery ring position must be overwritten at most once per group (k_assoc's per-frame row mask, k_newrow)
+    if (n_frames > c->cfg.nn_budget) return fail(c, SS_ERR_INVALID, "ss_track_update_group: n_frames <= nn_budget required");
     SSDev dev = c->dev;
+    dev.F = n_frames;
     dev.dets = d_dets; dev.n_dets = d_ndets; dev.feats_raw = d_feats; dev.img_hw = (int*)d_img_hw;
     dev.out_rows = d_out; dev.n_out = d_nout;
-    // The association kernels are persistent over device-built work lists (k_pre), so no launch dimension depends
-    // on the number of live tracks: nothing here needs a host round trip, and the same launch sequence can be
-    // captured into a HIP graph as is.
-    dev.grid_tracks = SS_MAXT;
+    // Every launch dimension is fixed by (streams, n_frames): track and detection counts are device-side values read
+    // from the work lists, so nothing here needs a host round trip and the sequence can be captured into a HIP graph.
     dev.cos_grid = c->cos_grid;
-    dev.stream_mode = c->stream_mode >= 0 ? c->stream_mode : (c->dev.S >= 4 ? 1 : 0);   // throughput form once enough streams share the launch
-    dev.ts_enable = c->ts_enable;
+    dev.ts_enable = c->inkernel ? 1 : 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -224,9 +225,15 @@ extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndet
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
-    ss_launch_frame(dev, c->prm, SS_MAXT, c->stream, e0, e1);
+    ss_launch_group(dev, c->prm, c->stream, e0, e1);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
+}
+
+extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndets, const float* d_feats,
+                               const int* d_img_hw, float* d_out, int* d_nout)
+{
+    return ss_track_update_group(c, 1, d_dets, d_ndets, d_feats, d_img_hw, d_out, d_nout);
 }
 
 extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, int n, const float* h_feats,
@@ -262,9 +269,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(c, SS_ERR_INVALID, "ss_set_option: null argument");
     const std::string n(name);
-    if (n == "stream_mode") { if (value < -1 || value > 1) return fail(c, SS_ERR_INVALID, "stream_mode: -1 (auto), 0, 1"); c->stream_mode = value; }
-    else if (n == "cos_grid") { if (value < 1 || value > 4096) return fail(c, SS_ERR_INVALID, "cos_grid: 1..4096"); c->cos_grid = value; }
-    else if (n == "timestamps") c->ts_enable = value != 0;
+    if (n == "cos_grid") { if (value < 1 || value > 4096) return fail(c, SS_ERR_INVALID, "cos_grid: 1..4096"); c->cos_grid = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;
 }
@@ -462,21 +467,22 @@ extern "C" int ss_get_tracks(ss_ctx* c, int s, int cap, int* n_tracks, int* next
     return SS_OK;
 }
 
-extern "C" int ss_get_debug(ss_ctx* c, int s, int* counts, float* cosd, double* maha, uint8_t* gated,
+extern "C" int ss_get_debug(ss_ctx* c, int s, int frame, int* counts, float* cosd, double* maha, uint8_t* gated,
                             double* cost_a, double* cost_b, int* lists)
 {
-    if (!c || s < 0 || s >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_get_debug: bad stream");
+    if (!c || s < 0 || s >= c->dev.S || frame < 0 || frame >= SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_get_debug: bad stream / frame");
     if (!c->cfg.debug) return fail(c, SS_ERR_INVALID, "ss_get_debug: context created without debug");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     SSDev& d = c->dev;
-    const size_t n = (size_t)SS_MAXT * SS_MAXD, o = (size_t)s * n;
-    if (counts) HIPCHK(c, hipMemcpy(counts, d.dbg_counts + s * 4, 16, hipMemcpyDeviceToHost));
+    const size_t fs = (size_t)frame * d.S + s;                     // [F][S] layout of the group
+    const size_t n = (size_t)SS_MAXT * SS_MAXD, o = fs * n;
+    if (counts) HIPCHK(c, hipMemcpy(counts, d.dbg_counts + fs * 4, 16, hipMemcpyDeviceToHost));
     if (cosd) HIPCHK(c, hipMemcpy(cosd, d.dbg_cos + o, n * 4, hipMemcpyDeviceToHost));
     if (maha) HIPCHK(c, hipMemcpy(maha, d.dbg_maha + o, n * 8, hipMemcpyDeviceToHost));
     if (gated) HIPCHK(c, hipMemcpy(gated, d.dbg_gated + o, n, hipMemcpyDeviceToHost));
     if (cost_a) HIPCHK(c, hipMemcpy(cost_a, d.dbg_cost_a + o, n * 8, hipMemcpyDeviceToHost));
     if (cost_b) HIPCHK(c, hipMemcpy(cost_b, d.dbg_cost_b + o, n * 8, hipMemcpyDeviceToHost));
-    if (lists) HIPCHK(c, hipMemcpy(lists, d.dbg_lists + (size_t)s * 4 * SS_MAXT, 4 * SS_MAXT * 4, hipMemcpyDeviceToHost));
+    if (lists) HIPCHK(c, hipMemcpy(lists, d.dbg_lists + fs * 4 * SS_MAXT, 4 * SS_MAXT * 4, hipMemcpyDeviceToHost));
     return SS_OK;
 }
 
@@ -500,11 +506,18 @@ extern "C" int ss_get_gallery(ss_ctx* c, int s, int track_index, float* rows, in
     return SS_OK;
 }
 
-extern "C" int ss_get_timestamps(ss_ctx* c, long long* out, int n)
+extern "C" int ss_assoc_inkernel_timing(ss_ctx* c, int enable, double* mean_us, int* launches)
 {
-    if (!c || !out || n > 16 * 8 * 64) return SS_ERR_INVALID;
+    if (!c) return SS_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->dev.ts, (size_t)n * 8, hipMemcpyDeviceToHost));
+    unsigned long long t[4] = { 0, 0, 0, 0 };
+    HIPCHK(c, hipMemcpy(t, c->dev.tstamp, sizeof t, hipMemcpyDeviceToHost));
+    if (c->inkernel && t[1] > t[0] && t[0] != ~0ull) { t[2] += t[1] - t[0]; t[3] += 1; }      // the last launch is not folded yet
+    if (mean_us) *mean_us = t[3] ? (double)t[2] / (double)t[3] / 100.0 : 0.0;                   // 100 MHz ticks
+    if (launches) *launches = (int)t[3];
+    const unsigned long long arm[4] = { ~0ull, 0, 0, 0 };
+    HIPCHK(c, hipMemcpy(c->dev.tstamp, arm, sizeof arm, hipMemcpyHostToDevice));
+    c->inkernel = enable != 0;
     return SS_OK;
 }
 

@@ -17,7 +17,11 @@
 #define SS_MAXT 256           // track slots per stream
 #define SS_MAXD 128           // detections per stream per frame
 #define SS_NCT (SS_MAXD / SS_TILE)
-#define SS_COST_CAP 14336     // LDS-resident cost entries (f64) of the assignment kernel
+#define SS_COST_CAP 12288     // LDS-resident cost entries (f64) of the per-frame kernel; larger matrices spill to HBM
+#define SS_FMAX 16            // frames of a stream that one tracker call (group) may carry
+#define SS_TLMAX (SS_MAXT * SS_NRT)          // gallery tiles of a stream
+#define SS_PLMAX (SS_FMAX * SS_NCT / 2)      // column-tile pairs of a stream's group
+#define SS_CHUNK 8            // gallery tiles per association work item (one per wave of the workgroup)
 
 #define SS_TENTATIVE 1
 #define SS_CONFIRMED 2
@@ -43,10 +47,12 @@ struct SSParams {
     int debug;
 };
 
-// Device-resident tracker state + per-frame scratch for S streams (all pointers device memory).
+// Device-resident tracker state + per-group scratch for S streams (all pointers device memory).
+// One tracker call carries a GROUP of F <= SS_FMAX consecutive frames of every stream; arrays marked [F] are indexed
+// by the frame's position in the group, in the caller's layout [F][S][...].
 struct SSDev {
-    int S;
-    int grid_tracks;            // confirmed-track capacity assumed by this launch
+    int S, F;
+    int budget;                 // nn_budget (ring length of a gallery)
     int cos_grid;               // workgroups of the persistent association kernel
     // persistent per stream
     int *n_tracks, *next_id, *frame, *err;
@@ -56,36 +62,62 @@ struct SSDev {
     float* conf;
     double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]
     float* smooth;              // [S][MAXT][512]
-    float* gallery;             // [S][MAXT][NRT][TILE_FLOATS]  fragment-major
-    // per-frame inputs
-    const float* dets;          // [S][MAXD][6]
-    const int* n_dets;          // [S]
-    const float* feats_raw;     // [S][MAXD][512]
-    // per-frame scratch
-    float* feat_unit;           // [S][MAXD][512]
-    float* feat_frag;           // [S][NCT][TILE_FLOATS]
-    double *tlwh, *xyah;        // [S][MAXD][4]
-    double* chol;               // [S][MAXT][16]  10 L entries + 4 projected mean (by track index)
-    double* ttlwh;              // [S][MAXT][4]   predicted track box (by track index)
-    int *n_conf, *conf_list;    // [S], [S][MAXT] track indices of confirmed tracks
-    float* part_min;            // [S][MAXT][NRT][MAXD]
-    int4* tiles;                // [2][S*MAXT*NRT] association work lists: {stream, conf row, slot, count | rt<<8 | D<<16}
-                                //   list 0 -> k_cosine_stream (wave per tile, D <= 32), list 1 -> k_cosine_wg
-    int* tile_count;            // [2] valid entries per list (re-armed by k_step)
-    int stream_mode;            // route D <= 32 tiles to the wave-per-tile kernel (throughput mode)
-    long long* ts;              // [16 blocks][8 waves][64] wall-clock stamps (100 MHz) when ts_enable (profiling aid)
-    int ts_enable;
-    // outputs
-    float* out_rows;            // [S][MAXT][8]
-    int* n_out;                 // [S]
+    float* gallery;             // [S][MAXT][NRT][TILE_FLOATS]  fragment-major ring of nn_budget rows
+    // group inputs / outputs (caller's buffers)
+    const float* dets;          // [F][S][MAXD][6]
+    const int* n_dets;          // [F][S]
+    const float* feats_raw;     // [F][S][MAXD][512]
+    float* out_rows;            // [F][S][MAXT][8]
+    int* n_out;                 // [F][S]
     int* img_hw;                // [S][2]
-    // debug (stage intermediates of the last frame)
-    float* dbg_cos;             // [S][MAXT][MAXD]
-    double *dbg_maha, *dbg_cost_a, *dbg_cost_b;   // [S][MAXT][MAXD]
+    // group scratch
+    float* feat_unit;           // [FMAX][S][MAXD][512]
+    float* feat_frag;           // [FMAX][S][NCT][TILE_FLOATS]
+    double *tlwh, *xyah;        // [FMAX][S][MAXD][4]
+    int* M;                     // [S][MAXT][FMAX][MAXD] ordered-int keys (ss_fkey) of the appearance distance
+                                //   min over the gallery rows of (slot) that are valid in frame f of the group
+    int4* tl;                   // [S][TLMAX] gallery tiles at group start {slot, row tile, count, head}
+    int* n_tl;                  // [S]
+    int2* pl;                   // [S][PLMAX] column-tile pairs of the group {frame, ct0 | two<<8 | D<<16}, by frame
+    int* n_pl;                  // [S]
+    int* pf;                    // [S][FMAX+1] first pair of frame f (pf[F] = n_pl)
+    int4* items;                // association work items {stream, pair, first tile, tiles (<= SS_CHUNK)}
+    int* n_items;               // [1]
+    // per-frame hand-off k_frame -> k_post -> k_newrow
+    int4* post;                 // [S][MAXT] surviving tracks in list order {slot, det or -1, flags, aux}
+    int* n_post;                // [S]
+    int* rowlist;               // [S][MAXT] slot | first_row<<16 of every gallery row appended this frame
+    int* n_rows;                // [S]
+    double* cost_spill;         // [S][MAXT*MAXD] cost matrices that do not fit the LDS
+    unsigned long long* tstamp; // [4] in-kernel timing of the association kernel: min start, max end (100 MHz), sum, count
+    int ts_enable;
+    // debug (stage intermediates, per frame of the group)
+    float* dbg_cos;             // [FMAX][S][MAXT][MAXD]
+    double *dbg_maha, *dbg_cost_a, *dbg_cost_b;
     uint8_t* dbg_gated;
-    int* dbg_lists;             // [S][4][MAXT]: pairs_a(det per conf row), cand, cols_b, pairs_b
-    int* dbg_counts;            // [S][4]: n_conf, n_cand, n_cols, unused
+    int* dbg_lists;             // [FMAX][S][4][MAXT]: pairs_a(det per conf row), cand, cols_b, pairs_b
+    int* dbg_counts;            // [FMAX][S][4]: n_conf, n_cand, n_cols, n_dets
 };
+
+// post[] flags
+#define SS_P_MATCHED 1          // Kalman update + EMA with detection .y
+#define SS_P_BIRTH 2            // new track from detection .y
+#define SS_P_APPEND 4           // append the EMA feature at ring position aux & 0xff
+#define SS_P_FIRSTROW 8         // ... and it is the gallery's first row
+#define SS_P_EMIT 16            // output row number aux >> 8
+
+// order-preserving int image of a float (signed compare == float compare, also for negative values)
+__host__ __device__ inline int ss_fkey(float v)
+{
+    union { float f; int i; } u; u.f = v;
+    return u.i ^ ((u.i >> 31) & 0x7fffffff);
+}
+__host__ __device__ inline float ss_fkey_inv(int k)
+{
+    union { float f; int i; } u; u.i = k ^ ((k >> 31) & 0x7fffffff);
+    return u.f;
+}
+#define SS_KEY_INF 0x7f800000
 
 // ---------------------------------------------------------------------------------------------
 // wave helpers
@@ -243,6 +275,65 @@ __device__ inline void ss_kf_update(double* mean, double* cov, const double z[4]
         }
 #pragma unroll
     for (int r = 0; r < 8; ++r) mean[r] = nm[r];
+}
+
+// Wave-cooperative form of ss_kf_update: lane l owns covariance entry (r, c) = (l >> 3, l & 7) and computes exactly
+// the operations the oracle performs for that entry (the gain rows r and c, column c of S K^T), so every result bit
+// equals the one-thread form.  ws = 72 doubles of per-wave LDS (covariance, then mean; the new mean is left in
+// ws[64..71]).  gmean / gcov are updated in place.
+__device__ inline void ss_kf_update_wave(double* gmean, double* gcov, const double z[4], double conf, double wp, double* ws)
+{
+    const int l = threadIdx.x & 63, r = l >> 3, c = l & 7;
+    const double p = gcov[l];
+    ws[l] = p;
+    if (l < 8) ws[64 + l] = gmean[l];
+    SS_WAVE_SYNC();
+    const double* cov = ws;
+    const double* mean = ws + 64;
+    double m4[4], S[16], L[16];
+    ss_kf_project(mean, cov, conf, wp, m4, S);
+    ss_chol4(S, L);
+    double Kr[4], Kc[4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass == 0 ? r : c;
+        double w[4], x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double sum = cov[row * 8 + i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) sum = fma(-L[i * 4 + k], w[k], sum);
+            w[i] = sum / L[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            double sum = w[i];
+#pragma unroll
+            for (int k = 3; k > i; --k) sum = fma(-L[k * 4 + i], x[k], sum);
+            x[i] = sum / L[i * 4 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (pass == 0) Kr[i] = x[i]; else Kc[i] = x[i]; }
+    }
+    double Mc[4];                                   // column c of M = S K^T
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = fma(S[i * 4 + k], Kc[k], acc);
+        Mc[i] = acc;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc = fma(Kr[k], Mc[k], acc);
+    const double mr = mean[r];
+    double a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a2 = fma(z[k] - m4[k], Kr[k], a2);
+    SS_WAVE_SYNC();                                 // every lane has read the old state
+    gcov[l] = p - acc;
+    if (c == 0) { const double nm = mr + a2; gmean[r] = nm; ws[64 + r] = nm; }
+    SS_WAVE_SYNC();
 }
 
 // gate + blend + threshold of one entry (oracle so_blend)

@@ -1,21 +1,22 @@
-// ss_track.hip — device-resident StrongSORT tracker update for S independent streams.
+// ss_track.hip — device-resident StrongSORT tracker update for S independent streams, a GROUP of F frames per call.
 //
-// Per frame three launches cover rows a6..a10 of SURVEY.md §8(a) for every stream at once:
-//   k_pre     one block per stream: Kalman predict of all live tracks (+ Cholesky of the projected
-//             covariance for the gate, confirmed-track list); further blocks: L2-normalise the
-//             detection embeddings and write them row-major and fragment-major.
-//   k_cosine  one 8-wave block per (confirmed track, 32-row gallery tile): streams the gallery
-//             tile with coalesced 16-B loads straight into v_mfma_f32_32x32x2_f32 operands
-//             (one k-segment per wave), combines the segments in LDS, min over gallery rows
-//             (registers -> wave shuffle -> LDS).  This is the HBM-bound association kernel.
-//   k_step    one block per stream: gate/blend cost matrix into LDS, LSAP (single wave, SciPy's
-//             scan order), IoU stage + LSAP, Kalman/EMA updates, births, deletions, gallery append,
-//             output rows.  No host round trip anywhere in the frame.
+// Rows a6..a10 of SURVEY.md §8(a).  Per group (F consecutive frames of every stream; F = 1 is the frame-at-a-time case):
+//   k_group_prep  detection embeddings of all F frames L2-normalised and written row-major and fragment-major; the
+//                 association work lists (gallery tiles of the confirmed tracks, column-tile pairs, work items).
+//   k_assoc       THE association kernel: every gallery tile against the detections of all F frames — coalesced
+//                 16-B gallery loads straight into v_mfma_f32_16x16x4_f32 operands, min over the rows that are
+//                 still in the ring at each frame — so the gallery is read once per group instead of once per frame.
+// and then per frame, in order (the tracker recurrence):
+//   k_frame       one workgroup per stream: Kalman predict, gate/blend cost matrix in LDS, LSAP (single wave, SciPy's
+//                 scan order), IoU stage + LSAP, track state machine, births, deletions, ring positions.
+//   k_post        one wave per track: NSA Kalman update (64 lanes), EMA feature, gallery append, output row.
+//   k_newrow      distances of the rows just appended to the detections of the group's later frames (MFMA, k-split).
+// No host round trip anywhere in the group.
 #include <hip/hip_ext.h>
 #include "ss_common.h"
 
 // =================================================================================================
-// k_pre
+// block / wave helpers
 // =================================================================================================
 __device__ inline void block_scan256(int flag, int* wtot /*LDS[4]*/, int& pos, int& total)
 {
@@ -67,102 +68,9 @@ __device__ inline void block_scan_sum256(int v, int* wtot /*LDS[4]*/, int& excl,
     total = tot;
 }
 
-__global__ __launch_bounds__(256) void k_pre(SSDev dev, SSParams prm)
-{
-    __shared__ int wtot[4];
-    __shared__ int tile_base;
-    __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
-    const int s = blockIdx.x;
-    const int tid = threadIdx.x;
-    if (blockIdx.y == 0) {
-        // ---- predict all live tracks of stream s (thread = position in the track list) ----
-        const int nT = dev.n_tracks[s];
-        int confirmed = 0, myslot = 0, mycount = 0;
-        if (tid < nT) {
-            const int slot = dev.order[s * SS_MAXT + tid];
-            myslot = slot;
-            const size_t g = (size_t)s * SS_MAXT + slot;
-            double mean[8], cov[64];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
-            ss_kf_predict(mean, cov, prm.wp, prm.wv);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
-            dev.age[g] += 1;
-            dev.tsu[g] += 1;
-            dev.det_idx[g] = -1;
-            // gate factorisation (projection with conf = 0) and predicted box, by track index
-            double m4[4], S[16], L[16];
-            ss_kf_project(mean, cov, 0.0, prm.wp, m4, S);
-            ss_chol4(S, L);
-            double* ch = dev.chol + ((size_t)s * SS_MAXT + tid) * 16;
-            ch[0] = L[0]; ch[1] = L[4]; ch[2] = L[5]; ch[3] = L[8]; ch[4] = L[9]; ch[5] = L[10];
-            ch[6] = L[12]; ch[7] = L[13]; ch[8] = L[14]; ch[9] = L[15];
-            ch[10] = m4[0]; ch[11] = m4[1]; ch[12] = m4[2]; ch[13] = m4[3];
-            double w = mean[2] * mean[3];
-            double* tb = dev.ttlwh + ((size_t)s * SS_MAXT + tid) * 4;
-            tb[0] = mean[0] - w / 2; tb[1] = mean[1] - mean[3] / 2; tb[2] = w; tb[3] = mean[3];
-            confirmed = dev.state[g] == SS_CONFIRMED;
-            mycount = dev.gal_count[g];
-        }
-        int pos, total;
-        block_scan256(confirmed, wtot, pos, total);
-        if (confirmed) dev.conf_list[s * SS_MAXT + pos] = tid;
-        // association work list: one entry per (confirmed track, 32-row gallery tile) that has rows
-        const int D = dev.n_dets[s];
-        const int ntile = (confirmed && D > 0) ? (mycount + SS_TILE - 1) / SS_TILE : 0;
-        const int tlist = (dev.stream_mode && D <= 2 * SS_TILE) ? 0 : 1;
-        int toff, ttot;
-        block_scan_sum256(ntile, wtot, toff, ttot);
-        if (tid == 0) {
-            dev.n_conf[s] = total;
-            tile_base = ttot ? atomicAdd(dev.tile_count + tlist, ttot) + tlist * dev.S * SS_MAXT * SS_NRT : 0;
-            if (total > dev.grid_tracks) dev.err[s] = SS_ERR_CAPACITY;
-        }
-        __syncthreads();
-        for (int rt = 0; rt < ntile; ++rt)
-            dev.tiles[tile_base + toff + rt] = make_int4(s, pos, myslot, mycount | (rt << 8) | (D << 16));
-        return;
-    }
-    // ---- detection prep: one wave per detection ----
-    const int w = tid >> 6, l = tid & 63;
-    const int d = (blockIdx.y - 1) * 4 + w;
-    const int D = dev.n_dets[s];
-    const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
-    if (d >= Dpad) return;
-    float4* frag = reinterpret_cast<float4*>(dev.feat_frag + ((size_t)s * SS_NCT + d / SS_TILE) * SS_TILE_FLOATS);
-    const int jj = d % SS_TILE;
-    if (d < D) {
-        const float* raw = dev.feats_raw + ((size_t)s * SS_MAXD + d) * SS_F;
-        float v[8], a = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { v[j] = raw[l + 64 * j]; a = fmaf(v[j], v[j], a); }
-        float n = sqrtf(ss_wave_sumsq_reduce(a));
-        float* unit = dev.feat_unit + ((size_t)s * SS_MAXD + d) * SS_F;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { float u = n > 0.0f ? v[j] / n : 0.0f; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }   // all-zero row stays zero (D-17)
-        SS_WAVE_SYNC();
-        frag_write_row(frag, jj, rowbuf[w], false);
-        if (l == 0) {
-            const float* b = dev.dets + ((size_t)s * SS_MAXD + d) * 6;
-            double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
-            double bw = x2 - x1, bh = y2 - y1;
-            double* t = dev.tlwh + ((size_t)s * SS_MAXD + d) * 4;
-            double* z = dev.xyah + ((size_t)s * SS_MAXD + d) * 4;
-            t[0] = x1; t[1] = y1; t[2] = bw; t[3] = bh;
-            z[0] = x1 + bw / 2; z[1] = y1 + bh / 2; z[2] = bw / bh; z[3] = bh;
-        }
-    } else {
-        frag_write_row(frag, jj, nullptr, true);
-    }
-}
-
 // =================================================================================================
-// k_cosine — the association kernel (gallery stream + f32 MFMA + min over gallery rows)
+// f32-MFMA dot products in oracle order, k-split form: one 8-wave workgroup per (16-row tile, pair of 16-column tiles),
+// one 64-long k-segment per wave.  Used by the stage KAT (ss_assoc_cost) and by k_newrow.
 // =================================================================================================
 // part_min[s][r][rt][d] = min over the valid rows b of gallery tile rt of (1 - g_b . f_d).
 // Shared by the tracker (gallery addressed through conf_list/order) and the KAT entry point
@@ -201,11 +109,10 @@ __device__ __forceinline__ void load_b(const float* __restrict__ feat_frag, int 
     for (int j = 0; j < 4; ++j) { b0[j] = fb0[(4 * w + j) * 64 + l]; b1[j] = fb1[(4 * w + j) * 64 + l]; }
 }
 
-// One pair of column tiles: 16 + 16 MFMAs (two independent accumulation chains), then
-//   LDS: per-segment partial tiles -> summed left to right (oracle order) -> 1 - dot -> min over rows.
-__device__ __forceinline__ void cosine_pair(const float4 a[4], const float4 b0[4], const float4 b1[4], int count, int rt,
-                                            int ct, bool two, int D, float* __restrict__ out, float* lds_part,
-                                            float* lds_red)
+// One pair of column tiles: 16 + 16 MFMAs per wave (two independent accumulation chains over the wave's k-segment),
+// per-segment partial tiles to LDS, then thread (ctl, reg, lane) sums the 8 segment partials of accumulator element
+// (row 4*(lane/16)+reg, column lane%16) of column tile ctl left to right (oracle order) and returns that dot product.
+__device__ __forceinline__ float cosine_dots(const float4 a[4], const float4 b0[4], const float4 b1[4], float* lds_part)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
@@ -222,11 +129,21 @@ __device__ __forceinline__ void cosine_pair(const float4 a[4], const float4 b0[4
         lds_part[((1 * 8 + w) * 4 + r) * 64 + l] = acc1[r];
     }
     SS_LDS_BARRIER();
-    // thread (ctl, reg, lane): sum the 8 segment partials of one accumulator element, left to right
     const int ctl = threadIdx.x >> 8, reg = (threadIdx.x >> 6) & 3;
     float tot = lds_part[((ctl * 8 + 0) * 4 + reg) * 64 + l];
 #pragma unroll
     for (int sg = 1; sg < SS_NSEG; ++sg) tot = tot + lds_part[((ctl * 8 + sg) * 4 + reg) * 64 + l];
+    return tot;
+}
+
+// ... -> 1 - dot -> min over the tile's valid rows (registers -> wave shuffle -> LDS).
+__device__ __forceinline__ void cosine_pair(const float4 a[4], const float4 b0[4], const float4 b1[4], int count, int rt,
+                                            int ct, bool two, int D, float* __restrict__ out, float* lds_part,
+                                            float* lds_red)
+{
+    const int l = threadIdx.x & 63;
+    const int ctl = threadIdx.x >> 8, reg = (threadIdx.x >> 6) & 3;
+    const float tot = cosine_dots(a, b0, b1, lds_part);
     float m = 1.0f - tot;
     const int row = rt * SS_TILE + 4 * (l >> 4) + reg;             // C/D layout of 16x16x4: row = 4*(lane/16)+reg
     if (row >= count) m = INFINITY;
@@ -255,211 +172,6 @@ __device__ __forceinline__ void cosine_tile(const float4 a[4], int count, int rt
     }
 }
 
-// ---- association kernel, latency form (work list 1) ------------------------------------------------
-// One 8-wave workgroup per gallery tile, one k-segment per wave: the shortest critical path for a
-// single stream (a tile's 256 MFMAs are spread over 8 waves).  Persistent over chunks of the list with a
-// register prefetch of the next tile; used for small batches and for D > 32.
-__global__ __launch_bounds__(512) void k_cosine_wg(SSDev dev)
-{
-    __shared__ float lds_part[2 * 8 * 4 * 64];
-    __shared__ float lds_red[2 * 4 * 16];
-    const int4* tiles = dev.tiles + (size_t)dev.S * SS_MAXT * SS_NRT;
-    const int G = gridDim.x;
-    const int4 spec = tiles[blockIdx.x];             // speculative: right whenever ntiles <= G (chunk == 1)
-    const int ntiles = dev.tile_count[1];
-    const int chunk = (ntiles + G - 1) / G;
-    const int t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, ntiles);
-    if (t0 >= t1) return;
-    auto tile_ptr = [&](int s, int slot, int rt) {
-        return reinterpret_cast<const float4*>(dev.gallery + (((size_t)s * SS_MAXT + slot) * SS_NRT + rt) * SS_TILE_FLOATS);
-    };
-    int4 v0 = (chunk == 1) ? spec : tiles[t0];
-    int s0 = __builtin_amdgcn_readfirstlane(v0.x), r0 = __builtin_amdgcn_readfirstlane(v0.y);
-    int sl0 = __builtin_amdgcn_readfirstlane(v0.z), cw0 = __builtin_amdgcn_readfirstlane(v0.w);
-    int s1 = s0, r1 = r0, sl1 = sl0, cw1 = cw0;
-    if (t0 + 1 < t1) {
-        int4 v1 = tiles[t0 + 1];
-        s1 = __builtin_amdgcn_readfirstlane(v1.x); r1 = __builtin_amdgcn_readfirstlane(v1.y);
-        sl1 = __builtin_amdgcn_readfirstlane(v1.z); cw1 = __builtin_amdgcn_readfirstlane(v1.w);
-    }
-    float4 a_cur[4], a_nxt[4], b0[4], b1[4];
-    int sB = -1;
-    load_a(tile_ptr(s0, sl0, (cw0 >> 8) & 7), (cw0 & 0xff) - ((cw0 >> 8) & 7) * SS_TILE, a_cur);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { a_nxt[j] = a_cur[j]; b0[j] = a_cur[j]; b1[j] = a_cur[j]; }
-    for (int t = t0; t < t1; ++t) {
-        int4 v2 = make_int4(s1, r1, sl1, cw1);
-        if (t + 2 < t1) v2 = tiles[t + 2];                                   // consumed at the end of the iteration
-        const int count = cw0 & 0xff, rt = (cw0 >> 8) & 7, D = cw0 >> 16;
-        const int nct = (D + SS_TILE - 1) / SS_TILE;
-        const float* ff = dev.feat_frag + (size_t)s0 * SS_NCT * SS_TILE_FLOATS;
-        float* out = dev.part_min + (((size_t)s0 * SS_MAXT + r0) * SS_NRT + rt) * SS_MAXD;
-        if (nct <= 2) {
-            if (sB != s0) { load_b(ff, 0, nct == 2, b0, b1); sB = s0; }      // before the prefetch: vmcnt is in-order
-            if (t + 1 < t1)
-                load_a(tile_ptr(s1, sl1, (cw1 >> 8) & 7), (cw1 & 0xff) - ((cw1 >> 8) & 7) * SS_TILE, a_nxt);
-            cosine_pair(a_cur, b0, b1, count, rt, 0, nct == 2, D, out, lds_part, lds_red);
-        } else {
-            sB = -1;
-            cosine_tile(a_cur, count, rt, ff, D, out, lds_part, lds_red);
-            if (t + 1 < t1)
-                load_a(tile_ptr(s1, sl1, (cw1 >> 8) & 7), (cw1 & 0xff) - ((cw1 >> 8) & 7) * SS_TILE, a_nxt);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
-        s0 = s1; r0 = r1; sl0 = sl1; cw0 = cw1;
-        s1 = __builtin_amdgcn_readfirstlane(v2.x); r1 = __builtin_amdgcn_readfirstlane(v2.y);
-        sl1 = __builtin_amdgcn_readfirstlane(v2.z); cw1 = __builtin_amdgcn_readfirstlane(v2.w);
-    }
-}
-
-// ---- association kernel, throughput form (work list 0, D <= 32) ------------------------------------
-// One WAVE per gallery tile: the wave walks the tile's 8 k-segments itself (8 x 16 MFMAs per column
-// tile), adds the segment sums left to right in registers and reduces min-over-rows with two shuffles.
-// No LDS combine, no barriers in steady state, waves fully decoupled.  The gallery is one continuous
-// stream of 4-KiB segment pieces per wave, prefetched 3 pieces ahead through a 4-deep register ring
-// (ordinary loads, so hipcc's counted vmcnt keeps 3 pieces in flight); the stream's detection operand
-// B (2 x 32 KiB fragment tiles) sits in LDS, shared by the 8 waves of the workgroup.
-#define SS_TS(idx) do { if (dev.ts_enable && blockIdx.x % 32 == 0 && blockIdx.x / 32 < 16 && (threadIdx.x & 63) == 0 && (idx) < 64) \
-        dev.ts[((blockIdx.x / 32) * 8 + (threadIdx.x >> 6)) * 64 + (idx)] = wall_clock64(); } while (0)
-
-__global__ __launch_bounds__(512) void k_cosine_stream(SSDev dev)
-{
-    int tsi = 0;
-    SS_TS(tsi++);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int G = gridDim.x;
-    const int ntiles = dev.tile_count[0];
-    const int chunk = (ntiles + G - 1) / G;
-    const int c0 = blockIdx.x * chunk, c1 = min(c0 + chunk, ntiles);
-    if (c0 >= c1) return;
-    int4* desc = reinterpret_cast<int4*>(smem + 2 * SS_TILE_FLOATS * 4);     // [512] descriptors of this pass
-    for (int p0 = c0; p0 < c1; p0 += 512) {
-    const int p1 = min(p0 + 512, c1);
-    __syncthreads();
-    if (p0 + (int)threadIdx.x < p1) desc[threadIdx.x] = dev.tiles[p0 + threadIdx.x];   // one parallel read, then LDS only
-    __syncthreads();
-    SS_TS(tsi++);
-    const int4* tiles = desc - p0;                                           // tiles[t] for t in [p0, p1)
-    int t0 = p0;
-    while (t0 < p1) {
-        // sub-range [t0, t1) of the pass that belongs to one stream
-        const int s = __builtin_amdgcn_readfirstlane(tiles[t0].x);
-        const int D = __builtin_amdgcn_readfirstlane(tiles[t0].w) >> 16;
-        int t1 = t0 + 1;
-        for (;;) {                                                           // 64 descriptors per step
-            const int tt = t1 + l;
-            const unsigned long long diff = __ballot(tt < p1 && tiles[tt].x != s);
-            if (diff) { t1 += __builtin_ctzll(diff); break; }
-            if (t1 + 64 >= p1) { t1 = p1; break; }
-            t1 += 64;
-        }
-        const bool two = D > SS_TILE;
-        // this wave's tiles: t0 + w, t0 + w + 8, ...
-        const int wu = __builtin_amdgcn_readfirstlane(w);
-        const int nmine = (t1 - t0 - wu + 7) / 8;                    // may be <= 0
-        // descriptors live in SGPRs; a tile is addressed as (uniform byte base) + (per-lane offset)
-        auto rd = [&](int t, int& r, int& cw, const char*& base) {
-            const int4 v = tiles[t];
-            const int sl = __builtin_amdgcn_readfirstlane(v.z);
-            r = __builtin_amdgcn_readfirstlane(v.y); cw = __builtin_amdgcn_readfirstlane(v.w);
-            base = reinterpret_cast<const char*>(dev.gallery) +
-                   ((((size_t)s * SS_MAXT + sl) * SS_NRT + ((cw >> 8) & 7)) * SS_TILE_FLOATS) * 4;
-        };
-        // lanes of rows past the gallery count re-read row 0 of the tile (same cache lines, no extra HBM
-        // traffic, no select); those rows are masked to +inf below
-        auto lane_off = [&](int cw) {
-            const bool ok = (l & 15) < (cw & 0xff) - ((cw >> 8) & 7) * SS_TILE;
-            return (unsigned)((ok ? l : (l & ~15)) * 16);
-        };
-        auto ld = [&](const char* base, unsigned voff, int sg, float4 a[4]) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + voff + sg * 4096 + j * 1024);
-        };
-        int r0 = 0, cw0 = 0, r1 = 0, cw1 = 0;
-        const char *base0 = reinterpret_cast<const char*>(dev.gallery), *base1 = base0;
-        unsigned vo0 = 0, vo1 = 0;
-        float4 ra[4][4];                                              // 4-deep ring of segment pieces
-        if (nmine > 0) {
-            // gallery pieces 0..2 of the first tile go on the wire BEFORE the B staging below
-            rd(t0 + wu, r0, cw0, base0);
-            vo0 = lane_off(cw0);
-            ld(base0, vo0, 0, ra[0]); ld(base0, vo0, 1, ra[1]); ld(base0, vo0, 2, ra[2]);
-        }
-        // stage B of stream s in LDS
-        __syncthreads();
-        {
-            const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (size_t)s * SS_NCT * SS_TILE_FLOATS);
-            // all loads first, then all LDS writes: one memory latency instead of one per 8 KiB slice
-            float4 tmp[8];
-            const int nu = two ? 8 : 4;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < nu) tmp[u] = ff[threadIdx.x + 512 * u];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (u < nu) bl[threadIdx.x + 512 * u] = tmp[u];
-        }
-        __syncthreads();
-        SS_TS(tsi++);
-        if (nmine > 0) {
-            const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
-            const char* bls1 = bls + (two ? 32768 : 0);          // single column tile: read tile 0 twice (result unused)
-            for (int k = 0; k < nmine; ++k) {
-                const bool more = k + 1 < nmine;
-                // the prefetch below is unconditional (static load count -> exact counted vmcnt, no drain at the tile
-                // boundary); the last tile of a wave prefetches its own first pieces again, which nobody reads
-                if (more) { rd(t0 + wu + 8 * (k + 1), r1, cw1, base1); vo1 = lane_off(cw1); }
-                else { base1 = base0; vo1 = vo0; }
-                f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
-                SS_TS(tsi++);
-#pragma unroll
-                for (int sg = 0; sg < 8; ++sg) {
-                    // prefetch piece sg+3 (possibly of the next tile) into ring slot (sg+3)%4
-                    if (sg + 3 < 8) ld(base0, vo0, sg + 3, ra[(sg + 3) & 3]);
-                    else ld(base1, vo1, sg + 3 - 8, ra[(sg + 3) & 3]);
-                    const float4* a = ra[sg & 3];
-                    f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(bls + (4 * sg + j) * 1024);
-                        const float4 b1 = *reinterpret_cast<const float4*>(bls1 + (4 * sg + j) * 1024);
-                        acc0 = SS_MFMA16(a[j].x, b0.x, acc0); acc1 = SS_MFMA16(a[j].x, b1.x, acc1);
-                        acc0 = SS_MFMA16(a[j].y, b0.y, acc0); acc1 = SS_MFMA16(a[j].y, b1.y, acc1);
-                        acc0 = SS_MFMA16(a[j].z, b0.z, acc0); acc1 = SS_MFMA16(a[j].z, b1.z, acc1);
-                        acc0 = SS_MFMA16(a[j].w, b0.w, acc0); acc1 = SS_MFMA16(a[j].w, b1.w, acc1);
-                    }
-                    if (sg == 0) { tot0 = acc0; tot1 = acc1; }
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
-                    if (sg == 0 || sg == 3) SS_TS(tsi++);
-                }
-                SS_TS(tsi++);
-                // 1 - dot, mask rows past the gallery count, min over the tile's 16 rows
-                const int count = cw0 & 0xff, rt = (cw0 >> 8) & 7;
-                float m0 = INFINITY, m1 = INFINITY;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = rt * SS_TILE + 4 * (l >> 4) + r < count;
-                    m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
-                    m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
-                }
-                m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
-                m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
-                float* out = dev.part_min + (((size_t)s * SS_MAXT + r0) * SS_NRT + rt) * SS_MAXD;
-                if (l < 16) { if (l < D) out[l] = m0; }
-                else if (l < 32) { if (l < D) out[l] = m1; }
-                r0 = r1; cw0 = cw1; base0 = base1; vo0 = vo1;
-            }
-        }
-        t0 = t1;
-    }
-    }
-}
-
 __global__ __launch_bounds__(512) void k_cosine_kat(CosineArgs a)
 {
     __shared__ float lds_part[2 * 8 * 4 * 64];
@@ -476,9 +188,7 @@ __global__ __launch_bounds__(512) void k_cosine_kat(CosineArgs a)
 // LSAP on one wave — shortest augmenting path in SciPy's scan order (oracle so_lsap)
 // =================================================================================================
 struct LsapLds {
-    double *u, *v, *sp;                          // [256] each
-    int *path, *row4col, *col4row, *remaining;   // [256] each
-    unsigned char *SR, *SC;                      // [256] each
+    int* col4row;                                // [256] result: column of every row (LDS)
 };
 
 // ---- wave-64 reductions on the DPP path (gfx9 row shifts + row broadcasts: an inclusive scan whose lane 63 holds
@@ -540,7 +250,7 @@ __device__ inline int lsap_wave_small(int nr, int nc, const double* cost, const 
         int num_remaining = nc, sink = -1, i = cur;
         while (sink == -1) {
             if (l == i) sr = true;
-            const double ui = __longlong_as_double(__builtin_amdgcn_readlane((int)(__double_as_longlong(u) & 0xffffffff), i) & 0xffffffffll |
+            const double ui = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(u) & 0xffffffff), i) & 0xffffffffll) |
                                                    ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(u) >> 32), i) << 32));
             if (active) {
                 const double r = minVal + cost[i * nc + l] - ui - v;
@@ -739,10 +449,7 @@ __device__ inline int lsap_wave(int nr, int nc, const double* cost, const LsapLd
 __device__ inline LsapLds carve_lsap(char*& p)
 {
     LsapLds L;
-    L.u = (double*)p; p += 256 * 8; L.v = (double*)p; p += 256 * 8; L.sp = (double*)p; p += 256 * 8;
-    L.path = (int*)p; p += 256 * 4; L.row4col = (int*)p; p += 256 * 4;
-    L.col4row = (int*)p; p += 256 * 4; L.remaining = (int*)p; p += 256 * 4;
-    L.SR = (unsigned char*)p; p += 256; L.SC = (unsigned char*)p; p += 256;
+    L.col4row = (int*)p; p += 256 * 4;
     return L;
 }
 
@@ -773,7 +480,7 @@ __global__ __launch_bounds__(64) void k_lsap_kat(const double* cost, int nr0, in
 }
 
 // =================================================================================================
-// k_step — per-stream association, assignment and bookkeeping
+// per-track wave helpers
 // =================================================================================================
 __device__ inline void ema_wave(const float* smooth_in, const float* feat, float a, float b, float* out)
 {
@@ -797,270 +504,601 @@ __device__ inline void gallery_append_wave(float* gal_track, int b, const float*
     frag_write_row(reinterpret_cast<float4*>(gal_track + (size_t)(b / SS_TILE) * SS_TILE_FLOATS), b % SS_TILE, src, false);
 }
 
-#define SS_TS_STEP(idx) do { if (dev.ts_enable && blockIdx.x == 0 && threadIdx.x == 0) dev.ts[(15 * 8 + 7) * 64 + (idx)] = wall_clock64(); } while (0)
 
-__global__ __launch_bounds__(256) void k_step(SSDev dev, SSParams prm)
+// =================================================================================================
+// k_group_prep — once per group: detection features of all F frames, association work lists, M rows
+// =================================================================================================
+// blockIdx.x = stream.  blockIdx.y = 0: work lists of the stream; 1..MAXT: M row of slot y-1; then 32 blocks per frame
+// (one wave per detection): L2-normalise the raw embedding, write it row-major and fragment-major.
+#define SS_PREP_FBLK (SS_MAXD / 4)
+__global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 {
-    SS_TS_STEP(0);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* p = smem;
-    double* cost = (double*)p; p += (size_t)SS_COST_CAP * 8;
-    LsapLds L = carve_lsap(p);
-    int* matchdet = (int*)p; p += 256 * 4;     // by track index: matched detection or -1
-    int* dettrk = (int*)p; p += 256 * 4;       // by detection: matched track index or -1
-    int* asg = (int*)p; p += 256 * 4;          // LSAP result by original row
-    int* cand = (int*)p; p += 256 * 4;         // IoU-stage rows (track indices)
-    int* cols = (int*)p; p += 256 * 4;         // IoU-stage columns (detection indices)
-    int* neworder = (int*)p; p += 256 * 4;
-    int* freelist = (int*)p; p += 256 * 4;
-    int* conf_l = (int*)p; p += 256 * 4;
-    int* wtot = (int*)p; p += 16;
-    int* flags = (int*)p; p += 16;
-
-    const int s = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
-    const int nT = dev.n_tracks[s], D = dev.n_dets[s], nC = dev.n_conf[s];
+    __shared__ int wtot[4];
+    __shared__ int item_base;
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
+    const int s = blockIdx.x, tid = threadIdx.x, F = dev.F, S = dev.S;
     const size_t sb = (size_t)s * SS_MAXT;
-    const size_t db = (size_t)s * SS_MAXD;
-    matchdet[tid] = -1; dettrk[tid] = -1; asg[tid] = -1;
-    if (tid < nC) conf_l[tid] = dev.conf_list[sb + tid];
-    if (tid == 0) { flags[0] = 0; }
-    int myslot = (tid < nT) ? dev.order[sb + tid] : -1;
-    int mystate = (tid < nT) ? dev.state[sb + myslot] : 0;
-    int mytsu = (tid < nT) ? dev.tsu[sb + myslot] : 0;
-    if (prm.debug) { dev.dbg_lists[(s * 4 + 0) * SS_MAXT + tid] = -1; dev.dbg_lists[(s * 4 + 3) * SS_MAXT + tid] = -1; }
+    if (blockIdx.y == 0) {
+        // gallery tiles of the tracks that are confirmed when the group starts (snapshot of count / ring head)
+        const int nT = dev.n_tracks[s];
+        int ntile = 0, slot = 0, count = 0, head = 0;
+        if (tid < nT) {
+            slot = dev.order[sb + tid];
+            if (dev.state[sb + slot] == SS_CONFIRMED) {
+                count = dev.gal_count[sb + slot]; head = dev.gal_head[sb + slot];
+                ntile = (count + SS_TILE - 1) / SS_TILE;
+            }
+        }
+        int toff, ttot;
+        block_scan_sum256(ntile, wtot, toff, ttot);
+        for (int rt = 0; rt < ntile; ++rt) dev.tl[(size_t)s * SS_TLMAX + toff + rt] = make_int4(slot, rt, count, head);
+        // column-tile pairs of the group, frame by frame (a pair never spans two frames)
+        int np = 0, D = 0;
+        if (tid < F) { D = min(dev.n_dets[tid * S + s], SS_MAXD); np = ((D + SS_TILE - 1) / SS_TILE + 1) / 2; }
+        int poff, ptot;
+        block_scan_sum256(np, wtot, poff, ptot);
+        if (tid < F) {
+            dev.pf[s * (SS_FMAX + 1) + tid] = poff;
+            const int nct = (D + SS_TILE - 1) / SS_TILE;
+            for (int q = 0; q < np; ++q)
+                dev.pl[(size_t)s * SS_PLMAX + poff + q] = make_int2(tid, (2 * q) | ((2 * q + 1 < nct) ? 256 : 0) | (D << 16));
+        }
+        if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_tl[s] = ttot; dev.n_pl[s] = ptot; }
+        // work items, chunk-major with the pair index fastest: the pairs of one tile chunk run back to back, so the
+        // chunk's gallery bytes come from HBM once and from L2 afterwards
+        const int nchunk = (ttot + SS_CHUNK - 1) / SS_CHUNK;
+        const int nit = nchunk * ptot;
+        if (tid == 0) item_base = nit ? atomicAdd(dev.n_items, nit) : 0;
+        __syncthreads();
+        for (int i = tid; i < nit; i += 256) {
+            const int ch = i / ptot, pp = i - ch * ptot;
+            dev.items[item_base + i] = make_int4(s, pp, ch * SS_CHUNK, min(SS_CHUNK, ttot - ch * SS_CHUNK));
+        }
+        return;
+    }
+    if (blockIdx.y <= SS_MAXT) {
+        // M[slot][f][d] = +inf for every confirmed track (the association kernel min-combines its tiles into it)
+        const int slot = blockIdx.y - 1;
+        if (!dev.slot_used[sb + slot] || dev.state[sb + slot] != SS_CONFIRMED) return;
+        int4* m = reinterpret_cast<int4*>(dev.M + (sb + slot) * SS_FMAX * SS_MAXD);
+        for (int i = tid; i < F * SS_MAXD / 4; i += 256) m[i] = make_int4(SS_KEY_INF, SS_KEY_INF, SS_KEY_INF, SS_KEY_INF);
+        return;
+    }
+    // ---- detection prep: one wave per detection of frame f ----
+    const int yy = blockIdx.y - 1 - SS_MAXT;
+    const int f = yy / SS_PREP_FBLK;
+    const int w = tid >> 6, l = tid & 63;
+    const int d = (yy - f * SS_PREP_FBLK) * 4 + w;
+    const size_t fs = (size_t)f * S + s;
+    const int D = min(dev.n_dets[fs], SS_MAXD);
+    const int Dpad = (D + SS_TILE - 1) / SS_TILE * SS_TILE;
+    if (d >= Dpad) return;
+    float4* frag = reinterpret_cast<float4*>(dev.feat_frag + (fs * SS_NCT + d / SS_TILE) * SS_TILE_FLOATS);
+    const int jj = d % SS_TILE;
+    if (d < D) {
+        const float* raw = dev.feats_raw + (fs * SS_MAXD + d) * SS_F;
+        float v[8], a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = raw[l + 64 * j]; a = fmaf(v[j], v[j], a); }
+        float n = sqrtf(ss_wave_sumsq_reduce(a));
+        float* unit = dev.feat_unit + (fs * SS_MAXD + d) * SS_F;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { float u = n > 0.0f ? v[j] / n : 0.0f; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }   // all-zero row stays zero (D-17)
+        SS_WAVE_SYNC();
+        frag_write_row(frag, jj, rowbuf[w], false);
+        if (l == 0) {
+            const float* b = dev.dets + (fs * SS_MAXD + d) * 6;
+            double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
+            double bw = x2 - x1, bh = y2 - y1;
+            double* t = dev.tlwh + (fs * SS_MAXD + d) * 4;
+            double* z = dev.xyah + (fs * SS_MAXD + d) * 4;
+            t[0] = x1; t[1] = y1; t[2] = bw; t[3] = bh;
+            z[0] = x1 + bw / 2; z[1] = y1 + bh / 2; z[2] = bw / bh; z[3] = bh;
+        }
+    } else {
+        frag_write_row(frag, jj, nullptr, true);
+    }
+}
+
+// =================================================================================================
+// k_assoc — the association kernel: gallery stream x detections of the whole group, f32 MFMA, row min
+// =================================================================================================
+// M[s][slot][f][d] = min over the gallery rows b of track `slot` that are still in its ring when frame f of the group
+// is associated of (1 - g_b . f_d).  Row at ring position pos is valid for frame f iff pos < count and
+// (pos - head) mod budget >= f: a confirmed track overwrites ring position head + j at the end of frame j of the
+// group, so frame f must not see the rows at head .. head + f - 1 (their replacements are added by k_newrow).
+// The gallery is therefore read ONCE per group, not once per frame.
+//
+// Work item = (stream, pair of 16-detection column tiles of one frame, chunk of <= 8 gallery tiles); one WAVE per
+// gallery tile: the wave walks the tile's 8 k-segments (8 x 16 v_mfma_f32_16x16x4_f32 per column tile, two
+// independent accumulation chains), adds the segment sums left to right in registers (oracle order) and reduces
+// min-over-rows with two shuffles; no LDS combine, no barriers while a tile is processed.  The tile arrives as 8
+// pieces of 4 KiB per wave, prefetched 3 pieces ahead through a 4-deep register ring (ordinary loads, so the counted
+// vmcnt keeps 3 pieces in flight); the pair's detection operand B (2 x 32 KiB fragment tiles) is staged once per
+// item in LDS and shared by the 8 waves; its global loads are issued together with the first gallery pieces.
+// Ragged last tile: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
+__global__ __launch_bounds__(512) void k_assoc(SSDev dev)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    if (dev.ts_enable && threadIdx.x == 0) atomicMin(dev.tstamp, (unsigned long long)wall_clock64());
+    const int n_items = *dev.n_items;
+    const int budget = dev.budget;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int4 item = dev.items[it];
+        const int s = __builtin_amdgcn_readfirstlane(item.x), p = __builtin_amdgcn_readfirstlane(item.y);
+        const int t0 = __builtin_amdgcn_readfirstlane(item.z), nt = __builtin_amdgcn_readfirstlane(item.w);
+        const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
+        const int f = __builtin_amdgcn_readfirstlane(pr.x), pw = __builtin_amdgcn_readfirstlane(pr.y);
+        const int ct0 = pw & 0xff, D = pw >> 16;
+        const bool two = (pw >> 8) & 1;
+        const bool has = wu < nt;
+        int slot = 0, rt = 0, count = 0, head = 0;
+        const char* base = reinterpret_cast<const char*>(dev.gallery);
+        unsigned vo = 0;
+        auto ld = [&](int sg, float4 a[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + vo + sg * 4096 + j * 1024);
+        };
+        float4 ra[4][4];                                              // 4-deep ring of segment pieces
+        if (has) {
+            const int4 td = dev.tl[(size_t)s * SS_TLMAX + t0 + wu];
+            slot = __builtin_amdgcn_readfirstlane(td.x); rt = __builtin_amdgcn_readfirstlane(td.y);
+            count = __builtin_amdgcn_readfirstlane(td.z); head = __builtin_amdgcn_readfirstlane(td.w);
+            base += ((((size_t)s * SS_MAXT + slot) * SS_NRT + rt) * SS_TILE_FLOATS) * 4;
+            const bool ok = (l & 15) < count - rt * SS_TILE;
+            vo = (unsigned)((ok ? l : (l & ~15)) * 16);
+            ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]);                 // on the wire before the B staging
+        }
+        // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
+        const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
+        // (a lone column tile is staged twice: branch-free, and the second copy's results are never stored)
+        const float4* ff1 = two ? ff + 4 * 512 : ff;
+        const int tx = threadIdx.x;
+        const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
+        const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
+        __syncthreads();                                             // the previous item's readers are done with bl
+        bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
+        bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
+        __syncthreads();
+        if (has) {
+            const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
+            const char* bls1 = bls + 32768;
+            f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int sg = 0; sg < 8; ++sg) {
+                if (sg + 3 < 8) ld(sg + 3, ra[(sg + 3) & 3]);       // prefetch piece sg+3 into ring slot (sg+3)%4
+                const float4* a = ra[sg & 3];
+                f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bls + (4 * sg + j) * 1024);
+                    const float4 b1 = *reinterpret_cast<const float4*>(bls1 + (4 * sg + j) * 1024);
+                    acc0 = SS_MFMA16(a[j].x, b0.x, acc0); acc1 = SS_MFMA16(a[j].x, b1.x, acc1);
+                    acc0 = SS_MFMA16(a[j].y, b0.y, acc0); acc1 = SS_MFMA16(a[j].y, b1.y, acc1);
+                    acc0 = SS_MFMA16(a[j].z, b0.z, acc0); acc1 = SS_MFMA16(a[j].z, b1.z, acc1);
+                    acc0 = SS_MFMA16(a[j].w, b0.w, acc0); acc1 = SS_MFMA16(a[j].w, b1.w, acc1);
+                }
+                if (sg == 0) { tot0 = acc0; tot1 = acc1; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
+            }
+            // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
+            float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = rt * SS_TILE + 4 * (l >> 4) + r;
+                int jrel = pos - head;
+                if (jrel < 0) jrel += budget;
+                const bool valid = pos < count && jrel >= f;
+                m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
+                m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+            }
+            m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
+            m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
+            int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
+            if (l < 16) { if (ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m0)); }
+            else if (l < 32) { if (two && ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m1)); }
+        }
+    }
+    if (dev.ts_enable) {
+        __builtin_amdgcn_s_waitcnt(0);                               // this wave's memory operations have completed
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(dev.tstamp + 1, (unsigned long long)wall_clock64());
+    }
+}
+
+// =================================================================================================
+// k_frame — per stream and frame: predict, cost matrix, LSAP, IoU stage, track bookkeeping (one workgroup)
+// =================================================================================================
+// Rows a6, a7, the gate/blend half of a8, a9 and the integer half of a10.  Everything that is per-track floating
+// point work after the assignment (Kalman update, EMA, gallery append, output boxes) is handed to k_post through
+// the `post` list; the appearance distances arrive ready-made in M (k_assoc + k_newrow).
+struct FrameLds {
+    double* cost;        // [SS_COST_CAP]
+    double* chol;        // [MAXT][14] by track index: L (10 entries) + projected mean (4)
+    double* ttl;         // [MAXT][4]  predicted tlwh by track index
+    double* zs;          // [MAXD][4]  detection xyah
+    double* dtl;         // [MAXD][4]  detection tlwh
+    LsapLds L;
+    int *matchdet, *dettrk, *asg, *cand, *cols, *neworder, *freelist, *conf_l, *slot_l, *tsu_l, *used, *wtot;
+};
+__device__ inline FrameLds carve_frame(char* p)
+{
+    FrameLds m;
+    m.cost = (double*)p; p += (size_t)SS_COST_CAP * 8;
+    m.chol = (double*)p; p += SS_MAXT * 14 * 8;
+    m.ttl = (double*)p; p += SS_MAXT * 4 * 8;
+    m.zs = (double*)p; p += SS_MAXD * 4 * 8;
+    m.dtl = (double*)p; p += SS_MAXD * 4 * 8;
+    m.L = carve_lsap(p);
+    int** a[] = { &m.matchdet, &m.dettrk, &m.asg, &m.cand, &m.cols, &m.neworder, &m.freelist, &m.conf_l, &m.slot_l, &m.tsu_l, &m.used };
+    for (auto q : a) { *q = (int*)p; p += 256 * 4; }
+    m.wtot = (int*)p; p += 64;
+    return m;
+}
+size_t ss_frame_lds_bytes() { return (size_t)SS_COST_CAP * 8 + SS_MAXT * 14 * 8 + SS_MAXT * 4 * 8 + 2 * SS_MAXD * 4 * 8 + 12 * 256 * 4 + 64; }
+
+// LSAP + threshold of one stage; cost is [nr][nc] after the transposition rule (rows = the smaller side)
+__device__ inline void frame_assign(int nr, int nc, bool tr, bool big, const double* cost_lds, const double* cost_glb,
+                                    const FrameLds& m, int* err)
+{
+    const int tid = threadIdx.x;
+    if ((tid >> 6) == 0) {
+        const int rc = big ? lsap_wave(nr, nc, cost_glb, m.L) : lsap_wave(nr, nc, cost_lds, m.L);
+        if (rc) { if (tid == 0) *err = SS_ERR_INFEASIBLE; }
+        else for (int i = tid; i < nr; i += 64) { if (tr) m.asg[m.L.col4row[i]] = i; else m.asg[i] = m.L.col4row[i]; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const FrameLds m = carve_frame(smem);
+    const int s = blockIdx.x, tid = threadIdx.x, S = dev.S;
+    const size_t sb = (size_t)s * SS_MAXT;
+    const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;        // (frame, stream) and its detection base
+    const int nT = dev.n_tracks[s], D = min(dev.n_dets[fs], SS_MAXD);
+    if (s == 0 && tid == 0) {
+        *dev.n_items = 0;                                            // re-arm the work list for the next group
+        if (dev.ts_enable && f == 0) {                               // fold the association kernel's in-kernel duration
+            const unsigned long long a = dev.tstamp[0], b = dev.tstamp[1];
+            if (b > a) { dev.tstamp[2] += b - a; dev.tstamp[3] += 1; }
+            dev.tstamp[0] = ~0ull; dev.tstamp[1] = 0;
+        }
+    }
+    m.matchdet[tid] = -1; m.dettrk[tid] = -1; m.asg[tid] = -1;
+    m.used[tid] = dev.slot_used[sb + tid];
+    const size_t dbg = fs * SS_MAXT;                                 // debug base (rows of [F][S][MAXT]...)
+    if (prm.debug) { dev.dbg_lists[(fs * 4 + 0) * SS_MAXT + tid] = -1; dev.dbg_lists[(fs * 4 + 3) * SS_MAXT + tid] = -1; }
+
+    // ---------------- predict every live track (thread = position in the track list) -----------------------
+    int myslot = -1, mystate = 0, mytsu = 0, confirmed = 0;
+    if (tid < nT) {
+        myslot = dev.order[sb + tid];
+        const size_t g = sb + myslot;
+        double mean[8], cov[64];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
+        ss_kf_predict(mean, cov, prm.wp, prm.wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
+        dev.age[g] += 1;
+        mytsu = dev.tsu[g] + 1;
+        dev.tsu[g] = mytsu;
+        dev.det_idx[g] = -1;
+        // gate factorisation (projection with conf = 0) and predicted box
+        double m4[4], Sm[16], L[16];
+        ss_kf_project(mean, cov, 0.0, prm.wp, m4, Sm);
+        ss_chol4(Sm, L);
+        double* ch = m.chol + tid * 14;
+        ch[0] = L[0]; ch[1] = L[4]; ch[2] = L[5]; ch[3] = L[8]; ch[4] = L[9]; ch[5] = L[10];
+        ch[6] = L[12]; ch[7] = L[13]; ch[8] = L[14]; ch[9] = L[15];
+        ch[10] = m4[0]; ch[11] = m4[1]; ch[12] = m4[2]; ch[13] = m4[3];
+        const double wd = mean[2] * mean[3];
+        double* tb = m.ttl + tid * 4;
+        tb[0] = mean[0] - wd / 2; tb[1] = mean[1] - mean[3] / 2; tb[2] = wd; tb[3] = mean[3];
+        mystate = dev.state[g];
+        confirmed = mystate == SS_CONFIRMED;
+    }
+    m.slot_l[tid] = myslot;
+    m.tsu_l[tid] = mytsu;
+    if (tid < D) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m.zs[tid * 4 + i] = dev.xyah[(fb + tid) * 4 + i]; m.dtl[tid * 4 + i] = dev.tlwh[(fb + tid) * 4 + i]; }
+    }
+    int pos, nC;
+    block_scan256(confirmed, m.wtot, pos, nC);
+    if (confirmed) m.conf_l[pos] = tid;
     __syncthreads();
 
     // ---------------- stage A: appearance + motion cost, LSAP --------------------------------
+    double* spill = dev.cost_spill + (size_t)s * SS_MAXT * SS_MAXD;
     if (nC > 0 && D > 0) {
         const bool tr = D < nC;
         const int nr = tr ? D : nC, nc = tr ? nC : D;
-        if (nr * nc > SS_COST_CAP) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; }
-        else {
-            for (int idx = tid; idx < nC * D; idx += 256) {
-                const int r = idx / D, d = idx % D;
-                const int ti = conf_l[r];
-                const int slot = dev.order[sb + ti];
-                const int count = dev.gal_count[sb + slot];
-                const float* pm = dev.part_min + ((sb + r) * SS_NRT) * SS_MAXD + d;
-                float c = pm[0];
-                for (int rt = 1; rt * SS_TILE < count; ++rt) c = fminf(c, pm[(size_t)rt * SS_MAXD]);
-                const double* ch = dev.chol + (sb + ti) * 16;
-                double Lm[16] = { ch[0], 0, 0, 0, ch[1], ch[2], 0, 0, ch[3], ch[4], ch[5], 0, ch[6], ch[7], ch[8], ch[9] };
-                double m4[4] = { ch[10], ch[11], ch[12], ch[13] };
-                const double* zz = dev.xyah + (db + d) * 4;
-                double z[4] = { zz[0], zz[1], zz[2], zz[3] };
-                double maha = ss_maha(Lm, m4, z);
-                int g;
-                double v = ss_blend(c, maha, prm, &g);
-                cost[tr ? d * nc + r : r * nc + d] = v;
-                if (prm.debug) {
-                    size_t o = (sb + r) * SS_MAXD + d;
-                    dev.dbg_cos[o] = c; dev.dbg_maha[o] = maha; dev.dbg_gated[o] = (uint8_t)g; dev.dbg_cost_a[o] = v;
-                }
+        const bool big = nr * nc > SS_COST_CAP;
+        double* cost = big ? spill : m.cost;
+        for (int idx = tid; idx < nC * D; idx += 256) {
+            const int r = idx / D, d = idx % D;
+            const int ti = m.conf_l[r];
+            const float c = ss_fkey_inv(dev.M[((sb + m.slot_l[ti]) * SS_FMAX + f) * SS_MAXD + d]);
+            const double* ch = m.chol + ti * 14;
+            double Lm[16] = { ch[0], 0, 0, 0, ch[1], ch[2], 0, 0, ch[3], ch[4], ch[5], 0, ch[6], ch[7], ch[8], ch[9] };
+            double m4[4] = { ch[10], ch[11], ch[12], ch[13] };
+            double z[4] = { m.zs[d * 4], m.zs[d * 4 + 1], m.zs[d * 4 + 2], m.zs[d * 4 + 3] };
+            const double maha = ss_maha(Lm, m4, z);
+            int gt;
+            const double v = ss_blend(c, maha, prm, &gt);
+            cost[tr ? d * nc + r : r * nc + d] = v;
+            if (prm.debug) {
+                const size_t o = (dbg + r) * SS_MAXD + d;
+                dev.dbg_cos[o] = c; dev.dbg_maha[o] = maha; dev.dbg_gated[o] = (uint8_t)gt; dev.dbg_cost_a[o] = v;
             }
-            __syncthreads();
-            SS_TS_STEP(1);
-            if (wave == 0) {
-                int rc = lsap_wave(nr, nc, cost, L);
-                if (rc) { if (tid == 0) dev.err[s] = SS_ERR_INFEASIBLE; }
-                else for (int i = tid; i < nr; i += 64) { if (tr) asg[L.col4row[i]] = i; else asg[i] = L.col4row[i]; }
+        }
+        if (big) __threadfence();                        // the spilled matrix is read back by another wave
+        __syncthreads();
+        frame_assign(nr, nc, tr, big, m.cost, spill, m, dev.err + s);
+        if (tid < nC) {
+            int d = m.asg[tid];
+            if (d >= 0) {
+                const double v = cost[tr ? d * nc + tid : tid * nc + d];
+                if (!(v > prm.max_dist)) { m.matchdet[m.conf_l[tid]] = d; m.dettrk[d] = m.conf_l[tid]; }
+                else d = -1;
             }
-            __syncthreads();
-            SS_TS_STEP(2);
-            if (tid < nC) {
-                int d = asg[tid];
-                if (d >= 0) {
-                    double v = cost[tr ? d * nc + tid : tid * nc + d];
-                    if (!(v > prm.max_dist)) { matchdet[conf_l[tid]] = d; dettrk[d] = conf_l[tid]; }
-                    else d = -1;
-                }
-                if (prm.debug) dev.dbg_lists[(s * 4 + 0) * SS_MAXT + tid] = d;
-            }
+            if (prm.debug) dev.dbg_lists[(fs * 4 + 0) * SS_MAXT + tid] = d;
         }
     }
     __syncthreads();
 
     // ---------------- stage B: IoU association ----------------------------------------------
-    SS_TS_STEP(3);
-    int pos, nU, nC1, nCols;
+    int nU, nC1, nCols;
     const int isU = (tid < nT) && (mystate != SS_CONFIRMED);
-    block_scan256(isU, wtot, pos, nU);
-    if (isU) cand[pos] = tid;
-    const int isC1 = (tid < nT) && (mystate == SS_CONFIRMED) && (matchdet[tid] < 0) && (mytsu == 1);
-    block_scan256(isC1, wtot, pos, nC1);
-    if (isC1) cand[nU + pos] = tid;
+    block_scan256(isU, m.wtot, pos, nU);
+    if (isU) m.cand[pos] = tid;
+    const int isC1 = (tid < nT) && (mystate == SS_CONFIRMED) && (m.matchdet[tid] < 0) && (mytsu == 1);
+    block_scan256(isC1, m.wtot, pos, nC1);
+    if (isC1) m.cand[nU + pos] = tid;
     const int nCand = nU + nC1;
-    const int isCol = (tid < D) && (dettrk[tid] < 0);
-    block_scan256(isCol, wtot, pos, nCols);
-    if (isCol) cols[pos] = tid;
-    asg[tid] = -1;
+    const int isCol = (tid < D) && (m.dettrk[tid] < 0);
+    block_scan256(isCol, m.wtot, pos, nCols);
+    if (isCol) m.cols[pos] = tid;
+    m.asg[tid] = -1;
     __syncthreads();
     if (prm.debug) {
-        if (tid < nCand) dev.dbg_lists[(s * 4 + 1) * SS_MAXT + tid] = cand[tid];
-        if (tid < nCols) dev.dbg_lists[(s * 4 + 2) * SS_MAXT + tid] = cols[tid];
-        if (tid == 0) { int* c = dev.dbg_counts + s * 4; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; }
+        if (tid < nCand) dev.dbg_lists[(fs * 4 + 1) * SS_MAXT + tid] = m.cand[tid];
+        if (tid < nCols) dev.dbg_lists[(fs * 4 + 2) * SS_MAXT + tid] = m.cols[tid];
+        if (tid == 0) { int* c = dev.dbg_counts + fs * 4; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; }
     }
     if (nCand > 0 && nCols > 0) {
         const bool tr = nCols < nCand;
         const int nr = tr ? nCols : nCand, nc = tr ? nCand : nCols;
-        if (nr * nc > SS_COST_CAP) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; }
-        else {
-            for (int idx = tid; idx < nCand * nCols; idx += 256) {
-                const int r = idx / nCols, c = idx % nCols;
-                const int ti = cand[r];
-                const double* tb = dev.ttlwh + (sb + ti) * 4;
-                const double* cb = dev.tlwh + (db + cols[c]) * 4;
-                double t[4] = { tb[0], tb[1], tb[2], tb[3] }, cc[4] = { cb[0], cb[1], cb[2], cb[3] };
-                double v = (dev.tsu[sb + dev.order[sb + ti]] > 1) ? prm.max_iou_distance + 1e-5
-                                                                : ss_iou_cost(t, cc, prm.max_iou_distance);
-                cost[tr ? c * nc + r : r * nc + c] = v;
-                if (prm.debug) dev.dbg_cost_b[(sb + r) * SS_MAXD + c] = v;
+        const bool big = nr * nc > SS_COST_CAP;
+        double* cost = big ? spill : m.cost;
+        for (int idx = tid; idx < nCand * nCols; idx += 256) {
+            const int r = idx / nCols, c = idx % nCols;
+            const int ti = m.cand[r];
+            const double* tb = m.ttl + ti * 4;
+            const double* cb = m.dtl + m.cols[c] * 4;
+            double t[4] = { tb[0], tb[1], tb[2], tb[3] }, cc[4] = { cb[0], cb[1], cb[2], cb[3] };
+            const double v = (m.tsu_l[ti] > 1) ? prm.max_iou_distance + 1e-5 : ss_iou_cost(t, cc, prm.max_iou_distance);
+            cost[tr ? c * nc + r : r * nc + c] = v;
+            if (prm.debug) dev.dbg_cost_b[(dbg + r) * SS_MAXD + c] = v;
+        }
+        if (big) __threadfence();
+        __syncthreads();
+        frame_assign(nr, nc, tr, big, m.cost, spill, m, dev.err + s);
+        if (tid < nCand) {
+            int c = m.asg[tid];
+            if (c >= 0) {
+                const double v = cost[tr ? c * nc + tid : tid * nc + c];
+                if (!(v > prm.max_iou_distance)) { m.matchdet[m.cand[tid]] = m.cols[c]; m.dettrk[m.cols[c]] = m.cand[tid]; }
+                else c = -1;
             }
-            __syncthreads();
-            if (wave == 0) {
-                int rc = lsap_wave(nr, nc, cost, L);
-                if (rc) { if (tid == 0) dev.err[s] = SS_ERR_INFEASIBLE; }
-                else for (int i = tid; i < nr; i += 64) { if (tr) asg[L.col4row[i]] = i; else asg[i] = L.col4row[i]; }
-            }
-            __syncthreads();
-            if (tid < nCand) {
-                int c = asg[tid];
-                if (c >= 0) {
-                    double v = cost[tr ? c * nc + tid : tid * nc + c];
-                    if (!(v > prm.max_iou_distance)) { matchdet[cand[tid]] = cols[c]; dettrk[cols[c]] = cand[tid]; }
-                    else c = -1;
-                }
-                if (prm.debug) dev.dbg_lists[(s * 4 + 3) * SS_MAXT + tid] = c;
-            }
+            if (prm.debug) dev.dbg_lists[(fs * 4 + 3) * SS_MAXT + tid] = c;
         }
     }
     __syncthreads();
 
-    // ---------------- stage C: matched / missed tracks ---------------------------------------
-    SS_TS_STEP(4);
-    int alive = 0;
+    // ---------------- stage C: track states, survivors, gallery ring positions, output slots -----------------
+    int alive = 0, md = -1, fl = 0, aux = 0, doapp = 0, emit = 0;
     if (tid < nT) {
         const size_t g = sb + myslot;
-        const int d = matchdet[tid];
-        if (d >= 0) {
-            double mean[8], cov[64];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
-            const double* zz = dev.xyah + (db + d) * 4;
-            double z[4] = { zz[0], zz[1], zz[2], zz[3] };
-            const float* det = dev.dets + (db + d) * 6;
-            ss_kf_update(mean, cov, z, (double)det[4], prm.wp);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
-#pragma unroll
-            for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
+        md = m.matchdet[tid];
+        if (md >= 0) {
+            const float* det = dev.dets + (fb + md) * 6;
             dev.conf[g] = det[4];
             dev.class_id[g] = (int)det[5];
-            int h = dev.hits[g] + 1;
+            const int h = dev.hits[g] + 1;
             dev.hits[g] = h;
             dev.tsu[g] = 0; mytsu = 0;
-            dev.det_idx[g] = d;
+            dev.det_idx[g] = md;
             if (mystate == SS_TENTATIVE && h >= prm.n_init) mystate = SS_CONFIRMED;
-        } else {
-            if (mystate == SS_TENTATIVE || mytsu > prm.max_age) mystate = SS_DELETED;
-        }
+            fl = SS_P_MATCHED;
+        } else if (mystate == SS_TENTATIVE || mytsu > prm.max_age) mystate = SS_DELETED;
         dev.state[g] = mystate;
         alive = mystate != SS_DELETED;
-        if (!alive) { dev.slot_used[g] = 0; dev.gal_count[g] = 0; dev.gal_head[g] = 0; }
+        if (!alive) { dev.slot_used[g] = 0; m.used[myslot] = 0; dev.gal_count[g] = 0; dev.gal_head[g] = 0; }
+        else if (mystate == SS_CONFIRMED) {
+            // every confirmed track appends its (possibly just updated) EMA feature to its gallery ring (D-05)
+            const int head = dev.gal_head[g], cnt = dev.gal_count[g];
+            dev.gal_head[g] = (head + 1 == prm.nn_budget) ? 0 : head + 1;
+            dev.gal_count[g] = min(cnt + 1, prm.nn_budget);
+            doapp = 1;
+            fl |= SS_P_APPEND | (cnt == 0 ? SS_P_FIRSTROW : 0);
+            aux = head;
+            emit = mytsu <= 1;
+        }
     }
-    // EMA of matched tracks: one wave per track
-    for (int ti = wave; ti < nT; ti += 4) {
-        const int d = matchdet[ti];
-        if (d < 0) continue;
-        float* sm = dev.smooth + (sb + dev.order[sb + ti]) * SS_F;
-        ema_wave(sm, dev.feat_unit + (db + d) * SS_F, prm.ema_alpha, prm.ema_one_minus_alpha, sm);
+    int nSurv, nApp, nOut, apos, epos;
+    block_scan256(alive, m.wtot, pos, nSurv);
+    block_scan256(doapp, m.wtot, apos, nApp);
+    block_scan256(emit, m.wtot, epos, nOut);
+    if (alive) {
+        if (emit) { fl |= SS_P_EMIT; aux |= epos << 8; }
+        m.neworder[pos] = myslot;
+        dev.post[sb + pos] = make_int4(myslot, md, fl, aux);
+        if (doapp) dev.rowlist[sb + apos] = myslot | ((fl & SS_P_FIRSTROW) ? 1 << 16 : 0);
     }
-    __threadfence_block();
-    // survivors keep their order
-    int nSurv;
-    block_scan256(alive, wtot, pos, nSurv);
-    if (alive) neworder[pos] = myslot;
-    // births: unmatched detections in ascending index
-    int nNew, nFree;
-    const int isNew = (tid < D) && (dettrk[tid] < 0);
-    int rank;
-    block_scan256(isNew, wtot, rank, nNew);
-    const int isFree = !dev.slot_used[sb + tid];      // includes slots freed above (same thread wrote or fenced)
-    __syncthreads();
-    block_scan256(isFree, wtot, pos, nFree);
-    if (isFree) freelist[pos] = tid;
+    // births: unmatched detections in ascending index take the free slots in ascending order
+    int nNew, nFree, rank;
+    const int isNew = (tid < D) && (m.dettrk[tid] < 0);
+    block_scan256(isNew, m.wtot, rank, nNew);
+    const int isFree = !m.used[tid];                     // includes the slots freed above (block_scan256 synchronised)
+    block_scan256(isFree, m.wtot, pos, nFree);
+    if (isFree) m.freelist[pos] = tid;
     __syncthreads();
     if (nSurv + nNew > SS_MAXT || nNew > nFree) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; nNew = min(nNew, min(nFree, SS_MAXT - nSurv)); }
     const int nid0 = dev.next_id[s];
     if (isNew && rank < nNew) {
-        const int slot = freelist[rank];
+        const int slot = m.freelist[rank];
         const size_t g = sb + slot;
-        const double* zz = dev.xyah + (db + tid) * 4;
-        double z[4] = { zz[0], zz[1], zz[2], zz[3] };
-        double mean[8], cov[64];
-        ss_kf_initiate(z, prm.wp, prm.wv, mean, cov);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
-        for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
-        const float* det = dev.dets + (db + tid) * 6;
+        const float* det = dev.dets + (fb + tid) * 6;
         dev.track_id[g] = nid0 + rank;
         dev.state[g] = SS_TENTATIVE; dev.hits[g] = 1; dev.age[g] = 1; dev.tsu[g] = 0;
         dev.class_id[g] = (int)det[5]; dev.conf[g] = det[4]; dev.det_idx[g] = tid;
         dev.gal_count[g] = 0; dev.gal_head[g] = 0; dev.slot_used[g] = 1;
-        neworder[nSurv + rank] = slot;
-        cols[rank] = tid;                         // detection of the rank-th birth (for the feature copy)
+        m.neworder[nSurv + rank] = slot;
+        dev.post[sb + nSurv + rank] = make_int4(slot, tid, SS_P_BIRTH, 0);
     }
     __syncthreads();
     const int nTot = nSurv + nNew;
-    for (int k = wave; k < nNew; k += 4) {          // smooth feature of a new track = its unit feature
-        const float* src = dev.feat_unit + (db + cols[k]) * SS_F;
-        float* dst = dev.smooth + (sb + neworder[nSurv + k]) * SS_F;
-        const int l = tid & 63;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dst[l + 64 * j] = src[l + 64 * j];
+    if (tid < nTot) dev.order[sb + tid] = m.neworder[tid];
+    if (tid == 0) {
+        dev.n_tracks[s] = nTot; dev.next_id[s] = nid0 + nNew; dev.frame[s] += 1;
+        dev.n_post[s] = nTot; dev.n_rows[s] = nApp; dev.n_out[fs] = nOut;
     }
-    if (tid < nTot) dev.order[sb + tid] = neworder[tid];
-    if (tid == 0) { dev.n_tracks[s] = nTot; dev.next_id[s] = nid0 + nNew; dev.frame[s] += 1; }
-    __threadfence_block();
-    __syncthreads();
+}
 
-    // ---------------- stage D: gallery append (every confirmed track) + output rows -----------
-    SS_TS_STEP(5);
-    for (int k = wave; k < nSurv; k += 4) {
-        const size_t g = sb + neworder[k];
-        if (dev.state[g] != SS_CONFIRMED) continue;
-        int head = dev.gal_head[g], cnt = dev.gal_count[g];
-        gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, head, dev.smooth + g * SS_F);
-        if ((tid & 63) == 0) {
-            dev.gal_head[g] = (head + 1 == prm.nn_budget) ? 0 : head + 1;
-            dev.gal_count[g] = min(cnt + 1, prm.nn_budget);
+// =================================================================================================
+// k_post — per-track floating-point work of the frame, one wave per surviving / new track
+// =================================================================================================
+// NSA Kalman update across the wave's 64 lanes (one covariance entry each), EMA feature, Kalman initiation of new
+// tracks, gallery append (fragment-major) and the output row.  grid = (streams, SS_POST_BLOCKS).
+#define SS_POST_BLOCKS 16
+__global__ __launch_bounds__(256) void k_post(SSDev dev, SSParams prm, int f)
+{
+    __shared__ double ws[4][72];
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
+    const int s = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63, S = dev.S;
+    const size_t sb = (size_t)s * SS_MAXT;
+    const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;
+    const int n = dev.n_post[s];
+    for (int k = blockIdx.y * 4 + w; k < n; k += gridDim.y * 4) {
+        const int4 e = dev.post[sb + k];
+        const int slot = __builtin_amdgcn_readfirstlane(e.x), d = __builtin_amdgcn_readfirstlane(e.y);
+        const int fl = __builtin_amdgcn_readfirstlane(e.z), aux = __builtin_amdgcn_readfirstlane(e.w);
+        const size_t g = sb + slot;
+        float* sm = dev.smooth + g * SS_F;
+        const float* src = sm;                                        // the row a confirmed track appends
+        if (fl & SS_P_MATCHED) {
+            const double* zz = dev.xyah + (fb + d) * 4;
+            const double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+            ss_kf_update_wave(dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws[w]);
+            ema_wave(sm, dev.feat_unit + (fb + d) * SS_F, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf[w]);
+            SS_WAVE_SYNC();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[l + 64 * j] = rowbuf[w][l + 64 * j];
+            src = rowbuf[w];
+        } else if (fl & SS_P_BIRTH) {
+            const double* zz = dev.xyah + (fb + d) * 4;
+            const double h = zz[3];
+            const int r = l >> 3, c = l & 7;
+            // ss_kf_initiate, one covariance entry per lane
+            const double sd = (r == 2) ? 1e-2 : (r == 6) ? 1e-5 : (r < 4) ? 2.0 * prm.wp * h : 10.0 * prm.wv * h;
+            dev.cov[g * 64 + l] = (r == c) ? sd * sd : 0.0;
+            if (l < 8) dev.mean[g * 8 + l] = (l < 4) ? zz[l] : 0.0;
+            const float* fu = dev.feat_unit + (fb + d) * SS_F;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm[l + 64 * j] = fu[l + 64 * j];
+        }
+        if (fl & SS_P_APPEND) gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, aux & 0xff, src);
+        if ((fl & SS_P_EMIT) && l == 0) {
+            double mm[4];
+            if (fl & SS_P_MATCHED) { mm[0] = ws[w][64]; mm[1] = ws[w][65]; mm[2] = ws[w][66]; mm[3] = ws[w][67]; }
+            else { const double* gm = dev.mean + g * 8; mm[0] = gm[0]; mm[1] = gm[1]; mm[2] = gm[2]; mm[3] = gm[3]; }
+            const double wd = mm[2] * mm[3];
+            const double x = mm[0] - wd / 2, y = mm[1] - mm[3] / 2;
+            const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];
+            const int x1 = max((int)x, 0), y1 = max((int)y, 0);
+            const int x2 = min((int)(x + wd), W - 1), y2 = min((int)(y + mm[3]), H - 1);
+            float* o = dev.out_rows + (fs * SS_MAXT + (aux >> 8)) * 8;
+            o[0] = (float)x1; o[1] = (float)y1; o[2] = (float)x2; o[3] = (float)y2;
+            o[4] = (float)dev.track_id[g]; o[5] = (float)dev.class_id[g]; o[6] = dev.conf[g];
+            o[7] = (float)dev.det_idx[g];
+        }
+        SS_WAVE_SYNC();                                               // rowbuf / ws are reused by the next track
+    }
+}
+
+// =================================================================================================
+// k_newrow — distances of the gallery rows appended in frame f to the detections of the later frames of the group
+// =================================================================================================
+// Unit = (16 appended rows = 16 tracks, pair of column tiles of a frame f2 > f): the k-split MFMA form
+// (cosine_dots), A gathered straight from the row-major EMA features.  Every (track, detection) entry is kept:
+// M[slot][f2][d] = min(M, 1 - dot), or just 1 - dot for a gallery's first row.
+__global__ __launch_bounds__(512) void k_newrow(SSDev dev, int f)
+{
+    __shared__ float lds_part[2 * 8 * 4 * 64];
+    __shared__ int s_slot[16];
+    const int S = dev.S, w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (int u = blockIdx.x;; u += gridDim.x) {
+        // decode the unit: streams in order, row tile major, pair fastest
+        int s = 0, base = 0, np = 0, p0 = 0;
+        for (; s < S; ++s) {
+            const int nrt = (dev.n_rows[s] + 15) / 16;
+            p0 = dev.pf[s * (SS_FMAX + 1) + f + 1];
+            np = dev.n_pl[s] - p0;
+            if (u < base + nrt * np) break;
+            base += nrt * np;
+        }
+        if (s == S) return;
+        const int loc = u - base, rti = loc / np, p = p0 + loc % np;
+        const size_t sb = (size_t)s * SS_MAXT;
+        const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
+        const int f2 = pr.x, ct0 = pr.y & 0xff, D2 = pr.y >> 16;
+        const bool two = (pr.y >> 8) & 1;
+        const int nrow = min(16, dev.n_rows[s] - rti * 16);
+        __syncthreads();                                              // the previous unit is done with s_slot / lds_part
+        if (threadIdx.x < 16) s_slot[threadIdx.x] = (int)threadIdx.x < nrow ? dev.rowlist[sb + rti * 16 + threadIdx.x] : -1;
+        __syncthreads();
+        // A: element k = 16(4w+j) + 4c + ks of row i, lane = ks*16 + i (the fragment-major float4 #((4w+j)*64 + lane))
+        const int i = l & 15, ks = l >> 4;
+        const int si = s_slot[i];
+        float4 a[4];
+        if (si >= 0) {
+            const float* row = dev.smooth + (sb + (si & 0xffff)) * SS_F + ks;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* q = row + 16 * (4 * w + j);
+                a[j] = make_float4(q[0], q[4], q[8], q[12]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 b0[4], b1[4];
+        load_b(dev.feat_frag + ((size_t)f2 * S + s) * SS_NCT * SS_TILE_FLOATS, ct0, two, b0, b1);
+        const float tot = cosine_dots(a, b0, b1, lds_part);
+        const int ctl = threadIdx.x >> 8, reg = (threadIdx.x >> 6) & 3;
+        const int row = 4 * (l >> 4) + reg, d = (ct0 + ctl) * SS_TILE + (l & 15);
+        if ((ctl == 0 || two) && row < nrow && d < D2) {
+            const int sl = s_slot[row];
+            int* mp = dev.M + ((sb + (sl & 0xffff)) * SS_FMAX + f2) * SS_MAXD + d;
+            const int key = ss_fkey(1.0f - tot);
+            *mp = (sl >> 16) ? key : min(*mp, key);
         }
     }
-    int emit = 0;
-    size_t g = 0;
-    if (tid < nTot) {
-        g = sb + neworder[tid];
-        emit = (dev.state[g] == SS_CONFIRMED) && (dev.tsu[g] <= 1);
-    }
-    int nOut;
-    block_scan256(emit, wtot, pos, nOut);
-    if (emit) {
-        const double* m = dev.mean + g * 8;
-        double w = m[2] * m[3];
-        double x = m[0] - w / 2, y = m[1] - m[3] / 2;
-        const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];
-        int x1 = max((int)x, 0), y1 = max((int)y, 0);
-        int x2 = min((int)(x + w), W - 1), y2 = min((int)(y + m[3]), H - 1);
-        float* o = dev.out_rows + (sb + pos) * 8;
-        o[0] = (float)x1; o[1] = (float)y1; o[2] = (float)x2; o[3] = (float)y2;
-        o[4] = (float)dev.track_id[g]; o[5] = (float)dev.class_id[g]; o[6] = dev.conf[g];
-        o[7] = (float)dev.det_idx[g];
-    }
-    if (tid == 0) dev.n_out[s] = nOut;
-    if (tid == 0 && s == 0) { dev.tile_count[0] = 0; dev.tile_count[1] = 0; }
-    SS_TS_STEP(6);          // re-arm the association work list for the next frame
 }
 
 // =================================================================================================
@@ -1159,35 +1197,28 @@ __global__ void k_kat_iou(const double* ttlwh, int T, const double* dtlwh, int D
 }
 
 // ---- launch helpers used by ss_api.hip -------------------------------------------------------------
-size_t ss_step_lds_bytes()
-{
-    return (size_t)SS_COST_CAP * 8 + (3 * 256 * 8 + 4 * 256 * 4 + 512) + 8 * 256 * 4 + 32;
-}
-size_t ss_lsap_lds_bytes() { return 3 * 256 * 8 + 4 * 256 * 4 + 512; }
-size_t ss_cosine_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 512 * 16; }
+size_t ss_lsap_lds_bytes() { return 256 * 4; }
+size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4; }
 
 extern "C" void ss_step_kernel_attr()
 {
     // a failure here surfaces as a launch error on first use (checked with hipGetLastError after every launch)
-    (void)hipFuncSetAttribute((const void*)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_step_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_lsap_kat, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_lsap_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_cosine_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_cosine_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_frame_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_assoc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
 }
 
-void ss_launch_frame(const SSDev& dev, const SSParams& prm, int grid_tracks, hipStream_t st,
-                     hipEvent_t ev0, hipEvent_t ev1)
+// One group of dev.F frames for every stream.  ev0/ev1 (optional) bracket the association kernel's dispatch.
+void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
-    hipLaunchKernelGGL(k_pre, dim3(dev.S, 1 + SS_MAXD / 4), dim3(256), 0, st, dev, prm);
-    // the association kernel that carries the gallery bytes of this launch gets the start/stop events
-    if (dev.stream_mode) {
-        if (ev0) hipExtLaunchKernelGGL(k_cosine_stream, dim3(dev.cos_grid), dim3(512), ss_cosine_lds_bytes(), st, ev0, ev1, 0, dev);
-        else     hipLaunchKernelGGL(k_cosine_stream, dim3(dev.cos_grid), dim3(512), ss_cosine_lds_bytes(), st, dev);
-        hipLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, dev);          // D > 32 leftovers (usually empty)
-    } else {
-        if (ev0) hipExtLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, ev0, ev1, 0, dev);
-        else     hipLaunchKernelGGL(k_cosine_wg, dim3(dev.cos_grid), dim3(512), 0, st, dev);
+    hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
+    if (ev0) hipExtLaunchKernelGGL(k_assoc, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
+    else     hipLaunchKernelGGL(k_assoc, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    const int newrow_grid = min(2048, 64 * dev.S);
+    for (int f = 0; f < dev.F; ++f) {
+        hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);
+        hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);
+        if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(newrow_grid), dim3(512), 0, st, dev, f);
     }
-    hipLaunchKernelGGL(k_step, dim3(dev.S), dim3(256), ss_step_lds_bytes(), st, dev, prm);
 }
 
 void ss_launch_normalize(const float* raw, int n, float* unit, hipStream_t st)

@@ -95,7 +95,7 @@ class TrackerEngine:
         self._ck(self.L.ss_reset(self.ctx, stream))
 
     def set_option(self, name: str, value: int):
-        """stream_mode (-1 auto / 0 / 1), cos_grid, timestamps — see include/strongsort_hip.h."""
+        """cos_grid — see include/strongsort_hip.h."""
         self._ck(self.L.ss_set_option(self.ctx, name.encode(), int(value)))
 
     def check_errors(self):
@@ -108,6 +108,14 @@ class TrackerEngine:
         self._ck(self.L.ss_track_update(self.ctx, _ptr(dets), _ptr(ndets), _ptr(feats), _ptr(img_hw),
                                         _ptr(self.out), _ptr(self.nout)))
         return self.out, self.nout
+
+    def update_group(self, n_frames, dets, ndets, feats, img_hw, out, nout):
+        """A group of n_frames (<= 16) consecutive frames of all streams: tensors [F,S,128,6] f32, [F,S] i32,
+        [F,S,128,512] f32, [S,2] i32 -> rows out [F,S,256,8], counts nout [F,S] (device tensors, asynchronous).
+        Frames are associated in order; the galleries are read once for the whole group."""
+        self._ck(self.L.ss_track_update_group(self.ctx, int(n_frames), _ptr(dets), _ptr(ndets), _ptr(feats), _ptr(img_hw),
+                                              _ptr(out), _ptr(nout)))
+        return out, nout
 
     def update_host(self, dets: np.ndarray, feats: np.ndarray, img_hw) -> np.ndarray:
         """Single-stream synchronous update with host arrays -> rows [M,8] float32."""
@@ -143,7 +151,7 @@ class TrackerEngine:
                  next_id=nid.value)
         return d
 
-    def debug(self, stream: int = 0) -> dict:
+    def debug(self, stream: int = 0, frame: int = 0) -> dict:
         T, D = MAX_TRACKS, MAX_DETS
         counts = np.zeros(4, np.int32)
         cosd = np.zeros((T, D), np.float32)
@@ -151,7 +159,7 @@ class TrackerEngine:
         gated = np.zeros((T, D), np.uint8)
         lists = np.zeros((4, T), np.int32)
         ip, fp, dp, up = C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
-        self._ck(self.L.ss_get_debug(self.ctx, stream, counts.ctypes.data_as(ip), cosd.ctypes.data_as(fp),
+        self._ck(self.L.ss_get_debug(self.ctx, stream, frame, counts.ctypes.data_as(ip), cosd.ctypes.data_as(fp),
                                      maha.ctypes.data_as(dp), gated.ctypes.data_as(up), cost_a.ctypes.data_as(dp),
                                      cost_b.ctypes.data_as(dp), lists.ctypes.data_as(ip)))
         nC, nCand, nCols, nD = (int(v) for v in counts)
@@ -165,10 +173,11 @@ class TrackerEngine:
         self._ck(self.L.ss_get_gallery(self.ctx, stream, track_index, rows.ctypes.data_as(C.POINTER(C.c_float)), 128, C.byref(cnt)))
         return rows[: cnt.value].copy()
 
-    def timestamps(self):
-        buf = np.zeros(16 * 8 * 64, np.int64)
-        self._ck(self.L.ss_get_timestamps(self.ctx, buf.ctypes.data_as(C.POINTER(C.c_longlong)), buf.size))
-        return buf.reshape(16, 8, 64)
+    def assoc_inkernel_timing(self, enable: bool):
+        """(mean microseconds, launches) of the association kernel measured by the kernel itself since the last call."""
+        us, n = C.c_double(), C.c_int()
+        self._ck(self.L.ss_assoc_inkernel_timing(self.ctx, int(enable), C.byref(us), C.byref(n)))
+        return us.value, n.value
 
     def assoc_timing(self, enable: bool):
         ms, n = C.c_float(), C.c_int()

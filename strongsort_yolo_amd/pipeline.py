@@ -348,14 +348,14 @@ class OverlappedPipeline(FramePipeline):
         self._select(b, emb)
 
     def _track_b(self, b: _Bufs, n_valid: int = None, group: int = None):
-        """Tracker update of the group's frames, one frame at a time in order (frame f = virtual streams f*S..);
-        `group` = index of the group's first frame (None while warming up / capturing: no callbacks)."""
-        e, S = self.eng, self.S
-        for f in range(self.F if n_valid is None else n_valid):
-            sl = slice(f * S, (f + 1) * S)
-            e._ck(e.L.ss_track_update(e.ctx, _p(b.dets6[sl]), _p(b.ndets[sl]), _p(b.feats_v[sl]), _p(self.img_hw),
-                                      _p(self.outs[f]), _p(self.nouts[f])))
-            if group is not None and self.on_result is not None:
+        """Tracker update of the group's frames in ONE call: the library associates them strictly in order (frame f =
+        virtual streams f*S..) and reads the galleries once for all of them; `group` = index of the group's first
+        frame (None while warming up / capturing: no callbacks)."""
+        e = self.eng
+        nv = self.F if n_valid is None else n_valid
+        e.update_group(nv, b.dets6, b.ndets, b.feats_v, self.img_hw, self.outs, self.nouts)
+        if group is not None and self.on_result is not None:
+            for f in range(nv):
                 self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
 
     def _ss_stream(self, st):

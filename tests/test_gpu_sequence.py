@@ -12,12 +12,12 @@ from tests.gpu_util import engine, bits_equal
 pytestmark = pytest.mark.gpu
 
 
-def _compare_frame(eng, orc, rows_g, rows_o, k, s=0):
+def _compare_frame(eng, orc, rows_g, rows_o, k, s=0, f=0, last=None):
+    """rows + every stage intermediate of frame k (position f of its group) of stream s"""
+    dbg, last = eng.debug(s, f), (orc.last if last is None else last)
     assert rows_g.shape == rows_o.shape, f"frame {k}: {rows_g.shape} vs {rows_o.shape}"
-    assert bits_equal(rows_g, rows_o), f"frame {k}: output rows differ"
-    dbg, last = eng.debug(s), orc.last
-    assert dbg["n_conf"] == len(last["confirmed"])
-    assert bits_equal(dbg["cos"], last["cos"]), f"frame {k}: cosine"
+    assert dbg["n_conf"] == len(last["confirmed"]), f"frame {k}: confirmed tracks"
+    assert bits_equal(dbg["cos"], last["cos"]), f"frame {k}: cosine (max abs diff {np.abs(dbg['cos'] - last['cos']).max() if dbg['cos'].shape == last['cos'].shape and dbg['cos'].size else 'shape'})"
     assert bits_equal(dbg["maha"], last["maha"]), f"frame {k}: maha"
     assert np.array_equal(dbg["gated"], last["gated"])
     assert bits_equal(dbg["cost_a"], last["cost_a"]), f"frame {k}: cost_a"
@@ -29,6 +29,7 @@ def _compare_frame(eng, orc, rows_g, rows_o, k, s=0):
     assert np.array_equal(dbg["cols_b"], np.asarray(last["cols_b"], np.int32))
     if dbg["n_cand"] and dbg["n_cols"]:
         assert bits_equal(dbg["cost_b"], last["cost_b"]), f"frame {k}: cost_b"
+    assert bits_equal(rows_g, rows_o), f"frame {k}: output rows differ"
 
 
 def _compare_table(eng, orc, s=0):
@@ -81,64 +82,87 @@ def test_births_deaths_and_empty_frames():
     eng.close()
 
 
-def _run_multi_stream(S, ids_of, frames, mode=-1, mute=(), late=()):
-    """S streams in one context (one batch of launches per frame) against S single-stream oracles, every frame, with
-    the stage intermediates of every stream (rows a8-a10 in the batched launch shapes).  `mute` streams
-    never see a detection, `late` streams see their first detection two frames before the end (tentative tracks only)."""
+def _run_streams(S, ids_of, frames, F=1, mute=(), late=(), cfg=None, wh=(1280, 720), stream_kw=None, empty_every=0):
+    """S streams in one context, fed in groups of F frames (one ss_track_update_group call per group: the
+    association kernel sees the detections of all F frames at once), against S single-stream oracles that run frame by
+    frame; rows and every stage intermediate of every frame and stream are compared (rows a6-a10).
+    `mute` streams never see a detection, `late` streams see their first detection two frames before the end
+    (tentative tracks only), `empty_every` drops all detections of every n-th frame."""
     import torch
-    cfg = StrongSortConfig()
-    W, H = 1280, 720
+    cfg = cfg or StrongSortConfig()
+    W, H = wh
     eng = engine(cfg, n_streams=S, debug=True)
-    eng.set_option("stream_mode", mode)
     orcs = [OracleStrongSort(cfg, "c") for _ in range(S)]
-    streams = [make_stream(10 + s, W, H, ids_of(s)) for s in range(S)]
+    streams = [make_stream(10 + s, W, H, ids_of(s), **(stream_kw or {})) for s in range(S)]
     dev = eng.device
     hw = torch.tensor([[H, W]] * S, dtype=torch.int32, device=dev)
+    out = torch.zeros(F, S, 256, 8, device=dev)
+    nout = torch.zeros(F, S, dtype=torch.int32, device=dev)
     seen_conf = [0] * S
-    for k in range(frames):
-        hd, hf, hn = np.zeros((S, 128, 6), np.float32), np.zeros((S, 128, 512), np.float32), np.zeros(S, np.int32)
-        ref = []
-        for s in range(S):
-            f = streams[s].next_frame()
-            n = len(f.dets)
-            if s in mute or (s in late and k < frames - 2):
-                n = 0
-            hd[s, :n], hf[s, :n], hn[s] = f.dets[:n], f.feats[:n], n
-            ref.append(orcs[s].update(f.dets[:n], f.feats[:n], (H, W)))
-        out, nout = eng.update_device(torch.from_numpy(hd).to(dev), torch.from_numpy(hn).to(dev),
-                                      torch.from_numpy(hf).to(dev), hw)
+    for k0 in range(0, frames, F):
+        nf = min(F, frames - k0)
+        hd, hf, hn = np.zeros((F, S, 128, 6), np.float32), np.zeros((F, S, 128, 512), np.float32), np.zeros((F, S), np.int32)
+        ref, lasts = [], []
+        for f in range(nf):
+            k = k0 + f
+            for s in range(S):
+                fr = streams[s].next_frame()
+                n = len(fr.dets)
+                if s in mute or (s in late and k < frames - 2) or (empty_every and k % empty_every == empty_every - 1):
+                    n = 0
+                hd[f, s, :n], hf[f, s, :n], hn[f, s] = fr.dets[:n], fr.feats[:n], n
+                ref.append(orcs[s].update(fr.dets[:n], fr.feats[:n], (H, W)))
+                lasts.append(orcs[s].last)
+                seen_conf[s] = max(seen_conf[s], len(orcs[s].last["confirmed"]))
+        eng.update_group(nf, torch.from_numpy(hd).to(dev), torch.from_numpy(hn).to(dev), torch.from_numpy(hf).to(dev), hw, out, nout)
         eng.check_errors()
-        out, nout = out.cpu().numpy(), nout.cpu().numpy()
-        for s in range(S):
-            _compare_frame(eng, orcs[s], out[s, :nout[s]], ref[s], k, s)
-            seen_conf[s] = max(seen_conf[s], len(orcs[s].last["confirmed"]))
+        ho, hno = out.cpu().numpy(), nout.cpu().numpy()
+        for f in range(nf):
+            for s in range(S):
+                _compare_frame(eng, orcs[s], ho[f, s, :hno[f, s]], ref[f * S + s], k0 + f, s, f, lasts[f * S + s])
     for s in range(S):
         _compare_table(eng, orcs[s], s)
     eng.close()
-    return seen_conf
+    return seen_conf, orcs
 
 
 def test_multi_stream_batch_equals_single_streams():
-    """latency form (S < 4)"""
-    _run_multi_stream(3, lambda s: 20 + 5 * s, 40)
+    _run_streams(3, lambda s: 20 + 5 * s, 40)
 
 
 @pytest.mark.parametrize("S,frames", [(4, 112), (8, 30), (32, 22)])
-def test_throughput_association_form(S, frames):
-    """The wave-per-tile association kernel (selected from 4 streams per context up; the form behind bench.py's
-    roofline_batched): detections per stream <= 16, 17..32 and > 32 (the latter leave through the workgroup-per-tile
-    kernel in the same frame), galleries of 1, 15, 16, 17 ... rows while they fill (100 rows at S = 4), a stream that
-    never sees a detection and one without a confirmed track."""
+def test_many_streams_per_launch(S, frames):
+    """Detections per stream <= 16, 17..32 and > 32 (one, two and three column-tile pairs), galleries of 1, 15, 16,
+    17 ... rows while they fill (100 rows at S = 4), a stream that never sees a detection and one without a confirmed
+    track — the launch shapes behind bench.py's roofline_batched."""
     ids = [10, 24, 40, 30]
-    conf = _run_multi_stream(S, lambda s: ids[s % 4], frames, mute=(S - 1,), late=(S - 2,) if S > 4 else ())
+    conf, _ = _run_streams(S, lambda s: ids[s % 4], frames, mute=(S - 1,), late=(S - 2,) if S > 4 else ())
     assert conf[0] > 0 and conf[1] > 16 and conf[2] > 32 and conf[S - 1] == 0
     if S > 4:
         assert conf[S - 2] == 0
 
 
-@pytest.mark.parametrize("S", [1, 2])
-def test_throughput_form_forced_on_small_contexts(S):
-    _run_multi_stream(S, lambda s: 28 + 4 * s, 24, mode=1)
+@pytest.mark.parametrize("S,F,frames,ids", [(1, 8, 124, 30), (1, 16, 120, 30), (2, 5, 63, 24), (4, 8, 112, 0), (1, 3, 30, 100)])
+def test_frame_groups_equal_frame_by_frame(S, F, frames, ids):
+    """The group call (galleries read once for F frames: rows that leave the ring during the group are masked per
+    frame in k_assoc, the rows appended during the group are added by k_newrow) == the oracle's frame-by-frame
+    result, every frame, every intermediate.  Covers ring wrap-around inside a group (gallery full from frame 103),
+    a partial last group, 100 detections per frame (4 column-tile pairs) and mixed streams."""
+    mixed = [10, 24, 40, 30]
+    wh = (1920, 1080) if ids == 100 else (1280, 720)
+    conf, orcs = _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + 3 * s), frames, F=F, wh=wh)
+    assert max(conf) >= (90 if ids == 100 else 20)
+    if frames > 110:
+        assert max(len(t.gallery) for t in orcs[0].tracks) == 100           # the ring wrapped
+
+
+def test_frame_groups_with_births_deaths_and_empty_frames():
+    """Tracks die, slots are reused and new tracks get confirmed in the middle of a group; whole frames without
+    detections."""
+    cfg = StrongSortConfig(max_age=5)
+    conf, orcs = _run_streams(2, lambda s: 10 + 2 * s, 120, F=6, cfg=cfg, wh=(640, 480),
+                              stream_kw=dict(p_vanish=0.15, vanish_max=12), empty_every=17)
+    assert orcs[0].next_id > 11 and orcs[1].next_id > 13                     # re-births happened
 
 
 def test_capacity_error_is_loud():
