@@ -169,12 +169,14 @@ def cpu_baseline(W, H, n_ids, geom, geom_scale, nc, n_anchors, cfg, dcfg, detect
             "host_cores": ncores}
 
 
-def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, timed=40, device=0):
-    """Association kernel at n_streams streams per launch (tracker path only, detections + features injected on
-    the device): the regime in which the kernel can be compared with the HBM roofline."""
+def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, timed=40, device=0, frame_batch=8, check=True):
+    """Association kernel at n_streams streams x frame_batch frames per launch (tracker path only, detections +
+    features injected on the device): the regime in which the kernel can be compared with the HBM roofline."""
     import torch
     from strongsort_yolo_amd.engine import TrackerEngine
     from strongsort_yolo_amd.synth import make_stream
+    FB = frame_batch
+    assert frames % FB == 0 and timed % FB == 0
     eng = TrackerEngine(cfg, n_streams, device)
     dev = eng.device
     dets = torch.zeros(frames, n_streams, 128, 6, device=dev)
@@ -192,54 +194,58 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=150, 
     rows_all = torch.zeros(frames, n_streams, 256, 8, device=dev)
     nrows_all = torch.zeros(frames, n_streams, dtype=torch.int32, device=dev)
 
-    def step(k):
-        out, nout = eng.update_device(dets[k], nd[k], feats[k], hw)
-        rows_all[k].copy_(out); nrows_all[k].copy_(nout)
+    def group(k0):                                  # frames k0 .. k0+FB-1 of every stream in one tracker call
+        eng.update_group(FB, dets[k0:k0 + FB], nd[k0:k0 + FB], feats[k0:k0 + FB], hw, rows_all[k0:k0 + FB], nrows_all[k0:k0 + FB])
 
-    for k in range(frames - timed):
-        step(k)
+    for k0 in range(0, frames - timed, FB):
+        group(k0)
     torch.cuda.synchronize()
-    eng.assoc_timing(True)
+    eng.assoc_timing(True); eng.assoc_inkernel_timing(True)
     t0 = time.perf_counter()
-    for k in range(frames - timed, frames):
-        step(k)
+    for k0 in range(frames - timed, frames, FB):
+        group(k0)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, n = eng.assoc_timing(False)
+    ik_us, ik_n = eng.assoc_inkernel_timing(False)
     eng.check_errors()
-    # parity of the batched launches: first and last stream against the exact-order oracle, every frame
-    from oracle.strongsort_np import OracleStrongSort
-    hr, hnr = rows_all.cpu().numpy(), nrows_all.cpu().numpy()
     tot = same = 0
-    for s in sorted({0, n_streams - 1}):
-        orc = OracleStrongSort(cfg, "c")
-        for k in range(frames):
-            nk = int(hn[k, s])
-            ref = orc.update(hd[k, s, :nk], hf[k, s, :nk], (H, W))
-            got = hr[k, s, :hnr[k, s]]
-            tot += max(len(ref), len(got))
-            if got.shape == ref.shape:
-                same += int((got == ref).all(axis=1).sum())
-    alg = 0.0
+    if check:                                       # first and last stream against the exact-order oracle, every frame
+        from oracle.strongsort_np import OracleStrongSort
+        hr, hnr = rows_all.cpu().numpy(), nrows_all.cpu().numpy()
+        for s in sorted({0, n_streams - 1}):
+            orc = OracleStrongSort(cfg, "c")
+            for k in range(frames):
+                nk = int(hn[k, s])
+                ref = orc.update(hd[k, s, :nk], hf[k, s, :nk], (H, W))
+                got = hr[k, s, :hnr[k, s]]
+                tot += max(len(ref), len(got))
+                if got.shape == ref.shape:
+                    same += int((got == ref).all(axis=1).sum())
+    alg = flops = 0.0
     for s in range(n_streams):
         t = eng.tracks(s)
         c = t["state"] == 2
-        Tc, B = int(c.sum()), float(t["gal_count"][c].mean()) if c.any() else 0.0
-        alg += Tc * B * 512 * 4 + float(hn[:, s].mean()) * 512 * 4 + Tc * float(hn[:, s].mean()) * 4 * max(1, int(np.ceil(B / 16)))
+        Tc, B, Dm = int(c.sum()), (float(t["gal_count"][c].mean()) if c.any() else 0.0), float(hn[frames - timed:, s].mean())
+        alg += FB * (Tc * B * 512 * 4 + Dm * 512 * 4 + Tc * 576 + Dm * 32 + Tc * Dm * 5)
+        flops += FB * (2 * Tc * B * Dm * 512 + 60 * Tc * Dm)
     eng.close()
     ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_assoc.json")
-    if os.path.exists(pmc) and n_streams == 32:
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_assoc.json")
+    if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("c2_b32", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(f"c2_b{n_streams}_f{FB}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"kernel": "k_cosine_stream", "streams_per_launch": n_streams, "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0,
-            "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg),
-            "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n,
+    return {"kernel": "k_assoc", "streams_per_launch": n_streams, "frames_per_launch": FB, "bound": "hbm", "achieved": round(ach, 1),
+            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(alg), "flops_per_launch": int(flops),
+            "f32_mfma_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
+            "frac_of_f32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4) if ms > 0 else None,
+            "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n, "inkernel_mean_us": round(ik_us, 2),
             "tracker_path_frames_per_s": round(n_streams * timed / dt, 1),
-            "batched_id_match_rate": round(same / max(tot, 1), 6), "rows_checked": tot}
+            "batched_id_match_rate": round(same / max(tot, 1), 6) if check else None, "rows_checked": tot}
 
 
 def main():
@@ -402,41 +408,45 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # ---- roofline of the association kernel (algorithmic bytes of one launch) ----
+    # ---- roofline of the association kernel ----
+    # algorithmic bytes: SURVEY §8(d)'s per-frame figure (gallery T*B*512*4 + detections D*512*4 + T*576 + D*32 + cost
+    # T*D*4 + mask T*D) x the frames one launch processes (one launch = one group of FB frames of every stream)
     T_conf = []
     for s in range(S):
         t = pipe.eng.tracks(s)
         T_conf.append((int((t["state"] == 2).sum()), float(t["gal_count"][t["state"] == 2].mean()) if (t["state"] == 2).any() else 0.0))
     Dm = float(np.mean([w["mean_dets"] for w in wls]))
-    alg_bytes = sum(Tc * B * 512 * 4 + Dm * 512 * 4 + Tc * Dm * 4 * max(1, int(np.ceil(B / 32))) for Tc, B in T_conf)
+    bytes_frame = sum(Tc * B * 512 * 4 + Dm * 512 * 4 + Tc * 576 + Dm * 32 + Tc * Dm * 5 for Tc, B in T_conf)
+    flops_frame = sum(2 * Tc * B * Dm * 512 + 60 * Tc * Dm for Tc, B in T_conf)
     roofline = None
     if assoc_n > 0 and assoc_ms > 0:
-        ach = alg_bytes / (assoc_ms * 1e-3) / 1e9
+        frames_launch = KF / assoc_n                      # frames of a stream per association launch
+        alg_bytes, flops = bytes_frame * frames_launch, flops_frame * frames_launch
+        t_ev, t_ik = assoc_ms * 1e-3, assoc_ik_us * 1e-6
+        fp32_bound = args.preset == "c4"                  # a8 at C4 is FP32-bound (AI 49 flop/B > ridge 20)
+        ach_b, ach_f = alg_bytes / t_ev / 1e9, flops / t_ev / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_assoc.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_assoc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}_f{FB}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "k_cosine (association: gallery stream + f32 MFMA + row min)", "bound": "hbm",
-                    "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                    "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+        roofline = {"kernel": "k_assoc (association: gallery stream x detections of the frame group, f32 MFMA, row min)",
+                    "bound": "mfma" if fp32_bound else "hbm",
+                    "achieved": round(ach_f if fp32_bound else ach_b, 2), "peak": 157.3 if fp32_bound else 8000.0,
+                    "unit": "TFLOP/s" if fp32_bound else "GB/s",
+                    "frac": round(ach_f / 157.3 if fp32_bound else ach_b / 8000.0, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r02_pmc_assoc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                    "frames_per_launch": round(frames_launch, 2), "algorithmic_bytes_per_frame": int(bytes_frame),
+                    "algorithmic_bytes_per_launch": int(alg_bytes), "flops_per_launch": int(flops),
                     "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n,
+                    "timing": "HIP start/stop events on the kernel's own dispatches inside the timed region",
+                    "hbm_equivalent_GBps": round(ach_b, 1), "frac_of_hbm_peak": round(ach_b / 8000.0, 4),
+                    "f32_mfma_TFLOPs": round(ach_f, 2), "frac_of_f32_mfma_peak": round(ach_f / 157.3, 4),
+                    "inkernel_mean_us": round(assoc_ik_us, 2), "inkernel_launches": assoc_ik_n,
+                    "frac_inkernel": (round((flops / t_ik / 1e12 / 157.3) if fp32_bound else (alg_bytes / t_ik / 1e9 / 8000.0), 4) if t_ik > 0 else None),
                     "tracks_confirmed_per_stream": [t for t, _ in T_conf], "gallery_rows": [round(b, 1) for _, b in T_conf]}
-        # The HIP events bracket the dispatch on a stream that shares the GPU with the other pipeline stage, so at large
-        # frame batches `mean_launch_us` includes time the kernel waits for compute units.  rocprofv3 serialises the
-        # dispatches it traces; the committed summary of this same command gives the kernel's own duration.
-        stats = os.path.join(ROOT, "profiles", "r01_rocprofv3_kernel_stats_c2_s1.csv")
-        if args.preset == "c2" and S == 1 and os.path.exists(stats):
-            try:
-                import csv
-                row = next(r for r in csv.DictReader(open(stats)) if r["Name"].startswith("k_cosine"))
-                us = float(row["AverageNs"]) / 1e3
-                roofline["rocprofv3_mean_us"] = round(us, 2)
-                roofline["frac_at_rocprofv3_duration"] = round(alg_bytes / (us * 1e-6) / 1e9 / 8000.0, 4)
-            except Exception:
-                pass
 
     if rank == 0:
         # ---- identical-ID rate vs the exact-order oracle on stream 0 ----
@@ -470,7 +480,8 @@ def main():
     pipe.close()
     if rank == 0:
         if world == 1 and not args.no_batched:
-            res["roofline_batched"] = batched_association(cfg, device=dev_index)
+            res["roofline_batched"] = batched_association(cfg, device=dev_index, frame_batch=FB if FB in (1, 2, 4, 8) else 8)
+            res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frame_batch=1, check=False)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, n_ids, pipe.geom, gs, nc, A, cfg, dcfg, detector)
         print(json.dumps(res), flush=True)

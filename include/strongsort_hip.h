@@ -129,7 +129,7 @@ int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, co
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
 
 /* Tuning switches of a context (host state, read at the next tracker call):
- *   "cos_grid"     persistent workgroups of the association kernel (default 512 = two per CU) */
+ *   "cos_grid"     persistent workgroups of the association kernel, a multiple of 8 (default 512 = two per CU) */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
@@ -160,7 +160,8 @@ int ss_get_tracks(ss_ctx* ctx, int stream, int cap, int* n_tracks, int* next_id,
                   int* state, int* hits, int* age, int* tsu, int* class_id, float* conf,
                   double* mean, double* cov, float* smooth, int* gal_count);
 /* Stage intermediates of frame `frame` of the last group (ctx created with debug != 0).
- * counts[4] = n_conf, n_cand, n_cols_b, n_dets; matrices are [SS_MAX_TRACKS][SS_MAX_DETS] strided. */
+ * counts[6] = n_conf, n_cand, n_cols_b, n_dets, assignment path of the appearance stage and of the IoU stage (0 stage
+ * skipped, 1 unique optimum read off the thresholded matrix, 2 LSAP); matrices are [SS_MAX_TRACKS][SS_MAX_DETS] strided. */
 int ss_get_debug(ss_ctx* ctx, int stream, int frame, int* counts, float* cos, double* maha, uint8_t* gated,
                  double* cost_a, double* cost_b, int* lists /* [4][SS_MAX_TRACKS] */);
 /* Gallery of one track (by position in the track list) in natural [count][512] order of slots. */

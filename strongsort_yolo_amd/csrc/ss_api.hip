@@ -119,11 +119,12 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(feat_unit, FM * S * D * SS_F); A(feat_frag, FM * S * SS_NCT * SS_TILE_FLOATS);
     A(tlwh, FM * S * D * 4); A(xyah, FM * S * D * 4);
     A(M, S * T * FM * D); A(tl, S * SS_TLMAX); A(n_tl, S); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
-    A(items, S * SS_PLMAX * (SS_TLMAX / SS_CHUNK)); A(n_items, 4);
+    d.items_cap = (int)(S * SS_PLMAX * (SS_TLMAX / SS_CHUNK / 8));
+    A(items, 8 * (size_t)d.items_cap); A(n_items, 8);
     A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4);
     if (cfg->debug) {
         A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);
-        A(dbg_gated, FM * S * T * D); A(dbg_lists, FM * S * 4 * T); A(dbg_counts, FM * S * 4);
+        A(dbg_gated, FM * S * T * D); A(dbg_lists, FM * S * 4 * T); A(dbg_counts, FM * S * 8);
     }
 #undef A
     if (rc == SS_OK) rc = dalloc(c, &c->d_dets, S * D * 6);
@@ -192,7 +193,7 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
         HIPCHK(c, hipMemcpyAsync(d.next_id + s, &one, 4, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    HIPCHK(c, hipMemsetAsync(d.n_items, 0, 16, c->stream));
+    HIPCHK(c, hipMemsetAsync(d.n_items, 0, 32, c->stream));
     if (stream < 0)
         for (int u = 0; u < c->nms_units; ++u) HIPCHK(c, hipMemsetAsync(ss_nms_error_flag(c->nms_ws, u), 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -269,7 +270,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
 {
     if (!c || !name) return fail(c, SS_ERR_INVALID, "ss_set_option: null argument");
     const std::string n(name);
-    if (n == "cos_grid") { if (value < 1 || value > 4096) return fail(c, SS_ERR_INVALID, "cos_grid: 1..4096"); c->cos_grid = value; }
+    if (n == "cos_grid") { if (value < 8 || value > 4096 || value % 8) return fail(c, SS_ERR_INVALID, "cos_grid: a multiple of 8 in 8..4096"); c->cos_grid = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;
 }
@@ -476,7 +477,7 @@ extern "C" int ss_get_debug(ss_ctx* c, int s, int frame, int* counts, float* cos
     SSDev& d = c->dev;
     const size_t fs = (size_t)frame * d.S + s;                     // [F][S] layout of the group
     const size_t n = (size_t)SS_MAXT * SS_MAXD, o = fs * n;
-    if (counts) HIPCHK(c, hipMemcpy(counts, d.dbg_counts + fs * 4, 16, hipMemcpyDeviceToHost));
+    if (counts) HIPCHK(c, hipMemcpy(counts, d.dbg_counts + fs * 8, 24, hipMemcpyDeviceToHost));
     if (cosd) HIPCHK(c, hipMemcpy(cosd, d.dbg_cos + o, n * 4, hipMemcpyDeviceToHost));
     if (maha) HIPCHK(c, hipMemcpy(maha, d.dbg_maha + o, n * 8, hipMemcpyDeviceToHost));
     if (gated) HIPCHK(c, hipMemcpy(gated, d.dbg_gated + o, n, hipMemcpyDeviceToHost));

@@ -81,8 +81,9 @@ struct SSDev {
     int2* pl;                   // [S][PLMAX] column-tile pairs of the group {frame, ct0 | two<<8 | D<<16}, by frame
     int* n_pl;                  // [S]
     int* pf;                    // [S][FMAX+1] first pair of frame f (pf[F] = n_pl)
-    int4* items;                // association work items {stream, pair, first tile, tiles (<= SS_CHUNK)}
-    int* n_items;               // [1]
+    int4* items;                // [8][items_cap] association work items per XCD {stream, pair, first tile, tiles (<= SS_CHUNK)}
+    int items_cap;
+    int* n_items;               // [8] (re-armed by k_frame)
     // per-frame hand-off k_frame -> k_post -> k_newrow
     int4* post;                 // [S][MAXT] surviving tracks in list order {slot, det or -1, flags, aux}
     int* n_post;                // [S]

@@ -498,6 +498,23 @@ __device__ inline void ema_wave(const float* smooth_in, const float* feat, float
     for (int j = 0; j < 8; ++j) out[l + 64 * j] = n > 0.0f ? v[j] / n : 0.0f;
 }
 
+// the same from registers (lane l holds elements l + 64 j)
+__device__ inline void ema_regs(const float sv[8], const float fv[8], float a, float b, float* out)
+{
+    const int l = threadIdx.x & 63;
+    float v[8], acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t1 = a * sv[j];
+        float t2 = b * fv[j];
+        v[j] = t1 + t2;
+        acc = fmaf(v[j], v[j], acc);
+    }
+    float n = sqrtf(ss_wave_sumsq_reduce(acc));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[l + 64 * j] = n > 0.0f ? v[j] / n : 0.0f;
+}
+
 // append row-major unit row `src` (global) as gallery row b of a track (fragment-major tiles)
 __device__ inline void gallery_append_wave(float* gal_track, int b, const float* src)
 {
@@ -514,7 +531,7 @@ __device__ inline void gallery_append_wave(float* gal_track, int b, const float*
 __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 {
     __shared__ int wtot[4];
-    __shared__ int item_base;
+    __shared__ int xcd_cnt[8], xcd_base[8];
     __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
     const int s = blockIdx.x, tid = threadIdx.x, F = dev.F, S = dev.S;
     const size_t sb = (size_t)s * SS_MAXT;
@@ -544,15 +561,25 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
                 dev.pl[(size_t)s * SS_PLMAX + poff + q] = make_int2(tid, (2 * q) | ((2 * q + 1 < nct) ? 256 : 0) | (D << 16));
         }
         if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_tl[s] = ttot; dev.n_pl[s] = ptot; }
-        // work items, chunk-major with the pair index fastest: the pairs of one tile chunk run back to back, so the
-        // chunk's gallery bytes come from HBM once and from L2 afterwards
+        // Work items = (tile chunk, pair), one list per XCD: chunk c of stream s goes to list (c + s) % 8 with its pairs
+        // adjacent, and k_assoc's workgroup b serves list b % 8 (the dispatcher places block b on XCD b % 8), so the
+        // workgroups that need the same 256 KiB of gallery run on the same XCD at the same time: one of them pulls it
+        // from HBM, the others hit that XCD's L2.
         const int nchunk = (ttot + SS_CHUNK - 1) / SS_CHUNK;
-        const int nit = nchunk * ptot;
-        if (tid == 0) item_base = nit ? atomicAdd(dev.n_items, nit) : 0;
+        if (tid < 8) {
+            const int c0 = (tid - s) & 7;                              // first chunk of this stream on XCD tid
+            const int cnt = c0 < nchunk ? (nchunk - c0 + 7) / 8 : 0;
+            xcd_cnt[tid] = cnt;
+            xcd_base[tid] = cnt * ptot ? atomicAdd(dev.n_items + tid, cnt * ptot) : 0;
+        }
         __syncthreads();
-        for (int i = tid; i < nit; i += 256) {
-            const int ch = i / ptot, pp = i - ch * ptot;
-            dev.items[item_base + i] = make_int4(s, pp, ch * SS_CHUNK, min(SS_CHUNK, ttot - ch * SS_CHUNK));
+        for (int x = 0; x < 8; ++x) {
+            const int nit = xcd_cnt[x] * ptot, c0 = (x - s) & 7;
+            int4* list = dev.items + (size_t)x * dev.items_cap + xcd_base[x];
+            for (int i = tid; i < nit; i += 256) {
+                const int ch = c0 + 8 * (i / ptot), pp = i % ptot;
+                list[i] = make_int4(s, pp, ch * SS_CHUNK, min(SS_CHUNK, ttot - ch * SS_CHUNK));
+            }
         }
         return;
     }
@@ -624,10 +651,12 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     if (dev.ts_enable && threadIdx.x == 0) atomicMin(dev.tstamp, (unsigned long long)wall_clock64());
-    const int n_items = *dev.n_items;
+    const int xcd = blockIdx.x & 7;                                  // this workgroup's list (see k_group_prep)
+    const int n_items = dev.n_items[xcd];
+    const int4* items = dev.items + (size_t)xcd * dev.items_cap;
     const int budget = dev.budget;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int4 item = dev.items[it];
+    for (int it = blockIdx.x >> 3; it < n_items; it += gridDim.x >> 3) {
+        const int4 item = items[it];
         const int s = __builtin_amdgcn_readfirstlane(item.x), p = __builtin_amdgcn_readfirstlane(item.y);
         const int t0 = __builtin_amdgcn_readfirstlane(item.z), nt = __builtin_amdgcn_readfirstlane(item.w);
         const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
@@ -726,7 +755,7 @@ struct FrameLds {
     double* zs;          // [MAXD][4]  detection xyah
     double* dtl;         // [MAXD][4]  detection tlwh
     LsapLds L;
-    int *matchdet, *dettrk, *asg, *cand, *cols, *neworder, *freelist, *conf_l, *slot_l, *tsu_l, *used, *wtot;
+    int *matchdet, *dettrk, *asg, *cand, *cols, *neworder, *freelist, *conf_l, *slot_l, *tsu_l, *used, *rcnt, *ccnt, *rsel, *wtot;
 };
 __device__ inline FrameLds carve_frame(char* p)
 {
@@ -737,24 +766,41 @@ __device__ inline FrameLds carve_frame(char* p)
     m.zs = (double*)p; p += SS_MAXD * 4 * 8;
     m.dtl = (double*)p; p += SS_MAXD * 4 * 8;
     m.L = carve_lsap(p);
-    int** a[] = { &m.matchdet, &m.dettrk, &m.asg, &m.cand, &m.cols, &m.neworder, &m.freelist, &m.conf_l, &m.slot_l, &m.tsu_l, &m.used };
+    int** a[] = { &m.matchdet, &m.dettrk, &m.asg, &m.cand, &m.cols, &m.neworder, &m.freelist, &m.conf_l, &m.slot_l, &m.tsu_l, &m.used,
+                  &m.rcnt, &m.ccnt, &m.rsel };
     for (auto q : a) { *q = (int*)p; p += 256 * 4; }
     m.wtot = (int*)p; p += 64;
     return m;
 }
-size_t ss_frame_lds_bytes() { return (size_t)SS_COST_CAP * 8 + SS_MAXT * 14 * 8 + SS_MAXT * 4 * 8 + 2 * SS_MAXD * 4 * 8 + 12 * 256 * 4 + 64; }
+size_t ss_frame_lds_bytes() { return (size_t)SS_COST_CAP * 8 + SS_MAXT * 14 * 8 + SS_MAXT * 4 * 8 + 2 * SS_MAXD * 4 * 8 + 15 * 256 * 4 + 64; }
 
-// LSAP + threshold of one stage; cost is [nr][nc] after the transposition rule (rows = the smaller side)
-__device__ inline void frame_assign(int nr, int nc, bool tr, bool big, const double* cost_lds, const double* cost_glb,
-                                    const FrameLds& m, int* err)
+// Assignment of one stage.  n_rows x n_cols is the matrix in its natural orientation (rows = tracks); cost is stored
+// [nr][nc] after the transposition rule (rows = the smaller side).  Result: m.asg[row] = column or -1.
+// Shortcut: rcnt / ccnt count the entries <= threshold per natural row / column (filled while the matrix is built,
+// rsel[row] = such a column).  Every other entry equals the replacement value threshold + 1e-5, so if no row and no
+// column holds more than one entry <= threshold, the optimal assignment is unique on those entries (swapping any of
+// them for a replacement-valued entry costs strictly more) and everything else it contains is rejected by the
+// threshold afterwards: the result of the LSAP is known without running it.  Otherwise: LSAP on one wave.
+// Returns 1 (shortcut) or 2 (LSAP) for the debug record.
+__device__ inline int frame_assign(int n_rows, int n_cols, bool big, const double* cost_lds, const double* cost_glb,
+                                   const FrameLds& m, int* err)
 {
     const int tid = threadIdx.x;
+    const bool tr = n_cols < n_rows;
+    const int nr = tr ? n_cols : n_rows, nc = tr ? n_rows : n_cols;
+    const int multi = __syncthreads_or((tid < n_rows && m.rcnt[tid] > 1) || (tid < n_cols && m.ccnt[tid] > 1));
+    if (!multi) {
+        if (tid < n_rows) m.asg[tid] = m.rcnt[tid] == 1 ? m.rsel[tid] : -1;
+        __syncthreads();
+        return 1;
+    }
     if ((tid >> 6) == 0) {
         const int rc = big ? lsap_wave(nr, nc, cost_glb, m.L) : lsap_wave(nr, nc, cost_lds, m.L);
         if (rc) { if (tid == 0) *err = SS_ERR_INFEASIBLE; }
         else for (int i = tid; i < nr; i += 64) { if (tr) m.asg[m.L.col4row[i]] = i; else m.asg[i] = m.L.col4row[i]; }
     }
     __syncthreads();
+    return 2;
 }
 
 __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
@@ -766,14 +812,15 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;        // (frame, stream) and its detection base
     const int nT = dev.n_tracks[s], D = min(dev.n_dets[fs], SS_MAXD);
     if (s == 0 && tid == 0) {
-        *dev.n_items = 0;                                            // re-arm the work list for the next group
+#pragma unroll
+        for (int x = 0; x < 8; ++x) dev.n_items[x] = 0;              // re-arm the work lists for the next group
         if (dev.ts_enable && f == 0) {                               // fold the association kernel's in-kernel duration
             const unsigned long long a = dev.tstamp[0], b = dev.tstamp[1];
             if (b > a) { dev.tstamp[2] += b - a; dev.tstamp[3] += 1; }
             dev.tstamp[0] = ~0ull; dev.tstamp[1] = 0;
         }
     }
-    m.matchdet[tid] = -1; m.dettrk[tid] = -1; m.asg[tid] = -1;
+    m.matchdet[tid] = -1; m.dettrk[tid] = -1; m.asg[tid] = -1; m.rcnt[tid] = 0; m.ccnt[tid] = 0;
     m.used[tid] = dev.slot_used[sb + tid];
     const size_t dbg = fs * SS_MAXT;                                 // debug base (rows of [F][S][MAXT]...)
     if (prm.debug) { dev.dbg_lists[(fs * 4 + 0) * SS_MAXT + tid] = -1; dev.dbg_lists[(fs * 4 + 3) * SS_MAXT + tid] = -1; }
@@ -841,6 +888,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
             int gt;
             const double v = ss_blend(c, maha, prm, &gt);
             cost[tr ? d * nc + r : r * nc + d] = v;
+            if (!(v > prm.max_dist)) { atomicAdd(&m.rcnt[r], 1); atomicAdd(&m.ccnt[d], 1); m.rsel[r] = d; }
             if (prm.debug) {
                 const size_t o = (dbg + r) * SS_MAXD + d;
                 dev.dbg_cos[o] = c; dev.dbg_maha[o] = maha; dev.dbg_gated[o] = (uint8_t)gt; dev.dbg_cost_a[o] = v;
@@ -848,7 +896,8 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         }
         if (big) __threadfence();                        // the spilled matrix is read back by another wave
         __syncthreads();
-        frame_assign(nr, nc, tr, big, m.cost, spill, m, dev.err + s);
+        const int path = frame_assign(nC, D, big, m.cost, spill, m, dev.err + s);
+        if (prm.debug && tid == 0) dev.dbg_counts[fs * 8 + 4] = path;
         if (tid < nC) {
             int d = m.asg[tid];
             if (d >= 0) {
@@ -873,12 +922,12 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     const int isCol = (tid < D) && (m.dettrk[tid] < 0);
     block_scan256(isCol, m.wtot, pos, nCols);
     if (isCol) m.cols[pos] = tid;
-    m.asg[tid] = -1;
+    m.asg[tid] = -1; m.rcnt[tid] = 0; m.ccnt[tid] = 0;
     __syncthreads();
     if (prm.debug) {
         if (tid < nCand) dev.dbg_lists[(fs * 4 + 1) * SS_MAXT + tid] = m.cand[tid];
         if (tid < nCols) dev.dbg_lists[(fs * 4 + 2) * SS_MAXT + tid] = m.cols[tid];
-        if (tid == 0) { int* c = dev.dbg_counts + fs * 4; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; }
+        if (tid == 0) { int* c = dev.dbg_counts + fs * 8; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; c[5] = 0; if (!(nC > 0 && D > 0)) c[4] = 0; }
     }
     if (nCand > 0 && nCols > 0) {
         const bool tr = nCols < nCand;
@@ -893,11 +942,13 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
             double t[4] = { tb[0], tb[1], tb[2], tb[3] }, cc[4] = { cb[0], cb[1], cb[2], cb[3] };
             const double v = (m.tsu_l[ti] > 1) ? prm.max_iou_distance + 1e-5 : ss_iou_cost(t, cc, prm.max_iou_distance);
             cost[tr ? c * nc + r : r * nc + c] = v;
+            if (!(v > prm.max_iou_distance)) { atomicAdd(&m.rcnt[r], 1); atomicAdd(&m.ccnt[c], 1); m.rsel[r] = c; }
             if (prm.debug) dev.dbg_cost_b[(dbg + r) * SS_MAXD + c] = v;
         }
         if (big) __threadfence();
         __syncthreads();
-        frame_assign(nr, nc, tr, big, m.cost, spill, m, dev.err + s);
+        const int path = frame_assign(nCand, nCols, big, m.cost, spill, m, dev.err + s);
+        if (prm.debug && tid == 0) dev.dbg_counts[fs * 8 + 5] = path;
         if (tid < nCand) {
             int c = m.asg[tid];
             if (c >= 0) {
@@ -1004,8 +1055,12 @@ __global__ __launch_bounds__(256) void k_post(SSDev dev, SSParams prm, int f)
         if (fl & SS_P_MATCHED) {
             const double* zz = dev.xyah + (fb + d) * 4;
             const double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+            const float* fu = dev.feat_unit + (fb + d) * SS_F;
+            float sv[8], fv[8];                                       // EMA operands on the wire before the Kalman arithmetic
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sv[j] = sm[l + 64 * j]; fv[j] = fu[l + 64 * j]; }
             ss_kf_update_wave(dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws[w]);
-            ema_wave(sm, dev.feat_unit + (fb + d) * SS_F, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf[w]);
+            ema_regs(sv, fv, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf[w]);
             SS_WAVE_SYNC();
 #pragma unroll
             for (int j = 0; j < 8; ++j) sm[l + 64 * j] = rowbuf[w][l + 64 * j];

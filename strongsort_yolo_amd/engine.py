@@ -153,7 +153,7 @@ class TrackerEngine:
 
     def debug(self, stream: int = 0, frame: int = 0) -> dict:
         T, D = MAX_TRACKS, MAX_DETS
-        counts = np.zeros(4, np.int32)
+        counts = np.zeros(6, np.int32)
         cosd = np.zeros((T, D), np.float32)
         maha, cost_a, cost_b = np.zeros((T, D)), np.zeros((T, D)), np.zeros((T, D))
         gated = np.zeros((T, D), np.uint8)
@@ -162,8 +162,8 @@ class TrackerEngine:
         self._ck(self.L.ss_get_debug(self.ctx, stream, frame, counts.ctypes.data_as(ip), cosd.ctypes.data_as(fp),
                                      maha.ctypes.data_as(dp), gated.ctypes.data_as(up), cost_a.ctypes.data_as(dp),
                                      cost_b.ctypes.data_as(dp), lists.ctypes.data_as(ip)))
-        nC, nCand, nCols, nD = (int(v) for v in counts)
-        return dict(n_conf=nC, n_cand=nCand, n_cols=nCols, n_dets=nD, cos=cosd[:nC, :nD], maha=maha[:nC, :nD],
+        nC, nCand, nCols, nD, path_a, path_b = (int(v) for v in counts)
+        return dict(n_conf=nC, n_cand=nCand, n_cols=nCols, n_dets=nD, path_a=path_a, path_b=path_b, cos=cosd[:nC, :nD], maha=maha[:nC, :nD],
                     gated=gated[:nC, :nD], cost_a=cost_a[:nC, :nD], cost_b=cost_b[:nCand, :nCols],
                     pairs_a=lists[0, :nC], cand=lists[1, :nCand], cols_b=lists[2, :nCols], pairs_b=lists[3, :nCand])
 

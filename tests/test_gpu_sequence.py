@@ -165,6 +165,55 @@ def test_frame_groups_with_births_deaths_and_empty_frames():
     assert orcs[0].next_id > 11 and orcs[1].next_id > 13                     # re-births happened
 
 
+@pytest.mark.parametrize("F", [1, 4])
+def test_ambiguous_costs_take_the_lsap_path(F):
+    """k_frame reads the assignment off the thresholded matrix when the optimum is unique (no row / column with two
+    entries under the threshold) and runs the one-wave LSAP otherwise.  Twin identities (co-located boxes, nearly equal
+    embeddings) make both stages ambiguous: both paths must occur and both must reproduce the oracle exactly."""
+    import torch
+    cfg = StrongSortConfig()
+    W, H = 1280, 720
+    eng, orc = engine(cfg, debug=True), OracleStrongSort(cfg, "c")
+    st = make_stream(3, W, H, 12)
+    rng = np.random.default_rng(11)
+    dev = eng.device
+    hw = torch.tensor([[H, W]], dtype=torch.int32, device=dev)
+    out, nout = torch.zeros(F, 1, 256, 8, device=dev), torch.zeros(F, 1, dtype=torch.int32, device=dev)
+    paths_a, paths_b = set(), set()
+    for k0 in range(0, 40, F):
+        hd, hf, hn = np.zeros((F, 1, 128, 6), np.float32), np.zeros((F, 1, 128, 512), np.float32), np.zeros((F, 1), np.int32)
+        ref, lasts = [], []
+        for f in range(F):
+            fr = st.next_frame()
+            twin = fr.dets.copy()
+            twin[:, :4] += np.array([3, 2, 3, 2], np.float32) * (1 if (k0 + f) % 9 else 0)     # some frames: exact ties
+            twin[:, 4] -= 0.01
+            tf = fr.feats + 0.005 * rng.standard_normal(fr.feats.shape).astype(np.float32)
+            tf = (tf / np.linalg.norm(tf, axis=1, keepdims=True)).astype(np.float32)
+            dets, feats = np.concatenate([fr.dets, twin]), np.concatenate([fr.feats, tf])
+            n = len(dets)
+            hd[f, 0, :n], hf[f, 0, :n], hn[f, 0] = dets, feats, n
+            ref.append(orc.update(dets, feats, (H, W)))
+            lasts.append(orc.last)
+        eng.update_group(F, torch.from_numpy(hd).to(dev), torch.from_numpy(hn).to(dev), torch.from_numpy(hf).to(dev), hw, out, nout)
+        eng.check_errors()
+        ho, hno = out.cpu().numpy(), nout.cpu().numpy()
+        for f in range(F):
+            _compare_frame(eng, orc, ho[f, 0, :hno[f, 0]], ref[f], k0 + f, 0, f, lasts[f])
+            d = eng.debug(0, f)
+            paths_a.add(d["path_a"]); paths_b.add(d["path_b"])
+    _compare_table(eng, orc)
+    assert 2 in paths_a and 2 in paths_b, (paths_a, paths_b)                   # LSAP ran in both stages
+    eng.close()
+    # ... and the plain streams of the other tests take the shortcut
+    eng, st = engine(cfg, debug=True), make_stream(0, W, H, 30)
+    for k in range(8):
+        fr = st.next_frame()
+        eng.update_host(fr.dets, fr.feats, (H, W))
+    assert eng.debug(0)["path_a"] == 1
+    eng.close()
+
+
 def test_capacity_error_is_loud():
     from strongsort_yolo_amd.lib import SSError
     eng = engine()
