@@ -76,12 +76,11 @@ struct SSDev {
     double *tlwh, *xyah;        // [FMAX][S][MAXD][4]
     int* M;                     // [S][MAXT][FMAX][MAXD] ordered-int keys (ss_fkey) of the appearance distance
                                 //   min over the gallery rows of (slot) that are valid in frame f of the group
-    int4* tl;                   // [S][TLMAX] gallery tiles at group start {slot, row tile, count, head}
-    int* n_tl;                  // [S]
     int2* pl;                   // [S][PLMAX] column-tile pairs of the group {frame, ct0 | two<<8 | D<<16}, by frame
     int* n_pl;                  // [S]
     int* pf;                    // [S][FMAX+1] first pair of frame f (pf[F] = n_pl)
-    int4* items;                // [8][items_cap] association work items per XCD {stream, pair, first tile, tiles (<= SS_CHUNK)}
+    int4* items;                // [8][items_cap][4] association work items per XCD: 64-byte records {stream, frame, pair word,
+                                //   tiles} + 8 packed tile words (slot | row tile<<8 | count<<12 | ring head<<20), snapshot at group start
     int items_cap;
     int* n_items;               // [8] (re-armed by k_frame)
     // per-frame hand-off k_frame -> k_post -> k_newrow

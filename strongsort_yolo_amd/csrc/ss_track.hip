@@ -532,6 +532,8 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 {
     __shared__ int wtot[4];
     __shared__ int xcd_cnt[8], xcd_base[8];
+    __shared__ int tlw[SS_TLMAX];             // packed gallery tiles of the stream (work-list block only)
+    __shared__ int2 plw[SS_PLMAX];
     __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
     const int s = blockIdx.x, tid = threadIdx.x, F = dev.F, S = dev.S;
     const size_t sb = (size_t)s * SS_MAXT;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         }
         int toff, ttot;
         block_scan_sum256(ntile, wtot, toff, ttot);
-        for (int rt = 0; rt < ntile; ++rt) dev.tl[(size_t)s * SS_TLMAX + toff + rt] = make_int4(slot, rt, count, head);
+        for (int rt = 0; rt < ntile; ++rt) tlw[toff + rt] = slot | (rt << 8) | (count << 12) | (head << 20);   // 8+3+8+7 bits
         // column-tile pairs of the group, frame by frame (a pair never spans two frames)
         int np = 0, D = 0;
         if (tid < F) { D = min(dev.n_dets[tid * S + s], SS_MAXD); np = ((D + SS_TILE - 1) / SS_TILE + 1) / 2; }
@@ -557,10 +559,13 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         if (tid < F) {
             dev.pf[s * (SS_FMAX + 1) + tid] = poff;
             const int nct = (D + SS_TILE - 1) / SS_TILE;
-            for (int q = 0; q < np; ++q)
-                dev.pl[(size_t)s * SS_PLMAX + poff + q] = make_int2(tid, (2 * q) | ((2 * q + 1 < nct) ? 256 : 0) | (D << 16));
+            for (int q = 0; q < np; ++q) {
+                const int2 pr = make_int2(tid, (2 * q) | ((2 * q + 1 < nct) ? 256 : 0) | (D << 16));
+                dev.pl[(size_t)s * SS_PLMAX + poff + q] = pr;
+                plw[poff + q] = pr;
+            }
         }
-        if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_tl[s] = ttot; dev.n_pl[s] = ptot; }
+        if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_pl[s] = ptot; }
         // Work items = (tile chunk, pair), one list per XCD: chunk c of stream s goes to list (c + s) % 8 with its pairs
         // adjacent, and k_assoc's workgroup b serves list b % 8 (the dispatcher places block b on XCD b % 8), so the
         // workgroups that need the same 256 KiB of gallery run on the same XCD at the same time: one of them pulls it
@@ -573,12 +578,19 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
             xcd_base[tid] = cnt * ptot ? atomicAdd(dev.n_items + tid, cnt * ptot) : 0;
         }
         __syncthreads();
+        // a work item is one self-contained 64-byte record: {stream, frame, pair word, tiles} + the 8 packed tile words
         for (int x = 0; x < 8; ++x) {
             const int nit = xcd_cnt[x] * ptot, c0 = (x - s) & 7;
-            int4* list = dev.items + (size_t)x * dev.items_cap + xcd_base[x];
+            int4* list = dev.items + ((size_t)x * dev.items_cap + xcd_base[x]) * 4;
             for (int i = tid; i < nit; i += 256) {
                 const int ch = c0 + 8 * (i / ptot), pp = i % ptot;
-                list[i] = make_int4(s, pp, ch * SS_CHUNK, min(SS_CHUNK, ttot - ch * SS_CHUNK));
+                const int t0 = ch * SS_CHUNK, nt = min(SS_CHUNK, ttot - t0);
+                int tw[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
+                list[i * 4 + 0] = make_int4(s, plw[pp].x, plw[pp].y, nt);
+                list[i * 4 + 1] = make_int4(tw[0], tw[1], tw[2], tw[3]);
+                list[i * 4 + 2] = make_int4(tw[4], tw[5], tw[6], tw[7]);
             }
         }
         return;
@@ -652,17 +664,23 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
     const int wu = __builtin_amdgcn_readfirstlane(w);
     if (dev.ts_enable && threadIdx.x == 0) atomicMin(dev.tstamp, (unsigned long long)wall_clock64());
     const int xcd = blockIdx.x & 7;                                  // this workgroup's list (see k_group_prep)
+    const int4* items = dev.items + (size_t)xcd * dev.items_cap * 4;
+    int it = blockIdx.x >> 3;
+    // the first record is fetched together with the list length (one memory latency, not two)
+    int4 r0 = items[it * 4], r1 = items[it * 4 + 1], r2 = items[it * 4 + 2];
     const int n_items = dev.n_items[xcd];
-    const int4* items = dev.items + (size_t)xcd * dev.items_cap;
     const int budget = dev.budget;
-    for (int it = blockIdx.x >> 3; it < n_items; it += gridDim.x >> 3) {
-        const int4 item = items[it];
-        const int s = __builtin_amdgcn_readfirstlane(item.x), p = __builtin_amdgcn_readfirstlane(item.y);
-        const int t0 = __builtin_amdgcn_readfirstlane(item.z), nt = __builtin_amdgcn_readfirstlane(item.w);
-        const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
-        const int f = __builtin_amdgcn_readfirstlane(pr.x), pw = __builtin_amdgcn_readfirstlane(pr.y);
+    for (; it < n_items; it += gridDim.x >> 3) {
+        const int s = __builtin_amdgcn_readfirstlane(r0.x), f = __builtin_amdgcn_readfirstlane(r0.y);
+        const int pw = __builtin_amdgcn_readfirstlane(r0.z), nt = __builtin_amdgcn_readfirstlane(r0.w);
         const int ct0 = pw & 0xff, D = pw >> 16;
         const bool two = (pw >> 8) & 1;
+        const int twv = wu == 0 ? r1.x : wu == 1 ? r1.y : wu == 2 ? r1.z : wu == 3 ? r1.w : wu == 4 ? r2.x : wu == 5 ? r2.y : wu == 6 ? r2.z : r2.w;
+        const int tword = __builtin_amdgcn_readfirstlane(twv);
+        {   // next record (consumed at the end of the iteration; stale values past the end are never used)
+            const int nx = it + (gridDim.x >> 3);
+            if (nx < n_items) { r0 = items[nx * 4]; r1 = items[nx * 4 + 1]; r2 = items[nx * 4 + 2]; }
+        }
         const bool has = wu < nt;
         int slot = 0, rt = 0, count = 0, head = 0;
         const char* base = reinterpret_cast<const char*>(dev.gallery);
@@ -673,9 +691,7 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
         if (has) {
-            const int4 td = dev.tl[(size_t)s * SS_TLMAX + t0 + wu];
-            slot = __builtin_amdgcn_readfirstlane(td.x); rt = __builtin_amdgcn_readfirstlane(td.y);
-            count = __builtin_amdgcn_readfirstlane(td.z); head = __builtin_amdgcn_readfirstlane(td.w);
+            slot = tword & 0xff; rt = (tword >> 8) & 7; count = (tword >> 12) & 0xff; head = (tword >> 20) & 0x7f;
             base += ((((size_t)s * SS_MAXT + slot) * SS_NRT + rt) * SS_TILE_FLOATS) * 4;
             const bool ok = (l & 15) < count - rt * SS_TILE;
             vo = (unsigned)((ok ? l : (l & ~15)) * 16);

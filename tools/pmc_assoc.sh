@@ -1,0 +1,38 @@
+#!/bin/bash
+# usage: tools/pmc_assoc.sh <tag> <streams> <frame_batch> [kernel=k_assoc]
+# One rocprofv3 --pmc pass per counter group over tools/batched_assoc.py; prints per-dispatch means of the kernel over
+# the last launches (steady state: galleries full) and writes gpurun_out/pmc_<tag>/summary.json.
+tag=$1; S=$2; FB=$3; K=${4:-k_assoc}
+cd /tmp && export TMPDIR=/tmp
+root=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+rm -rf $root; mkdir -p $root
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  out=$root/p$i; mkdir -p $out
+  (cd $GRAFT_REPO_ROOT && rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o run -- python tools/batched_assoc.py $S $FB > $out/log.txt 2>&1)
+  i=$((i+1))
+done
+python - "$root" "$K" "$S" "$FB" <<'PY'
+import csv, glob, json, sys, collections
+root, K, S, FB = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+agg = collections.defaultdict(list)
+for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        if not r["Kernel_Name"].startswith(K): continue
+        per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    ids = sorted(per, key=int)[-3:]                      # steady state: the last launches
+    for d in ids:
+        for k, v in per[d].items(): agg[k].append(v)
+res = {k: sum(v) / len(v) for k, v in agg.items()}
+res["_kernel"], res["_streams"], res["_frame_batch"], res["_launches_averaged"] = K, S, FB, 3
+if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950 for wide streaming reads (x2)
+    res["hbm_bytes_per_launch"] = int(res["FETCH_SIZE"] * 1024 * 2 + res["WRITE_SIZE"] * 1024)
+if "TCC_HIT_sum" in res: res["l2_hit_rate"] = res["TCC_HIT_sum"] / max(res["TCC_HIT_sum"] + res["TCC_MISS_sum"], 1)
+if "SQ_VALU_MFMA_BUSY_CYCLES" in res and "GRBM_GUI_ACTIVE" in res:
+    res["mfma_busy_frac_of_gui_active_x_simds"] = res["SQ_VALU_MFMA_BUSY_CYCLES"] / (res["GRBM_GUI_ACTIVE"] * 1024)
+print(json.dumps(res, indent=1))
+json.dump(res, open(root + "/summary.json", "w"), indent=1)
+PY
+find $root -name "*.csv" -size +4M -delete
