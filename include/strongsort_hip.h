@@ -231,6 +231,10 @@ int ss_assoc_timing(ss_ctx* ctx, int enable, float* mean_ms, int* launches);
  * kernel itself), i.e. without the time a dispatch waits for compute units behind other streams' kernels.  Returns
  * the mean over the launches since the last call (microseconds) and re-arms / disarms the stamps. */
 int ss_assoc_inkernel_timing(ss_ctx* ctx, int enable, double* mean_us, int* launches);
+/* enable = 2 above also records, for every workgroup of the last launch, the stamps of its first work item: [0] kernel
+ * entry, [1] work record read, [2] first gallery pieces + detection operand arrived, [3] operand staged in LDS, [4..11]
+ * k-segments 0..7 done, [12] results written.  out: [n_workgroups][16] 100 MHz ticks.  Profiling aid. */
+int ss_assoc_timeline(ss_ctx* ctx, long long* out, int n_workgroups);
 
 #ifdef __cplusplus
 }

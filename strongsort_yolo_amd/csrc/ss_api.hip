@@ -48,7 +48,7 @@ struct ss_ctx {
     size_t nms_ws_bytes;
     int nms_units;
     int cos_grid;               // persistent workgroups of the association kernel
-    bool inkernel;              // in-kernel timing of the association kernel armed
+    int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -94,7 +94,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->timing = false;
     c->ev_used = 0;
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
-    c->inkernel = false;
+    c->inkernel = 0;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -121,7 +121,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(M, S * T * FM * D); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
     d.items_cap = (int)(S * SS_PLMAX * (SS_TLMAX / SS_CHUNK / 8));
     A(items, 8 * (size_t)d.items_cap * 4); A(n_items, 8);
-    A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4);
+    A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4); A(timeline, 4096 * 16);
     if (cfg->debug) {
         A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);
         A(dbg_gated, FM * S * T * D); A(dbg_lists, FM * S * 4 * T); A(dbg_counts, FM * S * 8);
@@ -216,7 +216,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     // Every launch dimension is fixed by (streams, n_frames): track and detection counts are device-side values read
     // from the work lists, so nothing here needs a host round trip and the sequence can be captured into a HIP graph.
     dev.cos_grid = c->cos_grid;
-    dev.ts_enable = c->inkernel ? 1 : 0;
+    dev.ts_enable = c->inkernel;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {
@@ -518,7 +518,15 @@ extern "C" int ss_assoc_inkernel_timing(ss_ctx* c, int enable, double* mean_us, 
     if (launches) *launches = (int)t[3];
     const unsigned long long arm[4] = { ~0ull, 0, 0, 0 };
     HIPCHK(c, hipMemcpy(c->dev.tstamp, arm, sizeof arm, hipMemcpyHostToDevice));
-    c->inkernel = enable != 0;
+    c->inkernel = enable < 0 ? 0 : enable > 2 ? 2 : enable;
+    return SS_OK;
+}
+
+extern "C" int ss_assoc_timeline(ss_ctx* c, long long* out, int n_workgroups)
+{
+    if (!c || !out || n_workgroups < 1 || n_workgroups > 4096) return SS_ERR_INVALID;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->dev.timeline, (size_t)n_workgroups * 16 * 8, hipMemcpyDeviceToHost));
     return SS_OK;
 }
 

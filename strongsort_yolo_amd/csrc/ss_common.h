@@ -90,7 +90,8 @@ struct SSDev {
     int* n_rows;                // [S]
     double* cost_spill;         // [S][MAXT*MAXD] cost matrices that do not fit the LDS
     unsigned long long* tstamp; // [4] in-kernel timing of the association kernel: min start, max end (100 MHz), sum, count
-    int ts_enable;
+    int ts_enable;              // 1: first-start / last-end stamps; 2: + per-workgroup timeline
+    long long* timeline;        // [4096 workgroups][16] stamps of each workgroup's first item (profiling aid)
     // debug (stage intermediates, per frame of the group)
     float* dbg_cos;             // [FMAX][S][MAXT][MAXD]
     double *dbg_maha, *dbg_cost_a, *dbg_cost_b;

@@ -656,8 +656,15 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 // vmcnt keeps 3 pieces in flight); the pair's detection operand B (2 x 32 KiB fragment tiles) is staged once per
 // item in LDS and shared by the 8 waves; its global loads are issued together with the first gallery pieces.
 // Ragged last tile: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
+// profiling aid (ss_assoc_timeline): wall-clock stamps (100 MHz) of wave 0 of every workgroup's first item
+// (a separate instantiation: the stamps cost registers, the production kernel must keep 2 workgroups per CU)
+#define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) dev.timeline[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+
+template <bool TL>
 __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
 {
+    bool first_item = true;
+    SS_TL(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -681,6 +688,7 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
             const int nx = it + (gridDim.x >> 3);
             if (nx < n_items) { r0 = items[nx * 4]; r1 = items[nx * 4 + 1]; r2 = items[nx * 4 + 2]; }
         }
+        SS_TL(1);                                                    // record in registers
         const bool has = wu < nt;
         int slot = 0, rt = 0, count = 0, head = 0;
         const char* base = reinterpret_cast<const char*>(dev.gallery);
@@ -705,9 +713,11 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
         const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
         const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
         __syncthreads();                                             // the previous item's readers are done with bl
+        SS_TL(2);                                                    // first gallery pieces + B landed
         bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
         bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
         __syncthreads();
+        SS_TL(3);                                                    // B staged
         if (has) {
             const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
             const char* bls1 = bls + 32768;
@@ -732,6 +742,7 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
                     for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
+                SS_TL(4 + sg);
             }
             // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
             float m0 = INFINITY, m1 = INFINITY;
@@ -750,6 +761,8 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
             if (l < 16) { if (ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m0)); }
             else if (l < 32) { if (two && ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m1)); }
         }
+        SS_TL(12);
+        first_item = false;
     }
     if (dev.ts_enable) {
         __builtin_amdgcn_s_waitcnt(0);                               // this wave's memory operations have completed
@@ -1275,15 +1288,17 @@ extern "C" void ss_step_kernel_attr()
 {
     // a failure here surfaces as a launch error on first use (checked with hipGetLastError after every launch)
     (void)hipFuncSetAttribute((const void*)k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_frame_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_assoc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_assoc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_assoc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
 }
 
 // One group of dev.F frames for every stream.  ev0/ev1 (optional) bracket the association kernel's dispatch.
 void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
-    if (ev0) hipExtLaunchKernelGGL(k_assoc, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
-    else     hipLaunchKernelGGL(k_assoc, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    if (dev.ts_enable > 1) hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
+    else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
     const int newrow_grid = min(2048, 64 * dev.S);
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);

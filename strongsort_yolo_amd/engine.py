@@ -173,11 +173,17 @@ class TrackerEngine:
         self._ck(self.L.ss_get_gallery(self.ctx, stream, track_index, rows.ctypes.data_as(C.POINTER(C.c_float)), 128, C.byref(cnt)))
         return rows[: cnt.value].copy()
 
-    def assoc_inkernel_timing(self, enable: bool):
+    def assoc_inkernel_timing(self, enable):
         """(mean microseconds, launches) of the association kernel measured by the kernel itself since the last call."""
         us, n = C.c_double(), C.c_int()
         self._ck(self.L.ss_assoc_inkernel_timing(self.ctx, int(enable), C.byref(us), C.byref(n)))
         return us.value, n.value
+
+    def assoc_timeline(self, n_workgroups: int = 512):
+        """[n_workgroups, 16] wall-clock stamps (100 MHz) of the last association launch (assoc_inkernel_timing(2))."""
+        buf = np.zeros((n_workgroups, 16), np.int64)
+        self._ck(self.L.ss_assoc_timeline(self.ctx, buf.ctypes.data_as(C.POINTER(C.c_longlong)), n_workgroups))
+        return buf
 
     def assoc_timing(self, enable: bool):
         ms, n = C.c_float(), C.c_int()
