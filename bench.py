@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One "step" = one batch of `frames_per_step` consecutive frames (default 4 frame-batch groups of 8 = 32 frames) of
+One "step" = one batch of `frames_per_step` consecutive frames (default 2 frame-batch groups of 16 = 32 frames) of
 every stream owned by the rank through the whole hot path (letterbox -> detector -> NMS -> ReID crops -> OSNet ->
 StrongSORT update), inputs resident in HBM; `value` = frames/s = world * streams * steps * frames_per_step / time.
 With `--gpus N` and no WORLD_SIZE in the environment the script starts its N ranks itself (torch.distributed.run,
@@ -13,7 +13,7 @@ Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synt
 data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
 
 Throughput structure (all of it result-preserving — every frame runs every stage, rows are bit-identical to the
-oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 8)
+oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 16)
 consecutive frames of a stream at a time — a decoded video file or a capture queue supplies them; it costs
 frame_batch frame periods of latency on a live camera — and the tracker consumes them one by one in frame
 order; stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
@@ -55,7 +55,7 @@ PRESETS = {
     "c5": ("yolov8n-pose", 1280, 720, 30, 32), # configs[4] per GPU: pose head, keypoints carried by det_idx
 }
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}
-PREFILL = 104      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init)
+PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
 
 def spawn_ranks(n, argv):
@@ -253,7 +253,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30, help="timed steps; one step = --groups-per-step frame-batch groups of every stream")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--groups-per-step", type=int, default=4, help="frame-batch groups per step (frames_per_step = this x --frame-batch)")
+    ap.add_argument("--groups-per-step", type=int, default=2, help="frame-batch groups per step (frames_per_step = this x --frame-batch)")
     ap.add_argument("--dist-check", action="store_true", help="only start the ranks, run the barrier / max-over-ranks exchange and print n_gpus (no GPU work)")
     ap.add_argument("--streams", type=int, default=1, help="streams per GPU (configs[1] = 1)")
     ap.add_argument("--preset", default="c2", choices=sorted(PRESETS))
@@ -264,7 +264,7 @@ def main():
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
-    ap.add_argument("--frame-batch", type=int, default=8, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
+    ap.add_argument("--frame-batch", type=int, default=16, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -480,8 +480,8 @@ def main():
     pipe.close()
     if rank == 0:
         if world == 1 and not args.no_batched:
-            res["roofline_batched"] = batched_association(cfg, device=dev_index, frame_batch=FB if FB in (1, 2, 4, 8) else 8)
-            res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frame_batch=1, check=False)
+            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16) else 8)
+            res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=1, check=False)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, n_ids, pipe.geom, gs, nc, A, cfg, dcfg, detector)
         print(json.dumps(res), flush=True)

@@ -94,6 +94,11 @@ int ss_nms_batch(ss_ctx* ctx, const float* d_pred, int batch, long long pred_bat
                  int max_det, const float* d_geom, float* d_rows, int row_stride,
                  long long rows_batch_stride, int* d_keep, long long keep_batch_stride, int* d_count);
 
+/* The `classes` override of the reference (yolo_multi_model.py:22, commented out there): keep only anchors whose best
+ * class is in classes[0..n) (ids 0..127); n = 0 keeps every class (default).  Host state of the context, read by the
+ * following ss_nms / ss_nms_batch calls (and baked into a HIP graph that captures them). */
+int ss_nms_set_classes(ss_ctx* ctx, const int* classes, int n);
+
 /* ---- a4  ReID crop-extract  (StrongSORT._get_features, inside model.track) ---------------------
  * For each detection row (x1,y1,x2,y2,... ; det_stride floats) crop + bilinear to 256x128,
  * /255, ImageNet mean/std, RGB [n][3][256][128] (out_flags as ss_letterbox's dst_flags: SS_DST_F16,

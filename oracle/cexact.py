@@ -54,6 +54,9 @@ def lib():
         L.so_nms.restype = C.c_int
         L.so_nms.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                              C.c_int, C.c_int, i32p, f32p]
+        L.so_nms_classes.restype = C.c_int
+        L.so_nms_classes.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
+                                     C.c_int, C.c_int, u8p, i32p, f32p]
         L.so_scale_boxes.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
         L.so_letterbox.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p] + [C.c_int] * 7
         L.so_crop_norm.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
@@ -175,13 +178,18 @@ def lsap(cost):
 
 
 # ---- front end ---------------------------------------------------------------------------------------
-def nms(pred, nc, conf_thres, iou_thres, agnostic=False, max_wh=7680.0, max_nms=8192, max_det=1000):
+def nms(pred, nc, conf_thres, iou_thres, agnostic=False, max_wh=7680.0, max_nms=8192, max_det=1000, classes=None):
     pred = _f32(pred)
     N = pred.shape[1]
     keep = np.empty(max(min(N, max_det), 1), dtype=np.int32)
     rows = np.empty((max(min(N, max_det), 1), 6), dtype=np.float32)
-    k = lib().so_nms(_p(pred, C.c_float), N, nc, conf_thres, iou_thres, int(agnostic), max_wh,
-                     max_nms, max_det, _p(keep, C.c_int), _p(rows, C.c_float))
+    allow = None
+    if classes is not None:
+        allow = np.zeros(nc, np.uint8)
+        allow[list(classes)] = 1
+    k = lib().so_nms_classes(_p(pred, C.c_float), N, nc, conf_thres, iou_thres, int(agnostic), max_wh,
+                             max_nms, max_det, _p(allow, C.c_uint8) if allow is not None else None,
+                             _p(keep, C.c_int), _p(rows, C.c_float))
     return keep[:k].copy(), rows[:k].copy()
 
 

@@ -368,8 +368,19 @@ static int so_cand_cmp(const void* a, const void* b)
     return (x->anchor > y->anchor) - (x->anchor < y->anchor);
 }
 
+int so_nms_classes(const float* pred, int N, int nc, float conf_thres, float iou_thres, int agnostic,
+                   float max_wh, int max_nms, int max_det, const unsigned char* class_allow, int* keep_idx, float* rows);
+
 int so_nms(const float* pred, int N, int nc, float conf_thres, float iou_thres, int agnostic,
            float max_wh, int max_nms, int max_det, int* keep_idx, float* rows)
+{
+    return so_nms_classes(pred, N, nc, conf_thres, iou_thres, agnostic, max_wh, max_nms, max_det, 0, keep_idx, rows);
+}
+
+/* class_allow[nc] (NULL: all): Ultralytics `classes` filter, applied to the anchor's best class after the confidence
+ * test (the override yolo_multi_model.py:22 sets). */
+int so_nms_classes(const float* pred, int N, int nc, float conf_thres, float iou_thres, int agnostic,
+                   float max_wh, int max_nms, int max_det, const unsigned char* class_allow, int* keep_idx, float* rows)
 {
     so_cand* c = (so_cand*)malloc(sizeof(so_cand) * (N > 0 ? N : 1));
     int n = 0;
@@ -379,7 +390,7 @@ int so_nms(const float* pred, int N, int nc, float conf_thres, float iou_thres, 
             float s = pred[(size_t)(4 + k) * N + a];
             if (s > best) { best = s; bc = k; }
         }
-        if (best > conf_thres) { c[n].score = best; c[n].anchor = a; c[n].cls = bc; ++n; }
+        if (best > conf_thres && (!class_allow || class_allow[bc])) { c[n].score = best; c[n].anchor = a; c[n].cls = bc; ++n; }
     }
     qsort(c, n, sizeof(so_cand), so_cand_cmp);
     if (n > max_nms) n = max_nms;

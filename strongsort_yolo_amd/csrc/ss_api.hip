@@ -21,7 +21,8 @@ void ss_launch_lsap(const double*, int, int, int*, double*, int*, hipStream_t);
 int  ss_front_init();
 void ss_launch_letterbox(const uint8_t*, int, long long, int, int, int, void*, int, int, int, int, int, int, int, int, hipStream_t);
 int  ss_launch_nms(const float*, int, long long, int, int, int, float, float, int, float, int, float, float, float, float,
-                   float, const float*, float*, int, long long, int*, long long, int*, void*, size_t, hipStream_t);
+                   float, const float*, float*, int, long long, int*, long long, int*, void*, size_t, unsigned long long,
+                   unsigned long long, hipStream_t);
 int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
 void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t);
@@ -47,6 +48,7 @@ struct ss_ctx {
     void* nms_ws;               // nms_units workspace units (grown on demand outside graph capture)
     size_t nms_ws_bytes;
     int nms_units;
+    unsigned long long cls_mask[2];   // classes the NMS keeps (ss_nms_set_classes); all ones = every class
     int cos_grid;               // persistent workgroups of the association kernel
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
@@ -95,6 +97,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->ev_used = 0;
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
     c->inkernel = 0;
+    c->cls_mask[0] = c->cls_mask[1] = ~0ull;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -390,9 +393,23 @@ extern "C" int ss_nms_batch(ss_ctx* c, const float* pred, int batch, long long p
     if (rc) return rc;
     rc = ss_launch_nms(pred, batch, pred_batch_stride, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh,
                        max_det, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, d_geom, rows, row_stride, rows_batch_stride, keep,
-                       keep_batch_stride, count, c->nms_ws, c->nms_ws_bytes * (size_t)c->nms_units, c->stream);
+                       keep_batch_stride, count, c->nms_ws, c->nms_ws_bytes * (size_t)c->nms_units, c->cls_mask[0], c->cls_mask[1],
+                       c->stream);
     if (rc) return fail(c, rc, "ss_nms_batch: anchors exceed the workspace (n_anchors <= 32768)");
     HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_nms_set_classes(ss_ctx* c, const int* classes, int n)
+{
+    if (!c || n < 0 || (n > 0 && !classes)) return fail(c, SS_ERR_INVALID, "ss_nms_set_classes: bad argument");
+    if (n == 0) { c->cls_mask[0] = c->cls_mask[1] = ~0ull; return SS_OK; }
+    unsigned long long m[2] = { 0, 0 };
+    for (int i = 0; i < n; ++i) {
+        if (classes[i] < 0 || classes[i] >= 128) return fail(c, SS_ERR_INVALID, "ss_nms_set_classes: class ids 0..127");
+        m[classes[i] >> 6] |= 1ull << (classes[i] & 63);
+    }
+    c->cls_mask[0] = m[0]; c->cls_mask[1] = m[1];
     return SS_OK;
 }
 
@@ -404,7 +421,7 @@ extern "C" int ss_nms(ss_ctx* c, const float* pred, int n_anchors, int nc, int n
         return fail(c, SS_ERR_INVALID, "ss_nms: bad argument");
     int rc = ss_launch_nms(pred, 1, 0, n_anchors, nc, n_extra, conf_thres, iou_thres, agnostic, max_wh, max_det, gain,
                            pad_x, pad_y, w0, h0, nullptr, rows, row_stride, 0, keep, 0, count, c->nms_ws,
-                           c->nms_ws_bytes * (size_t)c->nms_units, c->stream);
+                           c->nms_ws_bytes * (size_t)c->nms_units, c->cls_mask[0], c->cls_mask[1], c->stream);
     if (rc) return fail(c, rc, "ss_nms: anchors exceed the workspace (n_anchors <= 32768)");
     HIPCHK(c, hipGetLastError());
     return SS_OK;

@@ -192,7 +192,8 @@ __device__ inline NmsWs nms_unit(const NmsBatch& nb, int img) { return carve_nms
 
 // candidate filter: best class per anchor, score > conf.  key = (~score_bits, anchor): ascending
 // key order == descending score, ties by ascending anchor (stable order of the oracle's sort).
-__global__ __launch_bounds__(512) void k_nms_filter(NmsBatch nb, int N, int nc, float conf)
+__global__ __launch_bounds__(512) void k_nms_filter(NmsBatch nb, int N, int nc, float conf, unsigned long long cm0,
+                                                    unsigned long long cm1)
 {
     const float* __restrict__ pred = nb.pred + (size_t)blockIdx.y * nb.pred_stride;
     const NmsWs w = nms_unit(nb, blockIdx.y);
@@ -215,7 +216,9 @@ __global__ __launch_bounds__(512) void k_nms_filter(NmsBatch nb, int N, int nc, 
         float s = sbest[q][l]; int c = scls[q][l];
         if (s > best || (s == best && c < bc)) { best = s; bc = c; }       // first maximum = lowest class
     }
-    if (best > conf) {
+    // `classes` override (yolo_multi_model.py:22): the anchor's best class must be in the allowed set
+    const bool allowed = bc < 64 ? (cm0 >> bc) & 1ull : bc < 128 ? (cm1 >> (bc - 64)) & 1ull : true;
+    if (best > conf && allowed) {
         int slot = atomicAdd(&w.counters[0], 1);
         w.keys[slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)a;
         w.cand_cls[a] = bc;
@@ -380,13 +383,14 @@ int* ss_nms_error_flag(void* ws, int unit) { return carve_nms((char*)ws + (size_
 int ss_launch_nms(const float* pred, int batch, long long pred_stride, int N, int nc, int n_extra, float conf, float iou,
                   int agnostic, float max_wh, int max_det, float gain, float pad_x, float pad_y, float w0, float h0,
                   const float* geom, float* rows, int row_stride, long long rows_batch_stride, int* keep,
-                  long long keep_batch_stride, int* count, void* ws, size_t ws_bytes, hipStream_t st)
+                  long long keep_batch_stride, int* count, void* ws, size_t ws_bytes, unsigned long long cm0,
+                  unsigned long long cm1, hipStream_t st)
 {
     if (batch <= 0) return 0;
     if (N > NMS_MAX_ANCHORS || ws_bytes < ss_nms_workspace_bytes() * (size_t)batch) return SS_ERR_CAPACITY;
     NmsBatch nb{ pred, pred_stride, (char*)ws, (long long)ss_nms_workspace_bytes() };
     // the candidate counter is re-armed by k_nms_scan itself (no memset node: graph-capture safe)
-    hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64, batch), dim3(512), 0, st, nb, N, nc, conf);
+    hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64, batch), dim3(512), 0, st, nb, N, nc, conf, cm0, cm1);
     hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(1024), NMS_MAX_CAND * 8, st, nb, N, agnostic, max_wh);
     // mask grid sized for the worst case the filter could produce; blocks beyond n exit at once
     const int nbmax = (min(N, NMS_MAX_CAND) + 63) / 64;

@@ -297,6 +297,12 @@ class TrackerEngine:
                                      rows.stride(0), _ptr(keep), keep.stride(0), _ptr(count)))
         return rows, keep, count
 
+    def nms_set_classes(self, classes=None):
+        """Keep only these class ids in the following NMS calls (None / empty: all) — overrides['classes']."""
+        cl = [] if classes is None else ([int(classes)] if np.isscalar(classes) else [int(c) for c in classes])
+        arr = (C.c_int * max(len(cl), 1))(*cl)
+        self._ck(self.L.ss_nms_set_classes(self.ctx, arr, len(cl)))
+
     def crop_norm_batch(self, frames: torch.Tensor, dets: torch.Tensor, n: int, counts=None, half: bool = False,
                         out=None, channels_last: bool = False):
         """frames uint8 [B,H,W,3], dets [B,cap,>=4] float32, counts [B] int32 -> crops [B*n,3,256,128]."""

@@ -17,8 +17,9 @@ Synthetic-workload switches (no weights / no decoder exist offline, SURVEY §0.8
               = "by_anchor" the tracker consumes gt_feats[anchor_gt[keep]]: the feature of the
                             synthetic identity whose anchor survived NMS (OSNet still runs)
   graph = "all"   whole step in one HIP graph;  "front" everything up to the ReID output in the
-          graph and the three tracker kernels launched eagerly (lets bench.py bracket the
-          association kernel with HIP events);  "none" eager.
+          graph and the tracker kernels launched eagerly (lets bench.py bracket the association
+          kernel with HIP events);  "split" three graphs (detection | ReID | tracker) so that a
+          detection-only call replays only the first;  "none" eager.
 """
 from __future__ import annotations
 
@@ -81,10 +82,10 @@ class FramePipeline:
         self.graph_mode = graph
 
     # ---- one frame for every stream, from the static buffers ----------------------------------------
-    def _step_impl(self):
+    def _detect_impl(self):
         # every frame-side stage is ONE launch (set) over all S streams, written straight in the NHWC layout the
         # convolutions read
-        e, S, g = self.eng, self.S, self.geom
+        e, g = self.eng, self.geom
         if self.run_nets:
             e.letterbox_batch(self.frames, g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb, channels_last=True)
             pred = self.detector(self.lb)                       # [S, 4+nc+nk, A]
@@ -94,6 +95,9 @@ class FramePipeline:
                     count=self.ndets, max_det=self.max_det)
         if self.nk:
             self.dets6.copy_(self.dets[:, :, :6])
+
+    def _reid_impl(self):
+        e, S = self.eng, self.S
         if self.run_nets:
             e.crop_norm_batch(self.frames, self.dets6, self.RB, counts=self.ndets, half=self.half, out=self.crops,
                               channels_last=True)
@@ -104,14 +108,20 @@ class FramePipeline:
             idx = self.anchor_gt.gather(1, self.keep.long().clamp_(0, self.n_anchors - 1))      # [S,128]
             torch.gather(self.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=self.feats_in)
 
+    def _step_impl(self):
+        self._detect_impl()
+        self._reid_impl()
+
     def _track(self):
         self.eng.update_device(self.dets6, self.ndets, self.feats_in, self.img_hw)
 
     def step(self, track: bool = True):
-        """Run one frame (all streams).  Asynchronous; results in self.out / self.nout (device)."""
+        """Run one frame (all streams).  Asynchronous; results in self.out / self.nout (device).
+        track=False (graph "none" / "split" only skip the work): detection only — letterbox, detector, NMS."""
         if self.graph_mode == "none":
-            self._step_impl()
+            self._detect_impl()
             if track:
+                self._reid_impl()
                 self._track()
             return
         if self.graph is None:
@@ -125,14 +135,28 @@ class FramePipeline:
                     self._track()
                 st.synchronize()
                 self._restore_tracker()
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=st):
-                    self._step_impl()
-                    if self.graph_mode == "all":
-                        self._track()
+                if self.graph_mode == "split":
+                    # three graphs on the same static buffers: detection | ReID | tracker, so a detection-only call
+                    # (model.predict, yolo_multi_model.py:173) replays just the first
+                    self.graph = []
+                    for fn in (self._detect_impl, self._reid_impl, self._track):
+                        gph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gph, stream=st):
+                            fn()
+                        self.graph.append(gph)
+                else:
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph, stream=st):
+                        self._step_impl()
+                        if self.graph_mode == "all":
+                            self._track()
             torch.cuda.current_stream(self.dev).wait_stream(st)
             self.eng.use_current_stream()
             self._restore_tracker()          # warm-up frames must not count: streams start fresh
+        if self.graph_mode == "split":
+            for gph in (self.graph if track else self.graph[:1]):
+                gph.replay()
+            return
         self.graph.replay()
         if self.graph_mode == "front":
             self._track()

@@ -76,60 +76,102 @@ class Results:
 
 
 class YOLO:
-    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False):
+    """`model = YOLO("yolo11n-pose.pt")` (yolo_multi_model.py:17).  `.track(frame)` / `.predict(frame)` replay HIP graphs
+    captured once per (frame shape, overrides): the frame goes through a pinned host buffer, every stage runs on the
+    device, the results come back through pinned buffers and there is ONE stream synchronisation per call.
+    `.track_stream(frames, batch=16)` is the throughput form for sources that can supply frames ahead (files): groups
+    of `batch` frames through the two-stream pipeline, same rows.
+
+    Changing `.overrides` (or the frame size) re-captures the graphs and restarts the tracker, as a new
+    `model.track(..., persist=False)` would."""
+
+    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128):
         self.weights = weights
         self.random_init_ok = random_init_ok
         self.arch = os.path.basename(weights).replace(".pt", "")
         self.overrides = {"conf": 0.25, "iou": 0.7, "agnostic_nms": False, "max_det": 300}
         self.seed = seed
+        self.reid_batch = reid_batch
         pose = "pose" in self.arch
         self.names = {0: "person"} if pose else dict(enumerate(COCO_NAMES))
         self._pipe = None
-        self._shape = None
+        self._key = None
+        self._stream_pipe = None
+        self._stream_key = None
+        # test / bench hooks (synthetic head tensors, no weights exist offline): extra pipeline keywords and a callable
+        # fill(buffers, virtual_stream, frame_index) that writes pred_in / anchor_gt / gt_feats before a frame runs
+        self._pipe_kw = {}
+        self._fill = None
+        self._frame_index = 0
 
     def _dcfg(self):
         o = self.overrides
         return DetectConfig(conf=float(o["conf"]), iou=float(o["iou"]), agnostic_nms=bool(o["agnostic_nms"]),
                             max_det=int(o["max_det"]))
 
+    def _state_key(self, shape, device):
+        cl = self.overrides.get("classes")
+        cl = None if cl is None else tuple(int(c) for c in (cl if isinstance(cl, (list, tuple)) else [cl]))
+        return (tuple(shape), int(device or 0), self._dcfg(), cl)
+
+    def _build(self, cls, shape, device, **kw):
+        from . import nets
+        args = dict(reid_batch=self.reid_batch, cfg=StrongSortConfig(), dcfg=self._dcfg(), det_source="detector",
+                    feat_source="reid", seed=self.seed)
+        args.update(self._pipe_kw)
+        args.update(kw)
+        pipe = cls(self.arch, 1, shape, device=int(device or 0), **args)
+        nets.load_weights(pipe.detector, self.weights, f"detector {self.arch}", self.random_init_ok)
+        pipe.eng.nms_set_classes(self.overrides.get("classes"))
+        return pipe
+
+    # ---- per-frame path -------------------------------------------------------------------------------------
     def _pipeline(self, image, device):
         from .pipeline import FramePipeline
-        shape = image.shape[:2]
-        if self._pipe is None or self._shape != shape:
+        key = self._state_key(image.shape[:2], device)
+        if self._pipe is None or key != self._key:
             if self._pipe is not None:
                 self._pipe.close()
-            self._pipe = FramePipeline(self.arch, 1, shape, device=int(device or 0), reid_batch=128, cfg=StrongSortConfig(),
-                                       dcfg=self._dcfg(), det_source="detector", feat_source="reid", graph="none",
-                                       seed=self.seed)
-            from . import nets
-            nets.load_weights(self._pipe.detector, self.weights, f"detector {self.arch}", self.random_init_ok)
-            self._shape = shape
-        self._pipe.dcfg = self._dcfg()
+            p = self._pipe = self._build(FramePipeline, image.shape[:2], device, graph="split")
+            self._key = key
+            self._frame_index = 0
+            H, W = image.shape[:2]
+            self._h_frame = torch.empty(H, W, 3, dtype=torch.uint8).pin_memory()
+            self._h_rows = torch.empty(p.out.shape[1], 8).pin_memory()
+            self._h_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
+            self._h_cnt = torch.zeros(2, dtype=torch.int32).pin_memory()
+            self._d_cnt = torch.zeros(2, dtype=torch.int32, device=p.dev)
         return self._pipe
 
     def _run(self, image, device, track):
         pipe = self._pipeline(image, device)
-        pipe.frames[0].copy_(torch.from_numpy(np.ascontiguousarray(image)))
+        self._h_frame.copy_(torch.from_numpy(np.ascontiguousarray(image)))
+        pipe.frames[0].copy_(self._h_frame, non_blocking=True)
+        if self._fill is not None:
+            self._fill(pipe, 0, self._frame_index)
         pipe.step(track=track)
-        torch.cuda.synchronize(pipe.dev)
-        n = int(pipe.ndets[0])
-        dets = pipe.dets[0, :n].cpu()
-        classes = self.overrides.get("classes")
+        self._d_cnt[0:1].copy_(pipe.ndets)
+        self._h_dets.copy_(pipe.dets[0], non_blocking=True)
+        if track:
+            self._d_cnt[1:2].copy_(pipe.nout)
+            self._h_rows.copy_(pipe.out[0], non_blocking=True)
+        self._h_cnt.copy_(self._d_cnt, non_blocking=True)
+        torch.cuda.current_stream(pipe.dev).synchronize()            # the one synchronisation of the call
+        pipe.eng.check_errors()
+        self._frame_index += 1
+        n, m = int(self._h_cnt[0]), int(self._h_cnt[1])
+        return self._results(image, pipe, self._h_dets[:n].clone(), self._h_rows[:m].clone() if track else None)
+
+    def _results(self, image, pipe, dets, rows):
         kpts = None
         if pipe.nk:
-            k = dets[:, 6:].reshape(n, pipe.nk // 3, 3).clone()
+            k = dets[:, 6:].reshape(dets.shape[0], pipe.nk // 3, 3).clone()
             k[..., 0] = (k[..., 0] - pipe.pad_x) / pipe.gain
             k[..., 1] = (k[..., 1] - pipe.pad_y) / pipe.gain
             kpts = k
-        if not track:
-            keep = torch.ones(n, dtype=torch.bool)
-            if classes is not None:
-                cl = classes if isinstance(classes, (list, tuple)) else [classes]
-                keep = torch.isin(dets[:, 5].long(), torch.tensor(cl))
-            return [Results(image, self.names, Boxes(dets[keep, :4], dets[keep, 4], dets[keep, 5]),
-                            None if kpts is None else Keypoints(kpts[keep]))]
-        pipe.eng.check_errors()
-        rows = pipe.out[0, : int(pipe.nout[0])].cpu()
+        if rows is None:
+            return [Results(image, self.names, Boxes(dets[:, :4], dets[:, 4], dets[:, 5]),
+                            None if kpts is None else Keypoints(kpts))]
         rows = rows[rows[:, 7] >= 0]                   # ultralytics semantics: results[i] = results[i][det_idx]
         if rows.shape[0] == 0:
             return [Results(image, self.names, Boxes(torch.zeros(0, 4), torch.zeros(0), torch.zeros(0), None))]
@@ -148,3 +190,99 @@ class YOLO:
         return self._run(image, device, False)
 
     __call__ = predict
+
+    # ---- throughput path ------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def track_stream(self, frames, batch: int = 16, device=0):
+        """Generator over `frames` (BGR uint8 arrays of one size): yields the same [Results] `track(frame)` would, in
+        order, `batch` frames at a time through the overlapped two-stream pipeline (stateless stages of group k+1 run
+        while the tracker consumes group k; the tracker reads its galleries once per group)."""
+        from .pipeline import OverlappedPipeline
+        it = iter(frames)
+        first = next(it, None)
+        if first is None:
+            return
+        key = self._state_key(first.shape[:2], device) + (batch,)
+        if self._stream_pipe is None or key != self._stream_key:
+            if self._stream_pipe is not None:
+                self._stream_pipe.close()
+            self._stream_pipe = self._build(OverlappedPipeline, first.shape[:2], device, graph="front", frame_batch=batch,
+                                            reid_split=2 if batch > 1 else None)
+            self._stream_key = key
+        pipe = self._stream_pipe
+        F, H, W = batch, first.shape[0], first.shape[1]
+        ring = 3                                                          # result slots: groups in flight + one
+        h_frames = [torch.empty(F, H, W, 3, dtype=torch.uint8).pin_memory() for _ in range(ring)]
+        h_rows = torch.empty(ring, F, pipe.outs.shape[2], 8).pin_memory()
+        h_dets = torch.empty(ring, F, pipe.bufs[0].dets.shape[1], pipe.bufs[0].dets.shape[2]).pin_memory()
+        h_cnt = torch.zeros(ring, 2, F, dtype=torch.int32).pin_memory()
+        done = [torch.cuda.Event() for _ in range(ring)]
+        pending = []                                                      # (group index, frames of the group)
+        state = {"group": 0}
+
+        def on_result(frame_idx, f):                                      # runs while the last stage is being enqueued
+            g, nv = state["cur"], state["nv"]
+            if f != nv - 1:
+                return
+            slot, b = g % ring, pipe.bufs[g % pipe.nb]
+            h_rows[slot, :nv].copy_(pipe.outs[:nv, 0], non_blocking=True)
+            h_cnt[slot, 1, :nv].copy_(pipe.nouts[:nv, 0], non_blocking=True)
+            h_cnt[slot, 0, :nv].copy_(b.ndets[:nv], non_blocking=True)
+            h_dets[slot, :nv].copy_(b.dets[:nv], non_blocking=True)
+            done[slot].record(torch.cuda.current_stream(pipe.dev))
+
+        # the last stage of group g is enqueued during submit() of group g+1 (or flush()): remember which group that is
+        orig_run = pipe._run_stage
+
+        def run_stage(j, group_idx):
+            if j == pipe.n - 1:
+                state["cur"], state["nv"] = group_idx, pipe.valid[group_idx % pipe.nb]
+            return orig_run(j, group_idx)
+
+        pipe._run_stage, pipe.on_result = run_stage, on_result
+
+        def finish(g, imgs):
+            slot = g % ring
+            done[slot].synchronize()
+            for f, img in enumerate(imgs):
+                n, m = int(h_cnt[slot, 0, f]), int(h_cnt[slot, 1, f])
+                yield self._results(img, pipe, h_dets[slot, f, :n].clone(), h_rows[slot, f, :m].clone())
+
+        try:
+            chunk = [first]
+            while chunk:
+                while len(chunk) < F:
+                    nxt = next(it, None)
+                    if nxt is None:
+                        break
+                    chunk.append(nxt)
+                g = state["group"]
+                hb = h_frames[g % ring]                                    # its last user (group g-3) has been synchronised
+                b = pipe.begin_frame()                                    # waits until this buffer set's last group left the tracker
+                for f, img in enumerate(chunk):
+                    hb[f].copy_(torch.from_numpy(np.ascontiguousarray(img)))
+                with torch.cuda.stream(pipe.sA):
+                    b.frames[:len(chunk)].copy_(hb[:len(chunk)], non_blocking=True)
+                    if self._fill is not None:
+                        for f in range(len(chunk)):
+                            self._fill(b, f, self._frame_index + f)
+                self._frame_index += len(chunk)
+                pipe.submit(len(chunk))
+                pending.append((g, chunk))
+                state["group"] = g + 1
+                while len(pending) > 2:                                   # results of group g-2 are certainly enqueued
+                    yield from finish(*pending.pop(0))
+                nxt = next(it, None)
+                chunk = [nxt] if nxt is not None else []
+            pipe.flush()
+            while pending:
+                yield from finish(*pending.pop(0))
+            pipe.eng.check_errors()
+        finally:
+            pipe._run_stage, pipe.on_result = orig_run, None
+
+    def close(self):
+        for p in (self._pipe, self._stream_pipe):
+            if p is not None:
+                p.close()
+        self._pipe = self._stream_pipe = None

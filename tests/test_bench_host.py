@@ -30,7 +30,7 @@ def test_workload_and_oracle_replay():
     assert wl["preds"].shape == (8, 84, A) and wl["agt"].shape == (8, A) and wl["pixels"].dtype == np.uint8
     rows = b.oracle_rows(wl, 8, W, H, gs, 80, StrongSortConfig(), DetectConfig())
     assert len(rows) == 8 and rows[-1].shape[1] == 8 and len(rows[-1]) > 0        # confirmed tracks by frame 3
-    assert set(b.PRESETS) >= {"c2", "c3", "c4", "c5"} and b.PREFILL >= 103 and b.PREFILL % 8 == 0
+    assert set(b.PRESETS) >= {"c2", "c3", "c4", "c5"} and b.PREFILL >= 103 and b.PREFILL % 16 == 0
 
 
 @settings(max_examples=15, deadline=None)

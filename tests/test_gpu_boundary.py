@@ -59,3 +59,110 @@ def test_yolo_track_and_predict_contract(weights):
     for bbox in r.boxes:
         for scores, classes, xyxy, id_ in zip(bbox.conf, bbox.cls, bbox.xyxy, bbox.id):
             assert int(id_) >= 1 and 0 <= float(scores) <= 1 and int(classes) in r.names
+
+
+# ---- the fast paths behind the drop-in calls ---------------------------------------------------------
+H_, W_, NF_ = 480, 640, 37
+
+
+def _synthetic_model(weights="yolov8n.pt", n_ids=9, nk=0):
+    """YOLO object whose NMS consumes a synthetic head tensor (the random-init detector still runs for load) and whose
+    tracker consumes the synthetic identity features: the oracle chain can be replayed on the same inputs."""
+    from oracle import cexact
+    from strongsort_yolo_amd.config import DetectConfig
+    from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
+    from strongsort_yolo_amd.synth import synth_prediction
+    from strongsort_yolo_amd.yolo import YOLO
+    model = YOLO(weights, random_init_ok=True)
+    model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)            # yolo_multi_model.py:18-21
+    model._pipe_kw = dict(det_source="synthetic", feat_source="by_anchor", reid_batch=32)
+    g = letterbox_geometry(H_, W_)
+    gs = scale_geometry(g, H_, W_)
+    A = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
+    nc = 1 if nk else 80
+    st, rng = make_stream(41, W_, H_, n_ids), np.random.default_rng(41)
+    frames, preds, agts, feats = [], [], [], []
+    for k in range(NF_):
+        fr = st.next_frame()
+        pred, agt = synth_prediction(fr.dets, A, nc, gs[0], (gs[1], gs[2]), rng)
+        if nk:                                               # keypoint rows: any values, they must follow their anchor
+            pred = np.concatenate([pred, rng.uniform(0, 400, (nk, A)).astype(np.float32)])
+        f = np.zeros((128, 512), np.float32)
+        f[:len(fr.feats)] = fr.feats
+        frames.append(st.frame_pixels(k).copy()); preds.append(pred); agts.append(agt); feats.append(f)
+    dev = torch.device("cuda", 0)
+    dp, da, df = (torch.from_numpy(np.stack(x)).to(dev) for x in (preds, agts, feats))
+
+    def fill(b, v, k):
+        b.pred_in[v].copy_(dp[k]); b.anchor_gt[v].copy_(da[k]); b.gt_feats[v].copy_(df[k])
+
+    model._fill = fill
+    dcfg, orc, ref = DetectConfig(), OracleStrongSort(StrongSortConfig(), "c"), []
+    for k in range(NF_):
+        keep, r = cexact.nms(preds[k][:4 + nc], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 32)
+        r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W_, H_)
+        rows = orc.update(r, feats[k][np.maximum(agts[k][keep], 0)], (H_, W_))
+        kp = None
+        if nk:
+            kp = preds[k][4 + nc:, keep].T.reshape(len(keep), nk // 3, 3).copy()
+            kp[..., 0] = (kp[..., 0] - np.float32(gs[1])) / np.float32(gs[0])
+            kp[..., 1] = (kp[..., 1] - np.float32(gs[2])) / np.float32(gs[0])
+        ref.append((r, rows[rows[:, 7] >= 0], kp))
+    return model, frames, ref
+
+
+def _check_tracked(res, ref_rows, ref_kp, k):
+    r = res[0]
+    if len(ref_rows) == 0:
+        assert len(r.boxes) == 0 and r.boxes.id is None, f"frame {k}"
+        return
+    assert np.array_equal(r.boxes.id.numpy(), ref_rows[:, 4]), f"frame {k}: ids"
+    assert np.array_equal(r.boxes.xyxy.numpy(), ref_rows[:, :4]) and np.array_equal(r.boxes.cls.numpy(), ref_rows[:, 5])
+    assert np.array_equal(r.boxes.conf.numpy(), ref_rows[:, 6])
+    if ref_kp is not None:                                   # keypoints follow det_idx (BASELINE configs[4], SURVEY §8d C5)
+        assert np.allclose(r.keypoints.data.numpy(), ref_kp[ref_rows[:, 7].astype(int)], rtol=0, atol=1e-4), f"frame {k}: keypoints"
+
+
+@pytest.mark.parametrize("weights,nk", [("yolov8n.pt", 0), ("yolov8n-pose.pt", 51)])
+def test_yolo_track_graph_path_equals_oracle(weights, nk):
+    """model.track(frame) per frame (yolo_multi_model.py:41): replayed HIP graphs, pinned buffers, one sync per call."""
+    model, frames, ref = _synthetic_model(weights, nk=nk)
+    for k in range(20):
+        _check_tracked(model.track(frames[k], verbose=False, device=0, persist=True, tracker="botsort.yaml"), ref[k][1], ref[k][2], k)
+    # model.predict on the same object: detection only, the tracker does not advance
+    det = model.predict(frames[20], verbose=False, device=0)[0]
+    assert np.array_equal(det.boxes.xyxy.numpy(), ref[20][0][:, :4]) and np.array_equal(det.boxes.conf.numpy(), ref[20][0][:, 4])
+    model.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4, 16])
+def test_yolo_track_stream_equals_oracle(batch):
+    """the throughput form: groups of `batch` frames through the overlapped pipeline, partial last group included"""
+    model, frames, ref = _synthetic_model()
+    n = 0
+    for k, res in enumerate(model.track_stream(iter(frames), batch=batch, device=0)):
+        _check_tracked(res, ref[k][1], ref[k][2], k)
+        assert res[0].orig_img is frames[k]
+        n += 1
+    assert n == NF_
+    model.close()
+
+
+def test_cli_process_video_on_the_gpu(tmp_path):
+    """labels file + class counts of the reference's --track --count loop (yolo_multi_model.py:244-339) through the real
+    model object, both the grouped and the per-frame call form giving the same file."""
+    from strongsort_yolo_amd.cli import process_video
+    outs = []
+    for batch in (8, 1):
+        model, frames, ref = _synthetic_model()
+        np.save(tmp_path / f"clip{batch}.npy", np.stack(frames))
+        out = process_video({"source": str(tmp_path / f"clip{batch}.npy"), "track": True, "count": True,
+                             "outdir": str(tmp_path), "batch": batch}, model)
+        assert out["frames"] == NF_ and out["counts"] == {"person": len({int(i) for _, rows, _ in ref for i in rows[:, 4]})}
+        lines = open(tmp_path / f"clip{batch}_labels.txt").read().strip().split("\n")
+        assert len(lines) == sum(len(rows) for _, rows, _ in ref)
+        f0 = lines[-1].split()
+        assert len(f0) == 12 and f0[0] == str(NF_ - 1) and f0[-4:] == ["-1"] * 4 and all("." not in v for v in f0[4:8])
+        outs.append(lines)
+        model.close()
+    assert outs[0] == outs[1]

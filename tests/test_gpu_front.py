@@ -240,3 +240,26 @@ def test_crop_norm_batch_bit_exact(eng, half, hwc):
         ref = cexact.crop_norm(imgs[b], dets[b, :counts[b]])
         assert bits_equal(got[b, :counts[b]], ref.astype(np.float16) if half else ref)
         assert np.all(got[b, counts[b]:] == 7.0)             # rows past the count stay untouched
+
+
+def test_nms_classes_override(eng):
+    """overrides['classes'] (yolo_multi_model.py:22): anchors whose best class is not listed never become candidates."""
+    W, H, nc = 1280, 720, 80
+    dcfg = DetectConfig()
+    g = letterbox_geometry(H, W)
+    gain, px, py = scale_geometry(g, H, W)
+    N = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
+    fr = make_stream(5, W, H, 40, n_classes=3).next_frame()
+    pred, _ = synth_prediction(fr.dets, N, nc, gain, (px, py), np.random.default_rng(2))
+    try:
+        for classes in ([0, 2], [1], [79]):
+            eng.nms_set_classes(classes)
+            rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, gain, px, py, W, H)
+            k = int(count.item())
+            rkeep, rrows = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, dcfg.max_det,
+                                      classes=classes)
+            assert np.array_equal(keep.cpu().numpy()[:k], rkeep)
+            assert bits_equal(rows.cpu().numpy()[:k], cexact.scale_boxes(rrows, gain, px, py, W, H))
+            assert set(rrows[:, 5].astype(int).tolist()) <= set(classes) and (k > 0) == (79 not in classes)
+    finally:
+        eng.nms_set_classes(None)
