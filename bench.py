@@ -73,19 +73,22 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def make_workload(seed, W, H, n_ids, n_frames, geom_scale, nc, n_anchors):
-    """Host arrays for one stream: head tensors, anchor->identity maps, identity features."""
+def make_workload(seed, W, H, n_ids, n_frames, geom_scale, nc, n_anchors, nk=0):
+    """Host arrays for one stream: head tensors, anchor->identity maps, identity features (nk > 0: pose head, nk
+    extra keypoint rows per anchor that NMS carries through with the kept anchors)."""
     from strongsort_yolo_amd.synth import make_stream, synth_prediction
     gain, px, py = geom_scale
     st = make_stream(seed, W, H, n_ids)
     rng = np.random.default_rng(seed + 104729)
-    preds = np.empty((n_frames, 4 + nc, n_anchors), np.float32)
+    preds = np.empty((n_frames, 4 + nc + nk, n_anchors), np.float32)
     agt = np.empty((n_frames, n_anchors), np.int64)
     feats = np.zeros((n_frames, 128, 512), np.float32)
     ndet = 0
     for k in range(n_frames):
         fr = st.next_frame()
-        preds[k], agt[k] = synth_prediction(fr.dets, n_anchors, nc, gain, (px, py), rng)
+        preds[k, :4 + nc], agt[k] = synth_prediction(fr.dets, n_anchors, nc, gain, (px, py), rng)
+        if nk:
+            preds[k, 4 + nc:] = rng.uniform(0, 640, (nk, n_anchors))
         feats[k, :len(fr.dets)] = fr.feats
         ndet += len(fr.dets)
     pixels = np.stack([st.frame_pixels(i) for i in range(st.cfg.frame_pool)])
@@ -100,7 +103,7 @@ def oracle_rows(wl, n_frames, W, H, geom_scale, nc, cfg, dcfg):
     orc = OracleStrongSort(cfg, "c")
     rows = []
     for k in range(n_frames):
-        keep, r = cexact.nms(wl["preds"][k], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh,
+        keep, r = cexact.nms(wl["preds"][k][:4 + nc], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh,
                              dcfg.max_nms, min(dcfg.max_det, 128))
         r = cexact.scale_boxes(r, gain, px, py, W, H)
         f = wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
@@ -248,6 +251,62 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, 
             "batched_id_match_rate": round(same / max(tot, 1), 6) if check else None, "rows_checked": tot}
 
 
+def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device=0, timed=192, batch=16):
+    """The drop-in calls themselves (what the reference's loop does at yolo_multi_model.py:41 / :270-278): per-frame
+    `model.track(frame)` with host frames in, Results out (replayed HIP graphs, one sync per call), and
+    `model.track_stream(frames, batch)` (overlapped pipeline behind the same object).  Same synthetic head-tensor
+    injection as the main measurement; host->device frame copies included."""
+    import torch
+    from strongsort_yolo_amd.yolo import YOLO
+    total = PREFILL + timed
+    wl = make_workload(4242, W, H, n_ids, total, geom_scale, nc, n_anchors)
+    dev = torch.device("cuda", device)
+    dp, da, df = (torch.from_numpy(wl[k]).to(dev) for k in ("preds", "agt", "feats"))
+    frames = [wl["pixels"][k % len(wl["pixels"])] for k in range(total)]
+    ref = oracle_rows(wl, total, W, H, geom_scale, nc, cfg, dcfg)
+
+    def fill(b, v, k):
+        b.pred_in[v].copy_(dp[k]); b.anchor_gt[v].copy_(da[k]); b.gt_feats[v].copy_(df[k])
+
+    def model():
+        m = YOLO(detector + ".pt", random_init_ok=True, reid_batch=32)
+        m.overrides.update(conf=dcfg.conf, iou=dcfg.iou, agnostic_nms=dcfg.agnostic_nms, max_det=dcfg.max_det)
+        m._pipe_kw = dict(det_source="synthetic", feat_source="by_anchor")
+        m._fill = fill
+        return m
+
+    def same(res, k):
+        r = ref[k][ref[k][:, 7] >= 0]
+        b = res[0].boxes
+        return (len(r) == 0 and len(b) == 0) or (b.id is not None and np.array_equal(b.id.numpy(), r[:, 4]) and np.array_equal(b.xyxy.numpy(), r[:, :4]))
+
+    import warnings
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        m = model()
+        ok = 0
+        for k in range(PREFILL):
+            ok += same(m.track(frames[k], verbose=False, device=device, persist=True), k)
+        t0 = time.perf_counter()
+        for k in range(PREFILL, total):
+            ok += same(m.track(frames[k], verbose=False, device=device, persist=True), k)
+        out["per_frame_track_frames_per_s"] = round(timed / (time.perf_counter() - t0), 1)
+        m.close()
+        m = model()
+        t0 = None
+        for k, res in enumerate(m.track_stream(iter(frames), batch=batch, device=device)):
+            ok += same(res, k)
+            if k == PREFILL - 1:
+                t0 = time.perf_counter()
+        out["track_stream_frames_per_s"] = round(timed / (time.perf_counter() - t0), 1)
+        out["track_stream_batch"] = batch
+        m.close()
+    out["frames_identical_to_oracle"] = f"{ok}/{2 * total}"
+    out["note"] = "host uint8 frames in, Results objects out; 1 stream; galleries full; synthetic head tensor + identity features"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,6 +320,7 @@ def main():
     ap.add_argument("--no-nets", action="store_true", help="skip detector/ReID (tracker-path microbench; not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
+    ap.add_argument("--no-api-path", action="store_true", help="skip the YOLO.track / track_stream measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
@@ -319,7 +379,7 @@ def main():
                    run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream} if overlap else {}))
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
-    wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A) for s in range(S)]
+    wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A, pipe.nk) for s in range(S)]
     dev = pipe.dev
     pools = [dict(preds=torch.from_numpy(w["preds"]).to(dev), agt=torch.from_numpy(w["agt"]).to(dev),
                   feats=torch.from_numpy(w["feats"]).to(dev), pixels=torch.from_numpy(w["pixels"]).to(dev)) for w in wls]
@@ -482,6 +542,8 @@ def main():
         if world == 1 and not args.no_batched:
             res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16) else 8)
             res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=1, check=False)
+        if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
+            res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, n_ids, pipe.geom, gs, nc, A, cfg, dcfg, detector)
         print(json.dumps(res), flush=True)
