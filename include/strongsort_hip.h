@@ -61,6 +61,11 @@ int  ss_set_hip_stream(ss_ctx* ctx, void* hip_stream);   /* e.g. torch.cuda.curr
 int  ss_reset(ss_ctx* ctx, int stream);                  /* stream < 0: all streams */
 int  ss_synchronize(ss_ctx* ctx);
 
+/* Frame source side of model.track(image) (yolo_multi_model.py:272 cap.read() -> :41): copy a host frame (any pageable
+ * memory, e.g. the array cv2 returned) into device memory through the context's write-combined pinned staging ring,
+ * asynchronously on `hip_stream`.  The host buffer may be reused as soon as the call returns. */
+int ss_upload(ss_ctx* ctx, void* hip_stream, void* d_dst, const void* h_src, size_t bytes);
+
 /* ---- a1  letterbox / preprocess  (inside model.track/.predict, yolo_multi_model.py:41,:173) ---
  * BGR u8 [h][w][3] (row_stride bytes) -> RGB [3][out_h][out_w], /255, pad 114.
  * dst_flags: bit 0 (SS_DST_F16) writes IEEE half, else float; bit 1 (SS_DST_HWC) writes

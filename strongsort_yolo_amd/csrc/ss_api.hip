@@ -49,6 +49,9 @@ struct ss_ctx {
     size_t nms_ws_bytes;
     int nms_units;
     unsigned long long cls_mask[2];   // classes the NMS keeps (ss_nms_set_classes); all ones = every class
+    // host -> device upload staging (ss_upload): write-combined pinned buffers, used round robin
+    struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
+    int stage_next = 0;
     int cos_grid;               // persistent workgroups of the association kernel
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
@@ -162,6 +165,7 @@ extern "C" void ss_destroy(ss_ctx* c)
     (void)hipDeviceSynchronize();
     for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void* p : c->allocs) (void)hipFree(p);
+    for (auto& st : c->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
     delete c;
 }
 
@@ -169,6 +173,29 @@ extern "C" int ss_set_hip_stream(ss_ctx* c, void* s)
 {
     if (!c) return SS_ERR_INVALID;
     c->stream = (hipStream_t)s;
+    return SS_OK;
+}
+
+// Frame upload: the caller's pageable buffer -> write-combined pinned staging (streaming CPU stores, no cache snooping
+// on the DMA read) -> device, asynchronous on `hip_stream`.  Measured on the MI355X box for a 1280x720x3 frame: a
+// cacheable pinned buffer costs 3.6 ms to fill + 2.8 ms to DMA right after the CPU wrote it; pageable hipMemcpy 1.7 ms.
+extern "C" int ss_upload(ss_ctx* c, void* hip_stream, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!c || !d_dst || !h_src) return fail(c, SS_ERR_INVALID, "ss_upload: null argument");
+    if (bytes == 0) return SS_OK;
+    ss_ctx::Stage& st = c->stage[c->stage_next];
+    c->stage_next = (c->stage_next + 1) & 3;
+    if (st.busy) { HIPCHK(c, hipEventSynchronize(st.ev)); st.busy = false; }        // its previous upload has left the buffer
+    if (st.cap < bytes) {
+        if (st.p) { HIPCHK(c, hipHostFree(st.p)); st.p = nullptr; st.cap = 0; }
+        HIPCHK(c, hipHostMalloc(&st.p, bytes, hipHostMallocWriteCombined));
+        st.cap = bytes;
+    }
+    if (!st.ev) HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    memcpy(st.p, h_src, bytes);
+    HIPCHK(c, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    HIPCHK(c, hipEventRecord(st.ev, (hipStream_t)hip_stream));
+    st.busy = true;
     return SS_OK;
 }
 

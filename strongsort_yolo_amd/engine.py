@@ -101,6 +101,15 @@ class TrackerEngine:
     def check_errors(self):
         self._ck(self.L.ss_check_errors(self.ctx))
 
+    def upload(self, dst: torch.Tensor, src: np.ndarray, stream=None):
+        """Host array -> device tensor through the library's write-combined staging ring (asynchronous on `stream`,
+        default the current torch stream).  `src` may be reused immediately."""
+        src = np.ascontiguousarray(src)
+        if src.nbytes != dst.numel() * dst.element_size() or not dst.is_contiguous():
+            raise ValueError("upload: size / layout mismatch")
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._ck(self.L.ss_upload(self.ctx, C.c_void_p(st.cuda_stream), _ptr(dst), src.ctypes.data_as(C.c_void_p), src.nbytes))
+
     # ---- tracker --------------------------------------------------------------------------------
     def update_device(self, dets, ndets, feats, img_hw):
         """All streams, one frame; tensors live on the device ([S,128,6] f32, [S] i32, [S,128,512] f32,

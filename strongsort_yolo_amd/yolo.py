@@ -136,7 +136,6 @@ class YOLO:
             self._key = key
             self._frame_index = 0
             H, W = image.shape[:2]
-            self._h_frame = torch.empty(H, W, 3, dtype=torch.uint8).pin_memory()
             self._h_rows = torch.empty(p.out.shape[1], 8).pin_memory()
             self._h_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
             self._h_cnt = torch.zeros(2, dtype=torch.int32).pin_memory()
@@ -145,8 +144,7 @@ class YOLO:
 
     def _run(self, image, device, track):
         pipe = self._pipeline(image, device)
-        self._h_frame.copy_(torch.from_numpy(np.ascontiguousarray(image)))
-        pipe.frames[0].copy_(self._h_frame, non_blocking=True)
+        pipe.eng.upload(pipe.frames[0], image)
         if self._fill is not None:
             self._fill(pipe, 0, self._frame_index)
         pipe.step(track=track)
@@ -212,7 +210,6 @@ class YOLO:
         pipe = self._stream_pipe
         F, H, W = batch, first.shape[0], first.shape[1]
         ring = 3                                                          # result slots: groups in flight + one
-        h_frames = [torch.empty(F, H, W, 3, dtype=torch.uint8).pin_memory() for _ in range(ring)]
         h_rows = torch.empty(ring, F, pipe.outs.shape[2], 8).pin_memory()
         h_dets = torch.empty(ring, F, pipe.bufs[0].dets.shape[1], pipe.bufs[0].dets.shape[2]).pin_memory()
         h_cnt = torch.zeros(ring, 2, F, dtype=torch.int32).pin_memory()
@@ -257,12 +254,10 @@ class YOLO:
                         break
                     chunk.append(nxt)
                 g = state["group"]
-                hb = h_frames[g % ring]                                    # its last user (group g-3) has been synchronised
                 b = pipe.begin_frame()                                    # waits until this buffer set's last group left the tracker
-                for f, img in enumerate(chunk):
-                    hb[f].copy_(torch.from_numpy(np.ascontiguousarray(img)))
                 with torch.cuda.stream(pipe.sA):
-                    b.frames[:len(chunk)].copy_(hb[:len(chunk)], non_blocking=True)
+                    for f, img in enumerate(chunk):
+                        pipe.eng.upload(b.frames[f], img, pipe.sA)
                     if self._fill is not None:
                         for f in range(len(chunk)):
                             self._fill(b, f, self._frame_index + f)
