@@ -66,6 +66,23 @@ int  ss_synchronize(ss_ctx* ctx);
  * asynchronously on `hip_stream`.  The host buffer may be reused as soon as the call returns. */
 int ss_upload(ss_ctx* ctx, void* hip_stream, void* d_dst, const void* h_src, size_t bytes);
 
+/* ... and back: device -> host through a pinned staging buffer; synchronous. */
+int ss_download(ss_ctx* ctx, void* hip_stream, void* h_dst, const void* d_src, size_t bytes);
+
+/* ---- N2  annotation overlay on device frames (the cv2 drawing of yolo_multi_model.py:58-162, :311-331) --------------
+ * d_frames: `batch` BGR u8 frames [h][w][3] (row_stride bytes per row, frame b at + b*frame_batch_stride bytes), drawn in
+ * place.  d_prims: primitives of all frames, 8 ints each {type, x0, y0, x1, y1, color B|G<<8|R<<16, a, b}; frame b owns
+ * d_prim_off[b] .. d_prim_off[b+1] and they are painted in list order:
+ *   type 0 rectangle outline, thickness a centred on the edge      type 1 filled rectangle
+ *   type 2 filled circle, centre (x0,y0), radius a                 type 3 line, thickness a
+ *   type 4 5x7 raster text, baseline-left (x0,y0), x1 characters at d_chars + a, scale b>>1
+ *   b bit 0: member of a blended group (composited opaquely inside the group, then 0.7 : 0.3 over the frame).
+ * All coverage tests are integer arithmetic (bit-exact against the NumPy rasteriser in oracle/overlay_np.py).
+ * ss_overlay_set_font uploads the 95 x 5 column-bitmap font (strongsort_yolo_amd/overlay_font.py) once per context. */
+int ss_overlay_set_font(ss_ctx* ctx, const uint8_t* h_font_95x5);
+int ss_overlay(ss_ctx* ctx, void* hip_stream, uint8_t* d_frames, int batch, long long frame_batch_stride, int h, int w,
+               int row_stride, const int* d_prims, const int* d_prim_off, const uint8_t* d_chars);
+
 /* ---- a1  letterbox / preprocess  (inside model.track/.predict, yolo_multi_model.py:41,:173) ---
  * BGR u8 [h][w][3] (row_stride bytes) -> RGB [3][out_h][out_w], /255, pad 114.
  * dst_flags: bit 0 (SS_DST_F16) writes IEEE half, else float; bit 1 (SS_DST_HWC) writes

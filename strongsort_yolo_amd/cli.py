@@ -1,10 +1,11 @@
 """Command line of the reference script, kept: `--source ... --track --count` (yolo_multi_model.py:341-354).
 
-Out of scope by SURVEY §2: drawing, imshow, video encode.  What is kept is the per-stream loop
-(:244-339), the labels file (:34-39, :165-169) and the class-count analytics (:284-305) — the latter as
-an incremental per-id majority-class counter instead of re-reading the whole CSV every frame (SURVEY §8f
-N1).  Frame sources (N3): `synthetic[:N]`, a `.npy` stack [T,H,W,3], or a directory of images (Pillow);
-there is no video decoder in this environment.
+What is kept is the per-stream loop (:244-339), the labels file (:34-39, :165-169), the class-count analytics
+(:284-305) — as an incremental per-id majority-class counter instead of re-reading the whole CSV every frame
+ — and, with `--save`, the annotated output (:58-162, :311-331): the drawing runs as an overlay kernel
+on the device (overlay.py, N2) and the frames go to a sink (N3).  Frame sources (N3): `synthetic[:N]`, a `.npy` stack
+[T,H,W,3], or a directory of images (Pillow); sinks: `.npy`, raw BGR24 or a PNG directory.  There is no video
+decoder / encoder and no GUI in this environment (imshow / VideoWriter are out of scope).
 """
 from __future__ import annotations
 
@@ -38,6 +39,47 @@ def frame_source(spec: str, limit: Optional[int] = None) -> Iterator[np.ndarray]
             yield np.asarray(Image.open(os.path.join(spec, f)).convert("RGB"))[:, :, ::-1].copy()   # BGR like cv2
     else:
         raise ValueError(f"cannot open source '{spec}' (synthetic[:N] | stack.npy | image directory)")
+
+
+# ---- frame sink (N3) ------------------------------------------------------------------------------------------
+class FrameSink:
+    """Where annotated frames go — the reference writes `output/<name>_output.mp4` with cv2.VideoWriter at 15 fps
+    (yolo_multi_model.py:258-260, :331); there is no encoder in this environment, so the sink writes
+      *.npy      one uint8 stack [T,H,W,3] (BGR), saved at close
+      *.bgr      raw BGR24 frames appended as they arrive + `<path>.json` {width, height, fps, frames} (ffmpeg -f rawvideo
+                 -pix_fmt bgr24 -s WxH -r fps turns it into the reference's mp4)
+      directory  frame_000000.png ... (Pillow)."""
+
+    def __init__(self, path: str, fps: int = 15):
+        self.path, self.fps, self.n, self.shape = path, fps, 0, None
+        self.kind = "npy" if path.endswith(".npy") else "bgr" if path.endswith((".bgr", ".raw")) else "dir"
+        if self.kind == "dir":
+            os.makedirs(path, exist_ok=True)
+        else:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self._frames = []
+        self._f = open(path, "wb") if self.kind == "bgr" else None
+
+    def write(self, frame: np.ndarray):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        self.shape = frame.shape
+        if self.kind == "npy":
+            self._frames.append(frame.copy())
+        elif self.kind == "bgr":
+            self._f.write(frame.tobytes())
+        else:
+            from PIL import Image
+            Image.fromarray(frame[:, :, ::-1]).save(os.path.join(self.path, f"frame_{self.n:06d}.png"))
+        self.n += 1
+
+    def close(self):
+        if self.kind == "npy":
+            np.save(self.path, np.stack(self._frames) if self._frames else np.zeros((0, 0, 0, 3), np.uint8))
+        elif self.kind == "bgr":
+            self._f.close()
+            import json
+            h, w = (self.shape or (0, 0, 3))[:2]
+            json.dump({"width": int(w), "height": int(h), "fps": self.fps, "frames": self.n, "pix_fmt": "bgr24"}, open(self.path + ".json", "w"))
 
 
 # ---- labels file + counting (N1) -------------------------------------------------------------------------
@@ -105,34 +147,44 @@ def process_video(args: dict, model=None) -> dict:
     frames, t0, fps = 0, time.time(), 0.0
     batch = int(args.get("batch", 16))
     src = frame_source(str(source), args.get("limit"))
+    sink = FrameSink(args["save"]) if args.get("save") else None       # annotated output (N2 + N3), off by default
+    overlay, fps_str = None, ""
+
+    def emit(frame, res):
+        """labels, counts and (with --save) the annotated frame of one processed frame; reference :284-331"""
+        nonlocal frames, t0, fps, overlay, fps_str
+        if track:
+            writer.write(frames, res)
+            if count:
+                counter.update(res)
+        frames += 1
+        if frames % 10 == 0:                     # reference :321-326 (10-frame window)
+            fps = 10 / max(time.time() - t0, 1e-9)
+            fps_str = f"FPS: {fps:.2f}"
+            t0 = time.time()
+        if sink is not None:
+            if overlay is None:
+                overlay = model.overlay()
+            sink.write(overlay.draw(frame, res, counter.counts() if (count and track) else None, fps_str))
+
     if track and batch > 1 and hasattr(model, "track_stream"):
         # a file / synthetic source can supply frames ahead: groups of `batch` frames through the overlapped pipeline
         # (same rows as frame-by-frame model.track; --batch 1 keeps the reference's per-frame call, :41)
         for res in model.track_stream(src, batch=batch, device=args.get("device", 0)):
-            writer.write(frames, res)
-            if count:
-                counter.update(res)
-            frames += 1
-            if frames % 10 == 0:                     # reference :321-326 (10-frame window)
-                fps = 10 / max(time.time() - t0, 1e-9)
-                t0 = time.time()
+            emit(res[0].orig_img, res)
         src = ()
     for frame in src:
         if track:
             res = model.track(frame, verbose=False, device=args.get("device", 0), persist=True, tracker="strongsort.yaml")
-            writer.write(frames, res)
-            if count:
-                counter.update(res)
         else:
             res = model.predict(frame, verbose=False, device=args.get("device", 0))
             if count:                                # reference :280-282: counting needs tracking
                 print("[INFO] count works only when objects are tracking.. so use both flags (--track --count)")
                 frames += 1
                 break
-        frames += 1
-        if frames % 10 == 0:                         # reference :321-326 (10-frame window)
-            fps = 10 / max(time.time() - t0, 1e-9)
-            t0 = time.time()
+        emit(frame, res)
+    if sink is not None:
+        sink.close()
     writer.close()
     return {"source": str(source), "frames": frames, "fps": fps, "counts": counter.counts() if count and track else {}}
 
@@ -144,10 +196,12 @@ def main(argv=None):
     p.add_argument("--count", action="store_true")
     p.add_argument("--weights", default="yolov8n.pt")
     p.add_argument("--limit", type=int, default=None)
+    p.add_argument("--save", default=None, help="write annotated frames: stack.npy | video.bgr (raw BGR24 + .json) | directory of PNGs")
     p.add_argument("--batch", type=int, default=16, help="frames per group on the throughput path (1: per-frame model.track calls as in the reference)")
     p.add_argument("--random-init", action="store_true", help="run seeded random-init networks when the weights file is missing")
     a = p.parse_args(argv)
-    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "limit": a.limit, "device": i, "random_init": a.random_init, "batch": a.batch}
+    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "limit": a.limit, "device": i, "random_init": a.random_init, "batch": a.batch,
+             "save": (a.save if len(a.source) == 1 else f"{os.path.splitext(a.save)[0]}_{i}{os.path.splitext(a.save)[1]}") if a.save else None}
             for i, s in enumerate(a.source)]
     import torch
     ngpu = max(torch.cuda.device_count(), 1)

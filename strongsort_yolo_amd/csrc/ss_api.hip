@@ -26,6 +26,7 @@ int  ss_launch_nms(const float*, int, long long, int, int, int, float, float, in
 int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
 void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t);
+void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
 extern "C" void ss_step_kernel_attr();
 
 static std::string g_last_error;
@@ -52,6 +53,8 @@ struct ss_ctx {
     // host -> device upload staging (ss_upload): write-combined pinned buffers, used round robin
     struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
     int stage_next = 0;
+    uint8_t* font;              // [95][5] overlay font (ss_overlay_set_font)
+    struct Back { void* p = nullptr; size_t cap = 0; } back;      // device -> host staging (ss_download)
     int cos_grid;               // persistent workgroups of the association kernel
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
@@ -143,6 +146,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     if (rc == SS_OK) rc = dalloc(c, &c->kat_partmin, T * SS_NRT * D);
     if (rc == SS_OK) rc = dalloc(c, &c->kat_lsap_t, (size_t)256 * 256);
     if (rc == SS_OK) rc = dalloc(c, &c->kat_err, 4);
+    if (rc == SS_OK) rc = dalloc(c, &c->font, 95 * 5);
     c->nms_ws_bytes = ss_nms_workspace_bytes();
     c->nms_units = 1;
     if (rc == SS_OK) { char* w; rc = dalloc(c, &w, c->nms_ws_bytes); c->nms_ws = w; }
@@ -166,6 +170,7 @@ extern "C" void ss_destroy(ss_ctx* c)
     for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& st : c->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
+    if (c->back.p) (void)hipHostFree(c->back.p);
     delete c;
 }
 
@@ -196,6 +201,40 @@ extern "C" int ss_upload(ss_ctx* c, void* hip_stream, void* d_dst, const void* h
     HIPCHK(c, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     HIPCHK(c, hipEventRecord(st.ev, (hipStream_t)hip_stream));
     st.busy = true;
+    return SS_OK;
+}
+
+// Device -> host through a pinned staging buffer; synchronous (returns when h_dst holds the bytes).
+extern "C" int ss_download(ss_ctx* c, void* hip_stream, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!c || !h_dst || !d_src) return fail(c, SS_ERR_INVALID, "ss_download: null argument");
+    if (bytes == 0) return SS_OK;
+    if (c->back.cap < bytes) {
+        if (c->back.p) { HIPCHK(c, hipHostFree(c->back.p)); c->back.p = nullptr; c->back.cap = 0; }
+        HIPCHK(c, hipHostMalloc(&c->back.p, bytes, hipHostMallocDefault));
+        c->back.cap = bytes;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->back.p, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)hip_stream));
+    memcpy(h_dst, c->back.p, bytes);
+    return SS_OK;
+}
+
+// ---- N2 overlay -----------------------------------------------------------------------------------------
+extern "C" int ss_overlay_set_font(ss_ctx* c, const uint8_t* h_font_95x5)
+{
+    if (!c || !h_font_95x5) return fail(c, SS_ERR_INVALID, "ss_overlay_set_font: null argument");
+    HIPCHK(c, hipMemcpy(c->font, h_font_95x5, 95 * 5, hipMemcpyHostToDevice));
+    return SS_OK;
+}
+
+extern "C" int ss_overlay(ss_ctx* c, void* hip_stream, uint8_t* d_frames, int batch, long long frame_batch_stride, int h, int w,
+                          int row_stride, const int* d_prims, const int* d_prim_off, const uint8_t* d_chars)
+{
+    if (!c || !d_frames || !d_prims || !d_prim_off || !d_chars || batch < 0 || batch > 65535 || row_stride < 3 * w)
+        return fail(c, SS_ERR_INVALID, "ss_overlay: bad argument");
+    ss_launch_overlay(d_frames, batch, frame_batch_stride, h, w, row_stride, d_prims, d_prim_off, d_chars, c->font, (hipStream_t)hip_stream);
+    HIPCHK(c, hipGetLastError());
     return SS_OK;
 }
 

@@ -110,6 +110,13 @@ class TrackerEngine:
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         self._ck(self.L.ss_upload(self.ctx, C.c_void_p(st.cuda_stream), _ptr(dst), src.ctypes.data_as(C.c_void_p), src.nbytes))
 
+    def download(self, dst: np.ndarray, src: torch.Tensor, stream=None):
+        """Device tensor -> host array (synchronous)."""
+        if dst.nbytes != src.numel() * src.element_size() or not src.is_contiguous() or not dst.flags["C_CONTIGUOUS"]:
+            raise ValueError("download: size / layout mismatch")
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._ck(self.L.ss_download(self.ctx, C.c_void_p(st.cuda_stream), dst.ctypes.data_as(C.c_void_p), _ptr(src), dst.nbytes))
+
     # ---- tracker --------------------------------------------------------------------------------
     def update_device(self, dets, ndets, feats, img_hw):
         """All streams, one frame; tensors live on the device ([S,128,6] f32, [S] i32, [S,128,512] f32,

@@ -20,7 +20,7 @@ DST_F16, DST_HWC = 1, 2
 
 EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
-    "ss_upload", "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_nms_set_classes", "ss_crop_norm", "ss_crop_norm_batch",
+    "ss_upload", "ss_download", "ss_overlay_set_font", "ss_overlay", "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_nms_set_classes", "ss_crop_norm", "ss_crop_norm_batch",
     "ss_track_update", "ss_track_update_group", "ss_track_update_host",
     "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
@@ -77,6 +77,9 @@ def load():
     L.ss_reset.argtypes = [vp, i]
     L.ss_synchronize.argtypes = [vp]
     L.ss_upload.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.ss_download.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.ss_overlay_set_font.argtypes = [vp, vp]
+    L.ss_overlay.argtypes = [vp, vp, vp, i, C.c_longlong, i, i, i, vp, vp, vp]
     L.ss_letterbox.argtypes = [vp, u8, i, i, i, vp, i, i, i, i, i, i, i, i]
     L.ss_nms.argtypes = [vp, fp, i, i, i, f, f, i, f, i, f, f, f, f, f, fp, i, ip, ip]
     L.ss_nms_set_classes.argtypes = [vp, C.POINTER(C.c_int), i]

@@ -1,0 +1,148 @@
+"""Annotation overlay — the drawing half of the reference's `process()` and count plate
+(/root/reference/yolo_multi_model.py:45-162, :284-331) as an ordered primitive list rasterised on the MI355X.
+
+`Overlay.commands(results, ...)` restates the reference's per-frame drawing sequence as data (it also keeps the
+5-point trajectories, :28, :101-110); `Overlay.draw(frame, results, ...)` uploads the frame (if it is a host array),
+runs `ss_overlay` and returns the annotated frame.  The stroke font of cv2.putText is replaced by a 5x7 raster font
+(overlay_font.py); rectangle / circle / line coverage is defined by integer tests (csrc/ss_overlay.hip), not by
+OpenCV's rasteriser — pixel parity with cv2 is therefore not claimed, parity with oracle/overlay_np.py is exact.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import deque
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .overlay_font import ADVANCE, font_table
+
+RECT, FILL, CIRCLE, LINE, TEXT = 0, 1, 2, 3, 4
+
+
+def bgr(b, g, r):
+    return int(b) | int(g) << 8 | int(r) << 16
+
+
+class CommandList:
+    """Ordered primitives of one frame: int32 [n,8] rows + the characters of its text primitives."""
+
+    def __init__(self):
+        self.rows, self.chars = [], bytearray()
+
+    def rect(self, x0, y0, x1, y1, color, thickness=2, group=False):
+        self.rows.append((RECT, int(x0), int(y0), int(x1), int(y1), color, int(thickness), int(group)))
+
+    def fill(self, x0, y0, x1, y1, color, group=False):
+        self.rows.append((FILL, int(x0), int(y0), int(x1), int(y1), color, 0, int(group)))
+
+    def circle(self, x, y, r, color, group=False):
+        self.rows.append((CIRCLE, int(x), int(y), 0, 0, color, int(r), int(group)))
+
+    def line(self, x0, y0, x1, y1, color, thickness=2, group=False):
+        self.rows.append((LINE, int(x0), int(y0), int(x1), int(y1), color, int(thickness), int(group)))
+
+    def text(self, s, x, y, color, scale=1, group=False):
+        s = s.encode("ascii", "replace")
+        self.rows.append((TEXT, int(x), int(y), len(s), 0, color, len(self.chars), (int(scale) << 1) | int(group)))
+        self.chars += s
+
+    def arrays(self):
+        return (np.asarray(self.rows, dtype=np.int32).reshape(-1, 8), np.frombuffer(bytes(self.chars) or b"\0", dtype=np.uint8).copy())
+
+
+class Overlay:
+    """Per-stream drawing state (trajectories) + the device launcher."""
+
+    def __init__(self, names: Dict[int, str], engine=None, trail_len: int = 5):
+        self.names, self.eng, self.trails = names, engine, {}
+        self.trail_len = trail_len
+        self._scratch = None
+        if engine is not None:
+            t = np.ascontiguousarray(font_table())
+            engine._ck(engine.L.ss_overlay_set_font(engine.ctx, t.ctypes.data_as(C.c_void_p)))
+
+    # ---- the reference's drawing sequence as data ---------------------------------------------------------
+    def commands(self, results, counts: Optional[dict] = None, fps_text: str = "") -> CommandList:
+        cl = CommandList()
+        live = {int(i) for r in results if r is not None and r.boxes is not None and r.boxes.id is not None for i in r.boxes.id}
+        for id_ in list(self.trails):                                   # yolo_multi_model.py:45-47
+            if id_ not in live:
+                del self.trails[id_]
+        for r in results:
+            if r is None or r.boxes is None:
+                continue
+            tracked = r.boxes.id is not None
+            if r.keypoints is not None and (tracked or not hasattr(r.boxes, "id")):           # :58-67 / :182-191
+                for kp in r.keypoints:
+                    for pts in kp.xy.tolist():
+                        for idx, (x, y) in enumerate(pts):
+                            if (x, y) != (0.0, 0.0):
+                                cl.circle(x, y, 5, bgr(0, 255, 0)); cl.circle(x, y, 2, bgr(0, 0, 0))
+                                cl.text(str(idx), int(x) + 5, int(y) - 5, bgr(0, 0, 255))
+            if not tracked:
+                for conf, cls, xyxy in zip(r.boxes.conf, r.boxes.cls, r.boxes.xyxy):          # detection only, :193-237
+                    self._box(cl, xyxy, f" {self.names.get(int(cls), int(cls))} {round(float(conf) * 100, 1)}%")
+                continue
+            for conf, cls, xyxy, id_ in zip(r.boxes.conf, r.boxes.cls, r.boxes.xyxy, r.boxes.id):   # :126-153
+                self._box(cl, xyxy, f" ID: {int(id_)} {self.names.get(int(cls), int(cls))} {round(float(conf) * 100, 1)}%")
+                t = self.trails.setdefault(int(id_), deque(maxlen=self.trail_len))
+                t.append(((float(xyxy[0]) + float(xyxy[2])) / 2, (float(xyxy[1]) + float(xyxy[3])) / 2))
+            for t in self.trails.values():                                                           # :156-162
+                for i in range(1, len(t)):
+                    cl.line(int(t[i - 1][0]), int(t[i - 1][1]), int(t[i][0]), int(t[i][1]), bgr(255, 255, 255), 2)
+        if counts is not None:                                                                       # :311-318 blended plate
+            s = str(counts)
+            cl.fill(10, 11, max(10 + ADVANCE * 2 * len(s) + 20, 60), 70, bgr(0, 0, 0), group=True)
+            cl.text(s, 20, 52, bgr(210, 210, 210), scale=2, group=True)
+        if fps_text:
+            cl.text(fps_text, 10, 30, bgr(0, 0, 255), scale=2)                                       # :331
+        return cl
+
+    @staticmethod
+    def _box(cl, xyxy, label):
+        x0, y0, x1, y1 = (int(v) for v in xyxy)
+        cl.rect(x0, y0, x1, y1, bgr(0, 0, 225), 2)                                                   # :80 / :132
+        cl.fill(x0, y0, x0 + ADVANCE * len(label) + 2, y0 - 12, bgr(30, 30, 30))                     # :92 label plate
+        cl.text(label, x0, y0 - 3, bgr(255, 255, 255))                                               # :95
+
+    # ---- device -------------------------------------------------------------------------------------------
+    def draw_device(self, frames: torch.Tensor, command_lists, stream=None) -> torch.Tensor:
+        """frames: uint8 [B,H,W,3] (or [H,W,3]) on the device, annotated in place with one CommandList per frame."""
+        e = self.eng
+        fr = frames if frames.dim() == 4 else frames.unsqueeze(0)
+        if len(command_lists) != fr.shape[0]:
+            raise ValueError("one command list per frame")
+        arr = [c.arrays() for c in command_lists]
+        off = np.zeros(len(arr) + 1, np.int32)
+        coff = 0
+        prims = []
+        for i, (p, ch) in enumerate(arr):
+            p = p.copy()
+            p[p[:, 0] == TEXT, 6] += coff                              # character offsets into the concatenated buffer
+            prims.append(p)
+            off[i + 1] = off[i] + len(p)
+            coff += len(ch)
+        prims = np.concatenate(prims) if prims else np.zeros((0, 8), np.int32)
+        chars = np.concatenate([ch for _, ch in arr])
+        dev = fr.device
+        d_prims = torch.from_numpy(prims if len(prims) else np.zeros((1, 8), np.int32)).to(dev)
+        d_off, d_chars = torch.from_numpy(off).to(dev), torch.from_numpy(chars).to(dev)
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        e._ck(e.L.ss_overlay(e.ctx, C.c_void_p(st.cuda_stream), C.c_void_p(fr.data_ptr()), fr.shape[0], fr.stride(0), fr.shape[1],
+                             fr.shape[2], fr.stride(1), C.c_void_p(d_prims.data_ptr()), C.c_void_p(d_off.data_ptr()),
+                             C.c_void_p(d_chars.data_ptr())))
+        self._keep = (d_prims, d_off, d_chars)                          # alive until the launch has run
+        return frames
+
+    def draw(self, frame: np.ndarray, results, counts: Optional[dict] = None, fps_text: str = "") -> np.ndarray:
+        """Host frame in, annotated host frame out (upload -> ss_overlay -> download)."""
+        e = self.eng
+        if self._scratch is None or self._scratch.shape != frame.shape:
+            self._scratch = torch.empty(frame.shape, dtype=torch.uint8, device=e.device)
+        e.upload(self._scratch, frame)
+        self.draw_device(self._scratch, [self.commands(results, counts, fps_text)])
+        out = np.empty_like(frame)
+        e.download(out, self._scratch)
+        return out

@@ -276,6 +276,14 @@ class YOLO:
         finally:
             pipe._run_stage, pipe.on_result = orig_run, None
 
+    def overlay(self):
+        """Annotation overlay bound to this model's device context (drawing of yolo_multi_model.py:58-162 as a kernel)."""
+        from .overlay import Overlay
+        pipe = self._stream_pipe or self._pipe
+        if pipe is None:
+            raise RuntimeError("overlay(): run track()/predict()/track_stream() once first (the device context is created there)")
+        return Overlay(self.names, pipe.eng)
+
     def close(self):
         for p in (self._pipe, self._stream_pipe):
             if p is not None:

@@ -1,0 +1,79 @@
+"""N2/N3 on the CPU: the overlay command builder restates the reference's drawing sequence, the NumPy rasteriser
+(oracle of the HIP kernel) obeys painter's order, and the frame sinks write what they are given."""
+import json
+
+import numpy as np
+import torch
+
+from oracle.overlay_np import rasterise
+from strongsort_yolo_amd.cli import FrameSink
+from strongsort_yolo_amd.overlay import CIRCLE, FILL, LINE, RECT, TEXT, CommandList, Overlay, bgr
+from strongsort_yolo_amd.overlay_font import font_table
+from strongsort_yolo_amd.yolo import Boxes, Keypoints, Results
+
+
+def _results(ids=(7, 9)):
+    n = len(ids)
+    xyxy = torch.tensor([[40., 60., 120., 200.], [150., 30., 210., 180.]][:n])
+    kp = torch.zeros(n, 17, 3)
+    kp[0, 3] = torch.tensor([60., 90., 0.9])
+    return [Results(np.zeros((240, 320, 3), np.uint8), {0: "person", 2: "car"}, Boxes(xyxy, torch.tensor([0.91, 0.5][:n]), torch.tensor([0., 2.][:n]),
+                                                                                        torch.tensor([float(i) for i in ids])), Keypoints(kp))]
+
+
+def test_commands_follow_the_reference_sequence():
+    ov = Overlay({0: "person", 2: "car"})
+    c1 = ov.commands(_results()).arrays()[0]
+    # frame 1: keypoint (2 circles + index text), per box: outline, label plate, label text; no trails yet
+    assert c1[:, 0].tolist() == [CIRCLE, CIRCLE, TEXT] + [RECT, FILL, TEXT] * 2
+    assert c1[3, 1:5].tolist() == [40, 60, 120, 200] and c1[3, 5] == bgr(0, 0, 225) and c1[3, 6] == 2       # yolo_multi_model.py:80
+    cl = ov.commands(_results(), counts={"person": 1}, fps_text="FPS: 30.00")
+    prims, chars = cl.arrays()
+    assert (prims[:, 0] == LINE).sum() == 2                              # one trajectory segment per id from the 2nd frame on (:156-162)
+    assert prims[-1, 0] == TEXT and prims[-1, 7] == (2 << 1) and bytes(chars[prims[-1, 6]:prims[-1, 6] + prims[-1, 3]]) == b"FPS: 30.00"
+    assert prims[-3, 0] == FILL and prims[-3, 7] & 1 and prims[-2, 7] & 1                                    # blended count plate (:311-318)
+    label = bytes(chars[prims[5, 6]:prims[5, 6] + prims[5, 3]]).decode()
+    assert label == " ID: 7 person 91.0%"                                                                    # :86
+    ov.commands(_results(ids=(7,)))                                      # id 9 left the scene: its trajectory is dropped (:45-47)
+    assert set(ov.trails) == {7}
+    for _ in range(8):
+        ov.commands(_results(ids=(7,)))
+    assert len(ov.trails[7]) == 5                                        # deque(maxlen=5), :102
+
+
+def test_numpy_rasteriser_painters_order_and_blend():
+    font = font_table()
+    img = np.full((40, 60, 3), 100, np.uint8)
+    cl = CommandList()
+    cl.fill(5, 5, 20, 15, bgr(10, 20, 30))
+    cl.rect(10, 10, 30, 30, bgr(0, 0, 225), 2)          # drawn later: wins where both cover
+    cl.circle(50, 8, 3, bgr(0, 255, 0))
+    cl.line(0, 39, 59, 35, bgr(255, 255, 255), 2)
+    cl.fill(40, 20, 55, 30, bgr(0, 0, 0), group=True)   # blended plate: 0.7 * black + 0.3 * 100 -> 30
+    cl.text("Az", 2, 38, bgr(1, 2, 3))
+    prims, chars = cl.arrays()
+    out = rasterise(img, prims, chars, font)
+    assert tuple(out[6, 6]) == (10, 20, 30) and tuple(out[10, 10]) == (0, 0, 225) and tuple(out[9, 9]) == (0, 0, 225)
+    assert tuple(out[12, 12]) == (10, 20, 30) and tuple(out[20, 20]) == (100, 100, 100)       # inside the outline: untouched
+    assert tuple(out[8, 50]) == (0, 255, 0) and tuple(out[8, 54]) == (100, 100, 100)
+    assert tuple(out[25, 45]) == (30, 30, 30)
+    assert (out[32:39, 2:7] == np.array([1, 2, 3])).all(axis=2).sum() == 18                  # the 18 pixels of the glyph 'A'
+    assert np.array_equal(img, np.full((40, 60, 3), 100, np.uint8))                          # input not modified
+    # clipping: primitives partly / fully outside the frame
+    cl = CommandList(); cl.circle(-2, -2, 5, bgr(9, 9, 9)); cl.rect(50, 30, 80, 70, bgr(1, 1, 1), 3); cl.text("x", 100, 100, 0)
+    out = rasterise(img, *cl.arrays(), font)
+    assert tuple(out[0, 0]) == (9, 9, 9) and tuple(out[39, 49]) == (1, 1, 1)
+
+
+def test_frame_sinks(tmp_path):
+    frames = np.random.default_rng(0).integers(0, 255, (3, 6, 8, 3), dtype=np.uint8)
+    for name in ("a.npy", "b.bgr", "dir"):
+        s = FrameSink(str(tmp_path / name))
+        for f in frames:
+            s.write(f)
+        s.close()
+    assert np.array_equal(np.load(tmp_path / "a.npy"), frames)
+    assert np.array_equal(np.fromfile(tmp_path / "b.bgr", np.uint8).reshape(frames.shape), frames)
+    assert json.load(open(tmp_path / "b.bgr.json")) == {"width": 8, "height": 6, "fps": 15, "frames": 3, "pix_fmt": "bgr24"}
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "dir" / "frame_000002.png"))[:, :, ::-1], frames[2])
