@@ -583,6 +583,16 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
     const __half* xi = x + (size_t)img * H * W * C;
     const int c8 = tid % C8, ps = tid / C8;
     float s8[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    // The band's input rows (R consecutive image rows = one contiguous span of x) go to X with coalesced 16-byte loads,
+    // all in flight at once; rows outside the image are zeros.  (Reading the first layer's MFMA operand straight from
+    // global memory was a chain of dependent 8-byte loads, one memory latency per 16 pixels: 357 us per launch at 512
+    // crops before, see profiles/.)
+    for (int i = tid; i < R * W * C8; i += 256) {
+        const int r = i / (W * C8), gr = y0 - t + r;
+        *reinterpret_cast<h8*>(X + (size_t)i * 8) =
+            (gr >= 0 && gr < H) ? *reinterpret_cast<const h8*>(xi + (size_t)gr * W * C + (size_t)(i - r * W * C8) * 8) : z8;
+    }
+    __syncthreads();
 
     for (int l = 1; l <= t; ++l) {
         const int Lw = lbase + l - 1;
@@ -597,16 +607,11 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
             }
         const int rlo = l - 1, NT = (R - 2 * l + 2) * W / 16;
         auto load_b = [&](int ti, h4 (&b)[KS]) {
-            const int p = ti * 16 + n16, rr = p / W, c = p - rr * W, r = rlo + rr, gr = y0 - t + r;
+            const int p = ti * 16 + n16, rr = p / W, c = p - rr * W, r = rlo + rr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int ic0 = ks * 16 + 4 * q;
-                if (l == 1) {
-                    const bool ok = ti < NT && gr >= 0 && gr < H && ic0 < C;
-                    b[ks] = ok ? *reinterpret_cast<const h4*>(xi + ((size_t)gr * W + c) * C + ic0) : z4;
-                } else {
-                    b[ks] = (ti < NT && ic0 < C) ? *reinterpret_cast<const h4*>(X + ((size_t)r * W + c) * C + ic0) : z4;
-                }
+                b[ks] = (ti < NT && ic0 < C) ? *reinterpret_cast<const h4*>(X + ((size_t)r * W + c) * C + ic0) : z4;
             }
         };
         h4 bcur[KS], bnext[KS];

@@ -166,3 +166,20 @@ def test_cli_process_video_on_the_gpu(tmp_path):
         outs.append(lines)
         model.close()
     assert outs[0] == outs[1]
+
+
+def test_cli_save_annotated_frames(tmp_path):
+    """--save: overlay kernel + sink behind the reference's loop (yolo_multi_model.py:58-162, :331)"""
+    from strongsort_yolo_amd.cli import process_video
+    model, frames, ref = _synthetic_model()
+    np.save(tmp_path / "clip.npy", np.stack(frames[:20]))
+    out = process_video({"source": str(tmp_path / "clip.npy"), "track": True, "count": True, "outdir": str(tmp_path), "batch": 8,
+                         "save": str(tmp_path / "annotated.bgr")}, model)
+    ann = np.fromfile(tmp_path / "annotated.bgr", np.uint8).reshape(20, H_, W_, 3)
+    assert out["frames"] == 20
+    assert np.array_equal(ann[0], frames[0])                              # no confirmed track yet: nothing drawn
+    changed = (ann[10] != frames[10]).any(axis=2)
+    assert changed.sum() > 500
+    x1, y1 = int(ref[10][1][0, 0]), int(ref[10][1][0, 1])
+    assert tuple(ann[10][y1, x1 + 5]) == (0, 0, 225)                      # the first track's box outline (BGR)
+    model.close()
