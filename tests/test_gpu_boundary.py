@@ -173,11 +173,11 @@ def test_cli_save_annotated_frames(tmp_path):
     from strongsort_yolo_amd.cli import process_video
     model, frames, ref = _synthetic_model()
     np.save(tmp_path / "clip.npy", np.stack(frames[:20]))
-    out = process_video({"source": str(tmp_path / "clip.npy"), "track": True, "count": True, "outdir": str(tmp_path), "batch": 8,
+    out = process_video({"source": str(tmp_path / "clip.npy"), "track": True, "count": False, "outdir": str(tmp_path), "batch": 8,
                          "save": str(tmp_path / "annotated.bgr")}, model)
     ann = np.fromfile(tmp_path / "annotated.bgr", np.uint8).reshape(20, H_, W_, 3)
     assert out["frames"] == 20
-    assert np.array_equal(ann[0], frames[0])                              # no confirmed track yet: nothing drawn
+    assert np.array_equal(ann[0], frames[0])                              # no confirmed track yet, no count plate: nothing drawn
     changed = (ann[10] != frames[10]).any(axis=2)
     assert changed.sum() > 500
     x1, y1 = int(ref[10][1][0, 0]), int(ref[10][1][0, 1])
