@@ -53,6 +53,23 @@ __global__ __launch_bounds__(256) void k_bias_act1(__half* __restrict__ x, const
     }
 }
 
+// One depthwise tap for 8 channels: acc[k] = fma(float(v[k]), float(w[k]), acc[k]) as v_fma_mix_f32 (f16 sources widened
+// inside the instruction, f32 accumulate, one rounding — bit-identical to cvt + v_fma_f32).  hipcc otherwise widens the
+// operands with 8 + 8 v_cvt_f32_f16 per tap and keeps the nine tap weights as 72 float registers; measured on
+// k_osnet_streams<16>: 245 VALU instructions per (pixel, 8 channels) and 160 VGPRs before (profiles/r02_pmc_nets.json).
+__device__ __forceinline__ float ss_mix_lo(unsigned a, unsigned b, float c)
+{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float ss_mix_hi(unsigned a, unsigned b, float c)
+{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ void ss_dw_tap8(const h8& v, const h8& w, float (&acc)[8])
+{
+    const uint4 vu = __builtin_bit_cast(uint4, v), wu = __builtin_bit_cast(uint4, w);
+    acc[0] = ss_mix_lo(vu.x, wu.x, acc[0]); acc[1] = ss_mix_hi(vu.x, wu.x, acc[1]);
+    acc[2] = ss_mix_lo(vu.y, wu.y, acc[2]); acc[3] = ss_mix_hi(vu.y, wu.y, acc[3]);
+    acc[4] = ss_mix_lo(vu.z, wu.z, acc[4]); acc[5] = ss_mix_hi(vu.z, wu.z, acc[5]);
+    acc[6] = ss_mix_lo(vu.w, wu.w, acc[6]); acc[7] = ss_mix_hi(vu.w, wu.w, acc[7]);
+}
+
 // depthwise 3x3, stride 1, pad 1, + bias + relu.  w9 is [9][C] (tap-major).  thread = (pixel, 8 channels).
 __global__ __launch_bounds__(256) void k_dw3x3(const __half* __restrict__ x, const __half* __restrict__ w9,
                                               const __half* __restrict__ bias, __half* __restrict__ y, int N, int H,
@@ -80,8 +97,7 @@ __global__ __launch_bounds__(256) void k_dw3x3(const __half* __restrict__ x, con
                 if (ww < 0 || ww >= W) continue;
                 h8 v = reinterpret_cast<const h8*>(x)[((nb + hh) * W + ww) * C8 + c8];
                 h8 k9 = reinterpret_cast<const h8*>(w9)[((dy + 1) * 3 + dx + 1) * C8 + c8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)k9[k], acc[k]);
+                ss_dw_tap8(v, k9, acc);
             }
         }
         h8 o;
@@ -527,8 +543,11 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
     for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9)[k * C8 + c8];
     const h8 bb = reinterpret_cast<const h8*>(bias)[c8];
     const int npx = TH * W;
-    for (int p = ps; p < npx; p += PXPAR) {
-        const int py = p / W, px = p - py * W, gy = y0 + py;
+    const int dpy = PXPAR / W, dpx = PXPAR - dpy * W;       // pixel step of the loop as (rows, columns): no division per pixel
+    int py = ps / W, px = ps - py * W;
+    for (int p = ps; p < npx; p += PXPAR, py += dpy, px += dpx) {
+        if (px >= W) { px -= W; ++py; }
+        const int gy = y0 + py;
         if (gy >= H) break;
         float acc[8];
 #pragma unroll
@@ -538,8 +557,7 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const h8 v = *reinterpret_cast<const h8*>(T + ((size_t)((py + ky) * WP + px + kx) * C + c8 * 8));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)wk[ky * 3 + kx][k], acc[k]);
+                ss_dw_tap8(v, wk[ky * 3 + kx], acc);
             }
         h8 o;
 #pragma unroll
@@ -642,8 +660,11 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
             for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9 + (size_t)Lw * 9 * C)[k * C8 + c8];
             const h8 bb = reinterpret_cast<const h8*>(bias + (size_t)Lw * C)[c8];
             const int npx = (R - 2 * l) * W;
-            for (int p = ps; p < npx; p += PXPAR) {
-                const int pr = p / W, px = p - pr * W, py = pr + l, gr = y0 - t + py;
+            const int dpr = PXPAR / W, dpx = PXPAR - dpr * W;               // pixel step as (rows, columns)
+            int pr = ps / W, px = ps - pr * W;
+            for (int p = ps; p < npx; p += PXPAR, pr += dpr, px += dpx) {
+                if (px >= W) { px -= W; ++pr; }
+                const int py = pr + l, gr = y0 - t + py;
                 const bool inside = gr >= 0 && gr < H;
                 float acc[8];
 #pragma unroll
@@ -653,8 +674,7 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const h8 v = *reinterpret_cast<const h8*>(P + ((size_t)((py - 1 + ky) * WP + px + kx) * C + c8 * 8));
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) acc[k] = fmaf((float)v[k], (float)wk[ky * 3 + kx][k], acc[k]);
+                        ss_dw_tap8(v, wk[ky * 3 + kx], acc);
                     }
                 h8 o;
 #pragma unroll
