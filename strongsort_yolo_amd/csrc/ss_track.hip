@@ -1136,18 +1136,11 @@ __global__ __launch_bounds__(512) void k_newrow(SSDev dev, int f)
     __shared__ float lds_part[2 * 8 * 4 * 64];
     __shared__ int s_slot[16];
     const int S = dev.S, w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    for (int u = blockIdx.x;; u += gridDim.x) {
-        // decode the unit: streams in order, row tile major, pair fastest
-        int s = 0, base = 0, np = 0, p0 = 0;
-        for (; s < S; ++s) {
-            const int nrt = (dev.n_rows[s] + 15) / 16;
-            p0 = dev.pf[s * (SS_FMAX + 1) + f + 1];
-            np = dev.n_pl[s] - p0;
-            if (u < base + nrt * np) break;
-            base += nrt * np;
-        }
-        if (s == S) return;
-        const int loc = u - base, rti = loc / np, p = p0 + loc % np;
+    const int s = blockIdx.y;                                            // grid = (units in flight per stream, streams)
+    const int nrt = (dev.n_rows[s] + 15) / 16;
+    const int p0 = dev.pf[s * (SS_FMAX + 1) + f + 1], np = dev.n_pl[s] - p0;
+    for (int u = blockIdx.x; u < nrt * np; u += gridDim.x) {
+        const int rti = u / np, p = p0 + u % np;                         // row tile major, pair fastest
         const size_t sb = (size_t)s * SS_MAXT;
         const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
         const int f2 = pr.x, ct0 = pr.y & 0xff, D2 = pr.y >> 16;
@@ -1299,11 +1292,10 @@ void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipE
     if (dev.ts_enable > 1) hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
     else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
     else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
-    const int newrow_grid = min(2048, 64 * dev.S);
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);
         hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);
-        if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(newrow_grid), dim3(512), 0, st, dev, f);
+        if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(64, dev.S), dim3(512), 0, st, dev, f);
     }
 }
 

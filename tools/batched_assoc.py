@@ -6,4 +6,4 @@ import bench
 from strongsort_yolo_amd.config import StrongSortConfig
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 fb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-print(json.dumps(bench.batched_association(StrongSortConfig(), n_streams=n, frames=128, timed=24, frame_batch=fb, check=False)))
+print(json.dumps(bench.batched_association(StrongSortConfig(), n_streams=n, frames=128, timed=32, frame_batch=fb, check=False)))

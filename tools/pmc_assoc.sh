@@ -19,7 +19,7 @@ agg = collections.defaultdict(list)
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
-        if not r["Kernel_Name"].startswith(K): continue
+        if not r["Kernel_Name"].replace("void ", "").startswith(K): continue
         per[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
     ids = sorted(per, key=int)[-3:]                      # steady state: the last launches
     for d in ids:
