@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 #define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) dev.timeline[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 
 template <bool TL>
-__global__ __launch_bounds__(512) void k_assoc(SSDev dev)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TL ? 2 : 4, 4))) void k_assoc(SSDev dev)
 {
     bool first_item = true;
     SS_TL(0);
@@ -722,6 +722,8 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
             const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
             const char* bls1 = bls + 32768;
             f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
+            // B fragments are read from LDS one step (8 MFMAs) ahead of their use, so the LDS latency never shows
+            float4 bq0 = *reinterpret_cast<const float4*>(bls), bq1 = *reinterpret_cast<const float4*>(bls1);
 #pragma unroll
             for (int sg = 0; sg < 8; ++sg) {
                 if (sg + 3 < 8) ld(sg + 3, ra[(sg + 3) & 3]);       // prefetch piece sg+3 into ring slot (sg+3)%4
@@ -729,19 +731,21 @@ __global__ __launch_bounds__(512) void k_assoc(SSDev dev)
                 f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(bls + (4 * sg + j) * 1024);
-                    const float4 b1 = *reinterpret_cast<const float4*>(bls1 + (4 * sg + j) * 1024);
+                    const float4 b0 = bq0, b1 = bq1;
+                    const int nx = 4 * sg + j + 1;                   // next step's fragments (the last step re-reads step 0: unused)
+                    bq0 = *reinterpret_cast<const float4*>(bls + (nx & 31) * 1024);
+                    bq1 = *reinterpret_cast<const float4*>(bls1 + (nx & 31) * 1024);
                     acc0 = SS_MFMA16(a[j].x, b0.x, acc0); acc1 = SS_MFMA16(a[j].x, b1.x, acc1);
                     acc0 = SS_MFMA16(a[j].y, b0.y, acc0); acc1 = SS_MFMA16(a[j].y, b1.y, acc1);
                     acc0 = SS_MFMA16(a[j].z, b0.z, acc0); acc1 = SS_MFMA16(a[j].z, b1.z, acc1);
                     acc0 = SS_MFMA16(a[j].w, b0.w, acc0); acc1 = SS_MFMA16(a[j].w, b1.w, acc1);
+                    __builtin_amdgcn_sched_barrier(0);      // keep this order: next fragments requested, then this step's MFMAs
                 }
                 if (sg == 0) { tot0 = acc0; tot1 = acc1; }
                 else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the B fragments of later segments out of this one
                 SS_TL(4 + sg);
             }
             // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
