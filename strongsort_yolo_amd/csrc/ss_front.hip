@@ -130,21 +130,70 @@ __global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, l
     }
 }
 
+// Channels-last form, vectorised: one thread = 8 consecutive output pixels x 3 channels = 24 values written as 16-byte
+// stores (3 for half, 6 for float) — a crop row is 128 x 3 values contiguous, so a 16-thread group writes 768 / 1536
+// contiguous bytes.  Same per-pixel arithmetic as k_crop (bit-identical).  block = 16 rows x 16 pixel groups.
+template <typename T>
+__global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ src, long long src_batch_stride, int H, int W,
+                                                   int stride, const float* __restrict__ dets, int det_stride,
+                                                   long long dets_batch_stride, int n, const int* __restrict__ d_count,
+                                                   T* __restrict__ dst)
+{
+    const int out_w = 128, out_h = 256;
+    const int img = blockIdx.z / n, d = blockIdx.z - img * n;
+    const int cnt = d_count ? d_count[img] : n;
+    if (d >= cnt) return;
+    src += (size_t)img * src_batch_stride;
+    const int y = blockIdx.y * 16 + (threadIdx.x >> 4), xg = (threadIdx.x & 15) * 8;
+    const float* b = dets + (size_t)img * dets_batch_stride + (size_t)d * det_stride;
+    int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];
+    if (x1 < 0) x1 = 0; if (y1 < 0) y1 = 0;
+    if (x2 > W - 1) x2 = W - 1; if (y2 > H - 1) y2 = H - 1;
+    if (x1 > W - 1) x1 = W - 1; if (y1 > H - 1) y1 = H - 1;
+    int cw = x2 - x1, ch = y2 - y1;
+    if (cw < 1) cw = 1; if (ch < 1) ch = 1;
+    const float sx = (float)cw / (float)out_w, sy = (float)ch / (float)out_h;
+    int yy0, yy1; float fy;
+    ss_axis(y, sy, ch, yy0, yy1, fy);
+    const uint8_t* r0 = src + (size_t)(y1 + yy0) * stride + (size_t)x1 * 3;
+    const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride + (size_t)x1 * 3;
+    const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
+    __attribute__((aligned(16))) T o[24];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        int xx0, xx1; float fx;
+        ss_axis(xg + p, sx, cw, xx0, xx1, fx);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int sc = 2 - c;
+            const float p00 = r0[xx0 * 3 + sc], p01 = r0[xx1 * 3 + sc], p10 = r1[xx0 * 3 + sc], p11 = r1[xx1 * 3 + sc];
+            const float q = ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f;
+            o[p * 3 + c] = ss_cvt<T>((q - mean[c]) / sd[c]);
+        }
+    }
+    constexpr int NV = 24 * sizeof(T) / 16;
+    uint4* out = reinterpret_cast<uint4*>(dst + ((size_t)blockIdx.z * out_h * out_w + (size_t)y * out_w + xg) * 3);
+    const uint4* ov = reinterpret_cast<const uint4*>(o);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = ov[v];
+}
+
 // flags: bit 0 = half output, bit 1 = channels-last output
 void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_stride, int h, int w, int stride,
                     const float* dets, int det_stride, long long dets_batch_stride, int n, const int* d_count,
                     void* out, int flags, hipStream_t st)
 {
     if (n <= 0 || batch <= 0) return;
+    if (flags & 2) {
+        dim3 grid(1, 16, n * batch), block(256);
+        if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out);
+        else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out);
+        return;
+    }
     dim3 grid(1, 256, n * batch), block(128);
 #define SS_CR(T, L) hipLaunchKernelGGL((k_crop<T, L>), grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, \
                                        det_stride, dets_batch_stride, n, d_count, (T*)out)
-    switch (flags & 3) {
-    case 0: SS_CR(float, 0); break;
-    case 1: SS_CR(__half, 0); break;
-    case 2: SS_CR(float, 1); break;
-    default: SS_CR(__half, 1); break;
-    }
+    if (flags & 1) SS_CR(__half, 0); else SS_CR(float, 0);
 #undef SS_CR
 }
 

@@ -38,7 +38,7 @@ class FramePipeline:
     def __init__(self, detector: str = "yolov8n", n_streams: int = 1, frame_hw=(720, 1280), device: int = 0,
                  half: bool = True, reid_batch: int = 32, cfg: Optional[StrongSortConfig] = None,
                  dcfg: Optional[DetectConfig] = None, det_source: str = "detector", feat_source: str = "reid",
-                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0):
+                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0):
         self.cfg, self.dcfg = cfg or StrongSortConfig(), dcfg or DetectConfig()
         self.S, (self.H, self.W) = n_streams, frame_hw
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
@@ -51,6 +51,12 @@ class FramePipeline:
         # Only the first reid_batch detections of a frame are cropped and embedded: with OSNet features feeding the
         # tracker, NMS keeps at most that many (highest scores first), so no detection reaches it without a feature.
         self.max_det = min(self.dcfg.max_det, MAX_DETS, reid_batch if (feat_source == "reid" and run_nets) else MAX_DETS)
+        # detect_only_rows > 0: a detection-only pipeline (model.predict, yolo_multi_model.py:173) whose NMS keeps up to
+        # that many rows (<= 1024, the reference's max_det is 1000) — it never feeds the tracker (128 detections per frame)
+        self.det_rows = MAX_DETS
+        if detect_only_rows:
+            self.det_rows = min(int(detect_only_rows), 1024)
+            self.max_det = min(self.dcfg.max_det, self.det_rows)
         self.geom = letterbox_geometry(self.H, self.W, self.dcfg.imgsz, self.dcfg.stride)
         self.gain, self.pad_x, self.pad_y = scale_geometry(self.geom, self.H, self.W)
         self.detector = self.reid = None
@@ -68,9 +74,9 @@ class FramePipeline:
         self.geom_dev = torch.tensor([[self.gain, self.pad_x, self.pad_y, float(self.W), float(self.H)]] * S,
                                      dtype=torch.float32, device=dev)      # per-image scale_boxes geometry for ss_nms_batch
         self.pred_in = torch.zeros(S, 4 + self.nc + self.nk, self.n_anchors, dtype=torch.float32, device=dev)
-        self.dets = torch.zeros(S, MAX_DETS, 6 + self.nk, dtype=torch.float32, device=dev)
-        self.dets6 = self.dets if self.nk == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
-        self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
+        self.dets = torch.zeros(S, self.det_rows, 6 + self.nk, dtype=torch.float32, device=dev)
+        self.dets6 = self.dets if self.nk == 0 else torch.zeros(S, self.det_rows, 6, dtype=torch.float32, device=dev)
+        self.keep = torch.zeros(S, self.det_rows, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
         self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.feats_in = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
@@ -118,6 +124,25 @@ class FramePipeline:
     def step(self, track: bool = True):
         """Run one frame (all streams).  Asynchronous; results in self.out / self.nout (device).
         track=False (graph "none" / "split" only skip the work): detection only — letterbox, detector, NMS."""
+        if self.det_rows != MAX_DETS:
+            if track:
+                raise RuntimeError("a detect_only_rows pipeline cannot track")
+            if self.graph_mode != "none":
+                if self.graph is None:                       # one graph: letterbox, detector, NMS
+                    st = torch.cuda.Stream(self.dev)
+                    st.wait_stream(torch.cuda.current_stream(self.dev))
+                    with torch.cuda.stream(st):
+                        self.eng.use_current_stream()
+                        for _ in range(3):
+                            self._detect_impl()
+                        st.synchronize()
+                        self.graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(self.graph, stream=st):
+                            self._detect_impl()
+                    torch.cuda.current_stream(self.dev).wait_stream(st)
+                    self.eng.use_current_stream()
+                self.graph.replay()
+                return
         if self.graph_mode == "none":
             self._detect_impl()
             if track:

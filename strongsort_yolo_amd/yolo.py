@@ -98,6 +98,8 @@ class YOLO:
         self._key = None
         self._stream_pipe = None
         self._stream_key = None
+        self._pred_pipe = None          # detection-only pipeline for predict() when max_det exceeds the tracker's 128 rows
+        self._pred_key = None
         # test / bench hooks (synthetic head tensors, no weights exist offline): extra pipeline keywords and a callable
         # fill(buffers, virtual_stream, frame_index) that writes pred_in / anchor_gt / gt_feats before a frame runs
         self._pipe_kw = {}
@@ -143,6 +145,8 @@ class YOLO:
         return self._pipe
 
     def _run(self, image, device, track):
+        if not track and int(self.overrides["max_det"]) > 128:
+            return self._run_predict_wide(image, device)
         pipe = self._pipeline(image, device)
         pipe.eng.upload(pipe.frames[0], image)
         if self._fill is not None:
@@ -159,6 +163,29 @@ class YOLO:
         self._frame_index += 1
         n, m = int(self._h_cnt[0]), int(self._h_cnt[1])
         return self._results(image, pipe, self._h_dets[:n].clone(), self._h_rows[:m].clone() if track else None)
+
+    def _run_predict_wide(self, image, device):
+        """model.predict with max_det > 128 (the reference sets 1000, yolo_multi_model.py:21): a detection-only pipeline
+        whose NMS keeps up to 1024 rows; the tracking pipeline (128 detections per frame) is not involved."""
+        from .pipeline import FramePipeline
+        key = self._state_key(image.shape[:2], device)
+        if self._pred_pipe is None or key != self._pred_key:
+            if self._pred_pipe is not None:
+                self._pred_pipe.close()
+            p = self._pred_pipe = self._build(FramePipeline, image.shape[:2], device, graph="split", detect_only_rows=1024)
+            self._pred_key = key
+            self._hp_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
+            self._hp_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+        pipe = self._pred_pipe
+        pipe.eng.upload(pipe.frames[0], image)
+        if self._fill is not None:
+            self._fill(pipe, 0, self._frame_index)
+        pipe.step(track=False)
+        self._hp_dets.copy_(pipe.dets[0], non_blocking=True)
+        self._hp_cnt.copy_(pipe.ndets, non_blocking=True)
+        torch.cuda.current_stream(pipe.dev).synchronize()
+        pipe.eng.check_errors()
+        return self._results(image, pipe, self._hp_dets[:int(self._hp_cnt[0])].clone(), None)
 
     def _results(self, image, pipe, dets, rows):
         kpts = None
@@ -285,7 +312,7 @@ class YOLO:
         return Overlay(self.names, pipe.eng)
 
     def close(self):
-        for p in (self._pipe, self._stream_pipe):
+        for p in (self._pipe, self._stream_pipe, self._pred_pipe):
             if p is not None:
                 p.close()
-        self._pipe = self._stream_pipe = None
+        self._pipe = self._stream_pipe = self._pred_pipe = None

@@ -183,3 +183,59 @@ def test_cli_save_annotated_frames(tmp_path):
     x1, y1 = int(ref[10][1][0, 0]), int(ref[10][1][0, 1])
     assert tuple(int(v) for v in ann[10][y1 + 20, x1]) == (0, 0, 225)     # left edge of the first track's box outline (BGR)
     model.close()
+
+
+def test_true_wiring_detector_nms_reid_tracker_edges():
+    """det_source='detector', feat_source='reid' (what a deployment runs): the head tensor the detector produced and the
+    embeddings OSNet produced are read back and pushed through the oracle chain (C NMS + scale_boxes + tracker); the
+    pipeline's rows must equal that bit for bit, i.e. the detector -> NMS and OSNet -> tracker data edges carry exactly
+    those tensors.  Random-init networks: the detections are arbitrary, the plumbing is not."""
+    from oracle import cexact
+    from strongsort_yolo_amd.config import DetectConfig
+    from strongsort_yolo_amd.engine import scale_geometry
+    from strongsort_yolo_amd.pipeline import FramePipeline
+    dcfg = DetectConfig(conf=0.52, iou=0.4)                      # random-init class scores sit around sigmoid(0) = 0.5
+    for graph in ("none", "split"):
+        pipe = FramePipeline("yolov8n", 1, (H_, W_), graph=graph, reid_batch=32, dcfg=dcfg, det_source="detector", feat_source="reid")
+        gs = scale_geometry(pipe.geom, H_, W_)
+        orc = OracleStrongSort(StrongSortConfig(), "c")
+        st = make_stream(77, W_, H_, 6)
+        seen = 0
+        for k in range(8):
+            pipe.frames[0].copy_(torch.from_numpy(st.frame_pixels(k)).to(pipe.dev))
+            pipe.step()
+            got = pipe.results()[0]
+            pred = pipe.pred_in[0].cpu().numpy()
+            keep, r = cexact.nms(pred, pipe.nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 32)
+            r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W_, H_)
+            n = int(pipe.ndets[0])
+            assert n == len(r) and np.array_equal(pipe.dets[0, :n].cpu().numpy(), r), f"{graph} frame {k}: NMS edge"
+            ref = orc.update(r, pipe.feats_in[0, :n].cpu().numpy(), (H_, W_))
+            assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), f"{graph} frame {k}: tracker edge"
+            seen += n
+        assert seen > 0
+        pipe.close()
+
+
+def test_predict_keeps_more_than_128_detections():
+    """model.predict with the reference's max_det = 1000 (yolo_multi_model.py:21): not capped at the tracker's 128 rows"""
+    from oracle import cexact
+    from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
+    from strongsort_yolo_amd.synth import synth_prediction
+    from strongsort_yolo_amd.yolo import YOLO
+    W, H = 1920, 1080
+    model = YOLO("yolov8n.pt", random_init_ok=True)
+    model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)
+    model._pipe_kw = dict(det_source="synthetic", feat_source="by_anchor", reid_batch=32)
+    g = letterbox_geometry(H, W)
+    gs = scale_geometry(g, H, W)
+    A = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
+    fr = make_stream(5, W, H, 220).next_frame()
+    pred, _ = synth_prediction(fr.dets, A, 80, gs[0], (gs[1], gs[2]), np.random.default_rng(3), dup=2, clutter=50)
+    dp = torch.from_numpy(pred).cuda()
+    model._fill = lambda b, v, k: b.pred_in[v].copy_(dp)
+    res = model.predict(np.zeros((H, W, 3), np.uint8), verbose=False, device=0)[0]
+    keep, r = cexact.nms(pred, 80, 0.3, 0.4, False, 7680.0, 8192, 1000)
+    r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W, H)
+    assert len(r) > 128 and np.array_equal(res.boxes.xyxy.numpy(), r[:, :4]) and np.array_equal(res.boxes.conf.numpy(), r[:, 4])
+    model.close()
