@@ -121,6 +121,7 @@ class FramePipeline:
     def _track(self):
         self.eng.update_device(self.dets6, self.ndets, self.feats_in, self.img_hw)
 
+    @torch.no_grad()
     def step(self, track: bool = True):
         """Run one frame (all streams).  Asynchronous; results in self.out / self.nout (device).
         track=False (graph "none" / "split" only skip the work): detection only — letterbox, detector, NMS."""
@@ -411,6 +412,7 @@ class OverlappedPipeline(FramePipeline):
         import ctypes as C
         self.eng._ck(self.eng.L.ss_set_hip_stream(self.eng.ctx, C.c_void_p(st.cuda_stream)))
 
+    @torch.no_grad()
     def _capture(self):
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
@@ -451,6 +453,7 @@ class OverlappedPipeline(FramePipeline):
         self.sA.wait_event(self.ev[self.n - 1][i])               # the group that used this set has left the tracker
         return self.bufs[i]
 
+    @torch.no_grad()
     def _run_stage(self, j: int, frame_idx: int):
         i = frame_idx % self.nb
         st = self.streams[j]
