@@ -371,124 +371,6 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
     }
 }
 
-// Large-M pointwise convolutions with K <= 64 (every OSNet 1x1 layer at 512 crops: M = 0.26 .. 1 M pixels): the
-// persistent form of k_pw.  Such a layer is one K chunk, so a k_pw workgroup is a serial chain load -> MFMA -> shortcut
-// load -> store with nothing of its own in flight during the last three (PMC, profiles/r02_pmc_nets_before_fma_mix.json:
-// waves parked on memory 50-55 % of their cycles, 2.4-3.4 TB/s).  Here a workgroup stages its weight tile once and walks
-// pixel tiles tile, tile + grid, ...: the NEXT tile's pixels and shortcut rows are requested before the current tile's
-// MFMAs and epilogue, so every wave always has a tile of loads on the wire.  Arithmetic and epilogue = k_pw<.., false, true>.
-template <int BN, int PT>
-__global__ __launch_bounds__(256) void k_pw1(const __half* __restrict__ x, const __half* __restrict__ w,
-                                            const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
-                                            int N, int act, int res_after, __half* __restrict__ out, int out_ld,
-                                            __half* __restrict__ out2, int c0, int cn, int ntiles)
-{
-    constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT, EP = BN + 8, CG = BN / 8, NIT = PT * 16 * CG / 64;
-    __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
-    __shared__ __attribute__((aligned(16))) _Float16 Et[4 * PT * 16 * EP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
-    const int n0 = blockIdx.y * BN;
-    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    constexpr int WV = (BN * (KC / 8) + 255) / 256;
-#pragma unroll
-    for (int j = 0; j < WV; ++j) {
-        const int i = tid + j * 256, r = i / (KC / 8), c8 = i - r * (KC / 8);
-        const int oc = n0 + r, k = c8 * 8;
-        if (i < BN * (KC / 8))
-            *reinterpret_cast<h8*>(Ws + r * PITCH + c8 * 8) = (oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
-    }
-    auto load_b = [&](size_t px0, h8 (&b)[KC / 32][PT]) {
-#pragma unroll
-        for (int ks = 0; ks < KC / 32; ++ks)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const size_t px = px0 + pt * 16 + n;
-                const int k = ks * 32 + 8 * q;
-                b[ks][pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
-            }
-    };
-    auto load_r = [&](size_t px0, h8 (&r)[NIT]) {               // the shortcut rows the epilogue of this tile will add
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-            const size_t px = px0 + row;
-            const int oc = n0 + cg * 8;
-            r[it] = (res && px < (size_t)M && oc < N) ? *reinterpret_cast<const h8*>(res + px * N + oc) : z8;
-        }
-    };
-    _Float16* tile_lds = Et + wave * (PT * 16 * EP);
-    h8 b[KC / 32][PT], bn[KC / 32][PT], r[NIT], rn[NIT];
-    int tile = blockIdx.x;
-    size_t px0 = (size_t)tile * BM + wave * (16 * PT);
-    if (tile < ntiles) { load_b(px0, b); load_r(px0, r); }
-    __syncthreads();                                         // weights staged
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int nxt = tile + gridDim.x;
-        const size_t px0n = (size_t)nxt * BM + wave * (16 * PT);
-        if (nxt < ntiles) { load_b(px0n, bn); load_r(px0n, rn); }
-        f4 acc[MT][PT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int ks = 0; ks < KC / 32; ++ks) {
-            if (ks * 32 >= K) break;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h8 a = *reinterpret_cast<const h8*>(Ws + (mt * 16 + n) * PITCH + ks * 32 + 8 * q);
-                const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    const h8 bv = b[ks][pt];
-                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
-                *reinterpret_cast<h4*>(tile_lds + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;     // conv rounded to half, as unfused
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-            const size_t px = px0 + row;
-            const int oc = n0 + cg * 8;
-            if (px >= (size_t)M || oc >= N) continue;
-            const h8 v = *reinterpret_cast<const h8*>(tile_lds + row * EP + cg * 8);
-            const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
-            const h8 rr = r[it];
-            h8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = (float)v[j] + (float)bb[j];
-                if (res && !res_after) f += (float)rr[j];
-                f = act_apply(f, act);
-                if (res && res_after) f = (float)(_Float16)f + (float)rr[j];
-                o[j] = (_Float16)f;
-            }
-            *reinterpret_cast<h8*>(out + px * out_ld + oc) = o;
-            if (out2 && oc >= c0 && oc < c0 + cn) *reinterpret_cast<h8*>(out2 + px * cn + (oc - c0)) = o;
-        }
-        __builtin_amdgcn_wave_barrier();                     // the wave's LDS tile is free again
-        if (nxt < ntiles) {
-#pragma unroll
-            for (int ks = 0; ks < KC / 32; ++ks)
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) b[ks][pt] = bn[ks][pt];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) r[it] = rn[it];
-        }
-        px0 = px0n;
-    }
-}
-
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
 // pad 1, crops [N][H][128][3] half -> [N][H/4][32][16] half.  MIOpen runs the C_in = 3 convolution at 186 us for 256
 // crops (5% of its data rate) and bias, ReLU and pooling are three more passes over the 67 MB conv output.
@@ -1027,22 +909,6 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
         else { if (vec) SS_PW(BN, PT, false, true); else SS_PW(BN, PT, false, false); }                                 \
     } while (0)
     const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
-    // one K chunk and >= 4 tiles per persistent workgroup: the pipelined persistent kernel (SS_PW_PERSIST=0: A/B switch)
-    static const bool persist_allowed = [] { const char* e = getenv("SS_PW_PERSIST"); return !(e && e[0] == '0'); }();
-    if (persist_allowed && !conv3 && vec && K <= 64 && M >= 262144) {
-#define SS_PW1(BN)                                                                                                      \
-    do {                                                                                                                \
-        const int ntiles = (int)((M + 127) / 128), nby = (N + BN - 1) / BN;                                             \
-        const int gx = std::min(ntiles, std::max(256, 1024 / nby));                                                     \
-        hipLaunchKernelGGL((k_pw1<BN, 2>), dim3(gx, nby), dim3(256), 0, st, (const __half*)x, (const __half*)w,         \
-                           (const __half*)bias, (const __half*)res, (int)M, K, N, act, res_after, (__half*)out, out_ld,  \
-                           (__half*)out2, c0, cn, ntiles);                                                              \
-    } while (0)
-        if (N <= 32) { SS_PW1(32); return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP; }
-        if (N <= 64) { SS_PW1(64); return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP; }
-        // N > 64: the prefetch registers do not fit beside 128 output channels of accumulators; k_pw<128,2> below
-    }
-#undef SS_PW1
     if (N <= 32) { if (big) SS_PW2(32, 2); else SS_PW2(32, 1); }
     else if (N <= 64 || !big) { if (big) SS_PW2(64, 2); else SS_PW2(64, 1); }
     else SS_PW2(128, 2);
