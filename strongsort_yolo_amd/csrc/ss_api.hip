@@ -275,7 +275,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
 {
     if (!c || !d_dets || !d_ndets || !d_feats || !d_img_hw || !d_out || !d_nout)
         return fail(c, SS_ERR_INVALID, "ss_track_update_group: null argument");
-    if (n_frames < 1 || n_frames > SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_track_update_group: 1 <= n_frames <= 16");
+    if (n_frames < 1 || n_frames > SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_track_update_group: 1 <= n_frames <= SS_FMAX");
     // a gallery ring position must be overwritten at most once per group (k_assoc's per-frame row mask, k_newrow)
     if (n_frames > c->cfg.nn_budget) return fail(c, SS_ERR_INVALID, "ss_track_update_group: n_frames <= nn_budget required");
     SSDev dev = c->dev;

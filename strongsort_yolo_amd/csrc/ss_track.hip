@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 #define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) dev.timeline[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
 
 template <bool TL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(TL ? 2 : 4, 4))) void k_assoc(SSDev dev)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc(SSDev dev)
 {
     bool first_item = true;
     SS_TL(0);
