@@ -313,34 +313,45 @@ __global__ __launch_bounds__(1024) void k_nms_sort(NmsBatch nb, int N, int agnos
     }
 }
 
-// suppression bit matrix: mask[i][jb] bit t set when j = jb*64+t > i and IoU(i,j) > thr
+// suppression bit matrix: mask[i][jb] bit t set when j = jb*64+t > i and IoU(i,j) > thr.
+// grid = (NMS_MASK_WG, images): the workgroups of an image walk the upper-triangle 64x64 blocks (ib <= jb) of ITS
+// candidate count with a stride loop — the count is only known on the device, and a grid sized for the worst case
+// (128 x 128 blocks per image) was ~100 k empty workgroups per launch (25 us).
+#define NMS_MASK_WG 256
 __global__ __launch_bounds__(64) void k_nms_mask(NmsBatch nb, float iou_thres)
 {
-    const NmsWs w = nms_unit(nb, blockIdx.z);
+    const NmsWs w = nms_unit(nb, blockIdx.y);
     __shared__ float sb[64 * 4];
     __shared__ float sa[64];
     const int n = min(w.counters[0], NMS_MAX_CAND);
-    const int ib = blockIdx.y, jb = blockIdx.x;
-    if (ib * 64 >= n || jb * 64 >= n || jb < ib) return;
+    const int nblk = (n + 63) / 64;
+    const int npair = nblk * (nblk + 1) / 2;
     const int t = threadIdx.x;
-    const int j = jb * 64 + t;
-    if (j < n) { sb[t * 4] = w.box[j * 4]; sb[t * 4 + 1] = w.box[j * 4 + 1]; sb[t * 4 + 2] = w.box[j * 4 + 2]; sb[t * 4 + 3] = w.box[j * 4 + 3]; sa[t] = w.area[j]; }
-    __syncthreads();
-    const int i = ib * 64 + t;
-    if (i >= n) return;
-    const float x1 = w.box[i * 4], y1 = w.box[i * 4 + 1], x2 = w.box[i * 4 + 2], y2 = w.box[i * 4 + 3], ai = w.area[i];
-    unsigned long long bits = 0;
-    const int jn = min(64, n - jb * 64);
-    for (int q = 0; q < jn; ++q) {
-        if (jb * 64 + q <= i) continue;
-        float xx1 = fmaxf(x1, sb[q * 4]), yy1 = fmaxf(y1, sb[q * 4 + 1]);
-        float xx2 = fminf(x2, sb[q * 4 + 2]), yy2 = fminf(y2, sb[q * 4 + 3]);
-        float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
-        float inter = iw * ih;
-        float iou = inter / (ai + sa[q] - inter);
-        if (iou > iou_thres) bits |= 1ull << q;
+    for (int pr = blockIdx.x; pr < npair; pr += gridDim.x) {
+        // pair index -> (ib, jb), ib <= jb, row-major over the upper triangle
+        int ib = 0, rem = pr;
+        while (rem >= nblk - ib) { rem -= nblk - ib; ++ib; }
+        const int jb = ib + rem;
+        const int j = jb * 64 + t;
+        __syncthreads();                                   // the previous block's readers are done with sb / sa
+        if (j < n) { sb[t * 4] = w.box[j * 4]; sb[t * 4 + 1] = w.box[j * 4 + 1]; sb[t * 4 + 2] = w.box[j * 4 + 2]; sb[t * 4 + 3] = w.box[j * 4 + 3]; sa[t] = w.area[j]; }
+        __syncthreads();
+        const int i = ib * 64 + t;
+        if (i >= n) continue;
+        const float x1 = w.box[i * 4], y1 = w.box[i * 4 + 1], x2 = w.box[i * 4 + 2], y2 = w.box[i * 4 + 3], ai = w.area[i];
+        unsigned long long bits = 0;
+        const int jn = min(64, n - jb * 64);
+        for (int q = 0; q < jn; ++q) {
+            if (jb * 64 + q <= i) continue;
+            float xx1 = fmaxf(x1, sb[q * 4]), yy1 = fmaxf(y1, sb[q * 4 + 1]);
+            float xx2 = fminf(x2, sb[q * 4 + 2]), yy2 = fminf(y2, sb[q * 4 + 3]);
+            float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
+            float inter = iw * ih;
+            float iou = inter / (ai + sa[q] - inter);
+            if (iou > iou_thres) bits |= 1ull << q;
+        }
+        w.mask[(size_t)i * NMS_WORDS + jb] = bits;
     }
-    w.mask[(size_t)i * NMS_WORDS + jb] = bits;
 }
 
 // greedy scan (one wave) + output rows in original-image pixels
@@ -441,9 +452,7 @@ int ss_launch_nms(const float* pred, int batch, long long pred_stride, int N, in
     // the candidate counter is re-armed by k_nms_scan itself (no memset node: graph-capture safe)
     hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64, batch), dim3(512), 0, st, nb, N, nc, conf, cm0, cm1);
     hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(1024), NMS_MAX_CAND * 8, st, nb, N, agnostic, max_wh);
-    // mask grid sized for the worst case the filter could produce; blocks beyond n exit at once
-    const int nbmax = (min(N, NMS_MAX_CAND) + 63) / 64;
-    hipLaunchKernelGGL(k_nms_mask, dim3(nbmax, nbmax, batch), dim3(64), 0, st, nb, iou);
+    hipLaunchKernelGGL(k_nms_mask, dim3(NMS_MASK_WG, batch), dim3(64), 0, st, nb, iou);
     hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), 0, st, nb, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
                        geom, rows, row_stride, rows_batch_stride, keep, keep_batch_stride, count);
     return 0;
