@@ -151,6 +151,19 @@ int ss_track_update_group(ss_ctx* ctx, int n_frames, const float* d_dets, const 
 int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const float* d_feats,
                     const int* d_img_hw, float* d_out, int* d_nout);
 
+/* ---- N4  camera-motion compensation (upstream StrongSORT: tracker.camera_update(prev, cur) before tracker.predict();
+ * not in the reference snapshot; optional) ----------------------------------------------------------
+ * ss_cmc_estimate: for the n_frames x n_streams BGR u8 frames at d_frames ([F][S] order, frame_stride bytes apart) build
+ * the 0.1x grey images and align each with its predecessor (the stream's last frame of the previous call for f = 0) by
+ * ECC, euclidean warp, <= 100 iterations: d_warps[f][s][8] = 2x3 matrix previous -> current in full-frame pixels,
+ * [6] = iterations (>= 1) or -1 (no usable alignment / no predecessor: identity), [7] = 0.  Asynchronous on hip_stream;
+ * stateless apart from the remembered last frames, so it can run beside the detector.
+ * ss_track_set_cmc: the following tracker calls move every track's box by warp [f][s] before predicting frame f
+ * (NULL switches compensation off, the default). */
+int ss_cmc_estimate(ss_ctx* ctx, void* hip_stream, const uint8_t* d_frames, int n_frames, long long frame_stride, int h, int w,
+                    int row_stride, double* d_warps);
+int ss_track_set_cmc(ss_ctx* ctx, const double* d_warps);
+
 /* Synchronous convenience for one stream with host buffers (used by StrongSORT.update). */
 int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, const float* h_feats,
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);

@@ -58,6 +58,11 @@ def lib():
         L.so_nms_classes.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float,
                                      C.c_int, C.c_int, u8p, i32p, f32p]
         L.so_scale_boxes.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.so_gray_small.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+        L.so_ecc.restype = C.c_int
+        L.so_ecc.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, f64p]
+        L.so_camera_update.argtypes = [f64p, f64p]
+        L.so_sincos.argtypes = [C.c_double, f64p, f64p]
         L.so_letterbox.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p] + [C.c_int] * 7
         L.so_crop_norm.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int]
     return _lib
@@ -219,3 +224,32 @@ def crop_norm(img, dets, out_h=256, out_w=128):
         lib().so_crop_norm(_p(img, C.c_uint8), H, W, img.strides[0], _p(dets, C.c_float),
                            dets.shape[1], D, _p(dst, C.c_float), out_h, out_w)
     return dst
+
+
+# ---- N4 camera-motion compensation --------------------------------------------------------------------
+def gray_small(img, hs, ws):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((hs, ws), dtype=np.uint8)
+    lib().so_gray_small(_p(img, C.c_uint8), img.shape[0], img.shape[1], img.strides[0], _p(out, C.c_uint8), hs, ws)
+    return out
+
+
+def ecc(template, image, max_iter=100, eps=1e-5):
+    """-> (warp [2,3] float64 mapping template to image coordinates (small-image pixels), iterations or -1)"""
+    t, i = np.ascontiguousarray(template, dtype=np.uint8), np.ascontiguousarray(image, dtype=np.uint8)
+    assert t.shape == i.shape
+    warp = np.empty(6)
+    it = lib().so_ecc(_p(t, C.c_uint8), _p(i, C.c_uint8), t.shape[0], t.shape[1], max_iter, eps, _p(warp, C.c_double))
+    return warp.reshape(2, 3), it
+
+
+def camera_update(mean, warp):
+    mean, warp = _f64(mean).copy(), _f64(warp).reshape(6)
+    lib().so_camera_update(_p(mean, C.c_double), _p(warp, C.c_double))
+    return mean
+
+
+def sincos(t):
+    s, c = C.c_double(), C.c_double()
+    lib().so_sincos(float(t), C.byref(s), C.byref(c))
+    return s.value, c.value

@@ -532,3 +532,195 @@ void so_crop_norm(const uint8_t* src, int H, int W, int stride, const float* det
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * N4  camera-motion compensation: ECC alignment of consecutive down-scaled grey frames + the warp
+ * applied to every track's box before the Kalman prediction.  NOT in the reference snapshot; stands where upstream
+ * StrongSORT calls `tracker.camera_update(prev_img, cur_img)` ahead of `tracker.predict()` inside model.track
+ * (yolo_multi_model.py:41).  PARITY UNPINNED twice over: the upstream code is recalled, not present (SURVEY App. A.1:
+ * cv2.findTransformECC, MOTION_EUCLIDEAN, 100 iterations, eps 1e-5, scale 0.1), and OpenCV itself is not installed, so
+ * this is the published forward-additive ECC iteration (Evangelidis & Psarakis 2008) written out with a DEFINED
+ * operation order, which the HIP kernel reproduces bit for bit (D-18).  All arithmetic float64.
+ * ---------------------------------------------------------------------------------------------- */
+#define SO_ECC_THREADS 1024            /* the reduction shape both sides use: 1024 strided partial sums, 64-wide
+                                          xor butterflies, then 16 group sums added left to right */
+#define SO_ECC_NS 15
+
+/* BGR u8 -> grey (OpenCV's fixed-point weights) -> bilinear down-scale to hs x ws (half-pixel centres, rounded to u8) */
+static inline float so_grey(const uint8_t* p) { return (float)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14); }
+
+void so_gray_small(const uint8_t* src, int H, int W, int stride, uint8_t* dst, int hs, int ws)
+{
+    const float sx = (float)W / (float)ws, sy = (float)H / (float)hs;
+    for (int y = 0; y < hs; ++y) {
+        int y0, y1; float fy;
+        so_axis(y, sy, H, &y0, &y1, &fy);
+        for (int x = 0; x < ws; ++x) {
+            int x0, x1; float fx;
+            so_axis(x, sx, W, &x0, &x1, &fx);
+            const uint8_t *r0 = src + (size_t)y0 * stride, *r1 = src + (size_t)y1 * stride;
+            dst[y * ws + x] = (uint8_t)so_bilerp_u8(so_grey(r0 + x0 * 3), so_grey(r0 + x1 * 3), so_grey(r1 + x0 * 3), so_grey(r1 + x1 * 3), fx, fy);
+        }
+    }
+}
+
+/* sin / cos by their Taylor polynomials in Horner form with fma (the same expression on both sides; |theta| small) */
+void so_sincos(double t, double* s, double* c)
+{
+    const double t2 = t * t;
+    double ps = -1.0 / 1307674368000.0;                       /* -1/15! */
+    ps = fma(ps, t2, 1.0 / 6227020800.0);                     /* +1/13! */
+    ps = fma(ps, t2, -1.0 / 39916800.0);
+    ps = fma(ps, t2, 1.0 / 362880.0);
+    ps = fma(ps, t2, -1.0 / 5040.0);
+    ps = fma(ps, t2, 1.0 / 120.0);
+    ps = fma(ps, t2, -1.0 / 6.0);
+    ps = fma(ps, t2, 1.0);
+    double pc = 1.0 / 20922789888000.0;                       /* +1/16! */
+    pc = fma(pc, t2, -1.0 / 87178291200.0);
+    pc = fma(pc, t2, 1.0 / 479001600.0);
+    pc = fma(pc, t2, -1.0 / 3628800.0);
+    pc = fma(pc, t2, 1.0 / 40320.0);
+    pc = fma(pc, t2, -1.0 / 720.0);
+    pc = fma(pc, t2, 1.0 / 24.0);
+    pc = fma(pc, t2, -0.5);
+    pc = fma(pc, t2, 1.0);
+    *s = t * ps; *c = pc;
+}
+
+static inline double so_px(const uint8_t* I, int ws, int hs, int x, int y)
+{
+    if (x < 0) x = 0; if (x > ws - 1) x = ws - 1;
+    if (y < 0) y = 0; if (y > hs - 1) y = hs - 1;
+    return (double)I[y * ws + x];
+}
+
+/* warped image value and gradients at template pixel (x, y); returns 0 when the warped point leaves the image */
+static inline int so_ecc_sample(const uint8_t* I, int ws, int hs, double c, double s, double tx, double ty, int x, int y,
+                                double* iw, double* gx, double* gy)
+{
+    const double xw = (c * (double)x - s * (double)y) + tx, yw = (s * (double)x + c * (double)y) + ty;
+    if (!(xw >= 0.0 && xw <= (double)(ws - 1) && yw >= 0.0 && yw <= (double)(hs - 1))) return 0;
+    int x0 = (int)xw, y0 = (int)yw;
+    if (x0 > ws - 2) x0 = ws - 2; if (y0 > hs - 2) y0 = hs - 2;
+    if (x0 < 0) x0 = 0; if (y0 < 0) y0 = 0;
+    const double fx = xw - (double)x0, fy = yw - (double)y0;
+    double v[3][4];
+    for (int k = 0; k < 4; ++k) {
+        const int xi = x0 + (k & 1), yi = y0 + (k >> 1);
+        v[0][k] = so_px(I, ws, hs, xi, yi);
+        v[1][k] = (so_px(I, ws, hs, xi + 1, yi) - so_px(I, ws, hs, xi - 1, yi)) * 0.5;
+        v[2][k] = (so_px(I, ws, hs, xi, yi + 1) - so_px(I, ws, hs, xi, yi - 1)) * 0.5;
+    }
+    double o[3];
+    for (int q = 0; q < 3; ++q) {
+        const double a = v[q][0] + fx * (v[q][1] - v[q][0]);
+        const double b = v[q][2] + fx * (v[q][3] - v[q][2]);
+        o[q] = a + fy * (b - a);
+    }
+    *iw = o[0]; *gx = o[1]; *gy = o[2];
+    return 1;
+}
+
+/* the reduction tree of the kernel: part[t][k] for t < 1024 -> 16 groups of 64 reduced by xor butterflies -> summed 0..15 */
+static void so_ecc_reduce(double (*part)[SO_ECC_NS], int ns, double* out)
+{
+    for (int k = 0; k < ns; ++k) {
+        double tot = 0.0;
+        for (int g = 0; g < SO_ECC_THREADS / 64; ++g) {
+            double p[64], q[64];
+            for (int l = 0; l < 64; ++l) p[l] = part[g * 64 + l][k];
+            for (int off = 32; off >= 1; off >>= 1) {
+                for (int l = 0; l < 64; ++l) q[l] = p[l] + p[l ^ off];
+                memcpy(p, q, sizeof p);
+            }
+            tot = (g == 0) ? p[0] : tot + p[0];
+        }
+        out[k] = tot;
+    }
+}
+
+/* T (previous frame) and I (current frame): grey u8 [hs][ws].  warp[6] = 2x3 matrix mapping T coordinates to I
+ * coordinates, translation in small-image pixels.  Returns the iterations run (>= 1), or -1 (no usable alignment:
+ * the caller keeps the identity). */
+int so_ecc(const uint8_t* T, const uint8_t* I, int hs, int ws, int max_iter, double eps, double* warp)
+{
+    static double part[SO_ECC_THREADS][SO_ECC_NS];
+    double theta = 0.0, tx = 0.0, ty = 0.0, last_rho = -2.0;
+    const int npx = hs * ws;
+    int it;
+    warp[0] = 1; warp[1] = 0; warp[2] = 0; warp[3] = 0; warp[4] = 1; warp[5] = 0;
+    for (it = 1; it <= max_iter; ++it) {
+        double s, c, sum[SO_ECC_NS];
+        so_sincos(theta, &s, &c);
+        /* pass 1: valid count, sum of warped image, sum of template */
+        for (int t = 0; t < SO_ECC_THREADS; ++t) {
+            double a0 = 0, a1 = 0, a2 = 0;
+            for (int p = t; p < npx; p += SO_ECC_THREADS) {
+                const int y = p / ws, x = p - y * ws;
+                double iw, gx, gy;
+                if (!so_ecc_sample(I, ws, hs, c, s, tx, ty, x, y, &iw, &gx, &gy)) continue;
+                a0 = a0 + 1.0; a1 = a1 + iw; a2 = a2 + (double)T[p];
+            }
+            part[t][0] = a0; part[t][1] = a1; part[t][2] = a2;
+        }
+        so_ecc_reduce(part, 3, sum);
+        if (!(sum[0] >= 64.0)) return -1;
+        const double mI = sum[1] / sum[0], mT = sum[2] / sum[0];
+        /* pass 2: Hessian, projections, correlation, norms */
+        for (int t = 0; t < SO_ECC_THREADS; ++t) {
+            double a[SO_ECC_NS];
+            for (int k = 0; k < SO_ECC_NS; ++k) a[k] = 0.0;
+            for (int p = t; p < npx; p += SO_ECC_THREADS) {
+                const int y = p / ws, x = p - y * ws;
+                double iwv, gx, gy;
+                if (!so_ecc_sample(I, ws, hs, c, s, tx, ty, x, y, &iwv, &gx, &gy)) continue;
+                const double iw = iwv - mI, tz = (double)T[p] - mT;
+                const double hx = -((double)x * s) - (double)y * c, hy = (double)x * c - (double)y * s;
+                const double j0 = gx * hx + gy * hy, j1 = gx, j2 = gy;
+                a[0] = a[0] + j0 * j0; a[1] = a[1] + j0 * j1; a[2] = a[2] + j0 * j2;
+                a[3] = a[3] + j1 * j1; a[4] = a[4] + j1 * j2; a[5] = a[5] + j2 * j2;
+                a[6] = a[6] + j0 * iw; a[7] = a[7] + j1 * iw; a[8] = a[8] + j2 * iw;
+                a[9] = a[9] + j0 * tz; a[10] = a[10] + j1 * tz; a[11] = a[11] + j2 * tz;
+                a[12] = a[12] + tz * iw; a[13] = a[13] + iw * iw; a[14] = a[14] + tz * tz;
+            }
+            for (int k = 0; k < SO_ECC_NS; ++k) part[t][k] = a[k];
+        }
+        so_ecc_reduce(part, SO_ECC_NS, sum);
+        const double h00 = sum[0], h01 = sum[1], h02 = sum[2], h11 = sum[3], h12 = sum[4], h22 = sum[5];
+        const double c00 = h11 * h22 - h12 * h12, c01 = h02 * h12 - h01 * h22, c02 = h01 * h12 - h02 * h11;
+        const double c11 = h00 * h22 - h02 * h02, c12 = h01 * h02 - h00 * h12, c22 = h00 * h11 - h01 * h01;
+        const double det = (h00 * c00 + h01 * c01) + h02 * c02;
+        const double ni = sum[13], nt = sum[14], corr = sum[12];
+        if (!(det != 0.0) || !(ni > 0.0) || !(nt > 0.0)) return -1;
+        const double rho = corr / (sqrt(ni) * sqrt(nt));
+        if (!(rho == rho)) return -1;
+        if (it > 1 && fabs(rho - last_rho) < eps) break;
+        last_rho = rho;
+        const double i00 = c00 / det, i01 = c01 / det, i02 = c02 / det, i11 = c11 / det, i12 = c12 / det, i22 = c22 / det;
+        const double ip0 = sum[6], ip1 = sum[7], ip2 = sum[8], tp0 = sum[9], tp1 = sum[10], tp2 = sum[11];
+        const double q0 = (i00 * ip0 + i01 * ip1) + i02 * ip2, q1 = (i01 * ip0 + i11 * ip1) + i12 * ip2, q2 = (i02 * ip0 + i12 * ip1) + i22 * ip2;
+        const double lam_n = ni - ((ip0 * q0 + ip1 * q1) + ip2 * q2), lam_d = corr - ((tp0 * q0 + tp1 * q1) + tp2 * q2);
+        if (!(lam_d > 0.0)) return -1;
+        const double lam = lam_n / lam_d;
+        const double e0 = lam * tp0 - ip0, e1 = lam * tp1 - ip1, e2 = lam * tp2 - ip2;
+        theta = theta + ((i00 * e0 + i01 * e1) + i02 * e2);
+        tx = tx + ((i01 * e0 + i11 * e1) + i12 * e2);
+        ty = ty + ((i02 * e0 + i12 * e1) + i22 * e2);
+    }
+    double s, c;
+    so_sincos(theta, &s, &c);
+    warp[0] = c; warp[1] = -s; warp[2] = tx; warp[3] = s; warp[4] = c; warp[5] = ty;
+    return it > max_iter ? max_iter : it;
+}
+
+/* the warp (translation already in full-frame pixels) applied to one track's box; mean[8] in place (D-18) */
+void so_camera_update(double* mean, const double* m)
+{
+    const double w = mean[2] * mean[3], h = mean[3];
+    const double x1 = mean[0] - w / 2, y1 = mean[1] - h / 2, x2 = x1 + w, y2 = y1 + h;
+    const double ax = (m[0] * x1 + m[1] * y1) + m[2], ay = (m[3] * x1 + m[4] * y1) + m[5];
+    const double bx = (m[0] * x2 + m[1] * y2) + m[2], by = (m[3] * x2 + m[4] * y2) + m[5];
+    const double nw = bx - ax, nh = by - ay;
+    mean[0] = ax + nw / 2; mean[1] = ay + nh / 2; mean[2] = nw / nh; mean[3] = nh;
+}

@@ -113,6 +113,16 @@ class NumpyNumerics:
     def lsap(self, cost):
         return self._opt.linear_sum_assignment(cost)
 
+    def camera_update(self, mean, warp):
+        w, h = mean[2] * mean[3], mean[3]
+        p1 = np.array([mean[0] - w / 2, mean[1] - h / 2, 1.0])
+        p2 = p1 + np.array([w, h, 0.0])
+        a, b = warp @ p1, warp @ p2
+        nw, nh = b[0] - a[0], b[1] - a[1]
+        out = mean.copy()
+        out[:4] = [a[0] + nw / 2, a[1] + nh / 2, nw / nh, nh]
+        return out
+
 
 class CNumerics:
     """Defined-order arithmetic from oracle/csrc/ss_oracle.c."""
@@ -141,6 +151,7 @@ class CNumerics:
         return self.x.iou_cost(tlwh, det_tlwh, self.cfg.max_iou_distance)
 
     def lsap(self, cost): return self.x.lsap(cost)
+    def camera_update(self, mean, warp): return self.x.camera_update(mean, warp)
 
 
 # ==================================================================================================
@@ -204,7 +215,9 @@ class OracleStrongSort:
         return pairs, sorted(urow), sorted(ucol)
 
     # -- the per-frame update ---------------------------------------------------------------------
-    def update(self, dets: np.ndarray, feats: np.ndarray, img_hw) -> np.ndarray:
+    def update(self, dets: np.ndarray, feats: np.ndarray, img_hw, warp: Optional[np.ndarray] = None) -> np.ndarray:
+        """warp (N4, optional): 2x3 camera-motion matrix previous frame -> this frame in full-frame pixels; applied to
+        every track's box before the prediction (upstream tracker.camera_update ahead of tracker.predict)."""
         cfg, nx = self.cfg, self.nx
         dets = np.asarray(dets, dtype=np.float32).reshape(-1, 6)
         D = dets.shape[0]
@@ -213,8 +226,10 @@ class OracleStrongSort:
         tlwh = xyxy_to_tlwh64(dets) if D else np.zeros((0, 4))
         xyah = tlwh_to_xyah(tlwh) if D else np.zeros((0, 4))
 
-        # 1. predict every live track
+        # 0. camera-motion compensation, 1. predict every live track
         for t in self.tracks:
+            if warp is not None:
+                t.mean = nx.camera_update(t.mean, np.asarray(warp, dtype=np.float64).reshape(2, 3))
             t.mean, t.cov = nx.kf_predict(t.mean, t.cov)
             t.age += 1
             t.tsu += 1

@@ -27,6 +27,7 @@ int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
 void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
+void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, double*, hipStream_t);
 extern "C" void ss_step_kernel_attr();
 
 static std::string g_last_error;
@@ -54,6 +55,12 @@ struct ss_ctx {
     struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
     int stage_next = 0;
     uint8_t* font;              // [95][5] overlay font (ss_overlay_set_font)
+    // N4 camera-motion compensation
+    uint8_t* cmc_small;         // [FMAX+1][S][cmc_stride] down-scaled grey frames (index 0 = last frame of the previous group)
+    size_t cmc_stride;          // bytes per small image (multiple of 16), 0 until the first ss_cmc_estimate
+    int cmc_hw[2];              // frame size the buffer was made for
+    int* cmc_prev_valid;        // [S]
+    const double* cmc_warps;    // what ss_track_set_cmc installed
     struct Back { void* p = nullptr; size_t cap = 0; } back;      // device -> host staging (ss_download)
     int cos_grid;               // persistent workgroups of the association kernel
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
@@ -104,6 +111,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
+    c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -147,6 +155,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     if (rc == SS_OK) rc = dalloc(c, &c->kat_lsap_t, (size_t)256 * 256);
     if (rc == SS_OK) rc = dalloc(c, &c->kat_err, 4);
     if (rc == SS_OK) rc = dalloc(c, &c->font, 95 * 5);
+    if (rc == SS_OK) rc = dalloc(c, &c->cmc_prev_valid, S);
     c->nms_ws_bytes = ss_nms_workspace_bytes();
     c->nms_units = 1;
     if (rc == SS_OK) { char* w; rc = dalloc(c, &w, c->nms_ws_bytes); c->nms_ws = w; }
@@ -220,6 +229,39 @@ extern "C" int ss_download(ss_ctx* c, void* hip_stream, void* h_dst, const void*
     return SS_OK;
 }
 
+// ---- N4 camera-motion compensation ------------------------------------------------------------------------
+extern "C" int ss_cmc_estimate(ss_ctx* c, void* hip_stream, const uint8_t* d_frames, int n_frames, long long frame_stride, int h,
+                               int w, int row_stride, double* d_warps)
+{
+    if (!c || !d_frames || !d_warps || n_frames < 1 || n_frames > SS_FMAX || h < 20 || w < 20 || row_stride < 3 * w)
+        return fail(c, SS_ERR_INVALID, "ss_cmc_estimate: bad argument");
+    const int hs = (int)(h * 0.1), ws = (int)(w * 0.1);
+    const size_t stride = ((size_t)hs * ws + 15) / 16 * 16;
+    if (c->cmc_hw[0] != h || c->cmc_hw[1] != w) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hip_stream) HIPCHK(c, hipStreamIsCapturing((hipStream_t)hip_stream, &cs));
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(c, SS_ERR_INVALID, "ss_cmc_estimate: first call for a frame size must not be inside a graph capture");
+        uint8_t* buf = nullptr;
+        int rc = dalloc(c, &buf, (size_t)(SS_FMAX + 1) * c->dev.S * stride);
+        if (rc) return rc;
+        c->cmc_small = buf; c->cmc_stride = stride; c->cmc_hw[0] = h; c->cmc_hw[1] = w;
+        HIPCHK(c, hipMemsetAsync(c->cmc_prev_valid, 0, (size_t)c->dev.S * 4, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    ss_launch_cmc(d_frames, n_frames * c->dev.S, frame_stride, h, w, row_stride, c->cmc_small, (long long)c->cmc_stride, c->dev.S,
+                  n_frames, hs, ws, 100, 1e-5, c->cmc_prev_valid, d_warps, (hipStream_t)hip_stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_track_set_cmc(ss_ctx* c, const double* d_warps)
+{
+    if (!c) return SS_ERR_INVALID;
+    c->cmc_warps = d_warps;
+    return SS_OK;
+}
+
 // ---- N2 overlay -----------------------------------------------------------------------------------------
 extern "C" int ss_overlay_set_font(ss_ctx* c, const uint8_t* h_font_95x5)
 {
@@ -263,6 +305,7 @@ extern "C" int ss_reset(ss_ctx* c, int stream)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     HIPCHK(c, hipMemsetAsync(d.n_items, 0, 32, c->stream));
+    for (int s = s0; s < s1; ++s) HIPCHK(c, hipMemsetAsync(c->cmc_prev_valid + s, 0, 4, c->stream));
     if (stream < 0)
         for (int u = 0; u < c->nms_units; ++u) HIPCHK(c, hipMemsetAsync(ss_nms_error_flag(c->nms_ws, u), 0, 4, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -286,6 +329,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     // from the work lists, so nothing here needs a host round trip and the sequence can be captured into a HIP graph.
     dev.cos_grid = c->cos_grid;
     dev.ts_enable = c->inkernel;
+    dev.cmc = c->cmc_warps;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used == c->ev.size()) {

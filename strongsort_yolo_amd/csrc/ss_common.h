@@ -88,6 +88,7 @@ struct SSDev {
     int* n_post;                // [S]
     int* rowlist;               // [S][MAXT] slot | first_row<<16 of every gallery row appended this frame
     int* n_rows;                // [S]
+    const double* cmc;          // [F][S][8] camera-motion warps of the group (ss_track_set_cmc) or NULL
     double* cost_spill;         // [S][MAXT*MAXD] cost matrices that do not fit the LDS
     unsigned long long* tstamp; // [4] in-kernel timing of the association kernel: min start, max end (100 MHz), sum, count
     int ts_enable;              // 1: first-start / last-end stamps; 2: + per-workgroup timeline
@@ -335,6 +336,17 @@ __device__ inline void ss_kf_update_wave(double* gmean, double* gcov, const doub
     gcov[l] = p - acc;
     if (c == 0) { const double nm = mr + a2; gmean[r] = nm; ws[64 + r] = nm; }
     SS_WAVE_SYNC();
+}
+
+// camera-motion warp m (2x3, full-frame pixels) applied to a track's box (oracle so_camera_update, D-18)
+__device__ inline void ss_camera_update(double* mean, const double* m)
+{
+    const double w = mean[2] * mean[3], h = mean[3];
+    const double x1 = mean[0] - w / 2, y1 = mean[1] - h / 2, x2 = x1 + w, y2 = y1 + h;
+    const double ax = (m[0] * x1 + m[1] * y1) + m[2], ay = (m[3] * x1 + m[4] * y1) + m[5];
+    const double bx = (m[0] * x2 + m[1] * y2) + m[2], by = (m[3] * x2 + m[4] * y2) + m[5];
+    const double nw = bx - ax, nh = by - ay;
+    mean[0] = ax + nw / 2; mean[1] = ay + nh / 2; mean[2] = nw / nh; mean[3] = nh;
 }
 
 // gate + blend + threshold of one entry (oracle so_blend)

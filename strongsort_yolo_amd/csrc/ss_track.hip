@@ -868,6 +868,10 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
 #pragma unroll
         for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
+        if (dev.cmc) {                                               // N4: camera motion between frame f-1 and f, before predicting
+            const double* wm = dev.cmc + fs * 8;
+            if (wm[6] >= 1.0) { const double m6[6] = { wm[0], wm[1], wm[2], wm[3], wm[4], wm[5] }; ss_camera_update(mean, m6); }
+        }
         ss_kf_predict(mean, cov, prm.wp, prm.wv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];

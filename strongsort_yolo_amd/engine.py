@@ -133,6 +133,21 @@ class TrackerEngine:
                                               _ptr(out), _ptr(nout)))
         return out, nout
 
+    def cmc_estimate(self, frames: torch.Tensor, n_frames: int, warps: torch.Tensor = None, stream=None):
+        """N4: ECC camera-motion warps of a group: frames uint8 [F*S,H,W,3] ([F][S] order) -> warps float64 [F,S,8]
+        (2x3 matrix previous -> current frame, [6] = iterations or -1).  Asynchronous."""
+        if warps is None:
+            warps = torch.zeros(n_frames, self.S, 8, dtype=torch.float64, device=self.device)
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        self._ck(self.L.ss_cmc_estimate(self.ctx, C.c_void_p(st.cuda_stream), _ptr(frames), int(n_frames), frames.stride(0),
+                                        frames.shape[1], frames.shape[2], frames.stride(1), _ptr(warps)))
+        return warps
+
+    def set_cmc(self, warps):
+        """The following tracker calls compensate camera motion with these warps ([F,S,8] float64); None: off."""
+        self._cmc_keep = warps
+        self._ck(self.L.ss_track_set_cmc(self.ctx, _ptr(warps)))
+
     def update_host(self, dets: np.ndarray, feats: np.ndarray, img_hw) -> np.ndarray:
         """Single-stream synchronous update with host arrays -> rows [M,8] float32."""
         dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)

@@ -38,7 +38,7 @@ class FramePipeline:
     def __init__(self, detector: str = "yolov8n", n_streams: int = 1, frame_hw=(720, 1280), device: int = 0,
                  half: bool = True, reid_batch: int = 32, cfg: Optional[StrongSortConfig] = None,
                  dcfg: Optional[DetectConfig] = None, det_source: str = "detector", feat_source: str = "reid",
-                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0):
+                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0, cmc: bool = False):
         self.cfg, self.dcfg = cfg or StrongSortConfig(), dcfg or DetectConfig()
         self.S, (self.H, self.W) = n_streams, frame_hw
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
@@ -86,12 +86,21 @@ class FramePipeline:
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.graph = None
         self.graph_mode = graph
+        # N4 (optional): ECC camera-motion warps estimated beside the detector, applied by the tracker before predicting
+        self.cmc = bool(cmc)
+        self.warps = torch.zeros(1, S, 8, dtype=torch.float64, device=dev) if self.cmc else None
+        if self.cmc:
+            self.eng.cmc_estimate(self.frames, 1, self.warps)            # sizes the small-frame buffer outside any capture
+            self.eng.reset(-1)
+            self.eng.set_cmc(self.warps)
 
     # ---- one frame for every stream, from the static buffers ----------------------------------------
     def _detect_impl(self):
         # every frame-side stage is ONE launch (set) over all S streams, written straight in the NHWC layout the
         # convolutions read
         e, g = self.eng, self.geom
+        if self.cmc:
+            e.cmc_estimate(self.frames, 1, self.warps)
         if self.run_nets:
             e.letterbox_batch(self.frames, g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb, channels_last=True)
             pred = self.detector(self.lb)                       # [S, 4+nc+nk, A]
@@ -234,6 +243,7 @@ class _Bufs:
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads
+        self.warps = torch.zeros(getattr(p, "F", 1), p.S, 8, dtype=torch.float64, device=dev) if getattr(p, "cmc", False) else None
 
 
 class OverlappedPipeline(FramePipeline):
@@ -325,6 +335,8 @@ class OverlappedPipeline(FramePipeline):
 
     # ---- stage bodies (b = the frame's buffer set) -------------------------------------------------------
     def _letterbox(self, b):
+        if self.cmc:                                           # the group's F warps, beside the detector (stateless stage)
+            self.eng.cmc_estimate(b.frames, self.F, b.warps)
         self.eng.letterbox_batch(b.frames, self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb,
                                  channels_last=True)
 
@@ -403,6 +415,8 @@ class OverlappedPipeline(FramePipeline):
         frame (None while warming up / capturing: no callbacks)."""
         e = self.eng
         nv = self.F if n_valid is None else n_valid
+        if self.cmc:
+            e.set_cmc(b.warps)
         e.update_group(nv, b.dets6, b.ndets, b.feats_v, self.img_hw, self.outs, self.nouts)
         if group is not None and self.on_result is not None:
             for f in range(nv):

@@ -85,7 +85,8 @@ class YOLO:
     Changing `.overrides` (or the frame size) re-captures the graphs and restarts the tracker, as a new
     `model.track(..., persist=False)` would."""
 
-    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128):
+    def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128,
+                 camera_motion: bool = False):
         self.weights = weights
         self.random_init_ok = random_init_ok
         self.arch = os.path.basename(weights).replace(".pt", "")
@@ -102,7 +103,7 @@ class YOLO:
         self._pred_key = None
         # test / bench hooks (synthetic head tensors, no weights exist offline): extra pipeline keywords and a callable
         # fill(buffers, virtual_stream, frame_index) that writes pred_in / anchor_gt / gt_feats before a frame runs
-        self._pipe_kw = {}
+        self._pipe_kw = {"cmc": True} if camera_motion else {}    # N4: ECC camera-motion compensation (off by default)
         self._fill = None
         self._frame_index = 0
 
