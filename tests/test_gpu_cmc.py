@@ -15,8 +15,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene(H, W, seed):
-    """A big textured BGR canvas to cut shifted views from."""
-    t = np.stack([_texture(H + 200, W + 200, seed + c) for c in range(3)], axis=2)
+    """A big BGR canvas to cut shifted views from, with structure at the scale the 0.1x grey images keep."""
+    small = np.stack([_texture((H + 200) // 10 + 1, (W + 200) // 10 + 1, seed + c) for c in range(3)], axis=2)
+    from scipy.ndimage import zoom
+    t = zoom(small, (10, 10, 1), order=1)[: H + 200, : W + 200]
+    t = t + np.random.default_rng(seed).normal(0, 3, t.shape)
     return np.clip(t, 0, 255).astype(np.uint8)
 
 
