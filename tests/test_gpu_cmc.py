@@ -89,7 +89,7 @@ def test_tracker_with_compensation_equals_oracle(F):
         ref = []
         for f in range(F):
             k = k0 + f
-            pan = 6 * k if k >= 8 else 0                                            # the camera starts panning at frame 8
+            pan = 3 * k if k >= 8 else 0                                            # the camera starts panning at frame 8
             cur = canvas[100:100 + H, 100 + pan:100 + pan + W]
             fr = st.next_frame()
             d = fr.dets.copy(); d[:, [0, 2]] -= pan                                # scene moves left in the image
