@@ -65,7 +65,7 @@ def test_yolo_track_and_predict_contract(weights):
 H_, W_, NF_ = 480, 640, 37
 
 
-def _synthetic_model(weights="yolov8n.pt", n_ids=9, nk=0):
+def _synthetic_model(weights="yolov8n.pt", n_ids=9, nk=0, cmc=False):
     """YOLO object whose NMS consumes a synthetic head tensor (the random-init detector still runs for load) and whose
     tracker consumes the synthetic identity features: the oracle chain can be replayed on the same inputs."""
     from oracle import cexact
@@ -73,9 +73,9 @@ def _synthetic_model(weights="yolov8n.pt", n_ids=9, nk=0):
     from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
     from strongsort_yolo_amd.synth import synth_prediction
     from strongsort_yolo_amd.yolo import YOLO
-    model = YOLO(weights, random_init_ok=True)
+    model = YOLO(weights, random_init_ok=True, camera_motion=cmc)
     model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)            # yolo_multi_model.py:18-21
-    model._pipe_kw = dict(det_source="synthetic", feat_source="by_anchor", reid_batch=32)
+    model._pipe_kw.update(det_source="synthetic", feat_source="by_anchor", reid_batch=32)
     g = letterbox_geometry(H_, W_)
     gs = scale_geometry(g, H_, W_)
     A = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
@@ -101,7 +101,13 @@ def _synthetic_model(weights="yolov8n.pt", n_ids=9, nk=0):
     for k in range(NF_):
         keep, r = cexact.nms(preds[k][:4 + nc], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 32)
         r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W_, H_)
-        rows = orc.update(r, feats[k][np.maximum(agts[k][keep], 0)], (H_, W_))
+        warp = None
+        if cmc and k > 0:                                    # N4: the oracle's own ECC on the same two frames
+            hs, ws = int(H_ * 0.1), int(W_ * 0.1)
+            wm, it = cexact.ecc(cexact.gray_small(frames[k - 1], hs, ws), cexact.gray_small(frames[k], hs, ws))
+            if it >= 1:
+                warp = wm.copy(); warp[0, 2] *= W_ / ws; warp[1, 2] *= H_ / hs
+        rows = orc.update(r, feats[k][np.maximum(agts[k][keep], 0)], (H_, W_), warp)
         kp = None
         if nk:
             kp = preds[k][4 + nc:, keep].T.reshape(len(keep), nk // 3, 3).copy()
@@ -145,6 +151,20 @@ def test_yolo_track_stream_equals_oracle(batch):
         assert res[0].orig_img is frames[k]
         n += 1
     assert n == NF_
+    model.close()
+
+
+@pytest.mark.parametrize("batch", [0, 4])
+def test_yolo_with_camera_motion_compensation_equals_oracle(batch):
+    """YOLO(..., camera_motion=True): ECC warps estimated beside the detector (per frame / per frame group) and applied
+    by the tracker == the oracle tracker fed its own ECC warps (N4)"""
+    model, frames, ref = _synthetic_model(cmc=True)
+    if batch:
+        for k, res in enumerate(model.track_stream(iter(frames), batch=batch, device=0)):
+            _check_tracked(res, ref[k][1], ref[k][2], k)
+    else:
+        for k in range(20):
+            _check_tracked(model.track(frames[k], verbose=False, device=0, persist=True), ref[k][1], ref[k][2], k)
     model.close()
 
 
