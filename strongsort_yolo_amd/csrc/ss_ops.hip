@@ -838,6 +838,197 @@ __global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const fl
     }
 }
 
+// Tail of an OSNet block and the 1x1 convolution that follows it, in one pass over the pixels:
+//   x2  = sum_t y_t * gate_t                 (k_gate_apply: gates from the band sums psum, fmaf in t order, rounded to half)
+//   o   = relu(conv3(x2) + b3 + idn)         (k_pw: MID -> C2, shortcut before the activation)         -> out (optional)
+//   o2  = relu(conv4(o) + b4)                (k_pw: C2 -> N2: the next block's conv1, or the stage's ConvBR) -> out2
+//   out2 = avgpool2x2(o2)                    (k_avgpool2, optional)
+// The unfused chain moves x2, o (twice or three times) and o2 through HBM: per 512 crops at stage 1 that is 1.0 GB for
+// the block before a transition and 0.63 GB for the block before another block; here 0.30 / 0.43 GB.  Workgroup = 128
+// consecutive pixels of one image (4 waves x 2 tiles of 16); o goes through a per-wave LDS tile both to vectorise the
+// shortcut read / output write and to re-enter the matrix cores as the B operand of the second product.  Operand
+// placement, accumulation order and rounding points are those of the separate kernels: outputs are bit-identical.
+template <int MID, int C2, int N2>
+__global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __restrict__ psum, int parts, float scale,
+                                                   const __half* __restrict__ gw1, const __half* __restrict__ gb1,
+                                                   const __half* __restrict__ gw2, const __half* __restrict__ gb2, int Cr,
+                                                   const __half* __restrict__ w3, const __half* __restrict__ b3,
+                                                   const __half* __restrict__ idn, __half* __restrict__ out,
+                                                   const __half* __restrict__ w4, const __half* __restrict__ b4,
+                                                   __half* __restrict__ out2, int pool, int Nimg, int HW, int W)
+{
+    constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8;
+    __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
+    __shared__ __attribute__((aligned(16))) _Float16 Et[128 * EP];
+    __shared__ float g[4][32];
+    __shared__ float hid[4][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const size_t px_wg = (size_t)blockIdx.x * 128, px0 = px_wg + wave * 32;
+    const int img = (int)(px_wg / HW);
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const bool kval = 8 * q < MID;
+
+    for (int i = tid; i < MT2 * 16 * K8; i += 256) {                        // second product's weights -> LDS
+        const int r = i / K8, c8 = i - r * K8;
+        *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? *reinterpret_cast<const h8*>(w4 + (size_t)r * C2 + c8 * 8) : z8;
+    }
+    h8 yv[2][4], a3[MT];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            yv[pt][t] = kval ? *reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q) : z8;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
+
+    // gates of this image (k_gate_apply's arithmetic)
+    for (int i = tid; i < 4 * MID; i += 256) {
+        const int t = i / MID, c = i - t * MID;
+        const float* m = psum + (((size_t)t * Nimg + img) * parts) * MID + c;
+        float a = 0.f;
+        for (int p = 0; p < parts; ++p) a += m[(size_t)p * MID];
+        g[t][c] = a * scale;
+    }
+    __syncthreads();
+    if (tid < 4 * Cr) {
+        const int t = tid / Cr, r = tid - t * Cr;
+        float a = __half2float(gb1[r]);
+        for (int c = 0; c < MID; ++c) a = fmaf(__half2float(gw1[r * MID + c]), g[t][c], a);
+        hid[t][r] = a > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * MID; i += 256) {
+        const int t = i / MID, c = i - t * MID;
+        float a = __half2float(gb2[c]);
+        for (int r = 0; r < Cr; ++r) a = fmaf(__half2float(gw2[c * Cr + r]), hid[t][r], a);
+        g[t][c] = 1.0f / (1.0f + __expf(-a));
+    }
+    __syncthreads();
+
+    // x2 as the B operand (lane (q, n): pixel n, channels 8q..8q+7), conv3 on the matrix cores
+    f4 acc[MT][2];
+    {
+        h8 b[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            float s[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+            if (kval) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s[k] = fmaf((float)yv[pt][t][k], g[t][8 * q + k], s[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) b[pt][k] = (_Float16)s[k];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 a0 = { a3[mt][0], a3[mt][1], a3[mt][2], a3[mt][3] }, a1 = { a3[mt][4], a3[mt][5], a3[mt][6], a3[mt][7] };
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const h4 b0 = { b[pt][0], b[pt][1], b[pt][2], b[pt][3] }, b1 = { b[pt][4], b[pt][5], b[pt][6], b[pt][7] };
+                f4 d = { 0.f, 0.f, 0.f, 0.f };
+                d = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, d, 0, 0, 0);
+                acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, d, 0, 0, 0);
+            }
+        }
+    }
+    _Float16* tile = Et + wave * 32 * EP;
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
+            *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * CG / 64; ++it) {                              // + bias + shortcut, ReLU; 16-byte vectors
+        const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+        const size_t px = px0 + row;
+        const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+        const h8 bb = *reinterpret_cast<const h8*>(b3 + cg * 8);
+        const h8 r = *reinterpret_cast<const h8*>(idn + px * C2 + cg * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] + (float)bb[j];
+            f += (float)r[j];
+            o[j] = (_Float16)(f > 0.f ? f : 0.f);
+        }
+        if (out) *reinterpret_cast<h8*>(out + px * C2 + cg * 8) = o;
+        *reinterpret_cast<h8*>(tile + row * EP + cg * 8) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // second product: o (LDS tile) x w4 (LDS)
+    f4 acc2[MT2][2];
+#pragma unroll
+    for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) acc2[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+        h8 bv[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) bv[pt] = *reinterpret_cast<const h8*>(tile + (pt * 16 + n) * EP + ks * 32 + 8 * q);
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const h8 a = *reinterpret_cast<const h8*>(Ws4 + (mt * 16 + n) * EP + ks * 32 + 8 * q);
+            const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const h4 b0 = { bv[pt][0], bv[pt][1], bv[pt][2], bv[pt][3] }, b1 = { bv[pt][4], bv[pt][5], bv[pt][6], bv[pt][7] };
+                acc2[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc2[mt][pt], 0, 0, 0);
+                acc2[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc2[mt][pt], 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt)
+            if (mt * 16 + 4 * q < N2) {
+                const h4 o = { (_Float16)acc2[mt][pt][0], (_Float16)acc2[mt][pt][1], (_Float16)acc2[mt][pt][2], (_Float16)acc2[mt][pt][3] };
+                *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
+            }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < (32 * CG2 + 63) / 64; ++it) {
+        const int i = it * 64 + lane, row = i / CG2, cg = i - row * CG2;
+        if (i >= 32 * CG2) break;
+        const size_t px = px0 + row;
+        const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+        const h8 bb = *reinterpret_cast<const h8*>(b4 + cg * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j] + (float)bb[j];
+            o[j] = (_Float16)(f > 0.f ? f : 0.f);
+        }
+        if (!pool) *reinterpret_cast<h8*>(out2 + px * N2 + cg * 8) = o;
+        else *reinterpret_cast<h8*>(tile + row * EP + cg * 8) = o;
+    }
+    if (!pool) return;
+    __syncthreads();
+    {                                                                        // 2x2 average of the workgroup's 128 / W rows
+        const int OWp = W / 2, r0 = (int)((px_wg - (size_t)img * HW) / W);
+        for (int i = tid; i < 32 * CG2; i += 256) {
+            const int pp = i / CG2, cg = i - pp * CG2, pr = pp / OWp, pc = pp - pr * OWp, l00 = 2 * pr * W + 2 * pc;
+            const h8 a = *reinterpret_cast<const h8*>(Et + (size_t)l00 * EP + cg * 8);
+            const h8 b = *reinterpret_cast<const h8*>(Et + (size_t)(l00 + 1) * EP + cg * 8);
+            const h8 c = *reinterpret_cast<const h8*>(Et + (size_t)(l00 + W) * EP + cg * 8);
+            const h8 d = *reinterpret_cast<const h8*>(Et + (size_t)(l00 + W + 1) * EP + cg * 8);
+            h8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (_Float16)(((((float)a[k] + (float)b[k]) + (float)c[k]) + (float)d[k]) / 4.0f);
+            const size_t op = (size_t)img * (HW / 4) + (size_t)(r0 / 2 + pr) * OWp + pc;
+            *reinterpret_cast<h8*>(out2 + op * N2 + cg * 8) = o;
+        }
+    }
+}
+
 static inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 extern "C" int ss_op_bias_act_f16(void* stream, void* x, const void* bias, const void* res, long long n_pix, int C, int act)
@@ -1032,5 +1223,32 @@ extern "C" int ss_op_avgpool2_f16(void* stream, const void* x, void* y, int N, i
     if (!x || !y || C % 8 || H < 2 || W < 2 || H % 2 || W % 2) return SS_ERR_INVALID;
     size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 8);
     hipLaunchKernelGGL(k_avgpool2, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (__half*)y, N, H, W, C / 8);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const float* psum, int parts, float scale, const void* gw1,
+                                    const void* gb1, const void* gw2, const void* gb2, int Cr, const void* w3, const void* b3,
+                                    const void* idn, void* out, const void* w4, const void* b4, void* out2, int pool, int N, int H,
+                                    int W, int MID, int C2, int N2)
+{
+    if (!ys || !psum || !gw1 || !gb1 || !gw2 || !gb2 || !w3 || !b3 || !idn || !w4 || !b4 || !out2 || parts < 1 || Cr < 1 || Cr > 16 ||
+        N < 1 || H < 1 || W < 2 || (H * W) % 128 || 128 % W || (pool && ((128 / W) % 2 || W % 2)))
+        return SS_ERR_INVALID;
+    GatePtrs p;
+    for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; p.x[t] = (const __half*)ys[t]; }
+    const dim3 grid((unsigned)((size_t)N * H * W / 128)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SS_TAIL(A, B, CC)                                                                                                       \
+    hipLaunchKernelGGL((k_osnet_tail<A, B, CC>), grid, block, 0, st, p, psum, parts, scale, (const __half*)gw1, (const __half*)gb1, \
+                       (const __half*)gw2, (const __half*)gb2, Cr, (const __half*)w3, (const __half*)b3, (const __half*)idn,    \
+                       (__half*)out, (const __half*)w4, (const __half*)b4, (__half*)out2, pool, N, H * W, W)
+    if (MID == 16 && C2 == 64 && N2 == 16) SS_TAIL(16, 64, 16);
+    else if (MID == 16 && C2 == 64 && N2 == 64) SS_TAIL(16, 64, 64);
+    else if (MID == 24 && C2 == 96 && N2 == 24) SS_TAIL(24, 96, 24);
+    else if (MID == 24 && C2 == 96 && N2 == 96) SS_TAIL(24, 96, 96);
+    else if (MID == 32 && C2 == 128 && N2 == 32) SS_TAIL(32, 128, 32);
+    else if (MID == 32 && C2 == 128 && N2 == 128) SS_TAIL(32, 128, 128);
+    else return SS_ERR_INVALID;
+#undef SS_TAIL
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

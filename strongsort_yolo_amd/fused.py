@@ -208,9 +208,12 @@ def osnet_stem(x, w_prep, bias):
 STREAMS = _flag("STREAMS")              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)
 
 
-def streams_ok(x) -> bool:
-    n, c, h, w = x.shape
+def streams_ok_dims(c, w) -> bool:
     return STREAMS and LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 24 * (2 * w + 2) * c * 2 <= 65536
+
+
+def streams_ok(x) -> bool:
+    return streams_ok_dims(x.shape[1], x.shape[3])
 
 
 def osnet_streams(x, w1, w9, bias):
@@ -234,6 +237,31 @@ def gate_apply(xs, psum, w1, b1, w2, b2):
     _ck(_lib.load().ss_op_gate_apply_f16(_st(out), arr, len(xs), _p(w1), _p(b1), _p(w2), _p(b2), _p(psum), psum.shape[2],
                                          1.0 / (h * w), _p(out), n, h * w, c, w1.shape[0]))
     return out
+
+
+TAIL = _flag("TAIL")                    # gate + conv3 + shortcut + ReLU + the following 1x1 ConvBR (+ 2x2 average) in one launch
+
+
+def tail_ok(mid, c2, n2, h, w, pool) -> bool:
+    return (TAIL and (mid, c2, n2) in ((16, 64, 16), (16, 64, 64), (24, 96, 24), (24, 96, 96), (32, 128, 32), (32, 128, 128))
+            and (h * w) % 128 == 0 and 128 % w == 0 and (not pool or ((128 // w) % 2 == 0 and w % 2 == 0)))
+
+
+def osnet_tail(ys, psum, gate_w, w3, b3, idn, want_out, w4, b4, pool):
+    """-> (o or None, o2): o = relu(conv3(sum_t ys[t]*gate_t) + b3 + idn), o2 = relu(conv4(o) + b4), 2x2-averaged when
+    `pool`; w3 [C2, MID], w4 [N2, C2] (out, in).  Bit-identical to gate_apply + pointwise + pointwise (+ avgpool2)."""
+    n, mid, h, w = ys[0].shape
+    idn = _cl(idn)
+    c2, n2 = w3.shape[0], w4.shape[0]
+    out = torch.empty_like(idn, memory_format=torch.channels_last) if want_out else None
+    oh, ow = (h // 2, w // 2) if pool else (h, w)
+    out2 = torch.empty((n, n2, oh, ow), dtype=idn.dtype, device=idn.device, memory_format=torch.channels_last)
+    arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
+    gw1, gb1, gw2, gb2 = gate_w
+    _ck(_lib.load().ss_op_osnet_tail_f16(_st(idn), arr, _p(psum), psum.shape[2], 1.0 / (h * w), _p(gw1), _p(gb1), _p(gw2), _p(gb2),
+                                         gw1.shape[0], _p(w3), _p(b3), _p(idn), _p(out), _p(w4), _p(b4),
+                                         _p(out2), int(pool), n, h, w, mid, c2, n2))
+    return out, out2
 
 
 def gate_sum(xs, w1, b1, w2, b2):

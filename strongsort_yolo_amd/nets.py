@@ -389,21 +389,48 @@ class OSBlock(nn.Module):
         self.conv3 = ConvBR(mid, c2, 1, relu=False)
         self.down = ConvBR(c1, c2, 1, relu=False) if c1 != c2 else None
 
-    def forward(self, x):
+    def _gate_w(self):
+        g = self.gate
+        cr, c = g.fc1.weight.shape[0], g.fc1.weight.shape[1]
+        return (g.fc1.weight.reshape(cr, c), g.fc1.bias, g.fc2.weight.reshape(c, cr), g.fc2.bias)
+
+    def _stream_w(self, x1):
+        sw = getattr(self, "_sw", None)
+        if sw is None or sw[0].device != x1.device:
+            c = x1.shape[1]
+            layers = [m for st in self.streams for m in st]
+            sw = self._sw = (torch.stack([m.pw.weight.detach().reshape(c, c) for m in layers]).contiguous(),
+                             torch.stack([m.dw.weight.detach().reshape(c, 9).t() for m in layers]).contiguous(),
+                             torch.stack([m.dw.bias.detach() for m in layers]).contiguous())
+        return sw
+
+    def tail_ok(self, x, nxt, pool) -> bool:
+        """The fused tail (gate + conv3 + shortcut + ReLU + the following 1x1 ConvBR [+ 2x2 average]) covers this block."""
+        n, _, h, w = x.shape
+        mid, c2 = self.conv1.conv.out_channels, self.conv3.conv.out_channels
+        return (fused.usable(x) and isinstance(nxt, ConvBR) and nxt.relu and fused.pointwise_ok(nxt.conv) and nxt.conv.in_channels == c2
+                and fused.pointwise_ok(self.conv3.conv) and fused.streams_ok_dims(mid, w)
+                and fused.tail_ok(mid, c2, nxt.conv.out_channels, h, w, pool))
+
+    def forward_tail(self, x, x1, nxt, pool, want_out):
+        """-> (block output or None, relu(nxt(block output)) [2x2-averaged when pool]); x1 = this block's conv1(x) if the previous
+        block's tail already produced it."""
         idn = x if self.down is None else self.down(x)
-        x1 = self.conv1(x)
+        if x1 is None:
+            x1 = self.conv1(x)
+        ys, psum = fused.osnet_streams(x1, *self._stream_w(x1))
+        c3, c4 = self.conv3.conv, nxt.conv
+        return fused.osnet_tail(ys, psum, self._gate_w(), fused.weight_nk(self.conv3, c3), c3.bias, idn, want_out,
+                                fused.weight_nk(nxt, c4), c4.bias, pool)
+
+    def forward(self, x, x1=None):
+        idn = x if self.down is None else self.down(x)
+        if x1 is None:
+            x1 = self.conv1(x)
         if fused.usable(x):          # all four gates + their sum in two launches; bias + residual + ReLU in one
-            g = self.gate
-            cr, c = g.fc1.weight.shape[0], g.fc1.weight.shape[1]
-            gw = (g.fc1.weight.reshape(cr, c), g.fc1.bias, g.fc2.weight.reshape(c, cr), g.fc2.bias)
+            gw = self._gate_w()
             if fused.streams_ok(x1):     # the ten LightConv layers of the four chains in one launch + gate from its sums
-                sw = getattr(self, "_sw", None)
-                if sw is None or sw[0].device != x1.device:
-                    layers = [m for st in self.streams for m in st]
-                    sw = self._sw = (torch.stack([m.pw.weight.detach().reshape(c, c) for m in layers]).contiguous(),
-                                     torch.stack([m.dw.weight.detach().reshape(c, 9).t() for m in layers]).contiguous(),
-                                     torch.stack([m.dw.bias.detach() for m in layers]).contiguous())
-                ys, psum = fused.osnet_streams(x1, *sw)
+                ys, psum = fused.osnet_streams(x1, *self._stream_w(x1))
                 x2 = fused.gate_apply(ys, psum, *gw)
             else:
                 x2 = fused.gate_sum([s(x1) for s in self.streams], *gw)
@@ -429,25 +456,39 @@ class OSNet(nn.Module):
 
     N_PARTS = 10
 
+    def _block_part(self, k, s):
+        """Parts 1, 2, 4, 5, 7, 8: an OSBlock.  On the GPU the block's tail also runs the 1x1 convolution that follows it —
+        the next block's conv1 (state becomes (block output, that conv1's output)) or the stage's ConvBR (+ average pool;
+        state becomes a 1-tuple: the following part is already applied)."""
+        blk, nxt, pool = {1: (self.conv2[0], self.conv2[1].conv1, False), 2: (self.conv2[1], self.conv2[2], True),
+                          4: (self.conv3[0], self.conv3[1].conv1, False), 5: (self.conv3[1], self.conv3[2], True),
+                          7: (self.conv4[0], self.conv4[1].conv1, False), 8: (self.conv4[1], self.conv5, False)}[k]
+        x, x1 = s if isinstance(s, tuple) else (s, None)
+        if blk.tail_ok(x, nxt, pool):
+            want_out = k in (1, 4, 7)
+            out, o2 = blk.forward_tail(x, x1, nxt, pool, want_out)
+            return (out, o2) if want_out else (o2,)
+        return blk(x, x1)
+
     def _part(self, k, x):
-        """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages."""
+        """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages.  The state
+        between parts is a tensor or a tuple of tensors (see _block_part)."""
         if k == 0:
             if fused.usable(x) and fused.stem_ok(x, self.conv1.conv) and self.conv1.relu:      # conv + bias + ReLU + pool, one launch
                 return fused.osnet_stem(x, fused.stem_weight(self.conv1, self.conv1.conv), self.conv1.conv.bias)
             x = self.conv1(x)
             return fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)
-        if k in (1, 2):
-            return self.conv2[k - 1](x)
+        if k in (1, 2, 4, 5, 7, 8):
+            return self._block_part(k, x)
+        if isinstance(x, tuple):                            # the previous block's tail already ran this part
+            assert len(x) == 1
+            return x[0]
         if k == 3:
             t = self.conv2[2](x)
             return fused.avgpool2(t) if fused.usable(t) else self.conv2[3](t)
-        if k in (4, 5):
-            return self.conv3[k - 4](x)
         if k == 6:
             t = self.conv3[2](x)
             return fused.avgpool2(t) if fused.usable(t) else self.conv3[3](t)
-        if k in (7, 8):
-            return self.conv4[k - 7](x)
         return self.conv5(x)
 
     def forward_a(self, x, upto: int = 5):
@@ -457,6 +498,7 @@ class OSNet(nn.Module):
         return x
 
     def forward_b(self, x, start: int = 5):
+        """`x`: what forward_a(., start) returned (a tensor or a tuple of tensors)."""
         for k in range(start, self.N_PARTS):
             x = self._part(k, x)
         return F.relu(self.fc(x.mean((2, 3))))

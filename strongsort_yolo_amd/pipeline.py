@@ -385,10 +385,12 @@ class OverlappedPipeline(FramePipeline):
 
     def _s_nms_crop_reid_a(self, b):
         self._nms_crop(b)
-        self._keep(b, "mid", [self.reid.forward_a(b.crops)])
+        st = self.reid.forward_a(b.crops)                    # a tensor or a tuple of tensors (nets.OSNet._block_part)
+        b.mid_tuple = isinstance(st, tuple)
+        self._keep(b, "mid", list(st) if b.mid_tuple else [st])
 
     def _s_reid_b_select(self, b):
-        self._select(b, self.reid.forward_b(b.mid[0]))
+        self._select(b, self.reid.forward_b(tuple(b.mid) if b.mid_tuple else b.mid[0]))
 
     def _s_nms_crop_reid_select(self, b):
         self._nms_crop(b)

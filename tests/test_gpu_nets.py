@@ -163,6 +163,59 @@ def test_osnet_streams_equal_layerwise_chains(shape):
     assert (a.float() - r.float()).abs().max().item() <= 2e-3 * (r.float().abs().max().item() + 1.0)
 
 
+@pytest.mark.parametrize("n,mid,c2,n2,h,w,pool,want", [(3, 16, 64, 16, 64, 32, False, True), (2, 16, 64, 64, 64, 32, True, False),
+                                                       (3, 24, 96, 24, 32, 16, False, True), (2, 24, 96, 96, 32, 16, True, False),
+                                                       (5, 32, 128, 32, 16, 8, False, True), (4, 32, 128, 128, 16, 8, False, False),
+                                                       (2, 16, 64, 64, 64, 32, False, True), (1, 24, 96, 96, 16, 16, True, True)])
+def test_osnet_tail_equals_separate_kernels(n, mid, c2, n2, h, w, pool, want):
+    """gate + conv3 + shortcut + ReLU + following 1x1 ConvBR (+ 2x2 average) in one launch == gate_apply, pointwise, pointwise,
+    avgpool2 run one after the other, bit for bit."""
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(mid * 131 + n2 + h)
+    rnd = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev, torch.float16)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    ys = [cl(rnd(n, mid, h, w).relu_()) for _ in range(4)]
+    bands = (h + 15) // 16
+    psum = torch.stack([torch.stack([y[:, :, bnd * 16:(bnd + 1) * 16].float().sum((2, 3)) for bnd in range(bands)], 1) for y in ys]).contiguous()
+    cr = max(mid // 16, 1)
+    gw = (rnd(cr, mid, s=mid ** -0.5), rnd(cr), rnd(mid, cr), rnd(mid))
+    w3, b3, idn = rnd(c2, mid, s=mid ** -0.5), rnd(c2, s=0.5), cl(rnd(n, c2, h, w))
+    w4, b4 = rnd(n2, c2, s=c2 ** -0.5), rnd(n2, s=0.5)
+    assert fused.tail_ok(mid, c2, n2, h, w, pool)
+    out, o2 = fused.osnet_tail(ys, psum, gw, w3, b3, idn, want, w4, b4, pool)
+    x2 = fused.gate_apply(ys, psum, *gw)
+    r1 = fused.pointwise(x2, w3, b3, "relu", res=idn)
+    r2 = fused.pointwise(r1, w4, b4, "relu")
+    if pool:
+        r2 = fused.avgpool2(r2)
+    assert (out is None) == (not want)
+    if want:
+        assert torch.equal(out, r1)
+    assert o2.shape == r2.shape and torch.equal(o2, r2)
+    assert r2.float().abs().max().item() > 0.1                           # not a comparison of zeros
+
+
+def test_osnet_with_fused_tails_equals_blockwise_path():
+    """The whole OSNet: block tails fused with the following 1x1 convolution vs one launch per operator — identical embeddings,
+    for every place a frame pipeline may cut the backbone."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    m = nets.build_reid().to(dev).half()
+    x = torch.randn(6, 3, 256, 128, generator=torch.Generator().manual_seed(3)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref_flag, fused.TAIL = fused.TAIL, False
+        try:
+            ref = m(x)
+        finally:
+            fused.TAIL = ref_flag
+        assert fused.TAIL
+        for split in range(0, m.N_PARTS + 1):
+            st = m.forward_a(x, split)
+            assert isinstance(st, tuple) == (split in (2, 3, 5, 6, 8, 9)), split
+            assert torch.equal(m.forward_b(st, split), ref), split
+
+
 @pytest.mark.parametrize("shape,N,stride,act", [((2, 16, 48, 80), 16, 1, "silu"), ((8, 16, 96, 160), 32, 2, "silu"), ((2, 64, 24, 40), 64, 1, "silu"),
                                                 ((3, 128, 12, 20), 128, 1, "relu"), ((1, 32, 7, 9), 64, 2, "none"), ((2, 64, 13, 11), 256, 2, "silu"),
                                                 ((1, 8, 5, 5), 8, 1, "sigmoid"), ((4, 24, 17, 16), 40, 1, "silu")])
