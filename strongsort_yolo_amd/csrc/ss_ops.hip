@@ -704,6 +704,246 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
     }
 }
 
+// ---- the LightConv chains as a register-resident row stream (W = 16 or 32) ----
+// k_osnet_streams keeps every layer's pointwise output in LDS and reads it back nine times per output (9 x 16 bytes per
+// (pixel, 8 channels)): at 512 crops the stage-1 launch is bound by VALU issue + LDS traffic (186 us, rocprofv3).  The MFMA
+// output layout makes LDS unnecessary: after v_mfma_f32_16x16x16_f16 (A = weights, B = 16 pixels of one image row) lane
+// (q, n) holds output channels 4q..4q+3 of pixel n —
+//   * the depthwise 3x3 is per channel, so its column neighbours are the same registers of lanes n-1 / n+1 of the same
+//     16-lane DPP row (v_mov_dpp row_shr:1 / row_shl:1; across the two tiles of a 32-wide row: row_ror of the other tile's
+//     register as the `old` operand; the image's left / right zero padding is DPP's bound_ctrl zero),
+//   * its row neighbours are the previous two rows' registers of the same lane when a wave walks down the rows,
+//   * and the depthwise output — 4 channels of pixel n in lane (q, n) — IS the B operand of the next layer's MFMA.
+// So a wave streams the rows of its band through all layers of a chain (layer l runs one row behind layer l-1) with no
+// LDS, no barrier and no address arithmetic besides the row pointer; arithmetic per output is k_lightconv's, bit for bit
+// (same MFMA operands, taps in (ky, kx) order on a float accumulator that starts at the bias, ReLU, one rounding to half).
+// Rows outside the image are zero at every layer (the per-layer zero padding), rows of the band's halo that are not
+// computed from real data only feed rows that are discarded.
+__device__ __forceinline__ unsigned ss_dpp_shr1_z(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned ss_dpp_shl1_z(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned ss_dpp_shr1_o(unsigned old, unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned ss_dpp_shl1_o(unsigned old, unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x101, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned ss_dpp_ror1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned ss_dpp_ror15(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xf, 0xf, true); }
+// first tap: the accumulator starts at the (half) bias, widened inside the instruction
+__device__ __forceinline__ float ss_mix_lo_b(unsigned a, unsigned b, unsigned c)
+{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float ss_mix_hi_b(unsigned a, unsigned b, unsigned c)
+{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+// A depthwise output row is finished over three steps without changing the order of its additions: when pointwise row r
+// arrives, the accumulator of output row r+1 starts (bias + its ky = 0 taps), that of row r continues (ky = 1) and that of
+// row r-1 finishes (ky = 2) — two partial accumulators per layer instead of two rows x (left, centre, right) of history.
+// Tap weights (per lane: 4 channels) come from LDS per layer and step.
+template <int C, int NT, int T>
+struct OsChain {
+    static constexpr int MT = (C + 15) / 16, KS = MT, CP = MT * 16;
+    uint2 A[T][MT][KS];                  // pointwise weights (MFMA A operand)
+    uint2 Bs[T][MT];                     // depthwise bias
+    float acc0[T][NT][MT][4], acc1[T][NT][MT][4];
+    float s[MT][4];                      // channel sums of the stored outputs
+
+    __device__ __forceinline__ void init(const __half* w1, const __half* bias, int q, int n)
+    {
+        constexpr int lbase = (T * (T - 1)) / 2;
+        const uint2 z = { 0u, 0u };
+#pragma unroll
+        for (int l = 0; l < T; ++l)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int oc = mt * 16 + n, c4 = mt * 16 + 4 * q;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int ic0 = ks * 16 + 4 * q;
+                    A[l][mt][ks] = (oc < C && ic0 < C) ? *reinterpret_cast<const uint2*>(w1 + ((size_t)(lbase + l) * C + oc) * C + ic0) : z;
+                }
+                Bs[l][mt] = c4 < C ? *reinterpret_cast<const uint2*>(bias + (size_t)(lbase + l) * C + c4) : z;
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc0[l][j][mt][e] = acc1[l][j][mt][e] = 0.f;
+            }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[mt][j] = 0.f;
+    }
+
+    // One step: `in` = layer 0's input row `row` (zeros outside the image); layer l finishes its output row (row - l - 1);
+    // `out` = the last layer's (row - T).  taps: LDS [10][9][CP] halfs, this lane's 4 channels at + 4q.
+    __device__ __forceinline__ void step(const uint2 (&in)[NT][KS], int row, int H, const _Float16* taps, int q, uint2 (&out)[NT][MT])
+    {
+        constexpr int lbase = (T * (T - 1)) / 2;
+        uint2 x[NT][KS];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) x[j][ks] = in[j][ks];
+        int toff = 4 * q;
+        asm volatile("" : "+v"(toff));                      // keeps the tap reads inside the row loop (hoisted, they cost 18 VGPRs per layer)
+#pragma unroll
+        for (int l = 0; l < T; ++l) {
+            uint2 w[MT][9];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    w[mt][k] = *reinterpret_cast<const uint2*>(taps + ((lbase + l) * 9 + k) * CP + mt * 16 + toff);
+            uint2 pc[NT][MT], pl[NT][MT], pr[NT][MT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f4 d = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks)
+                        d = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, A[l][mt][ks]), __builtin_bit_cast(h4, x[j][ks]), d, 0, 0, 0);
+                    const h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
+                    pc[j][mt] = __builtin_bit_cast(uint2, o);
+                }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const uint2 c = pc[j][mt];
+                    if (j == 0) { pl[j][mt].x = ss_dpp_shr1_z(c.x); pl[j][mt].y = ss_dpp_shr1_z(c.y); }
+                    else {
+                        const uint2 pv = pc[j - 1][mt];
+                        pl[j][mt].x = ss_dpp_shr1_o(ss_dpp_ror1(pv.x), c.x); pl[j][mt].y = ss_dpp_shr1_o(ss_dpp_ror1(pv.y), c.y);
+                    }
+                    if (j == NT - 1) { pr[j][mt].x = ss_dpp_shl1_z(c.x); pr[j][mt].y = ss_dpp_shl1_z(c.y); }
+                    else {
+                        const uint2 nx = pc[j + 1][mt];
+                        pr[j][mt].x = ss_dpp_shl1_o(ss_dpp_ror15(nx.x), c.x); pr[j][mt].y = ss_dpp_shl1_o(ss_dpp_ror15(nx.y), c.y);
+                    }
+                }
+            const int orow = row - l - 1;
+            const bool inside = orow >= 0 && orow < H;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const uint2 L = pl[j][mt], Cn = pc[j][mt], R = pr[j][mt];
+                    float (&a0)[4] = acc0[l][j][mt];
+                    float (&a1)[4] = acc1[l][j][mt];
+                    float f[4];
+                    // finish row (orow): ky = 2
+                    f[0] = ss_mix_lo(L.x, w[mt][6].x, a1[0]); f[1] = ss_mix_hi(L.x, w[mt][6].x, a1[1]);
+                    f[2] = ss_mix_lo(L.y, w[mt][6].y, a1[2]); f[3] = ss_mix_hi(L.y, w[mt][6].y, a1[3]);
+                    f[0] = ss_mix_lo(Cn.x, w[mt][7].x, f[0]); f[1] = ss_mix_hi(Cn.x, w[mt][7].x, f[1]);
+                    f[2] = ss_mix_lo(Cn.y, w[mt][7].y, f[2]); f[3] = ss_mix_hi(Cn.y, w[mt][7].y, f[3]);
+                    f[0] = ss_mix_lo(R.x, w[mt][8].x, f[0]); f[1] = ss_mix_hi(R.x, w[mt][8].x, f[1]);
+                    f[2] = ss_mix_lo(R.y, w[mt][8].y, f[2]); f[3] = ss_mix_hi(R.y, w[mt][8].y, f[3]);
+                    // continue row (orow + 1): ky = 1
+                    a1[0] = ss_mix_lo(L.x, w[mt][3].x, a0[0]); a1[1] = ss_mix_hi(L.x, w[mt][3].x, a0[1]);
+                    a1[2] = ss_mix_lo(L.y, w[mt][3].y, a0[2]); a1[3] = ss_mix_hi(L.y, w[mt][3].y, a0[3]);
+                    a1[0] = ss_mix_lo(Cn.x, w[mt][4].x, a1[0]); a1[1] = ss_mix_hi(Cn.x, w[mt][4].x, a1[1]);
+                    a1[2] = ss_mix_lo(Cn.y, w[mt][4].y, a1[2]); a1[3] = ss_mix_hi(Cn.y, w[mt][4].y, a1[3]);
+                    a1[0] = ss_mix_lo(R.x, w[mt][5].x, a1[0]); a1[1] = ss_mix_hi(R.x, w[mt][5].x, a1[1]);
+                    a1[2] = ss_mix_lo(R.y, w[mt][5].y, a1[2]); a1[3] = ss_mix_hi(R.y, w[mt][5].y, a1[3]);
+                    // start row (orow + 2): bias, ky = 0
+                    const uint2 b = Bs[l][mt];
+                    a0[0] = ss_mix_lo_b(L.x, w[mt][0].x, b.x); a0[1] = ss_mix_hi_b(L.x, w[mt][0].x, b.x);
+                    a0[2] = ss_mix_lo_b(L.y, w[mt][0].y, b.y); a0[3] = ss_mix_hi_b(L.y, w[mt][0].y, b.y);
+                    a0[0] = ss_mix_lo(Cn.x, w[mt][1].x, a0[0]); a0[1] = ss_mix_hi(Cn.x, w[mt][1].x, a0[1]);
+                    a0[2] = ss_mix_lo(Cn.y, w[mt][1].y, a0[2]); a0[3] = ss_mix_hi(Cn.y, w[mt][1].y, a0[3]);
+                    a0[0] = ss_mix_lo(R.x, w[mt][2].x, a0[0]); a0[1] = ss_mix_hi(R.x, w[mt][2].x, a0[1]);
+                    a0[2] = ss_mix_lo(R.y, w[mt][2].y, a0[2]); a0[3] = ss_mix_hi(R.y, w[mt][2].y, a0[3]);
+                    const h4 o = { (_Float16)(f[0] > 0.f ? f[0] : 0.f), (_Float16)(f[1] > 0.f ? f[1] : 0.f), (_Float16)(f[2] > 0.f ? f[2] : 0.f),
+                                   (_Float16)(f[3] > 0.f ? f[3] : 0.f) };
+                    uint2 ov = __builtin_bit_cast(uint2, o);
+                    if (!inside) ov = uint2{ 0u, 0u };
+                    if (l + 1 < T) x[j][mt] = ov; else out[j][mt] = ov;
+                }
+        }
+    }
+};
+
+template <int C, int NT, int T>
+__device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, const __half* __restrict__ w1, const _Float16* taps,
+                                             const __half* __restrict__ bias, __half* __restrict__ yo, float* __restrict__ ps, int H,
+                                             int y0, int TH, int lane)
+{
+    constexpr int MT = (C + 15) / 16, KS = MT, W = 16 * NT;
+    const int q = lane >> 4, n = lane & 15;
+    OsChain<C, NT, T> ch;
+    ch.init(w1, bias, q, n);
+    const uint2 z = { 0u, 0u };
+    auto load_row = [&](int row, uint2 (&r)[NT][KS]) {
+        const bool ok = row >= 0 && row < H;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int ic0 = ks * 16 + 4 * q;
+                r[j][ks] = (ok && ic0 < C) ? *reinterpret_cast<const uint2*>(xi + ((size_t)row * W + j * 16 + n) * C + ic0) : z;
+            }
+    };
+    const int yend = (y0 + TH < H ? y0 + TH : H);
+    auto emit = [&](int orow, const uint2 (&o)[NT][MT]) {
+        if (orow < y0 || orow >= yend) return;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int c4 = mt * 16 + 4 * q;
+                if (c4 < C) {
+                    *reinterpret_cast<uint2*>(yo + ((size_t)orow * W + j * 16 + n) * C + c4) = o[j][mt];
+                    const h4 v = __builtin_bit_cast(h4, o[j][mt]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ch.s[mt][e] += (float)v[e];
+                }
+            }
+    };
+    // rows y0 - T .. yend - 1 + T enter layer 0; three rows are in flight ahead of the one being processed
+    const int r_first = y0 - T, r_last = yend - 1 + T;
+    uint2 r0[NT][KS], r1[NT][KS], r2[NT][KS], o[NT][MT];
+    load_row(r_first, r0); load_row(r_first + 1, r1); load_row(r_first + 2, r2);
+    for (int row = r_first; row <= r_last; row += 3) {
+        ch.step(r0, row, H, taps, q, o); load_row(row + 3, r0); emit(row - T, o);
+        if (row + 1 <= r_last) { ch.step(r1, row + 1, H, taps, q, o); load_row(row + 4, r1); emit(row + 1 - T, o); }
+        if (row + 2 <= r_last) { ch.step(r2, row + 2, H, taps, q, o); load_row(row + 5, r2); emit(row + 2 - T, o); }
+    }
+    // band sums of this lane's channels: over the 16 pixel lanes of the DPP row, fixed order
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = ch.s[mt][e];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (n == 0 && mt * 16 + 4 * q + e < C) ps[mt * 16 + 4 * q + e] = v;
+        }
+}
+
+// wave = (image, band of TH rows); blockIdx.y selects the chains the wave runs (bit t-1 of nibble blockIdx.y of `masks`)
+template <int C, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
+                                                     const __half* __restrict__ w9, const __half* __restrict__ bias,
+                                                     StreamOut out, float* __restrict__ psum, int N, int H, int TH, int bands,
+                                                     unsigned masks)
+{
+    constexpr int W = 16 * NT, MT = (C + 15) / 16, CP = MT * 16;
+    __shared__ __attribute__((aligned(16))) _Float16 taps[10 * 9 * CP];
+    for (int i = threadIdx.x; i < 10 * 9 * CP; i += 256) {
+        const int c = i % CP, lk = i / CP;
+        taps[i] = c < C ? (_Float16)__half2float(w9[(size_t)lk * C + c]) : (_Float16)0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= N * bands) return;
+    const int img = item / bands, band = item - img * bands, y0 = band * TH;
+    const unsigned m = (masks >> (4 * blockIdx.y)) & 15u;
+    const __half* xi = x + (size_t)img * H * W * C;
+    const size_t io = (size_t)img * H * W * C;
+#define SS_CH(TT)                                                                                                              \
+    if (m & (1u << (TT - 1)))                                                                                                  \
+        os_chain_run<C, NT, TT>(xi, w1, taps, bias, out.y[TT - 1] + io, psum + (((size_t)(TT - 1) * N + img) * bands + band) * C, H, y0, \
+                                TH, lane)
+    SS_CH(4); SS_CH(3); SS_CH(2); SS_CH(1);
+#undef SS_CH
+}
+
 // 2x2 / stride 2 average pooling (OSNet's stage transitions): thread = (output pixel, 8 channels), fp32 sum in the
 // library's order ((a00 + a01) + a10) + a11, / 4.  (torch's NHWC kernel runs at 1.1 TB/s on these shapes.)
 __global__ __launch_bounds__(256) void k_avgpool2(const __half* __restrict__ x, __half* __restrict__ y, int N, int H, int W, int C8)
@@ -1186,12 +1426,25 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
                                        void* const* ys, float* psum, int N, int H, int W, int C)
 {
     if (!x || !w1 || !w9 || !bias || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
-    const size_t lds = (size_t)(LC_TH + 2 * OS_TMAX) * (2 * W + 2) * C * 2;
-    if (lds > 65536) return SS_ERR_INVALID;
     const int bands = (H + LC_TH - 1) / LC_TH;
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
     hipStream_t st = (hipStream_t)stream;
+    // register-resident row stream for 16- and 32-wide images (SS_OSNET_CHAINS=0: the LDS form, A/B switch)
+    static const bool chains = [] { const char* e = getenv("SS_OSNET_CHAINS"); return !(e && e[0] == '0'); }();
+    if (chains && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)))) {
+        // one wave per (image, band); 32-wide: a wave runs all four chains (10 layers); 16-wide: two waves, chains {4,1} and {3,2}
+        const unsigned masks = W == 32 ? 0xFu : 0x69u;
+        dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), W == 32 ? 1 : 2), block(256);
+#define SS_CHN(CC, NT) hipLaunchKernelGGL((k_osnet_chains<CC, NT>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
+                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, LC_TH, bands, masks)
+        if (W == 32) SS_CHN(16, 2);                          // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
+        else { if (C == 16) SS_CHN(16, 1); else if (C == 24) SS_CHN(24, 1); else SS_CHN(32, 1); }
+#undef SS_CHN
+        return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+    }
+    const size_t lds = (size_t)(LC_TH + 2 * OS_TMAX) * (2 * W + 2) * C * 2;
+    if (lds > 65536) return SS_ERR_INVALID;
     dim3 grid((unsigned)((size_t)N * bands), 4), block(256);
 #define SS_OS(CC) hipLaunchKernelGGL(k_osnet_streams<CC>, grid, block, lds, st, (const __half*)x, (const __half*)w1, \
                                      (const __half*)w9, (const __half*)bias, o, psum, N, H, W, bands)
