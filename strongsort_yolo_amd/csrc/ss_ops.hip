@@ -725,6 +725,7 @@ __device__ __forceinline__ unsigned ss_dpp_shr1_o(unsigned old, unsigned v) { re
 __device__ __forceinline__ unsigned ss_dpp_shl1_o(unsigned old, unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x101, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned ss_dpp_ror1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned ss_dpp_ror15(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xf, 0xf, true); }
+__device__ __forceinline__ unsigned ss_pk_relu(unsigned v) { unsigned d; asm("v_pk_max_f16 %0, %1, 0" : "=v"(d) : "v"(v)); return d; }
 // first tap: the accumulator starts at the (half) bias, widened inside the instruction
 __device__ __forceinline__ float ss_mix_lo_b(unsigned a, unsigned b, unsigned c)
 { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
@@ -849,9 +850,10 @@ struct OsChain {
                     a0[2] = ss_mix_lo(Cn.y, w[mt][1].y, a0[2]); a0[3] = ss_mix_hi(Cn.y, w[mt][1].y, a0[3]);
                     a0[0] = ss_mix_lo(R.x, w[mt][2].x, a0[0]); a0[1] = ss_mix_hi(R.x, w[mt][2].x, a0[1]);
                     a0[2] = ss_mix_lo(R.y, w[mt][2].y, a0[2]); a0[3] = ss_mix_hi(R.y, w[mt][2].y, a0[3]);
-                    const h4 o = { (_Float16)(f[0] > 0.f ? f[0] : 0.f), (_Float16)(f[1] > 0.f ? f[1] : 0.f), (_Float16)(f[2] > 0.f ? f[2] : 0.f),
-                                   (_Float16)(f[3] > 0.f ? f[3] : 0.f) };
+                    // ReLU after the rounding (round(max(x,0)) == max(round(x),0)): one v_pk_max_f16 per two channels
+                    const h4 o = { (_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3] };
                     uint2 ov = __builtin_bit_cast(uint2, o);
+                    ov.x = ss_pk_relu(ov.x); ov.y = ss_pk_relu(ov.y);
                     if (!inside) ov = uint2{ 0u, 0u };
                     if (l + 1 < T) x[j][mt] = ov; else out[j][mt] = ov;
                 }
@@ -917,7 +919,7 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
 
 // wave = (image, band of TH rows); blockIdx.y selects the chains the wave runs (bit t-1 of nibble blockIdx.y of `masks`)
 template <int C, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 16 ? 3 : 2, C == 16 ? 3 : 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                      const __half* __restrict__ w9, const __half* __restrict__ bias,
                                                      StreamOut out, float* __restrict__ psum, int N, int H, int TH, int bands,
                                                      unsigned masks)
@@ -1422,22 +1424,36 @@ extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, co
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
+// register-resident row stream for 16- and 32-wide images (SS_OSNET_CHAINS=0: the LDS form, A/B switch)
+static bool os_chain_form(int W, int C)
+{
+    static const bool chains = [] { const char* e = getenv("SS_OSNET_CHAINS"); return !(e && e[0] == '0'); }();
+    return chains && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)));
+}
+// band height: 32-wide (3 waves per SIMD): three bands per image x two chain groups = 3072 waves at 512 crops, one round
+static int os_band_rows(int H, int W, int C) { return os_chain_form(W, C) && W == 32 ? ((H + 2) / 3 < 8 ? 8 : (H + 2) / 3) : LC_TH; }
+
+extern "C" int ss_op_osnet_streams_bands(int H, int W, int C)
+{
+    if (H < 1) return SS_ERR_INVALID;
+    const int th = os_band_rows(H, W, C);
+    return (H + th - 1) / th;
+}
+
 extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* w1, const void* w9, const void* bias,
                                        void* const* ys, float* psum, int N, int H, int W, int C)
 {
     if (!x || !w1 || !w9 || !bias || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
-    const int bands = (H + LC_TH - 1) / LC_TH;
+    const int TH = os_band_rows(H, W, C), bands = (H + TH - 1) / TH;
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
     hipStream_t st = (hipStream_t)stream;
-    // register-resident row stream for 16- and 32-wide images (SS_OSNET_CHAINS=0: the LDS form, A/B switch)
-    static const bool chains = [] { const char* e = getenv("SS_OSNET_CHAINS"); return !(e && e[0] == '0'); }();
-    if (chains && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)))) {
-        // one wave per (image, band); 32-wide: a wave runs all four chains (10 layers); 16-wide: two waves, chains {4,1} and {3,2}
-        const unsigned masks = W == 32 ? 0xFu : 0x69u;
-        dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), W == 32 ? 1 : 2), block(256);
+    if (os_chain_form(W, C)) {
+        // one wave per (image, band, chain group); groups {4,1} and {3,2}: five layers each
+        const unsigned masks = 0x69u;
+        dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), 2), block(256);
 #define SS_CHN(CC, NT) hipLaunchKernelGGL((k_osnet_chains<CC, NT>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
-                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, LC_TH, bands, masks)
+                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, TH, bands, masks)
         if (W == 32) SS_CHN(16, 2);                          // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
         else { if (C == 16) SS_CHN(16, 1); else if (C == 24) SS_CHN(24, 1); else SS_CHN(32, 1); }
 #undef SS_CHN

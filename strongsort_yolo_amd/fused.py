@@ -218,10 +218,10 @@ def streams_ok(x) -> bool:
 
 def osnet_streams(x, w1, w9, bias):
     """x [N,C,H,W] channels-last half; w1 [10,C,C], w9 [10,9,C], bias [10,C]: the layers of the 1-, 2-, 3- and 4-deep
-    chains in that order.  Returns the four chain outputs and the per-band channel sums psum [4,N,bands,C] (float)."""
+    chains in that order.  Returns the four chain outputs and the per-band channel sums psum [4,N,bands,C] (float; the library picks the band height)."""
     x = _cl(x)
     n, c, h, w = x.shape
-    bands = (h + 15) // 16
+    bands = _lib.load().ss_op_osnet_streams_bands(h, w, c)
     ys = [torch.empty_like(x, memory_format=torch.channels_last) for _ in range(4)]
     psum = torch.empty(4, n, bands, c, dtype=torch.float32, device=x.device)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])

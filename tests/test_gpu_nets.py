@@ -177,7 +177,7 @@ def test_osnet_tail_equals_separate_kernels(n, mid, c2, n2, h, w, pool, want):
     rnd = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev, torch.float16)
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
     ys = [cl(rnd(n, mid, h, w).relu_()) for _ in range(4)]
-    bands = (h + 15) // 16
+    bands = (h + 15) // 16                                  # any partition of the rows will do: the tail only adds the parts up
     psum = torch.stack([torch.stack([y[:, :, bnd * 16:(bnd + 1) * 16].float().sum((2, 3)) for bnd in range(bands)], 1) for y in ys]).contiguous()
     cr = max(mid // 16, 1)
     gw = (rnd(cr, mid, s=mid ** -0.5), rnd(cr), rnd(mid, cr), rnd(mid))
