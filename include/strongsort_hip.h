@@ -241,8 +241,8 @@ int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]
 int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                         void* d_y, int N, int H, int W, int C);
 /* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
- * half -> [N][H/4][32][16]; d_w_prep [16][7][24] = per (out channel, ky) the taps 3*kx+ch, zero-padded.  W == 128,
- * H % 16 == 0. */
+ * half -> [N][H/4][32][16]; d_w_prep [4][7][16][32] = for conv columns c = 4n + r, per (ky, out channel) the taps 3*kx+ch
+ * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0. */
 int ss_op_osnet_stem_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int N, int H,
                          int W);
 /* The four LightConv3x3 chains of an OSNet block (1..4 layers deep, same input) in one launch; the intermediates stay in

@@ -374,73 +374,67 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
 // pad 1, crops [N][H][128][3] half -> [N][H/4][32][16] half.  MIOpen runs the C_in = 3 convolution at 186 us for 256
 // crops (5% of its data rate) and bias, ReLU and pooling are three more passes over the 67 MB conv output.
-// Workgroup = 4 pooled rows x 32 columns of one crop: the 23 input rows it needs sit in LDS as flat rows of halfs
-// (9 halfs = 3 pixels of zero margin in front), so the 21 taps (kx, ch) of conv pixel c on row ky start at half 6c —
-// 4-byte aligned — and become the MFMA's K axis directly: per ky two v_mfma_f32_16x16x16_f16 (k = 0..15, 16..23,
-// weights zero-padded to 24 per ky and held in registers), 14 per 16 conv pixels.  ReLU(conv+bias) lands in LDS as
-// half; out-of-image conv rows / the left pad column hold 0, which is the identity of max over ReLU outputs; the
-// pool phase reads 3x3 windows and writes the pooled tile.
-typedef _Float16 h4u __attribute__((ext_vector_type(4), aligned(4)));
+// Workgroup = 4 pooled rows x 32 columns of one crop: the 23 input rows it needs sit in LDS as flat rows of halfs with
+// 16 halfs of zero margin in front, so the 21 taps (kx, ch) of conv pixel c on row ky are the window starting at half
+// 6c + 7.  The MFMA's K axis is that row cut into ALIGNED 8-half blocks: wave r takes the conv pixels c = 4n + r
+// (n = 0..15), whose windows all start (6r + 7) % 8 halfs into block 3n + (6r + 7) / 8 — so one 16-byte ds_read_b128
+// per lane (lane (q, n): block 3n + .. + q; 48-byte lane stride = conflict-free) feeds one v_mfma_f32_16x16x32_f16 per
+// ky against the weights pre-shifted by (6r + 7) % 8 inside a 32-wide K (host: fused.stem_weight, [4][7][16][32]).
+// (Round 1 read 12-byte-strided 8-byte pieces for two 16x16x16 MFMAs per ky and staged with 2-byte LDS stores: 204 us per
+// 512 crops, LDS-issue-bound.)  ReLU(conv+bias) lands in LDS as half; out-of-image conv rows / the left pad column hold 0,
+// the identity of max over ReLU outputs; the pool phase reads 3x3 windows and writes the pooled tile.
 #define STEM_W 128
-#define STEM_PITCH 404      // halfs per LDS input row: 9 margin + 384 + tail read by the last window
+#define STEM_M 16           // zero margin (halfs) in front of an LDS input row
+#define STEM_PITCH 416      // 16 + 384 + 16 halfs
 #define STEM_IN_ROWS 23
 #define STEM_CR 9           // conv rows per tile
 #define STEM_CW 65          // conv columns + left pad
 
-__global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x, const __half* __restrict__ wp /*[16][7][24]*/,
+__global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x, const __half* __restrict__ wp /*[4][7][16][32]*/,
                                                    const __half* __restrict__ bias, __half* __restrict__ y, int H, int tiles)
 {
     __shared__ __attribute__((aligned(16))) _Float16 In[STEM_IN_ROWS * STEM_PITCH];
     __shared__ __attribute__((aligned(16))) _Float16 Cv[STEM_CR * STEM_CW * 16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, q = lane >> 4, n = lane & 15;
     const int img = blockIdx.x / tiles, j0 = (blockIdx.x - img * tiles) * 4;           // first pooled row of the tile
     const int OHc = H / 2, OHp = OHc / 2;
     const int in_r0 = 4 * j0 - 5, cv_r0 = 2 * j0 - 1;
-    const _Float16 zero = (_Float16)0.f;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
 
-    // ---- stage the input rows (zeros outside the image and in the margins) ----
-    for (int i = tid; i < STEM_IN_ROWS * STEM_PITCH; i += 256) In[i] = zero;
-    for (int i = tid; i < STEM_CR * 16; i += 256) Cv[(i / 16) * STEM_CW * 16 + (i % 16)] = zero;     // left pad column
-    __syncthreads();
+    // ---- stage the input rows: 16-byte chunks, zeros outside the image and in the margins ----
     const __half* xi = x + (size_t)img * H * STEM_W * 3;
-    for (int i = tid; i < STEM_IN_ROWS * (STEM_W * 3 / 2); i += 256) {
-        const int r = i / (STEM_W * 3 / 2), d = i - r * (STEM_W * 3 / 2), gr = in_r0 + r;
-        if (gr < 0 || gr >= H) continue;
-        const __half2 v = reinterpret_cast<const __half2*>(xi + (size_t)gr * STEM_W * 3)[d];
-        In[r * STEM_PITCH + 9 + 2 * d] = (_Float16)__low2float(v);
-        In[r * STEM_PITCH + 10 + 2 * d] = (_Float16)__high2float(v);
+    constexpr int CH = STEM_PITCH / 8;                                                 // 52 chunks per LDS row
+    for (int i = tid; i < STEM_IN_ROWS * CH; i += 256) {
+        const int rr = i / CH, ch = i - rr * CH, gr = in_r0 + rr;
+        const bool ok = ch >= STEM_M / 8 && ch < STEM_M / 8 + STEM_W * 3 / 8 && gr >= 0 && gr < H;
+        *reinterpret_cast<h8*>(In + rr * STEM_PITCH + ch * 8) =
+            ok ? *reinterpret_cast<const h8*>(xi + (size_t)gr * STEM_W * 3 + (ch - STEM_M / 8) * 8) : z8;
     }
-    // weights: A operand, lane (q, oc = n): k = 4q..4q+3 and 16+4q..16+4q+3 (zero beyond 24) of every ky
-    h4 a0[7], a1[7];
+    if (tid < STEM_CR * 2) *reinterpret_cast<h8*>(Cv + (tid >> 1) * STEM_CW * 16 + (tid & 1) * 8) = z8;      // left pad column
+    // weights of this wave's residue: A operand, lane (q, oc = n): k = 8q..8q+7 of every ky
+    h8 a[7];
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-        a0[ky] = *reinterpret_cast<const h4*>(wp + ((size_t)n * 7 + ky) * 24 + 4 * q);
-        a1[ky] = q < 2 ? *reinterpret_cast<const h4*>(wp + ((size_t)n * 7 + ky) * 24 + 16 + 4 * q) : h4{ 0, 0, 0, 0 };
-    }
+    for (int ky = 0; ky < 7; ++ky) a[ky] = *reinterpret_cast<const h8*>(wp + ((size_t)(r * 7 + ky) * 16 + n) * 32 + 8 * q);
     const h4 bb = *reinterpret_cast<const h4*>(bias + 4 * q);
     __syncthreads();
 
-    // ---- convolution on the matrix cores: 9 conv rows x 64 columns = 36 tiles of 16 pixels ----
-    for (int t = wave; t < STEM_CR * 4; t += 4) {
-        const int r = t >> 2, c = (t & 3) * 16 + n;                  // conv row (local), conv column of this lane's pixel
+    // ---- convolution on the matrix cores: 9 conv rows; this wave's 16 pixels of a row are c = 4n + r ----
+    const int c = 4 * n + r;
+    const _Float16* bp = In + 8 * (3 * n + (6 * r + 7) / 8 + q);
+#pragma unroll 3
+    for (int cr = 0; cr < STEM_CR; ++cr) {
         f4 d = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            const _Float16* row = In + (2 * r + ky) * STEM_PITCH + 6 * c;
-            const h4u b0 = *reinterpret_cast<const h4u*>(row + 4 * q);
-            h4u b1 = { 0, 0, 0, 0 };
-            if (q < 2) b1 = *reinterpret_cast<const h4u*>(row + 16 + 4 * q);
-            d = __builtin_amdgcn_mfma_f32_16x16x16f16(a0[ky], h4{ b0[0], b0[1], b0[2], b0[3] }, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x16f16(a1[ky], h4{ b1[0], b1[1], b1[2], b1[3] }, d, 0, 0, 0);
-        }
-        const int gr = cv_r0 + r;
+        for (int ky = 0; ky < 7; ++ky)
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ky], *reinterpret_cast<const h8*>(bp + (2 * cr + ky) * STEM_PITCH), d, 0, 0, 0);
+        const int gr = cv_r0 + cr;
         h4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float f = (float)(_Float16)d[j] + (float)bb[j];    // conv rounded to half, then the bias pass (as unfused)
-            o[j] = (gr >= 0 && gr < OHc) ? (_Float16)(f > 0.f ? f : 0.f) : zero;
+            o[j] = (gr >= 0 && gr < OHc) ? (_Float16)(f > 0.f ? f : 0.f) : (_Float16)0.f;
         }
-        *reinterpret_cast<h4*>(Cv + ((size_t)(r * STEM_CW + c + 1) * 16 + 4 * q)) = o;
+        *reinterpret_cast<h4*>(Cv + ((size_t)(cr * STEM_CW + c + 1) * 16 + 4 * q)) = o;
     }
     __syncthreads();
 

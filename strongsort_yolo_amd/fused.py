@@ -188,11 +188,15 @@ def stem_ok(x, conv) -> bool:
 
 
 def stem_weight(mod, conv):
-    """[16][7][24]: per (out channel, ky) the 21 (kx, ch) taps in the order they lie in an NHWC input row, zero-padded."""
+    """[4][7][16][32]: for conv columns c = 4n + r (r = 0..3), per (ky, out channel) the 21 (kx, ch) taps in the order they lie
+    in an NHWC input row, placed (6r + 7) % 8 halfs into a 32-wide K window of aligned 8-half blocks (k_osnet_stem)."""
     w = getattr(mod, "_w_stem", None)
     if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
-        w = torch.zeros(16, 7, 24, dtype=conv.weight.dtype, device=conv.weight.device)
-        w[:, :, :21] = conv.weight.detach().permute(0, 2, 3, 1).reshape(16, 7, 21)
+        taps = conv.weight.detach().permute(2, 0, 3, 1).reshape(7, 16, 21)          # [ky][oc][3*kx + ch]
+        w = torch.zeros(4, 7, 16, 32, dtype=conv.weight.dtype, device=conv.weight.device)
+        for r in range(4):
+            sh = (6 * r + 7) % 8
+            w[r, :, :, sh:sh + 21] = taps
         mod._w_stem = w
     return w
 

@@ -47,23 +47,30 @@ def test_weight_nk_and_the_permuted_k_assignment():
 
 
 def test_stem_weight_and_flat_row_windows():
-    """k_osnet_stem keeps each NHWC input row as a flat array of halfs with 9 halfs (3 pixels) of zero margin in front;
-    the 21 taps (kx, ch) of conv column c on row ky are then the contiguous window starting at 6c, multiplied with the
-    weights laid out [oc][ky][3*kx+ch] (padded to 24; the 3 extra window elements meet zero weights)."""
+    """k_osnet_stem keeps each NHWC input row as a flat array of halfs with 16 halfs of zero margin in front; the 21 taps
+    (kx, ch) of conv column c on row ky are then the window starting at half 6c + 7.  Wave r handles the columns c = 4n + r:
+    their windows start (6r + 7) % 8 halfs into the ALIGNED 8-half block 3n + (6r + 7) // 8, and the MFMA's 32-wide K axis is
+    that block and the next three, against weights [r][ky][oc][32] shifted by the same amount (zeros elsewhere)."""
     torch.manual_seed(2)
     conv = torch.nn.Conv2d(3, 16, 7, 2, 3)
     wp = fused.stem_weight(torch.nn.Module(), conv)
-    assert wp.shape == (16, 7, 24) and (wp[:, :, 21:] == 0).all()
+    assert wp.shape == (4, 7, 16, 32)
+    for r in range(4):
+        sh = (6 * r + 7) % 8
+        assert sh + 21 <= 32 and (wp[r, :, :, :sh] == 0).all() and (wp[r, :, :, sh + 21:] == 0).all()
     H = 16
     x = torch.randn(1, 3, H, 128)
     assert fused.stem_ok(x, conv)
-    rows = torch.zeros(H + 6, 404)                                           # 3 zero rows above and below, margins zero
-    rows[3:H + 3, 9:9 + 384] = x[0].permute(1, 2, 0).reshape(H, 384)
+    rows = torch.zeros(H + 6, 416)                                           # 3 zero rows above and below, margins zero
+    rows[3:H + 3, 16:16 + 384] = x[0].permute(1, 2, 0).reshape(H, 384)
     out = torch.empty(16, H // 2, 64)
-    for r in range(H // 2):
+    for rr in range(H // 2):
         for c in range(64):
-            win = torch.stack([rows[2 * r + ky, 6 * c:6 * c + 24] for ky in range(7)])      # [7, 24]
-            out[:, r, c] = (wp * win).sum((1, 2))
+            r, n = c % 4, c // 4
+            blk = 3 * n + (6 * r + 7) // 8
+            assert 8 * blk + (6 * r + 7) % 8 == 6 * c + 7 and 8 * blk + 32 <= 416
+            win = torch.stack([rows[2 * rr + ky, 8 * blk:8 * blk + 32] for ky in range(7)])      # [7, 32]
+            out[:, rr, c] = (wp[r] * win[:, None, :]).sum((0, 2))
     ref = F.conv2d(x, conv.weight, None, 2, 3)[0]
     assert torch.allclose(out, ref, atol=1e-4)
     # ReLU outputs are >= 0, so a 0 in a padded pooling position never changes the maximum (the kernel's pad value)
