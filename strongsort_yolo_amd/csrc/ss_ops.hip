@@ -1084,45 +1084,21 @@ __global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const fl
 // consecutive pixels of one image (4 waves x 2 tiles of 16); o goes through a per-wave LDS tile both to vectorise the
 // shortcut read / output write and to re-enter the matrix cores as the B operand of the second product.  Operand
 // placement, accumulation order and rounding points are those of the separate kernels: outputs are bit-identical.
-template <int MID, int C2, int N2>
-__global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __restrict__ psum, int parts, float scale,
-                                                   const __half* __restrict__ gw1, const __half* __restrict__ gb1,
-                                                   const __half* __restrict__ gw2, const __half* __restrict__ gb2, int Cr,
-                                                   const __half* __restrict__ w3, const __half* __restrict__ b3,
-                                                   const __half* __restrict__ idn, __half* __restrict__ out,
-                                                   const __half* __restrict__ w4, const __half* __restrict__ b4,
-                                                   __half* __restrict__ out2, int pool, int Nimg, int HW, int W)
+// gates of every image: gv[img][t][32] = sigmoid(fc2(relu(fc1(mean_hw(y_t))))) from the band sums (k_gate_apply's arithmetic)
+__global__ __launch_bounds__(128) void k_gate_vec(const float* __restrict__ psum, int parts, float scale, const __half* __restrict__ gw1,
+                                                 const __half* __restrict__ gb1, const __half* __restrict__ gw2,
+                                                 const __half* __restrict__ gb2, int Cr, int MID, int Nimg, float* __restrict__ gv)
 {
-    constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8;
-    __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
-    __shared__ __attribute__((aligned(16))) _Float16 Et[128 * EP];
     __shared__ float g[4][32];
     __shared__ float hid[4][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
-    const size_t px_wg = (size_t)blockIdx.x * 128, px0 = px_wg + wave * 32;
-    const int img = (int)(px_wg / HW);
-    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    const bool kval = 8 * q < MID;
-
-    for (int i = tid; i < MT2 * 16 * K8; i += 256) {                        // second product's weights -> LDS
-        const int r = i / K8, c8 = i - r * K8;
-        *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? *reinterpret_cast<const h8*>(w4 + (size_t)r * C2 + c8 * 8) : z8;
-    }
-    h8 yv[2][4], a3[MT];
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            yv[pt][t] = kval ? *reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q) : z8;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
-
-    // gates of this image (k_gate_apply's arithmetic)
-    for (int i = tid; i < 4 * MID; i += 256) {
-        const int t = i / MID, c = i - t * MID;
-        const float* m = psum + (((size_t)t * Nimg + img) * parts) * MID + c;
+    const int tid = threadIdx.x, img = blockIdx.x;
+    {
+        const int t = tid >> 5, c = tid & 31;
         float a = 0.f;
-        for (int p = 0; p < parts; ++p) a += m[(size_t)p * MID];
+        if (c < MID) {
+            const float* m = psum + (((size_t)t * Nimg + img) * parts) * MID + c;
+            for (int p = 0; p < parts; ++p) a += m[(size_t)p * MID];
+        }
         g[t][c] = a * scale;
     }
     __syncthreads();
@@ -1133,11 +1109,57 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
         hid[t][r] = a > 0.f ? a : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < 4 * MID; i += 256) {
-        const int t = i / MID, c = i - t * MID;
-        float a = __half2float(gb2[c]);
-        for (int r = 0; r < Cr; ++r) a = fmaf(__half2float(gw2[c * Cr + r]), hid[t][r], a);
-        g[t][c] = 1.0f / (1.0f + __expf(-a));
+    {
+        const int t = tid >> 5, c = tid & 31;
+        float o = 0.f;
+        if (c < MID) {
+            float a = __half2float(gb2[c]);
+            for (int r = 0; r < Cr; ++r) a = fmaf(__half2float(gw2[c * Cr + r]), hid[t][r], a);
+            o = 1.0f / (1.0f + __expf(-a));
+        }
+        gv[((size_t)img * 4 + t) * 32 + c] = o;
+    }
+}
+
+template <int MID, int C2, int N2>
+__global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __restrict__ gv,
+                                                   const __half* __restrict__ w3, const __half* __restrict__ b3,
+                                                   const __half* __restrict__ idn, __half* __restrict__ out,
+                                                   const __half* __restrict__ w4, const __half* __restrict__ b4,
+                                                   __half* __restrict__ out2, int pool, int Nimg, int HW, int W)
+{
+    constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8, IT = 32 * CG / 64;
+    __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
+    __shared__ __attribute__((aligned(16))) _Float16 Et[128 * EP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const size_t px_wg = (size_t)blockIdx.x * 128, px0 = px_wg + wave * 32;
+    const int img = (int)(px_wg / HW);
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const bool kval = 8 * q < MID;
+
+    // everything this workgroup reads from global memory is requested up front: one memory round trip
+    float4 gq[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4* gp = reinterpret_cast<const float4*>(gv + ((size_t)img * 4 + t) * 32 + 8 * q);
+        gq[t][0] = gp[0]; gq[t][1] = gp[1];
+    }
+    h8 yv[2][4], a3[MT], rs[IT];
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            yv[pt][t] = kval ? *reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q) : z8;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+        rs[it] = *reinterpret_cast<const h8*>(idn + (px0 + row) * C2 + cg * 8);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
+    for (int i = tid; i < MT2 * 16 * K8; i += 256) {                        // second product's weights -> LDS
+        const int r = i / K8, c8 = i - r * K8;
+        *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? *reinterpret_cast<const h8*>(w4 + (size_t)r * C2 + c8 * 8) : z8;
     }
     __syncthreads();
 
@@ -1150,9 +1172,11 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
             float s[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
             if (kval) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    const float gk[8] = { gq[t][0].x, gq[t][0].y, gq[t][0].z, gq[t][0].w, gq[t][1].x, gq[t][1].y, gq[t][1].z, gq[t][1].w };
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) s[k] = fmaf((float)yv[pt][t][k], g[t][8 * q + k], s[k]);
+                    for (int k = 0; k < 8; ++k) s[k] = fmaf((float)yv[pt][t][k], gk[k], s[k]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) b[pt][k] = (_Float16)s[k];
@@ -1184,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
         const size_t px = px0 + row;
         const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
         const h8 bb = *reinterpret_cast<const h8*>(b3 + cg * 8);
-        const h8 r = *reinterpret_cast<const h8*>(idn + px * C2 + cg * 8);
+        const h8 r = rs[it];
         h8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1490,21 +1514,22 @@ extern "C" int ss_op_avgpool2_f16(void* stream, const void* x, void* y, int N, i
 }
 
 extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const float* psum, int parts, float scale, const void* gw1,
-                                    const void* gb1, const void* gw2, const void* gb2, int Cr, const void* w3, const void* b3,
-                                    const void* idn, void* out, const void* w4, const void* b4, void* out2, int pool, int N, int H,
-                                    int W, int MID, int C2, int N2)
+                                    const void* gb1, const void* gw2, const void* gb2, int Cr, float* gates_ws, const void* w3,
+                                    const void* b3, const void* idn, void* out, const void* w4, const void* b4, void* out2, int pool,
+                                    int N, int H, int W, int MID, int C2, int N2)
 {
-    if (!ys || !psum || !gw1 || !gb1 || !gw2 || !gb2 || !w3 || !b3 || !idn || !w4 || !b4 || !out2 || parts < 1 || Cr < 1 || Cr > 16 ||
-        N < 1 || H < 1 || W < 2 || (H * W) % 128 || 128 % W || (pool && ((128 / W) % 2 || W % 2)))
+    if (!ys || !psum || !gw1 || !gb1 || !gw2 || !gb2 || !gates_ws || !w3 || !b3 || !idn || !w4 || !b4 || !out2 || parts < 1 || Cr < 1 ||
+        Cr > 16 || N < 1 || H < 1 || W < 2 || (H * W) % 128 || 128 % W || (pool && ((128 / W) % 2 || W % 2)) || MID > 32)
         return SS_ERR_INVALID;
     GatePtrs p;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; p.x[t] = (const __half*)ys[t]; }
     const dim3 grid((unsigned)((size_t)N * H * W / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_gate_vec, dim3(N), dim3(128), 0, st, psum, parts, scale, (const __half*)gw1, (const __half*)gb1,
+                       (const __half*)gw2, (const __half*)gb2, Cr, MID, N, gates_ws);
 #define SS_TAIL(A, B, CC)                                                                                                       \
-    hipLaunchKernelGGL((k_osnet_tail<A, B, CC>), grid, block, 0, st, p, psum, parts, scale, (const __half*)gw1, (const __half*)gb1, \
-                       (const __half*)gw2, (const __half*)gb2, Cr, (const __half*)w3, (const __half*)b3, (const __half*)idn,    \
-                       (__half*)out, (const __half*)w4, (const __half*)b4, (__half*)out2, pool, N, H * W, W)
+    hipLaunchKernelGGL((k_osnet_tail<A, B, CC>), grid, block, 0, st, p, (const float*)gates_ws, (const __half*)w3, (const __half*)b3, \
+                       (const __half*)idn, (__half*)out, (const __half*)w4, (const __half*)b4, (__half*)out2, pool, N, H * W, W)
     if (MID == 16 && C2 == 64 && N2 == 16) SS_TAIL(16, 64, 16);
     else if (MID == 16 && C2 == 64 && N2 == 64) SS_TAIL(16, 64, 64);
     else if (MID == 24 && C2 == 96 && N2 == 24) SS_TAIL(24, 96, 24);

@@ -262,8 +262,9 @@ def osnet_tail(ys, psum, gate_w, w3, b3, idn, want_out, w4, b4, pool):
     out2 = torch.empty((n, n2, oh, ow), dtype=idn.dtype, device=idn.device, memory_format=torch.channels_last)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
     gw1, gb1, gw2, gb2 = gate_w
+    gates = torch.empty((n, 4, 32), dtype=torch.float32, device=idn.device)
     _ck(_lib.load().ss_op_osnet_tail_f16(_st(idn), arr, _p(psum), psum.shape[2], 1.0 / (h * w), _p(gw1), _p(gb1), _p(gw2), _p(gb2),
-                                         gw1.shape[0], _p(w3), _p(b3), _p(idn), _p(out), _p(w4), _p(b4),
+                                         gw1.shape[0], _p(gates), _p(w3), _p(b3), _p(idn), _p(out), _p(w4), _p(b4),
                                          _p(out2), int(pool), n, h, w, mid, c2, n2))
     return out, out2
 
