@@ -249,9 +249,9 @@ int ss_op_osnet_stem_f16(void* stream, const void* d_x, const void* d_w_prep, co
  * registers (16- / 32-wide images: a wave streams the rows of a band through the layers) or in LDS:
  * d_w1 [10][C][C], d_w9 [10][9][C], d_bias [10][C] = the layers of the 1-, 2-, 3-, 4-deep chain in that order;
  * d_ys[4] the chain outputs [N][H][W][C]; d_psum [4][N][bands][C] float = per-band channel sums of each output
- * (for ss_op_gate_apply_f16 / ss_op_osnet_tail_f16), bands = ss_op_osnet_streams_bands(H, W, C).  C in {16,24,32},
+ * (for ss_op_gate_apply_f16 / ss_op_osnet_tail_f16), bands = ss_op_osnet_streams_bands(N, H, W, C).  C in {16,24,32},
  * W % 8 == 0, 24*(2W+2)*C*2 <= 65536. */
-int ss_op_osnet_streams_bands(int H, int W, int C);
+int ss_op_osnet_streams_bands(int N, int H, int W, int C);
 int ss_op_osnet_streams_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                             void* const* d_ys, float* d_psum, int N, int H, int W, int C);
 /* Aggregation gate with the channel means given as `parts` partial sums per (stream, image) times `scale`. */

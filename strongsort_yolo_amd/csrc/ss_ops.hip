@@ -1442,19 +1442,30 @@ extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, co
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
-// register-resident row stream for 16- and 32-wide images (SS_OSNET_CHAINS=0: the LDS form, A/B switch)
-static bool os_chain_form(int W, int C)
+// register-resident row stream for 16- and 32-wide images (SS_OSNET_CHAINS=0: the LDS form, A/B switch).  A wave of the
+// stream form runs its band's rows one after the other (~4 us per row of 5 layers), so it needs enough images to fill the
+// chip with waves: below 96 images the LDS form (256 threads per band and chain) is the faster one.
+static bool os_chain_form(int N, int W, int C)
 {
     static const bool chains = [] { const char* e = getenv("SS_OSNET_CHAINS"); return !(e && e[0] == '0'); }();
-    return chains && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)));
+    return chains && N >= 96 && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)));
 }
-// band height: 32-wide (3 waves per SIMD): three bands per image x two chain groups = 3072 waves at 512 crops, one round
-static int os_band_rows(int H, int W, int C) { return os_chain_form(W, C) && W == 32 ? ((H + 2) / 3 < 8 ? 8 : (H + 2) / 3) : LC_TH; }
-
-extern "C" int ss_op_osnet_streams_bands(int H, int W, int C)
+// band height of the stream form: as many bands as give one round of waves (32-wide: 3 waves per SIMD = 3072, 16-wide:
+// 2048; two chain groups per band), at least 8 rows per band
+static int os_band_rows(int N, int H, int W, int C)
 {
-    if (H < 1) return SS_ERR_INVALID;
-    const int th = os_band_rows(H, W, C);
+    if (!os_chain_form(N, W, C)) return LC_TH;
+    const int target = W == 32 ? 3072 : 2048;
+    int bands = target / (2 * N);
+    if (bands < 1) bands = 1;
+    if (bands > (H + 7) / 8) bands = (H + 7) / 8;
+    return (H + bands - 1) / bands;
+}
+
+extern "C" int ss_op_osnet_streams_bands(int N, int H, int W, int C)
+{
+    if (H < 1 || N < 1) return SS_ERR_INVALID;
+    const int th = os_band_rows(N, H, W, C);
     return (H + th - 1) / th;
 }
 
@@ -1462,11 +1473,11 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
                                        void* const* ys, float* psum, int N, int H, int W, int C)
 {
     if (!x || !w1 || !w9 || !bias || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
-    const int TH = os_band_rows(H, W, C), bands = (H + TH - 1) / TH;
+    const int TH = os_band_rows(N, H, W, C), bands = (H + TH - 1) / TH;
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
     hipStream_t st = (hipStream_t)stream;
-    if (os_chain_form(W, C)) {
+    if (os_chain_form(N, W, C)) {
         // one wave per (image, band, chain group); groups {4,1} and {3,2}: five layers each
         const unsigned masks = 0x69u;
         dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), 2), block(256);

@@ -225,7 +225,7 @@ def osnet_streams(x, w1, w9, bias):
     chains in that order.  Returns the four chain outputs and the per-band channel sums psum [4,N,bands,C] (float; the library picks the band height)."""
     x = _cl(x)
     n, c, h, w = x.shape
-    bands = _lib.load().ss_op_osnet_streams_bands(h, w, c)
+    bands = _lib.load().ss_op_osnet_streams_bands(n, h, w, c)
     ys = [torch.empty_like(x, memory_format=torch.channels_last) for _ in range(4)]
     psum = torch.empty(4, n, bands, c, dtype=torch.float32, device=x.device)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
