@@ -371,6 +371,112 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
     }
 }
 
+// Split-K form of k_pw for layers whose pixel count cannot fill the chip with 64-pixel workgroups (the detector's
+// stride-16 / stride-32 levels at batch 16: 60-480 workgroups for 256 CUs, each walking 9-36 K chunks with two barriers
+// per chunk: 10-30 us per layer, latency-bound).  Workgroup = 16 pixels x BN channels; the four waves take the 64-wide K
+// chunks round-robin (wave w: chunks w, w+4, ..), both operands straight from global memory as 16-byte vectors in the
+// v_mfma_f32_16x16x32_f16 layout (lane (q, n): k = 8q..8q+7 of a 32-wide block; A row = output channel n, B column =
+// pixel n), next chunk's loads in flight during this chunk's MFMAs, no LDS and no barrier inside the loop; the four
+// partial tiles are added in wave order through LDS and go through the same vector epilogue (conv rounded to half, bias,
+// shortcut, activation).  4x the workgroups, 1/4 of the serial K walk per wave; weights are re-read from L2 per 16
+// pixels instead of per 64-128, which is why large layers stay on k_pw.
+template <int BN, bool CONV3>
+__global__ __launch_bounds__(256) void k_pw_splitk(const __half* __restrict__ x, const __half* __restrict__ w,
+                                                  const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
+                                                  int N, int act, int res_after, __half* __restrict__ out, int out_ld,
+                                                  __half* __restrict__ out2, int c0, int cn, ConvGeom g)
+{
+    constexpr int MT = BN / 16, KC = 64, RP = 17;
+    __shared__ float Red[4 * BN * RP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int n0 = blockIdx.y * BN;
+    const size_t px = (size_t)blockIdx.x * 16 + n;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    size_t ibase = 0;
+    int iy0 = 0, ix0 = 0;
+    if (CONV3) {
+        const int ohw = g.OH * g.OW;
+        const int bimg = (int)(px / ohw), rem = (int)(px - (size_t)bimg * ohw), oy = rem / g.OW, ox = rem - oy * g.OW;
+        ibase = (size_t)bimg * g.H * g.W;
+        iy0 = oy * g.stride - 1; ix0 = ox * g.stride - 1;
+    }
+    auto load_a = [&](int kc, h8 (&a)[MT][2]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int oc = n0 + mt * 16 + n, k = kc + ks * 32 + 8 * q;
+                a[mt][ks] = (oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
+            }
+    };
+    auto load_b = [&](int kc, h8 (&b)[2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int k = kc + ks * 32 + 8 * q;
+            if (!CONV3) {
+                b[ks] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
+            } else {
+                const int tap = k / g.Cin, c = k - tap * g.Cin, dy = tap / 3, dx = tap - dy * 3;
+                const int iy = iy0 + dy, ix = ix0 + dx;
+                const bool ok = px < (size_t)M && k < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+                b[ks] = ok ? *reinterpret_cast<const h8*>(x + (ibase + (size_t)iy * g.W + ix) * g.Cin + c) : z8;
+            }
+        }
+    };
+    f4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f4{ 0.f, 0.f, 0.f, 0.f };
+    h8 a[MT][2], b[2], an[MT][2], bn[2];
+    int kc = wave * KC;
+    if (kc < K) { load_a(kc, a); load_b(kc, b); }
+    for (; kc < K; kc += 4 * KC) {
+        const bool more = kc + 4 * KC < K;
+        if (more) { load_a(kc + 4 * KC, an); load_b(kc + 4 * KC, bn); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (kc + ks * 32 >= K) break;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { a[mt][0] = an[mt][0]; a[mt][1] = an[mt][1]; }
+            b[0] = bn[0]; b[1] = bn[1];
+        }
+    }
+    // partial tiles -> LDS [wave][channel][pixel]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Red[(wave * BN + mt * 16 + 4 * q + j) * RP + n] = acc[mt][j];
+    __syncthreads();
+    constexpr int CG = BN / 8;
+    if (tid < 16 * CG) {
+        const int row = tid / CG, cg = tid - row * CG;
+        const size_t p = (size_t)blockIdx.x * 16 + row;
+        const int oc = n0 + cg * 8;
+        if (p < (size_t)M && oc < N) {
+            const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
+            h8 r = z8;
+            if (res) r = *reinterpret_cast<const h8*>(res + p * N + oc);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = cg * 8 + j;
+                const float sum = ((Red[(0 * BN + ch) * RP + row] + Red[(1 * BN + ch) * RP + row]) + Red[(2 * BN + ch) * RP + row]) +
+                                  Red[(3 * BN + ch) * RP + row];
+                float f = (float)(_Float16)sum + (float)bb[j];                // conv rounded to half, then the bias pass
+                if (res && !res_after) f += (float)r[j];
+                f = act_apply(f, act);
+                if (res && res_after) f = (float)(_Float16)f + (float)r[j];
+                o[j] = (_Float16)f;
+            }
+            *reinterpret_cast<h8*>(out + p * out_ld + oc) = o;
+            if (out2 && oc >= c0 && oc < c0 + cn) *reinterpret_cast<h8*>(out2 + p * cn + (oc - c0)) = o;
+        }
+    }
+}
+
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
 // pad 1, crops [N][H][128][3] half -> [N][H/4][32][16] half.  MIOpen runs the C_in = 3 convolution at 186 us for 256
 // crops (5% of its data rate) and bias, ReLU and pooling are three more passes over the 67 MB conv output.
@@ -1359,6 +1465,19 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
         if (conv3) { if (vec) SS_PW(BN, PT, true, true); else SS_PW(BN, PT, true, false); }                             \
         else { if (vec) SS_PW(BN, PT, false, true); else SS_PW(BN, PT, false, false); }                                 \
     } while (0)
+    // too few pixels for 64-pixel workgroups to fill 256 CUs, and a K walk long enough to matter: 16-pixel workgroups, K
+    // split over the waves (needs the 16-byte epilogue; SS_PW_SPLITK=0: A/B switch)
+    static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
+    if (splitk_allowed && vec && K >= 192 && ((M + 63) / 64) * ((N + 63) / 64) < 512) {
+        const dim3 grid((unsigned)((M + 15) / 16), (N + ((N <= 32) ? 31 : 63)) / ((N <= 32) ? 32 : 64));
+#define SS_SK(BN, CV)                                                                                                   \
+    hipLaunchKernelGGL((k_pw_splitk<BN, CV>), grid, dim3(256), 0, st, (const __half*)x, (const __half*)w, (const __half*)bias, \
+                       (const __half*)res, (int)M, K, N, act, res_after, (__half*)out, out_ld, (__half*)out2, c0, cn, g)
+        if (N <= 32) { if (conv3) SS_SK(32, true); else SS_SK(32, false); }
+        else { if (conv3) SS_SK(64, true); else SS_SK(64, false); }
+#undef SS_SK
+        return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+    }
     const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
     if (N <= 32) { if (big) SS_PW2(32, 2); else SS_PW2(32, 1); }
     else if (N <= 64 || !big) { if (big) SS_PW2(64, 2); else SS_PW2(64, 1); }
