@@ -372,8 +372,8 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
 }
 
 // Split-K form of k_pw for layers whose pixel count cannot fill the chip with 64-pixel workgroups (the detector's
-// stride-16 / stride-32 levels at batch 16: 60-480 workgroups for 256 CUs, each walking 9-36 K chunks with two barriers
-// per chunk: 10-30 us per layer, latency-bound).  Workgroup = 16 pixels x BN channels; the four waves take the 64-wide K
+// stride-32 level at batch 16: 60-120 workgroups for 256 CUs, each walking 18-36 K chunks with two barriers per chunk:
+// 17-31 us per layer, latency-bound).  Workgroup = 16 pixels x BN channels; the four waves take the 64-wide K
 // chunks round-robin (wave w: chunks w, w+4, ..), both operands straight from global memory as 16-byte vectors in the
 // v_mfma_f32_16x16x32_f16 layout (lane (q, n): k = 8q..8q+7 of a 32-wide block; A row = output channel n, B column =
 // pixel n), next chunk's loads in flight during this chunk's MFMAs, no LDS and no barrier inside the loop; the four
@@ -1465,10 +1465,12 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
         if (conv3) { if (vec) SS_PW(BN, PT, true, true); else SS_PW(BN, PT, true, false); }                             \
         else { if (vec) SS_PW(BN, PT, false, true); else SS_PW(BN, PT, false, false); }                                 \
     } while (0)
-    // too few pixels for 64-pixel workgroups to fill 256 CUs, and a K walk long enough to matter: 16-pixel workgroups, K
-    // split over the waves (needs the 16-byte epilogue; SS_PW_SPLITK=0: A/B switch)
+    // too few pixels for 64-pixel workgroups to fill 256 CUs and a long K walk (3x3 layers of the stride-32 level at batch
+    // 16, every 3x3 layer at batch 1): 16-pixel workgroups, K split over the waves.  Measured at batch 16: M = 3840,
+    // K = 1152..2304: 17.5 -> 14, 31 -> 15 us; M = 15360 (960 workgroups re-reading the weights from L2): 11 -> 17 us, so
+    // those stay on k_pw.  (Needs the 16-byte epilogue; SS_PW_SPLITK=0: A/B switch)
     static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
-    if (splitk_allowed && vec && K >= 192 && ((M + 63) / 64) * ((N + 63) / 64) < 512) {
+    if (splitk_allowed && vec && conv3 && K >= 512 && M <= 4096) {
         const dim3 grid((unsigned)((M + 15) / 16), (N + ((N <= 32) ? 31 : 63)) / ((N <= 32) ? 32 : 64));
 #define SS_SK(BN, CV)                                                                                                   \
     hipLaunchKernelGGL((k_pw_splitk<BN, CV>), grid, dim3(256), 0, st, (const __half*)x, (const __half*)w, (const __half*)bias, \
