@@ -1482,6 +1482,7 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
     }
     const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups
     if (N <= 32) { if (big) SS_PW2(32, 2); else SS_PW2(32, 1); }
+    else if (N == 80) { if (big) SS_PW2(80, 2); else SS_PW2(80, 1); }     // the detector's class branch: no padded channel tiles
     else if (N <= 64 || !big) { if (big) SS_PW2(64, 2); else SS_PW2(64, 1); }
     else SS_PW2(128, 2);
 #undef SS_PW2
