@@ -243,7 +243,6 @@ def gate_apply(xs, psum, w1, b1, w2, b2):
     return out
 
 
-DETECT_STREAMS = _flag("DETECT_STREAMS")  # the detect head's six branches on forked streams (parallel graph branches)
 TAIL = _flag("TAIL")                    # gate + conv3 + shortcut + ReLU + the following 1x1 ConvBR (+ 2x2 average) in one launch
 
 

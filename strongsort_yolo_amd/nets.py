@@ -151,32 +151,6 @@ class Detect(nn.Module):
             strd.append(torch.full((1, h * w), float(s), device=f.device, dtype=f.dtype))
         return torch.cat(pts, 1).unsqueeze(0), torch.cat(strd, 1).unsqueeze(0)
 
-    def _branches(self, feats, last):
-        """The six independent branches (3 levels x {box, class}): 18 launches, most of them too small to fill the chip (60-960
-        workgroups).  They run on side streams forked from the current one and joined before the decode — parallel branches
-        of the captured graph — so the small levels hide behind the stride-8 level.  SS_FUSED_DETECT_STREAMS=0: one stream."""
-        jobs = [(self.cv2[i], f) for i, f in enumerate(feats)] + [(self.cv3[i], f) for i, f in enumerate(feats)]
-        if not fused.DETECT_STREAMS:
-            outs = [last(seq, f) for seq, f in jobs]
-            return outs[:3], outs[3:]
-        dev = feats[0].device
-        cur = torch.cuda.current_stream(dev)
-        side = getattr(self, "_side", None)
-        if side is None or side[0].device != dev:
-            side = self._side = [torch.cuda.Stream(dev) for _ in range(len(jobs) - 1)]
-        outs = [None] * len(jobs)
-        order = [3, 0, 4, 1, 5, 2]                               # largest first: class / box branch of the stride-8 level, ...
-        for s in side:
-            s.wait_stream(cur)
-        for j, s in zip(order[1:], side):
-            with torch.cuda.stream(s):
-                outs[j] = last(*jobs[j])
-        outs[order[0]] = last(*jobs[order[0]])
-        for j, s in zip(order[1:], side):
-            cur.wait_stream(s)
-            outs[j].record_stream(cur)
-        return outs[:3], outs[3:]
-
     def forward(self, feats):
         B = feats[0].shape[0]
         if fused.usable(feats[0]) and self.nk == 0:          # six branch tensors -> [B,4+nc,A] float in one launch
@@ -190,8 +164,8 @@ class Detect(nn.Module):
             else:
                 last = lambda seq, f: F.conv2d(seq[1](seq[0](f)), seq[2].weight)
                 bb, cb = [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3]
-            box, cls = self._branches(feats, last)
-            return fused.v8_decode(box, cls, bb, cb, self.strides, self.nc)
+            return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)],
+                                   [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, self.strides, self.nc)
         box = torch.cat([self.cv2[i](f).view(B, 64, -1) for i, f in enumerate(feats)], 2)
         cls = torch.cat([self.cv3[i](f).view(B, self.nc, -1) for i, f in enumerate(feats)], 2)
         if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:
