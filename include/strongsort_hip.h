@@ -228,6 +228,14 @@ int ss_op_pointwise_f16(void* stream, const void* d_x, const void* d_w, const vo
 int ss_op_conv3x3_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, int B, int H,
                       int W, int Cin, int N, int conv_stride, int act, int res_after, void* d_out, int out_ld,
                       void* d_out2, int c0, int cn);
+/* Several independent convolutions in ONE launch (the detect head's branches: nets.Detect): every entry is a 3x3 / pad 1
+ * (stride 1|2) or 1x1 convolution + bias + activation on NHWC half, dense output [B][OH][OW][N]; all entries of a call have
+ * the same ksize; N <= 80, n <= 8.  Weights as ss_op_conv3x3_f16 ([N][3][3][Cin]) / ss_op_pointwise_f16 ([N][Cin]). */
+typedef struct ss_conv_desc {
+    const void* x; const void* w; const void* bias; void* out;
+    int B, H, W, Cin, N, ksize, stride, act;
+} ss_conv_desc;
+int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* descs);
 /* YOLOv8 anchor-free head decode: per level l<3 the branch outputs d_box[l] [B][H][W][64] and d_cls[l] [B][H][W][nc]
  * (NHWC half, final 1x1 conv without bias; the biases are added here) -> d_pred [B][4+nc][A] float (xywh in input
  * pixels, class sigmoid), A = sum H[l]*W[l] — the tensor ss_nms reads.  H, W, strides are host int[3]. */

@@ -209,17 +209,25 @@ struct ConvGeom { int H, W, Cin, OH, OW, stride; };
 // VEC_EPI: the accumulators (4 channels x 1 pixel per lane and tile) are transposed through a per-wave LDS tile so the
 // epilogue reads the shortcut and writes the output as 16-byte vectors, 128 contiguous bytes per 8 lanes, instead
 // of 8-byte pieces of 32-byte segments.
+struct PwArgs {
+    const __half* x; const __half* w; const __half* bias; const __half* res;
+    int M, K, N, act, res_after;
+    __half* out; int out_ld; __half* out2; int c0, cn;
+    ConvGeom g;
+};
+
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
-__global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const __half* __restrict__ w,
-                                           const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
-                                           int N, int act, int res_after, __half* __restrict__ out, int out_ld,
-                                           __half* __restrict__ out2, int c0, int cn, ConvGeom g)
+__device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int by)
 {
+    const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
+    const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
+    const int M = A.M, K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    const ConvGeom g = A.g;
     constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT;
     __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
-    const int n0 = blockIdx.y * BN;
-    const size_t px0 = (size_t)blockIdx.x * BM + wave * (16 * PT);
+    const int n0 = by * BN;
+    const size_t px0 = (size_t)bx * BM + wave * (16 * PT);
     f4 acc[MT][PT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -371,6 +379,9 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
     }
 }
 
+template <int BN, int PT, bool CONV3, bool VEC_EPI>
+__global__ __launch_bounds__(256) void k_pw(PwArgs A) { pw_body<BN, PT, CONV3, VEC_EPI>(A, blockIdx.x, blockIdx.y); }
+
 // Split-K form of k_pw for layers whose pixel count cannot fill the chip with 64-pixel workgroups (the detector's
 // stride-32 level at batch 16: 60-120 workgroups for 256 CUs, each walking 18-36 K chunks with two barriers per chunk:
 // 17-31 us per layer, latency-bound).  Workgroup = 16 pixels x BN channels; the four waves take the 64-wide K
@@ -381,16 +392,17 @@ __global__ __launch_bounds__(256) void k_pw(const __half* __restrict__ x, const 
 // shortcut, activation).  4x the workgroups, 1/4 of the serial K walk per wave; weights are re-read from L2 per 16
 // pixels instead of per 64-128, which is why large layers stay on k_pw.
 template <int BN, bool CONV3>
-__global__ __launch_bounds__(256) void k_pw_splitk(const __half* __restrict__ x, const __half* __restrict__ w,
-                                                  const __half* __restrict__ bias, const __half* __restrict__ res, int M, int K,
-                                                  int N, int act, int res_after, __half* __restrict__ out, int out_ld,
-                                                  __half* __restrict__ out2, int c0, int cn, ConvGeom g)
+__device__ __forceinline__ void pw_splitk_body(const PwArgs& A, const int bx, const int by)
 {
+    const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
+    const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
+    const int M = A.M, K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    const ConvGeom g = A.g;
     constexpr int MT = BN / 16, KC = 64, RP = 17;
     __shared__ float Red[4 * BN * RP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
-    const int n0 = blockIdx.y * BN;
-    const size_t px = (size_t)blockIdx.x * 16 + n;
+    const int n0 = by * BN;
+    const size_t px = (size_t)bx * 16 + n;
     const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
     size_t ibase = 0;
     int iy0 = 0, ix0 = 0;
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(256) void k_pw_splitk(const __half* __restrict__ x,
     constexpr int CG = BN / 8;
     if (tid < 16 * CG) {
         const int row = tid / CG, cg = tid - row * CG;
-        const size_t p = (size_t)blockIdx.x * 16 + row;
+        const size_t p = (size_t)bx * 16 + row;
         const int oc = n0 + cg * 8;
         if (p < (size_t)M && oc < N) {
             const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
@@ -475,6 +487,26 @@ __global__ __launch_bounds__(256) void k_pw_splitk(const __half* __restrict__ x,
             if (out2 && oc >= c0 && oc < c0 + cn) *reinterpret_cast<h8*>(out2 + p * cn + (oc - c0)) = o;
         }
     }
+}
+
+template <int BN, bool CONV3>
+__global__ __launch_bounds__(256) void k_pw_splitk(PwArgs A) { pw_splitk_body<BN, CONV3>(A, blockIdx.x, blockIdx.y); }
+
+// Several independent convolutions of one shape class (all 3x3 or all 1x1, N <= BN) in ONE launch: the detect head's six
+// branches are 18 launches of 60-1920 workgroups each, run one after the other; grouped by depth they are 3 launches whose
+// small levels fill the CUs the stride-8 level leaves idle.  blockIdx.x walks the problems' workgroup ranges; a problem is
+// either in k_pw's form (64 pixels per workgroup) or in the split-K form (16 pixels, long K walk, few pixels).
+#define PW_GROUP_MAX 8
+struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int split[PW_GROUP_MAX]; int n; };
+
+template <int BN, bool CONV3>
+__global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
+{
+    int bx = blockIdx.x, p = 0;
+    for (int i = 1; i < G.n; ++i) if (bx >= G.start[i]) p = i;
+    bx -= G.start[p];
+    if (G.split[p]) pw_splitk_body<BN, CONV3>(G.p[p], bx, 0);
+    else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0);
 }
 
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
@@ -1456,10 +1488,10 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
     static const bool vec_allowed = [] { const char* e = getenv("SS_PW_EPILOGUE"); return !(e && e[0] == '0'); }();
     const bool vec = vec_allowed && out_ld % 8 == 0 && c0 % 8 == 0 && cn % 8 == 0 && ((uintptr_t)out % 16) == 0 &&
                      (!out2 || ((uintptr_t)out2 % 16) == 0) && (!res || ((uintptr_t)res % 16) == 0);
+    const PwArgs A{ (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act, res_after,
+                    (__half*)out, out_ld, (__half*)out2, c0, cn, g };
 #define SS_PW(BN, PT, CV, VE)                                                                                           \
-    hipLaunchKernelGGL((k_pw<BN, PT, CV, VE>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, \
-                       (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act,     \
-                       res_after, (__half*)out, out_ld, (__half*)out2, c0, cn, g)
+    hipLaunchKernelGGL((k_pw<BN, PT, CV, VE>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, A)
 #define SS_PW2(BN, PT)                                                                                                  \
     do {                                                                                                                \
         if (conv3) { if (vec) SS_PW(BN, PT, true, true); else SS_PW(BN, PT, true, false); }                             \
@@ -1472,9 +1504,7 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
     static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
     if (splitk_allowed && vec && conv3 && K >= 512 && M <= 4096) {
         const dim3 grid((unsigned)((M + 15) / 16), (N + ((N <= 32) ? 31 : 63)) / ((N <= 32) ? 32 : 64));
-#define SS_SK(BN, CV)                                                                                                   \
-    hipLaunchKernelGGL((k_pw_splitk<BN, CV>), grid, dim3(256), 0, st, (const __half*)x, (const __half*)w, (const __half*)bias, \
-                       (const __half*)res, (int)M, K, N, act, res_after, (__half*)out, out_ld, (__half*)out2, c0, cn, g)
+#define SS_SK(BN, CV) hipLaunchKernelGGL((k_pw_splitk<BN, CV>), grid, dim3(256), 0, st, A)
         if (N <= 32) { if (conv3) SS_SK(32, true); else SS_SK(32, false); }
         else { if (conv3) SS_SK(64, true); else SS_SK(64, false); }
 #undef SS_SK
@@ -1671,5 +1701,52 @@ extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const f
     else if (MID == 32 && C2 == 128 && N2 == 128) SS_TAIL(32, 128, 128);
     else return SS_ERR_INVALID;
 #undef SS_TAIL
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+// Independent convolutions (all 3x3 / pad 1 or all 1x1, stride 1|2, bias + activation, dense outputs) in one launch.
+extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
+{
+    if (!d || n < 1 || n > PW_GROUP_MAX) return SS_ERR_INVALID;
+    static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
+    const bool conv3 = d[0].ksize == 3;
+    int nmax = 0, order[PW_GROUP_MAX];
+    long long cost[PW_GROUP_MAX];
+    PwGroup G;
+    for (int i = 0; i < n; ++i) {
+        const ss_conv_desc& c = d[i];
+        if (!c.x || !c.w || !c.bias || !c.out || (c.ksize != 1 && c.ksize != 3) || (c.ksize == 3) != conv3 || c.B < 1 || c.H < 1 || c.W < 1 ||
+            c.Cin < 8 || c.Cin % 8 || c.N < 8 || c.N % 8 || c.N > 80 || (c.stride != 1 && c.stride != 2) || (c.ksize == 1 && c.stride != 1) ||
+            ((uintptr_t)c.out % 16) || ((uintptr_t)c.x % 16) || ((uintptr_t)c.w % 16))
+            return SS_ERR_INVALID;
+        if (c.N > nmax) nmax = c.N;
+        order[i] = i;
+        cost[i] = (long long)c.ksize * c.ksize * c.Cin;               // serial K walk of a workgroup: longest first
+    }
+    for (int i = 1; i < n; ++i)                                        // insertion sort, stable
+        for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    int wgs = 0;
+    for (int s = 0; s < n; ++s) {
+        const ss_conv_desc& c = d[order[s]];
+        ConvGeom g{ c.H, c.W, c.Cin, (c.H - 1) / c.stride + 1, (c.W - 1) / c.stride + 1, c.stride };
+        const long long M = (long long)c.B * g.OH * g.OW;
+        if (M > 0x7fffffffLL) return SS_ERR_INVALID;
+        const int K = c.ksize * c.ksize * c.Cin;
+        G.p[s] = PwArgs{ (const __half*)c.x, (const __half*)c.w, (const __half*)c.bias, nullptr, (int)M, K, c.N, c.act, 0, (__half*)c.out,
+                         c.N, nullptr, 0, 0, g };
+        G.split[s] = splitk_allowed && conv3 && K >= 512 && M <= 4096;
+        G.start[s] = wgs;
+        wgs += (int)(G.split[s] ? (M + 15) / 16 : (M + 63) / 64);
+    }
+    for (int s = n; s < PW_GROUP_MAX; ++s) { G.p[s] = G.p[0]; G.split[s] = 0; G.start[s] = wgs; }
+    G.start[PW_GROUP_MAX] = wgs;
+    G.n = n;
+    hipStream_t st = (hipStream_t)stream;
+#define SS_GRP(BN) do { if (conv3) hipLaunchKernelGGL((k_pw_group<BN, true>), dim3(wgs), dim3(256), 0, st, G);            \
+                        else hipLaunchKernelGGL((k_pw_group<BN, false>), dim3(wgs), dim3(256), 0, st, G); } while (0)
+    if (nmax <= 32) SS_GRP(32);
+    else if (nmax <= 64) SS_GRP(64);
+    else SS_GRP(80);
+#undef SS_GRP
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -136,6 +136,28 @@ def conv3x3(x, w_n9k, bias, stride=1, act="none", res=None, res_after=False, out
     return ret
 
 
+GROUP = _flag("GROUP")                  # independent convolutions of the detect head in one launch per depth
+
+
+def conv_group(items):
+    """items: [(x, w_prepared, bias, ksize, stride, act)], all 3x3 (pad 1; weight_n9k) or all 1x1 (weight_nk), N <= 80, at most
+    8 entries.  Returns the dense channels-last outputs; ONE launch (csrc k_pw_group)."""
+    n = len(items)
+    descs = (_lib.ss_conv_desc * n)()
+    outs, keep = [], []
+    for d, (x, w, bias, ksize, stride, act) in zip(descs, items):
+        x = _cl(x)
+        b, cin, h, wd = x.shape
+        N = w.shape[0]
+        oh, ow = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        y = torch.empty((b, N, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        d.x, d.w, d.bias, d.out = x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr()
+        d.B, d.H, d.W, d.Cin, d.N, d.ksize, d.stride, d.act = b, h, wd, cin, N, ksize, stride, ACT[act]
+        outs.append(y); keep.append(x)
+    _ck(_lib.load().ss_op_conv_group_f16(_st(outs[0]), n, descs))
+    return outs
+
+
 def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 

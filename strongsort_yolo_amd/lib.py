@@ -24,7 +24,7 @@ EXPORTS = [
     "ss_track_update", "ss_track_update_group", "ss_cmc_estimate", "ss_track_set_cmc", "ss_track_update_host",
     "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
-    "ss_get_gallery", "ss_assoc_timing", "ss_assoc_inkernel_timing", "ss_assoc_timeline", "ss_op_bias_act_f16", "ss_op_bias_act_place_f16", "ss_op_pointwise_f16", "ss_op_conv3x3_f16", "ss_op_v8_decode_f16", "ss_op_dwconv3x3_f16", "ss_op_lightconv_f16", "ss_op_osnet_stem_f16", "ss_op_osnet_streams_f16", "ss_op_osnet_streams_bands", "ss_op_gate_apply_f16", "ss_op_osnet_tail_f16", "ss_op_gate_sum_f16", "ss_op_avgpool2_f16", "ss_op_maxpool_f16",
+    "ss_get_gallery", "ss_assoc_timing", "ss_assoc_inkernel_timing", "ss_assoc_timeline", "ss_op_bias_act_f16", "ss_op_bias_act_place_f16", "ss_op_pointwise_f16", "ss_op_conv3x3_f16", "ss_op_conv_group_f16", "ss_op_v8_decode_f16", "ss_op_dwconv3x3_f16", "ss_op_lightconv_f16", "ss_op_osnet_stem_f16", "ss_op_osnet_streams_f16", "ss_op_osnet_streams_bands", "ss_op_gate_apply_f16", "ss_op_osnet_tail_f16", "ss_op_gate_sum_f16", "ss_op_avgpool2_f16", "ss_op_maxpool_f16",
 ]
 
 
@@ -42,6 +42,11 @@ class ss_config(C.Structure):
         ("ema_alpha", C.c_double), ("max_age", C.c_int), ("n_init", C.c_int), ("nn_budget", C.c_int),
         ("n_streams", C.c_int), ("debug", C.c_int),
     ]
+
+
+class ss_conv_desc(C.Structure):                 # mirrors `typedef struct ss_conv_desc`
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p), ("B", C.c_int), ("H", C.c_int),
+                ("W", C.c_int), ("Cin", C.c_int), ("N", C.c_int), ("ksize", C.c_int), ("stride", C.c_int), ("act", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -117,6 +122,7 @@ def load():
     L.ss_op_bias_act_place_f16.argtypes = [vp, vp, vp, vp, C.c_longlong, i, i, i, vp, i, vp, i, i]
     L.ss_op_pointwise_f16.argtypes = [vp, vp, vp, vp, vp, C.c_longlong, i, i, i, i, vp, i, vp, i, i]
     L.ss_op_conv3x3_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp, i, vp, i, i]
+    L.ss_op_conv_group_f16.argtypes = [vp, i, C.POINTER(ss_conv_desc)]
     L.ss_op_v8_decode_f16.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), hi, hi, hi, i, i, vp]
     L.ss_op_lightconv_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i]
     L.ss_op_osnet_stem_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i]

@@ -154,6 +154,19 @@ class Detect(nn.Module):
     def forward(self, feats):
         B = feats[0].shape[0]
         if fused.usable(feats[0]) and self.nk == 0:          # six branch tensors -> [B,4+nc,A] float in one launch
+            seqs = list(self.cv2) + list(self.cv3)
+            if (fused.GROUP and len(feats) == 3 and all(fused.pointwise_ok(s[2]) and fused.conv3x3_ok(s[0].conv) and
+                                                         fused.conv3x3_ok(s[1].conv) and isinstance(s[0].act, nn.SiLU) and
+                                                         s[2].out_channels <= 80 and s[0].conv.out_channels <= 80 for s in seqs)):
+                # the six branches are independent: one grouped launch per depth instead of 18 small ones
+                xs = list(feats) * 2
+                t = fused.conv_group([(x, fused.weight_n9k(s[0], s[0].conv), s[0].conv.bias, 3, 1, "silu") for s, x in zip(seqs, xs)])
+                t = fused.conv_group([(x, fused.weight_n9k(s[1], s[1].conv), s[1].conv.bias, 3, 1, "silu") for s, x in zip(seqs, t)])
+                t = fused.conv_group([(x, fused.weight_nk(s[2], s[2]), s[2].bias, 1, 1, "none") for s, x in zip(seqs, t)])
+                z = getattr(self, "_zeros", None)
+                if z is None or z.device != feats[0].device:
+                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
+                return fused.v8_decode(t[:3], t[3:], [z] * 3, [z] * 3, self.strides, self.nc)
             if all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
                 # final 1x1 of every branch on the pointwise kernel (bias in its epilogue; the decode adds zeros)
                 last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)

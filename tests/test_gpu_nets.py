@@ -199,6 +199,26 @@ def test_osnet_tail_equals_separate_kernels(n, mid, c2, n2, h, w, pool, want):
     assert r2.float().abs().max().item() > 0.1                           # not a comparison of zeros
 
 
+@pytest.mark.parametrize("name,B", [("yolov8n", 16), ("yolov8n", 1), ("yolov8s", 2)])
+def test_detect_head_grouped_launches_equal_separate_launches(name, B):
+    """The detect head's six branches as three grouped launches (one per depth) vs 18 separate launches: same kernels' bodies,
+    identical predictions."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    m = nets.build_detector(name).to(dev).half().to(memory_format=torch.channels_last)
+    x = torch.randn(B, 3, 384, 640, generator=torch.Generator().manual_seed(5)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        flag, fused.GROUP = fused.GROUP, False
+        try:
+            ref = m(x)
+        finally:
+            fused.GROUP = flag
+        assert fused.GROUP
+        got = m(x)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert ref[:, 4:].float().max().item() > 0.0
+
+
 def test_osnet_with_fused_tails_equals_blockwise_path():
     """The whole OSNet: block tails fused with the following 1x1 convolution vs one launch per operator — identical embeddings,
     for every place a frame pipeline may cut the backbone."""
