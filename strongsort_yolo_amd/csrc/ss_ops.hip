@@ -328,11 +328,11 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
         __builtin_amdgcn_wave_barrier();
         constexpr int CG = BN / 8;                                           // 8-channel groups per row
 #pragma unroll
-        for (int it = 0; it < PT * 16 * CG / 64; ++it) {
+        for (int it = 0; it < (PT * 16 * CG + 63) / 64; ++it) {
             const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
             const size_t px = px0 + row;
             const int oc = n0 + cg * 8;
-            if (px >= (size_t)M || oc >= N) continue;
+            if (i >= PT * 16 * CG || px >= (size_t)M || oc >= N) continue;       // (16 x 10 vectors of an 80-channel tile: 2.5 rounds)
             const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
             const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
             h8 r = z8;

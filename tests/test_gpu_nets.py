@@ -100,7 +100,8 @@ def test_v8_decode_matches_float_reference():
 
 @pytest.mark.parametrize("M_hw,K,N,act", [((8, 48, 80), 64, 32, "silu"), ((2, 12, 20), 384, 128, "silu"), ((64, 64, 32), 16, 64, "relu"),
                                           ((3, 7, 9), 24, 96, "none"), ((5, 16, 8), 128, 128, "relu"), ((1, 5, 5), 512, 256, "silu"),
-                                          ((40, 64, 32), 16, 16, "relu"), ((2, 3, 5), 8, 8, "sigmoid")])
+                                          ((40, 64, 32), 16, 16, "relu"), ((2, 3, 5), 8, 8, "sigmoid"),
+                                          ((8, 48, 80), 64, 80, "none"), ((2, 12, 20), 80, 80, "silu"), ((3, 24, 40), 128, 80, "silu")])
 def test_pointwise_matches_conv_bias_act(M_hw, K, N, act):
     """MFMA 1x1 conv kernel vs conv2d (fp32 accumulate, rounded to half as the library conv writes it) + bias + act,
     with and without the shortcut (before / after the activation), over every tile configuration and ragged M."""
@@ -241,7 +242,9 @@ def test_osnet_with_fused_tails_equals_blockwise_path():
 
 @pytest.mark.parametrize("shape,N,stride,act", [((2, 16, 48, 80), 16, 1, "silu"), ((8, 16, 96, 160), 32, 2, "silu"), ((2, 64, 24, 40), 64, 1, "silu"),
                                                 ((3, 128, 12, 20), 128, 1, "relu"), ((1, 32, 7, 9), 64, 2, "none"), ((2, 64, 13, 11), 256, 2, "silu"),
-                                                ((1, 8, 5, 5), 8, 1, "sigmoid"), ((4, 24, 17, 16), 40, 1, "silu")])
+                                                ((1, 8, 5, 5), 8, 1, "sigmoid"), ((4, 24, 17, 16), 40, 1, "silu"),
+                                                # 80-channel tiles (class branch): 64- and 128-pixel workgroups, split-K
+                                                ((6, 64, 24, 40), 80, 1, "silu"), ((2, 64, 24, 40), 80, 1, "silu"), ((9, 80, 48, 80), 80, 1, "silu")])
 def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
     """Implicit-GEMM 3x3 kernel vs conv2d (pad 1) + bias + act, shortcut before/after, placement; odd sizes and stride 2."""
     import torch.nn.functional as F
