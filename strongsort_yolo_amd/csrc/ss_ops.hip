@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_pw_splitk(PwArgs A) { pw_splitk_body<BN
 // Several independent convolutions of one shape class (all 3x3 or all 1x1, N <= BN) in ONE launch: the detect head's six
 // branches are 18 launches of 60-1920 workgroups each, run one after the other; grouped by depth they are 3 launches whose
 // small levels fill the CUs the stride-8 level leaves idle.  blockIdx.x walks the problems' workgroup ranges; a problem is
-// in k_pw's form (64 or 128 pixels per workgroup) or in the split-K form (16 pixels, long K walk, few pixels): `split` = 0 | 1 | 2.
+// either in k_pw's form (64 pixels per workgroup) or in the split-K form (16 pixels, long K walk, few pixels).
 #define PW_GROUP_MAX 8
 struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int split[PW_GROUP_MAX]; int n; };
 
@@ -505,8 +505,7 @@ __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
     int bx = blockIdx.x, p = 0;
     for (int i = 1; i < G.n; ++i) if (bx >= G.start[i]) p = i;
     bx -= G.start[p];
-    if (G.split[p] == 2) pw_splitk_body<BN, CONV3>(G.p[p], bx, 0);
-    else if (G.split[p] == 1) pw_body<BN, 2, CONV3, true>(G.p[p], bx, 0);
+    if (G.split[p]) pw_splitk_body<BN, CONV3>(G.p[p], bx, 0);
     else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0);
 }
 
@@ -1735,9 +1734,9 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
         const int K = c.ksize * c.ksize * c.Cin;
         G.p[s] = PwArgs{ (const __half*)c.x, (const __half*)c.w, (const __half*)c.bias, nullptr, (int)M, K, c.N, c.act, 0, (__half*)c.out,
                          c.N, nullptr, 0, 0, g };
-        G.split[s] = (splitk_allowed && conv3 && K >= 512 && M <= 4096) ? 2 : (M >= 32768 ? 1 : 0);     // launch_pw's rules
+        G.split[s] = splitk_allowed && conv3 && K >= 512 && M <= 4096;
         G.start[s] = wgs;
-        wgs += (int)(G.split[s] == 2 ? (M + 15) / 16 : (G.split[s] == 1 ? (M + 127) / 128 : (M + 63) / 64));
+        wgs += (int)(G.split[s] ? (M + 15) / 16 : (M + 63) / 64);
     }
     for (int s = n; s < PW_GROUP_MAX; ++s) { G.p[s] = G.p[0]; G.split[s] = 0; G.start[s] = wgs; }
     G.start[PW_GROUP_MAX] = wgs;
