@@ -276,6 +276,12 @@ int ss_op_osnet_tail_f16(void* stream, const void* const* d_ys, const float* d_p
                          const void* d_gb1, const void* d_gw2, const void* d_gb2, int Cr, float* d_gates_ws /*[N][4][32]*/,
                          const void* d_w3, const void* d_b3, const void* d_idn, void* d_out, const void* d_w4, const void* d_b4,
                          void* d_out2, int pool, int N, int H, int W, int MID, int C2, int N2);
+/* concat(nearest-neighbour x2 upsampling of d_lo [B][h][w][C1], d_hi [B][2h][2w][C2]) along channels -> d_out
+ * [B][2h][2w][C1+C2] (lo_first: the upsampled tensor's channels first), one pass (the detector neck). */
+int ss_op_upcat_f16(void* stream, const void* d_lo, const void* d_hi, void* d_out, int B, int h, int w, int C1, int C2, int lo_first);
+/* SPPF's pooling pyramid: d_out [B][H][W][4C] = concat(x, m(x), m(m(x)), m(m(m(x)))), m = max pool 5x5 / 1 / pad 2.
+ * H*W <= 1024, C % 8 == 0. */
+int ss_op_sppf_pools_f16(void* stream, const void* d_x, void* d_out, int B, int H, int W, int C);
 /* 2x2 / stride 2 average pooling, NHWC half (H, W even; C % 8 == 0). */
 int ss_op_avgpool2_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */

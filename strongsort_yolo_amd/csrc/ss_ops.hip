@@ -1099,6 +1099,74 @@ __global__ __launch_bounds__(256) void k_avgpool2(const __half* __restrict__ x, 
     }
 }
 
+// concat(nearest-upsample x2 (lo), hi) along channels in one pass (the detector neck: F.interpolate + torch.cat were two
+// launches and an extra round trip of the upsampled tensor).  thread = (output pixel, 8 channels).
+__global__ __launch_bounds__(256) void k_upcat(const __half* __restrict__ lo, const __half* __restrict__ hi, __half* __restrict__ out,
+                                              int B, int h, int w, int C1_8, int C2_8, int lo_first)
+{
+    const int H = 2 * h, W = 2 * w, CT = C1_8 + C2_8;
+    const size_t total = (size_t)B * H * W * CT;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cg = (int)(i % CT);
+        const size_t p = i / CT;
+        const int x = (int)(p % W), y = (int)((p / W) % H);
+        const size_t b = p / ((size_t)W * H);
+        const bool from_lo = lo_first ? cg < C1_8 : cg >= C2_8;
+        const int c = lo_first ? (from_lo ? cg : cg - C1_8) : (from_lo ? cg - C2_8 : cg);
+        reinterpret_cast<h8*>(out)[i] = from_lo ? reinterpret_cast<const h8*>(lo)[((b * h + (y >> 1)) * w + (x >> 1)) * C1_8 + c]
+                                                 : reinterpret_cast<const h8*>(hi)[p * C2_8 + c];
+    }
+}
+
+// SPPF's pooling pyramid in one launch: out = concat(x, m(x), m(m(x)), m(m(m(x)))) with m = max pool 5x5 / stride 1 / pad 2
+// (padding never wins a max, so the cascade is exact).  Workgroup = (image, 8 channels): the map lives in LDS, each pool is
+// a horizontal then a vertical pass of 5 taps.  H*W <= 1024.
+__global__ __launch_bounds__(256) void k_sppf_pools(const __half* __restrict__ x, __half* __restrict__ out, int H, int W, int C8)
+{
+    extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+    h8* a = reinterpret_cast<h8*>(sp_smem);
+    h8* t = a + H * W;
+    const int b = blockIdx.x / C8, cg = blockIdx.x - b * C8, HW = H * W;
+    const h8* xi = reinterpret_cast<const h8*>(x) + (size_t)b * HW * C8 + cg;
+    h8* oi = reinterpret_cast<h8*>(out) + (size_t)b * HW * 4 * C8 + cg;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const h8 v = xi[(size_t)p * C8];
+        a[p] = v;
+        oi[(size_t)p * 4 * C8] = v;
+    }
+    __syncthreads();
+    for (int lvl = 1; lvl <= 3; ++lvl) {
+        for (int p = threadIdx.x; p < HW; p += 256) {               // horizontal
+            const int y = p / W, xx = p - y * W;
+            h8 m = a[p];
+            for (int d = -2; d <= 2; ++d) {
+                const int xs = xx + d;
+                if (d == 0 || xs < 0 || xs >= W) continue;
+                const h8 v = a[y * W + xs];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
+            }
+            t[p] = m;
+        }
+        __syncthreads();
+        for (int p = threadIdx.x; p < HW; p += 256) {               // vertical
+            const int y = p / W, xx = p - y * W;
+            h8 m = t[p];
+            for (int d = -2; d <= 2; ++d) {
+                const int ys = y + d;
+                if (d == 0 || ys < 0 || ys >= H) continue;
+                const h8 v = t[ys * W + xx];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
+            }
+            oi[((size_t)p * 4 + lvl) * C8] = m;
+            // the next level reads `a`; nobody reads it any more in this level
+            a[p] = m;
+        }
+        __syncthreads();
+    }
+}
+
 // OSNet unified aggregation gate over T <= 4 streams.
 //   step 1: mean over H*W of every stream -> means[t][n][C] (f32)
 //   step 2: g_t = sigmoid(fc2(relu(fc1(mean_t)))) per sample, out = sum_t x_t * g_t
@@ -1748,5 +1816,22 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
     else if (nmax <= 64) SS_GRP(64);
     else SS_GRP(80);
 #undef SS_GRP
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_upcat_f16(void* stream, const void* lo, const void* hi, void* out, int B, int h, int w, int C1, int C2, int lo_first)
+{
+    if (!lo || !hi || !out || B < 1 || h < 1 || w < 1 || C1 < 8 || C1 % 8 || C2 < 8 || C2 % 8) return SS_ERR_INVALID;
+    const size_t total = (size_t)B * 4 * h * w * ((C1 + C2) / 8);
+    hipLaunchKernelGGL(k_upcat, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)lo, (const __half*)hi,
+                       (__half*)out, B, h, w, C1 / 8, C2 / 8, lo_first);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_sppf_pools_f16(void* stream, const void* x, void* out, int B, int H, int W, int C)
+{
+    if (!x || !out || B < 1 || H < 1 || W < 1 || C < 8 || C % 8 || H * W > 1024) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(k_sppf_pools, dim3((unsigned)(B * (C / 8))), dim3(256), (size_t)2 * H * W * 16, (hipStream_t)stream,
+                       (const __half*)x, (__half*)out, H, W, C / 8);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

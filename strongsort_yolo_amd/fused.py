@@ -313,6 +313,37 @@ def maxpool(x, k, stride, pad):
     return y
 
 
+GLUE = _flag("GLUE")                    # upsample + concat and the SPPF pooling pyramid as single launches
+
+
+def upcat_ok(lo, hi) -> bool:
+    return (GLUE and usable(lo) and usable(hi) and lo.shape[1] % 8 == 0 and hi.shape[1] % 8 == 0 and hi.shape[0] == lo.shape[0]
+            and hi.shape[2] == 2 * lo.shape[2] and hi.shape[3] == 2 * lo.shape[3])
+
+
+def upcat(lo, hi, lo_first=True):
+    """torch.cat((F.interpolate(lo, scale_factor=2, mode="nearest"), hi), 1) (or hi first) in one launch."""
+    lo, hi = _cl(lo), _cl(hi)
+    b, c1, h, w = lo.shape
+    c2 = hi.shape[1]
+    out = torch.empty((b, c1 + c2, 2 * h, 2 * w), dtype=lo.dtype, device=lo.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_upcat_f16(_st(lo), _p(lo), _p(hi), _p(out), b, h, w, c1, c2, int(lo_first)))
+    return out
+
+
+def sppf_pools_ok(x) -> bool:
+    return GLUE and usable(x) and x.shape[1] % 8 == 0 and x.shape[2] * x.shape[3] <= 1024
+
+
+def sppf_pools(x):
+    """cat(x, m(x), m(m(x)), m(m(m(x)))) with m = max_pool2d(5, 1, 2), one launch."""
+    x = _cl(x)
+    b, c, h, w = x.shape
+    out = torch.empty((b, 4 * c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_sppf_pools_f16(_st(x), _p(x), _p(out), b, h, w, c))
+    return out
+
+
 def avgpool2(x):
     """2x2 / stride 2 average pooling on a channels-last half tensor (even H, W; C % 8 == 0), else torch's."""
     x = _cl(x)

@@ -119,6 +119,8 @@ class SPPF(nn.Module):
 
     def forward(self, x):
         y = [self.cv1(x)]
+        if fused.sppf_pools_ok(y[0]):                        # the three pools and the concat in one launch
+            return self.cv2(fused.sppf_pools(y[0]))
         pool = (lambda t: fused.maxpool(t, 5, 1, 2)) if fused.usable(x) else self.m
         y.extend(pool(y[-1]) for _ in range(3))
         return self.cv2(torch.cat(y, 1))
@@ -226,8 +228,8 @@ class YOLOv8(nn.Module):
         return p3, p4, p5
 
     def forward_head(self, p3, p4, p5):
-        h12 = self.h12(torch.cat((F.interpolate(p5, scale_factor=2.0, mode="nearest"), p4), 1))
-        h15 = self.h15(torch.cat((F.interpolate(h12, scale_factor=2.0, mode="nearest"), p3), 1))
+        h12 = self.h12(_upcat(p5, p4))
+        h15 = self.h15(_upcat(h12, p3))
         h18 = self.h18(torch.cat((self.h16(h15), h12), 1))
         h21 = self.h21(torch.cat((self.h19(h18), p5), 1))
         return self.detect([h15, h18, h21])
@@ -260,8 +262,8 @@ class YOLOv5u(nn.Module):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
         p4 = self.b6(self.b5(p3))
         p5 = self.h10(self.b9(self.b8(self.b7(p4))))
-        h13 = self.h14(self.h13(torch.cat((F.interpolate(p5, scale_factor=2.0, mode="nearest"), p4), 1)))
-        h17 = self.h17(torch.cat((F.interpolate(h13, scale_factor=2.0, mode="nearest"), p3), 1))
+        h13 = self.h14(self.h13(_upcat(p5, p4)))
+        h17 = self.h17(_upcat(h13, p3))
         h20 = self.h20(torch.cat((self.h18(h17), h13), 1))
         h23 = self.h23(torch.cat((self.h21(h20), p5), 1))
         return self.detect([h17, h20, h23])
@@ -330,8 +332,8 @@ class YOLOv7(nn.Module):
         c3 = self.e2(self.mp1(self.e1(self.stem(x))))
         c4 = self.e3(self.mp2(c3))
         c5 = self.spp(self.e4(self.mp3(c4)))
-        p4 = self.n1(torch.cat((self.r1(c4), F.interpolate(self.l1(c5), scale_factor=2.0, mode="nearest")), 1))
-        p3 = self.n2(torch.cat((self.r2(c3), F.interpolate(self.l2(p4), scale_factor=2.0, mode="nearest")), 1))
+        p4 = self.n1(_upcat(self.l1(c5), self.r1(c4), lo_first=False))
+        p3 = self.n2(_upcat(self.l2(p4), self.r2(c3), lo_first=False))
         n4 = self.n3(torch.cat((self.d1(p3), p4), 1))
         n5 = self.n4(torch.cat((self.d2(n4), c5), 1))
         return self.detect([p3, n4, n5])
@@ -518,6 +520,14 @@ class OSNet(nn.Module):
 
     def forward(self, x):
         return self.forward_b(self.forward_a(x, 0), 0)
+
+
+def _upcat(lo, hi, lo_first=True):
+    """cat(upsample2x(lo), hi) (or cat(hi, upsample2x(lo))) along channels."""
+    if fused.upcat_ok(lo, hi):
+        return fused.upcat(lo, hi, lo_first)
+    up = F.interpolate(lo, scale_factor=2.0, mode="nearest")
+    return torch.cat((up, hi) if lo_first else (hi, up), 1)
 
 
 def osnet_x0_25():

@@ -293,6 +293,34 @@ def test_osnet_stem_matches_conv_relu_pool(N, H):
     assert (got.float() != ref).float().mean().item() < 0.02
 
 
+@pytest.mark.parametrize("b,c1,c2,h,w,lo_first", [(16, 256, 128, 12, 20, True), (3, 128, 64, 24, 40, True), (2, 8, 24, 5, 7, False), (1, 64, 64, 1, 1, False)])
+def test_upcat_equals_interpolate_plus_cat(b, c1, c2, h, w, lo_first):
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(c1 + h)
+    lo = torch.randn(b, c1, h, w, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    hi = torch.randn(b, c2, 2 * h, 2 * w, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    assert fused.upcat_ok(lo, hi)
+    up = F.interpolate(lo, scale_factor=2.0, mode="nearest")
+    ref = torch.cat((up, hi) if lo_first else (hi, up), 1)
+    got = fused.upcat(lo, hi, lo_first)
+    assert got.is_contiguous(memory_format=torch.channels_last) and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(16, 128, 12, 20), (2, 256, 20, 20), (1, 8, 3, 2), (3, 64, 32, 32), (2, 16, 1, 9)])
+def test_sppf_pools_equal_the_pool_cascade(b, c, h, w):
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    x = torch.randn(b, c, h, w, generator=torch.Generator().manual_seed(c + w)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    assert fused.sppf_pools_ok(x)
+    y = [x]
+    for _ in range(3):
+        y.append(F.max_pool2d(y[-1], 5, 1, 2))
+    assert torch.equal(fused.sppf_pools(x), torch.cat(y, 1))
+
+
 def test_avgpool2_equals_torch():
     import torch.nn.functional as F
     from strongsort_yolo_amd import fused
