@@ -1,3 +1,4 @@
+"""Kernel sequence of the last detector pass in a rocprofv3 kernel trace (name, workgroups, us).  usage: python tools/detector_sequence.py <kernel_trace.csv>"""
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
