@@ -383,6 +383,10 @@ def main():
     dev = pipe.dev
     pools = [dict(preds=torch.from_numpy(w["preds"]).to(dev), agt=torch.from_numpy(w["agt"]).to(dev),
                   feats=torch.from_numpy(w["feats"]).to(dev), pixels=torch.from_numpy(w["pixels"]).to(dev)) for w in wls]
+    for p in pools:                                         # the frame pool laid out cyclically, one group longer than itself: any
+        npix = p["pixels"].shape[0]                         # FB consecutive frames of the cycle are one contiguous slice
+        p["npix"] = npix
+        p["cycle"] = p["pixels"].repeat((FB + npix - 1) // npix + 1, 1, 1, 1)
     out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
     nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
 
@@ -398,13 +402,8 @@ def main():
         """Frames g0..g0+n-1 of every stream into the group's buffers: one device copy per input tensor per stream
         (stands for the decoder writing its frames into the batch buffer)."""
         for s, p in enumerate(pools):
-            npix = p["pixels"].shape[0]
-            k0 = g0 % npix
-            if k0 + n <= npix:
-                b.frames.view(FB, S, *b.frames.shape[1:])[:n, s].copy_(p["pixels"][k0:k0 + n])
-            else:
-                for f in range(n):
-                    b.frames[f * S + s].copy_(p["pixels"][(g0 + f) % npix])
+            k0 = g0 % p["npix"]
+            b.frames.view(FB, S, *b.frames.shape[1:])[:n, s].copy_(p["cycle"][k0:k0 + n])
             b.pred_in.view(FB, S, *b.pred_in.shape[1:])[:n, s].copy_(p["preds"][g0:g0 + n])
             b.anchor_gt.view(FB, S, *b.anchor_gt.shape[1:])[:n, s].copy_(p["agt"][g0:g0 + n])
             b.gt_feats.view(FB, S, *b.gt_feats.shape[1:])[:n, s].copy_(p["feats"][g0:g0 + n])

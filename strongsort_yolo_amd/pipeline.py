@@ -417,9 +417,12 @@ class OverlappedPipeline(FramePipeline):
         frame (None while warming up / capturing: no callbacks)."""
         e = self.eng
         nv = self.F if n_valid is None else n_valid
-        if self.cmc:
-            e.set_cmc(b.warps)
-        e.update_group(nv, b.dets6, b.ndets, b.feats_v, self.img_hw, self.outs, self.nouts)
+        G, S = 16, self.S                                       # the library takes up to 16 frames per call (SS_FMAX)
+        for f0 in range(0, nv, G):
+            n, v0, v1 = min(G, nv - f0), f0 * S, min(nv, f0 + G) * S
+            if self.cmc:
+                e.set_cmc(b.warps[f0:f0 + n])
+            e.update_group(n, b.dets6[v0:v1], b.ndets[v0:v1], b.feats_v[v0:v1], self.img_hw, self.outs[f0:f0 + n], self.nouts[f0:f0 + n])
         if group is not None and self.on_result is not None:
             for f in range(nv):
                 self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
