@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One "step" = one batch of `frames_per_step` consecutive frames (default 2 frame-batch groups of 16 = 32 frames) of
+One "step" = one batch of `frames_per_step` consecutive frames (default one frame-batch group of 32 frames) of
 every stream owned by the rank through the whole hot path (letterbox -> detector -> NMS -> ReID crops -> OSNet ->
 StrongSORT update), inputs resident in HBM; `value` = frames/s = world * streams * steps * frames_per_step / time.
 With `--gpus N` and no WORLD_SIZE in the environment the script starts its N ranks itself (torch.distributed.run,
@@ -13,10 +13,10 @@ Default workload = BASELINE.json configs[1]: yolov8n + StrongSORT, 1280x720 synt
 data-path collective — RCCL is used for the barrier and the max-over-ranks time only.
 
 Throughput structure (all of it result-preserving — every frame runs every stage, rows are bit-identical to the
-oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 16)
+oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 32)
 consecutive frames of a stream at a time — a decoded video file or a capture queue supplies them; it costs
 frame_batch frame periods of latency on a live camera — and the tracker consumes them one by one in frame
-order; stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
+order (library calls of up to 16 frames: the galleries are read once per call); stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
 stage B of group k (rest of OSNet, feature select, tracker) on a second HIP stream (`--overlap`).
 `--frame-batch 1 --overlap 0` is the strictly frame-at-a-time pipeline (profiles/ keeps these lines too).
 
@@ -312,7 +312,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30, help="timed steps; one step = --groups-per-step frame-batch groups of every stream")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--groups-per-step", type=int, default=2, help="frame-batch groups per step (frames_per_step = this x --frame-batch)")
+    ap.add_argument("--groups-per-step", type=int, default=1, help="frame-batch groups per step (frames_per_step = this x --frame-batch)")
     ap.add_argument("--dist-check", action="store_true", help="only start the ranks, run the barrier / max-over-ranks exchange and print n_gpus (no GPU work)")
     ap.add_argument("--streams", type=int, default=1, help="streams per GPU (configs[1] = 1)")
     ap.add_argument("--preset", default="c2", choices=sorted(PRESETS))
@@ -323,8 +323,8 @@ def main():
     ap.add_argument("--no-api-path", action="store_true", help="skip the YOLO.track / track_stream measurement")
     ap.add_argument("--check-frames", type=int, default=160, help="frames compared with the oracle")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
-    ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
-    ap.add_argument("--frame-batch", type=int, default=16, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
+    ap.add_argument("--reid-split", type=int, default=3, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
+    ap.add_argument("--frame-batch", type=int, default=32, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -488,7 +488,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_assoc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}_f{FB}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}_f{int(round(frames_launch))}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"kernel": "k_assoc (association: gallery stream x detections of the frame group, f32 MFMA, row min)",
@@ -544,7 +544,7 @@ def main():
     pipe.close()
     if rank == 0:
         if world == 1 and not args.no_batched:
-            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16) else 8)
+            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16) else (16 if FB > 16 else 8))
             res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=1, check=False)
         if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
             res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)

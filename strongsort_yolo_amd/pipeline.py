@@ -309,9 +309,11 @@ class OverlappedPipeline(FramePipeline):
             st += [self._s_nms_crop_reid_select]
         self.stages = st
         self.n = len(st)
-        # the last stage carries the tracker's short dependent launches: SS_TRACK_PRIORITY=1 gives its stream high priority
+        # the last stage carries the tracker's short dependent launches and the association kernel: its stream gets high
+        # priority, so their workgroups are dispatched ahead of the other stream's network kernels (measured at frame batch
+        # 32: association launch 61 -> 50 us beside the network kernels, 8640 -> 8790 frames/s; SS_TRACK_PRIORITY=0: A/B)
         import os as _os
-        hi = _os.environ.get("SS_TRACK_PRIORITY", "0") == "1"
+        hi = _os.environ.get("SS_TRACK_PRIORITY", "1") == "1"
         self.streams = [torch.cuda.Stream(self.dev, priority=(-1 if (hi and j == self.n - 1) else 0)) for j in range(self.n)]
         # tracker_stream=True gives the tracker (one-workgroup kernels, ~70 us a frame) a stream of its own next to the
         # last stage of the following group, with one more buffer set so that stage 0 does not wait for it.  Measured
