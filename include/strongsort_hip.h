@@ -248,6 +248,11 @@ int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]
  * {16,24,32}, W % 8 == 0, 18*(W+2)*C*2 <= 65536 (the band lives in LDS; SS_ERR_INVALID otherwise). */
 int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                         void* d_y, int N, int H, int W, int C);
+/* The detector's first convolution: 3x3 / stride 2 / pad 1, 3 -> Cout in {16, 32, 48} channels, + bias + activation on
+ * [B][H][W][3] half -> [B][(H-1)/2+1][W/2][Cout]; d_w_prep [4][3][Cout][16] = for conv columns c = 4n + r, per (ky, out
+ * channel) the taps 3*kx+ch placed (6r + 5) % 8 halfs into a zero-padded 16-wide K window (fused.conv0_weight).  W % 128 == 0. */
+int ss_op_conv0_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int B, int H, int W, int Cout,
+                    int act);
 /* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
  * half -> [N][H/4][32][16]; d_w_prep [4][7][16][32] = for conv columns c = 4n + r, per (ky, out channel) the taps 3*kx+ch
  * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0. */

@@ -594,6 +594,63 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
     }
 }
 
+// The detector's first convolution: 3x3 / stride 2 / pad 1 on the 3-channel letterboxed frame + bias + SiLU, [B][H][W][3]
+// half -> [B][H/2][W/2][COUT].  (MIOpen's igemm + our bias pass: 32 + 15 us per 16 frames, C_in = 3 wastes its K tiles.)
+// Same idea as k_osnet_stem: a row of the NHWC input is a flat array of halfs, the 9 taps (kx, ch) of conv column c on row ky
+// are the window starting at flat 6c - 3; with 8 halfs of margin in front of a 64-column tile's span, the columns c = 4n + r
+// start (6r + 5) % 8 halfs into the aligned 8-half block 3n + (6r + 5) / 8, and 9 taps from there never leave the next block:
+// K = 16 per ky, one v_mfma_f32_16x16x16_f16 per ky against weights pre-shifted per residue r (wave r) — host:
+// fused.conv0_weight, [4][3][COUT][16].  Workgroup = 8 conv rows x 64 columns; 17 input rows staged with 16-byte copies.
+#define C0_PITCH 400        // halfs per LDS row: 8 margin + 384 (64 columns x 2 x 3) + 8 tail
+#define C0_ROWS 8
+
+template <int COUT>
+__global__ __launch_bounds__(256) void k_conv0(const __half* __restrict__ x, const __half* __restrict__ wp, const __half* __restrict__ bias,
+                                              __half* __restrict__ y, int H, int W, int act)
+{
+    constexpr int MT = COUT / 16, IN_ROWS = 2 * C0_ROWS + 1, CH = C0_PITCH / 8;
+    __shared__ __attribute__((aligned(16))) _Float16 In[IN_ROWS * C0_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int OH = (H - 1) / 2 + 1, OW = W / 2;
+    const int c0 = blockIdx.x * 64, oy0 = blockIdx.y * C0_ROWS, b = blockIdx.z;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const __half* xi = x + (size_t)b * H * W * 3;
+    const int row_halfs = W * 3, f0 = 6 * c0 - 8;                      // flat index of LDS half 0 within an input row
+    for (int i = tid; i < IN_ROWS * CH; i += 256) {
+        const int rr = i / CH, ch = i - rr * CH, gr = 2 * oy0 - 1 + rr, f = f0 + ch * 8;
+        *reinterpret_cast<h8*>(In + rr * C0_PITCH + ch * 8) =
+            (gr >= 0 && gr < H && f >= 0 && f + 8 <= row_halfs) ? *reinterpret_cast<const h8*>(xi + (size_t)gr * row_halfs + f) : z8;
+    }
+    h4 a[MT][3], bb[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) a[mt][ky] = *reinterpret_cast<const h4*>(wp + ((size_t)(r * 3 + ky) * COUT + mt * 16 + n) * 16 + 4 * q);
+        bb[mt] = *reinterpret_cast<const h4*>(bias + mt * 16 + 4 * q);
+    }
+    __syncthreads();
+    const _Float16* bp = In + 8 * (3 * n + (6 * r + 5) / 8) + 4 * q;
+    const int c = c0 + 4 * n + r;
+#pragma unroll 2
+    for (int cr = 0; cr < C0_ROWS; ++cr) {
+        const int oy = oy0 + cr;
+        if (oy >= OH) break;
+        h4 bv[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) bv[ky] = *reinterpret_cast<const h4*>(bp + (2 * cr + ky) * C0_PITCH);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f4 d = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) d = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt][ky], bv[ky], d, 0, 0, 0);
+            h4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (_Float16)act_apply((float)(_Float16)d[j] + (float)bb[mt][j], act);
+            if (c < OW) *reinterpret_cast<h4*>(y + (((size_t)b * OH + oy) * OW + c) * COUT + mt * 16 + 4 * q) = o;
+        }
+    }
+}
+
 // OSNet "LightConv3x3" in one pass: y = relu(dw3x3(pw1x1(x)) + bias), C in {16, 24, 32}.
 //
 // The two-launch form (GEMM, then k_dw3x3) writes and re-reads the C-channel intermediate through HBM and
@@ -1833,5 +1890,19 @@ extern "C" int ss_op_sppf_pools_f16(void* stream, const void* x, void* out, int 
     if (!x || !out || B < 1 || H < 1 || W < 1 || C < 8 || C % 8 || H * W > 1024) return SS_ERR_INVALID;
     hipLaunchKernelGGL(k_sppf_pools, dim3((unsigned)(B * (C / 8))), dim3(256), (size_t)2 * H * W * 16, (hipStream_t)stream,
                        (const __half*)x, (__half*)out, H, W, C / 8);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_conv0_f16(void* stream, const void* x, const void* w_prep, const void* bias, void* y, int B, int H, int W, int Cout,
+                               int act)
+{
+    if (!x || !w_prep || !bias || !y || B < 1 || H < 2 || W < 128 || W % 128 || (W * 3) % 8 || (Cout != 16 && Cout != 32 && Cout != 48))
+        return SS_ERR_INVALID;
+    const int OH = (H - 1) / 2 + 1;
+    const dim3 grid(W / 128, (OH + C0_ROWS - 1) / C0_ROWS, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SS_C0(CO) hipLaunchKernelGGL(k_conv0<CO>, grid, block, 0, st, (const __half*)x, (const __half*)w_prep, (const __half*)bias, (__half*)y, H, W, act)
+    if (Cout == 16) SS_C0(16); else if (Cout == 32) SS_C0(32); else SS_C0(48);
+#undef SS_C0
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -200,6 +200,40 @@ def lightconv(x, w1, w9, bias):
     return y
 
 
+CONV0 = _flag("CONV0")                  # the detector's first convolution (3 input channels) on its own MFMA kernel
+
+
+def conv0_ok(x, conv) -> bool:
+    n, c, h, w = x.shape
+    return (CONV0 and usable(x) and c == 3 and w % 128 == 0 and h >= 2 and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.out_channels in (16, 32, 48)
+            and conv.bias is not None)
+
+
+def conv0_weight(mod, conv):
+    """[4][3][Cout][16]: for conv columns c = 4n + r, per (ky, out channel) the 9 (kx, ch) taps in the order they lie in an
+    NHWC input row, placed (6r + 5) % 8 halfs into a 16-wide K window of two aligned 8-half blocks (k_conv0)."""
+    w = getattr(mod, "_w_c0", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        co = conv.out_channels
+        taps = conv.weight.detach().permute(2, 0, 3, 1).reshape(3, co, 9)           # [ky][oc][3*kx + ch]
+        w = torch.zeros(4, 3, co, 16, dtype=conv.weight.dtype, device=conv.weight.device)
+        for r in range(4):
+            sh = (6 * r + 5) % 8
+            w[r, :, :, sh:sh + 9] = taps
+        mod._w_c0 = w
+    return w
+
+
+def conv0(x, w_prep, bias, act="silu"):
+    x = _cl(x)
+    n, c, h, w = x.shape
+    co = w_prep.shape[2]
+    y = torch.empty((n, co, (h - 1) // 2 + 1, w // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_conv0_f16(_st(x), _p(x), _p(w_prep), _p(bias), _p(y), n, h, w, co, ACT[act]))
+    return y
+
+
 STEM = _flag("STEM")                    # OSNet conv1 7x7/2 + bias + ReLU + max pool 3x3/2 in one launch
 
 

@@ -39,6 +39,8 @@ class Conv(nn.Module):
                 return fused.pointwise(x, fused.weight_nk(self, c), c.bias, act)
             if fused.conv3x3_ok(c):          # 3x3: the same kernel as an implicit GEMM
                 return fused.conv3x3(x, fused.weight_n9k(self, c), c.bias, c.stride[0], act)
+            if fused.conv0_ok(x, c):         # the first convolution (3 input channels, stride 2)
+                return fused.conv0(x, fused.conv0_weight(self, c), c.bias, act)
             # k x k: conv without bias (MIOpen) + one fused bias+SiLU pass
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
             return fused.bias_act_(y, c.bias, act)

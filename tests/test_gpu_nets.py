@@ -321,6 +321,22 @@ def test_sppf_pools_equal_the_pool_cascade(b, c, h, w):
     assert torch.equal(fused.sppf_pools(x), torch.cat(y, 1))
 
 
+@pytest.mark.parametrize("B,H,W,co", [(16, 384, 640, 16), (2, 384, 640, 32), (1, 30, 128, 48), (3, 17, 256, 16)])
+def test_conv0_matches_conv_bias_silu(B, H, W, co):
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(co + H)
+    x = torch.randn(B, 3, H, W, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(3, co, 3, 2, 1).to(dev, torch.float16)
+    assert fused.conv0_ok(x, conv)
+    got = fused.conv0(x, fused.conv0_weight(torch.nn.Module(), conv), conv.bias, "silu")
+    ref = F.silu(F.conv2d(x.float(), conv.weight.float(), None, 2, 1).half().float() + conv.bias.float().view(1, co, 1, 1))
+    assert got.shape == ref.shape
+    assert (got.float() - ref).abs().max().item() <= 4e-3 * (ref.abs().max().item() + 1.0)
+    assert (got.float() - ref).abs().mean().item() <= 2e-4
+
+
 def test_avgpool2_equals_torch():
     import torch.nn.functional as F
     from strongsort_yolo_amd import fused

@@ -79,6 +79,31 @@ def test_stem_weight_and_flat_row_windows():
     assert torch.equal(pooled_zero_pad, F.max_pool2d(a, 3, 2, 1))
 
 
+def test_conv0_weight_and_flat_row_windows():
+    """k_conv0 (3x3 / stride 2 / pad 1 on 3 channels): with 8 halfs of margin in front of a 64-column tile's span of the flat
+    NHWC row, the 9 taps of conv column c = 4n + r start (6r + 5) % 8 halfs into the aligned block 3n + (6r + 5) // 8 and stay
+    inside a 16-wide window; weights [r][ky][oc][16] are shifted by the same amount."""
+    torch.manual_seed(4)
+    conv = torch.nn.Conv2d(3, 16, 3, 2, 1)
+    wp = fused.conv0_weight(torch.nn.Module(), conv)
+    assert wp.shape == (4, 3, 16, 16)
+    H, W = 6, 256
+    x = torch.randn(1, 3, H, W)
+    rows = torch.zeros(H + 2, 8 + W * 3 + 8)                                 # one zero row above / below, margins zero
+    rows[1:H + 1, 8:8 + W * 3] = x[0].permute(1, 2, 0).reshape(H, W * 3)
+    out = torch.empty(16, H // 2, W // 2)
+    for oy in range(H // 2):
+        for c in range(W // 2):
+            c0, cl = (c // 64) * 64, c % 64
+            r, n = cl % 4, cl // 4
+            blk, sh = 3 * n + (6 * r + 5) // 8, (6 * r + 5) % 8
+            assert 8 * blk + sh == 6 * cl + 5 and sh + 9 <= 16 and 8 * blk + 16 <= 400
+            base = 6 * c0                                                    # LDS half 0 of the tile = flat 6 c0 - 8 = rows[.., 6 c0]
+            win = torch.stack([rows[2 * oy + ky, base + 8 * blk:base + 8 * blk + 16] for ky in range(3)])      # [3, 16]
+            out[:, oy, c] = (wp[r] * win[:, None, :]).sum((0, 2))
+    assert torch.allclose(out, F.conv2d(x, conv.weight, None, 2, 1)[0], atol=1e-4)
+
+
 def test_osnet_block_layer_order_matches_the_chain_kernel():
     """k_osnet_streams takes the ten LightConv layers as [chain1: 1 layer][chain2: 2][chain3: 3][chain4: 4]; chain t
     starts at index t(t-1)/2.  The module order `for st in streams for m in st` must be that order."""

@@ -1,14 +1,15 @@
 """OSNet-x0.25 forward on 512 crops (16 frames x 32) and the detector on 16 frames, each as one replayed HIP graph:
-milliseconds per replay.  A/B switches: SS_FUSED_<NAME>=0 (fused.py).  usage: python tools/osnet_time.py [reps=20]"""
+milliseconds per replay.  A/B switches: SS_FUSED_<NAME>=0 (fused.py).  usage: python tools/osnet_time.py [reps=20] [frames=16]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd import nets
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 det = nets.build_detector("yolov8n").to(dev, torch.float16).to(memory_format=torch.channels_last)
 reid = nets.build_reid().to(dev, torch.float16).to(memory_format=torch.channels_last)
-x = torch.randn(16, 3, 384, 640, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
-c = torch.randn(512, 3, 256, 128, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+x = torch.randn(F, 3, 384, 640, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+c = torch.randn(32 * F, 3, 256, 128, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
 
 
 def timed(fn):
@@ -29,5 +30,5 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps
 
 
-print({"osnet_512_ms": round(timed(lambda: reid(c)), 4), "detector_16_ms": round(timed(lambda: det(x)), 4),
+print({"frames": F, "osnet_ms": round(timed(lambda: reid(c)), 4), "detector_ms": round(timed(lambda: det(x)), 4),
        "flags": {k: v for k, v in os.environ.items() if k.startswith("SS_FUSED_")}})
