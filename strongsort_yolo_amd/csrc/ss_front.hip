@@ -132,19 +132,30 @@ __global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, l
 
 // Channels-last form, vectorised: one thread = 8 consecutive output pixels x 3 channels = 24 values written as 16-byte
 // stores (3 for half, 6 for float) — a crop row is 128 x 3 values contiguous, so a 16-thread group writes 768 / 1536
-// contiguous bytes.  Same per-pixel arithmetic as k_crop (bit-identical).  block = 16 rows x 16 pixel groups.
+// contiguous bytes.  block = 16 output rows x 16 pixel groups of one crop.  Per-pixel arithmetic is k_crop's, bit for bit:
+//  * the bilinear value is rounded to an integer 0..255 before the normalisation, so ((q / 255) - mean) / sd is one of
+//    256 x 3 numbers: a table in LDS filled with exactly that expression replaces two correctly-rounded divisions per value
+//    (~30 VALU instructions);
+//  * the source rows the 16 output rows touch (the box's own columns) are staged in LDS with aligned dword loads and a
+//    pixel's three bytes come out of two LDS dwords + a 64-bit shift (the byte-wide global loads — 96 per thread — were the
+//    kernel's limit: 82 us per 512 crops).  Boxes whose row span does not fit the LDS budget take the global loads.
+#define CROP_LDS_BYTES 30720
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ src, long long src_batch_stride, int H, int W,
                                                    int stride, const float* __restrict__ dets, int det_stride,
                                                    long long dets_batch_stride, int n, const int* __restrict__ d_count,
                                                    T* __restrict__ dst)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char crop_smem[];
+    T* lut = reinterpret_cast<T*>(crop_smem);                                  // [3][256]
+    uint32_t* Ls = reinterpret_cast<uint32_t*>(crop_smem + 768 * sizeof(T));   // staged source rows
     const int out_w = 128, out_h = 256;
     const int img = blockIdx.z / n, d = blockIdx.z - img * n;
     const int cnt = d_count ? d_count[img] : n;
     if (d >= cnt) return;
     src += (size_t)img * src_batch_stride;
-    const int y = blockIdx.y * 16 + (threadIdx.x >> 4), xg = (threadIdx.x & 15) * 8;
+    const int tid = threadIdx.x, yb = blockIdx.y * 16, y = yb + (tid >> 4), xg = (tid & 15) * 8;
     const float* b = dets + (size_t)img * dets_batch_stride + (size_t)d * det_stride;
     int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];
     if (x1 < 0) x1 = 0; if (y1 < 0) y1 = 0;
@@ -153,22 +164,69 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     int cw = x2 - x1, ch = y2 - y1;
     if (cw < 1) cw = 1; if (ch < 1) ch = 1;
     const float sx = (float)cw / (float)out_w, sy = (float)ch / (float)out_h;
+    const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
+    for (int i = tid; i < 768; i += 256) {
+        const int c = i >> 8;
+        const float q = (float)(i & 255) / 255.0f;
+        lut[i] = ss_cvt<T>((q - mean[c]) / sd[c]);
+    }
+    // source rows of this band (uniform): first row's upper tap .. last row's lower tap
+    int ra0, ra1, rb0, rb1; float fa, fb;
+    ss_axis(yb, sy, ch, ra0, ra1, fa);
+    ss_axis(yb + 15, sy, ch, rb0, rb1, fb);
+    const int nrows = rb1 - ra0 + 1;
+    const size_t rowb = (size_t)x1 * 3;
+    const int mis = (int)(rowb & 3), ndw = (mis + cw * 3 + 3) >> 2, pitch = ndw + 1;
+    const bool staged = (stride & 3) == 0 && ((uintptr_t)src & 3) == 0 && (size_t)nrows * pitch * 4 <= CROP_LDS_BYTES;
+    if (staged) {
+        const size_t end = (size_t)H * stride;
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            const int rr = i / ndw, dw = i - rr * ndw;
+            const size_t off = (size_t)(y1 + ra0 + rr) * stride + (rowb - mis) + (size_t)dw * 4;
+            uint32_t v;
+            if (off + 4 <= end) v = *reinterpret_cast<const uint32_t*>(src + off);
+            else { v = 0; for (int k = 0; k < 4 && off + k < end; ++k) v |= (uint32_t)src[off + k] << (8 * k); }
+            Ls[rr * pitch + dw] = v;
+        }
+    }
+    __syncthreads();
     int yy0, yy1; float fy;
     ss_axis(y, sy, ch, yy0, yy1, fy);
-    const uint8_t* r0 = src + (size_t)(y1 + yy0) * stride + (size_t)x1 * 3;
-    const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride + (size_t)x1 * 3;
-    const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
     __attribute__((aligned(16))) T o[24];
+    if (staged) {
+        const uint32_t* l0 = Ls + (yy0 - ra0) * pitch;
+        const uint32_t* l1 = Ls + (yy1 - ra0) * pitch;
+        auto px = [&](const uint32_t* row, int xs) -> uint32_t {             // bytes 0..2 = B, G, R of source pixel xs
+            const int ob = mis + 3 * xs, dw = ob >> 2;
+            const uint64_t two = ((uint64_t)row[dw + 1] << 32) | row[dw];
+            return (uint32_t)(two >> (8 * (ob & 3)));
+        };
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        int xx0, xx1; float fx;
-        ss_axis(xg + p, sx, cw, xx0, xx1, fx);
+        for (int p = 0; p < 8; ++p) {
+            int xx0, xx1; float fx;
+            ss_axis(xg + p, sx, cw, xx0, xx1, fx);
+            const uint32_t v00 = px(l0, xx0), v01 = px(l0, xx1), v10 = px(l1, xx0), v11 = px(l1, xx1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int sc = 2 - c;
-            const float p00 = r0[xx0 * 3 + sc], p01 = r0[xx1 * 3 + sc], p10 = r1[xx0 * 3 + sc], p11 = r1[xx1 * 3 + sc];
-            const float q = ss_bilerp_u8(p00, p01, p10, p11, fx, fy) / 255.0f;
-            o[p * 3 + c] = ss_cvt<T>((q - mean[c]) / sd[c]);
+            for (int c = 0; c < 3; ++c) {
+                const int sh = 8 * (2 - c);
+                const float p00 = (float)((v00 >> sh) & 255u), p01 = (float)((v01 >> sh) & 255u), p10 = (float)((v10 >> sh) & 255u),
+                            p11 = (float)((v11 >> sh) & 255u);
+                o[p * 3 + c] = lut[c * 256 + (int)ss_bilerp_u8(p00, p01, p10, p11, fx, fy)];
+            }
+        }
+    } else {
+        const uint8_t* r0 = src + (size_t)(y1 + yy0) * stride + rowb;
+        const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride + rowb;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            int xx0, xx1; float fx;
+            ss_axis(xg + p, sx, cw, xx0, xx1, fx);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int sc = 2 - c;
+                const float p00 = r0[xx0 * 3 + sc], p01 = r0[xx1 * 3 + sc], p10 = r1[xx0 * 3 + sc], p11 = r1[xx1 * 3 + sc];
+                o[p * 3 + c] = lut[c * 256 + (int)ss_bilerp_u8(p00, p01, p10, p11, fx, fy)];
+            }
         }
     }
     constexpr int NV = 24 * sizeof(T) / 16;
@@ -186,8 +244,8 @@ void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_strid
     if (n <= 0 || batch <= 0) return;
     if (flags & 2) {
         dim3 grid(1, 16, n * batch), block(256);
-        if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out);
-        else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 0, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out);
+        if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 768 * sizeof(__half) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out);
+        else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 768 * sizeof(float) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out);
         return;
     }
     dim3 grid(1, 256, n * batch), block(128);

@@ -216,7 +216,7 @@ def test_nms_candidate_overflow_is_reported(eng):
     eng.check_errors()
 
 
-@pytest.mark.parametrize("half,hwc", [(False, False), (True, True)])
+@pytest.mark.parametrize("half,hwc", [(False, False), (True, True), (False, True)])
 def test_crop_norm_batch_bit_exact(eng, half, hwc):
     W, H, B, n = 1280, 720, 3, 16
     imgs, dets, counts = [], np.zeros((B, 32, 6), np.float32), []
@@ -229,6 +229,15 @@ def test_crop_norm_batch_bit_exact(eng, half, hwc):
         counts.append(k)
     dets[0, 0, :4] = [-5.0, -3.0, 20.5, 30.2]
     dets[1, 1, :4] = [W - 10.0, H - 12.0, W + 50.0, H + 50.0]
+    # the channels-last kernel stages a band's source rows in LDS: a box too large for it (global-load path), the last bytes
+    # of the last frame, one-pixel-wide / one-pixel-high boxes, every byte alignment of the first column
+    dets[2, 0, :4] = [0.0, 0.0, W, H]
+    dets[2, 1, :4] = [W - 3.0, H - 2.0, W, H]
+    dets[0, 1, :4] = [101.0, 50.0, 102.5, 400.0]
+    dets[1, 0, :4] = [30.0, 300.0, 500.0, 301.2]
+    for j in range(2, 6):
+        dets[2, j, :4] = [200.0 + j, 100.0, 260.0 + 2 * j, 290.0]
+    counts[0], counts[1], counts[2] = max(counts[0], 2), max(counts[1], 2), max(counts[2], 6)
     out = torch.full((B * n, 3, 256, 128), 7.0, dtype=torch.float16 if half else torch.float32, device=eng.device)
     if hwc:
         out = out.contiguous(memory_format=torch.channels_last)
