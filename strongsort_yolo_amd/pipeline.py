@@ -268,7 +268,7 @@ class OverlappedPipeline(FramePipeline):
     """
 
     def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
-                 tracker_stream: bool = False, **kw):
+                 tracker_stream: bool = False, defer_track: bool = False, **kw):
         kw = dict(kw)
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
@@ -321,7 +321,14 @@ class OverlappedPipeline(FramePipeline):
         # chain costs more in the dispatcher than the queue stall it removes (same finding as the 4-stage split) — so
         # it is off by default.
         self.sT = torch.cuda.Stream(self.dev) if (tracker_stream and self.graph_mode == "front") else None
-        self.nb = self.n + (1 if self.sT is not None else 0)                              # buffer sets
+        # defer_track: the tracker call of group k is enqueued on the last stage's stream AFTER that stream has waited for
+        # stage 0 of group k+1 — it then runs beside the START of the other stream's next group (letterbox, the detector's
+        # short-lived workgroups) instead of beside whatever that stream happens to be in.  The association kernel needs
+        # whole CUs' worth of registers at once; beside the OSNet row-stream kernel (waves that live ~100-200 us and own the
+        # register file) its launch took 50-83 us instead of 30.  Results arrive one group later; one more buffer set.
+        self.defer = bool(defer_track) and self.sT is None and self.graph_mode == "front"
+        self._pending_track = None
+        self.nb = self.n + (1 if (self.sT is not None or self.defer) else 0)              # buffer sets
         self.bufs = [_Bufs(self) for _ in range(self.nb)]
         self.ev = [[torch.cuda.Event() for _ in range(self.nb)] for _ in range(self.n)]   # ev[stage][set]
         self.ev_graph = [torch.cuda.Event() for _ in range(self.nb)]                      # last stage's graph done (tracker may start)
@@ -481,8 +488,12 @@ class OverlappedPipeline(FramePipeline):
         with torch.cuda.stream(st):
             if j > 0:
                 st.wait_event(self.ev[j - 1][i])
+            if j == self.n - 1 and self.defer:
+                self._flush_track(st)                            # the previous group's tracker call, now that stage 0 moved on
             self.graphs[j][i].replay()
-            if j == self.n - 1 and self.sT is not None:          # tracker of this group on its own stream
+            if j == self.n - 1 and self.defer:
+                self._pending_track = i
+            elif j == self.n - 1 and self.sT is not None:        # tracker of this group on its own stream
                 self.ev_graph[i].record(st)
                 with torch.cuda.stream(self.sT):
                     self.sT.wait_event(self.ev_graph[i])
@@ -496,6 +507,13 @@ class OverlappedPipeline(FramePipeline):
                         self.on_result(self.base[i], 0)          # graph == "all" implies frame_batch == 1
                 self.ev[j][i].record(st)
         self.stage_done[j] = frame_idx + 1
+
+    def _flush_track(self, st):
+        i = self._pending_track
+        if i is not None:
+            self._pending_track = None
+            self._track_b(self.bufs[i], self.valid[i], self.base[i])
+            self.ev[self.n - 1][i].record(st)
 
     def submit(self, n_valid: int = None):
         """Stage 0 of the group of frames just filled (n_valid <= frame_batch of them are real), and stage j of
@@ -516,6 +534,9 @@ class OverlappedPipeline(FramePipeline):
         for j in range(1, self.n):
             while self.stage_done[j] < self.stage_done[j - 1]:
                 self._run_stage(j, self.stage_done[j])
+        if self.defer and self._pending_track is not None:
+            with torch.cuda.stream(self.streams[self.n - 1]):
+                self._flush_track(self.streams[self.n - 1])
 
     def step(self, track: bool = True):
         raise RuntimeError("use begin_frame()/submit()/flush() on an OverlappedPipeline")
