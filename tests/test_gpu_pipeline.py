@@ -61,15 +61,19 @@ def test_sequential_pipeline_equals_oracle(graph):
 
 @pytest.mark.parametrize("graph,n_stages,fb,kw", [("front", 4, 1, {}), ("all", 2, 1, {}), ("front", 2, 1, {}), ("front", 2, 3, {}),
                                                   ("front", 2, 3, {"reid_split": 2}), ("front", 2, 2, {"reid_split": 0}),
-                                                  ("front", 2, 2, {"reid_split": 1, "tracker_stream": True})])
+                                                  ("front", 2, 2, {"reid_split": 1, "tracker_stream": True}),
+                                                  ("front", 2, 3, {"reid_split": 2, "defer_track": True}),
+                                                  ("front", 2, 1, {"defer_track": True})])
 def test_overlapped_pipeline_equals_oracle(graph, n_stages, fb, kw):
     """fb = 3 with 14 frames: groups of 3,3,3,3 and a partial group of 2.  kw: stage cut inside the ReID backbone,
-    tracker on the last stage's stream (default) or on its own stream with three buffer sets."""
+    tracker on the last stage's stream (default) or on its own stream with three buffer sets; defer_track: the tracker call of
+    a group enqueued after the wait for the next group's first stage (three buffer sets, results one group later)."""
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
     pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph=graph, det_source="synthetic", feat_source="by_anchor",
                               n_stages=n_stages, frame_batch=fb, **kw)
     assert pipe.n == n_stages
     assert (pipe.sT is not None) == (graph == "front" and kw.get("tracker_stream", False))
+    assert pipe.nb == n_stages + (1 if (pipe.sT is not None or kw.get("defer_track", False)) else 0)
     gs, items = _workload(pipe)
     ref = _oracle(gs, items, pipe.nc)
     out_host = torch.empty(FRAMES, 256, 8).pin_memory()
