@@ -275,12 +275,15 @@ int ss_op_gate_apply_f16(void* stream, const void* const* d_xs, int T, const voi
  * stage's ConvBR [+ AvgPool2d(2,2)]): x2 = sum_t ys[t]*gate_t (as ss_op_gate_apply_f16), o = relu(w3 x2 + b3 + idn) -> d_out
  * (may be NULL), o2 = relu(w4 o + b4) -> d_out2, 2x2-averaged first when pool != 0.  ys[4] [N][H][W][MID], idn/out
  * [N][H][W][C2], out2 [N][H][W][N2] or [N][H/2][W/2][N2]; (MID, C2, N2) in {(16,64,16|64), (24,96,24|96), (32,128,32|128)},
- * H*W % 128 == 0, 128 % W == 0; d_gates_ws: scratch for the gates (a small kernel computes them once per image).
+ * H*W % 128 == 0, 128 % W == 0; C1 == 0: d_idn is the shortcut tensor [N][H][W][C2]; C1 > 0 ((C1, C2) in {(16,64), (64,96),
+ * (96,128)}, N2 == MID): d_idn is the block INPUT [N][H][W][C1] and the shortcut is its 1x1 `down` convolution d_wd [C2][C1] +
+ * d_bd (no activation), computed inside; d_gates_ws: scratch for the gates (a small kernel computes them once per image).
  * Bit-identical to the separate calls. */
 int ss_op_osnet_tail_f16(void* stream, const void* const* d_ys, const float* d_psum, int parts, float scale, const void* d_gw1,
                          const void* d_gb1, const void* d_gw2, const void* d_gb2, int Cr, float* d_gates_ws /*[N][4][32]*/,
-                         const void* d_w3, const void* d_b3, const void* d_idn, void* d_out, const void* d_w4, const void* d_b4,
-                         void* d_out2, int pool, int N, int H, int W, int MID, int C2, int N2);
+                         const void* d_w3, const void* d_b3, const void* d_idn, int C1, const void* d_wd, const void* d_bd,
+                         void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N, int H, int W, int MID,
+                         int C2, int N2);
 /* concat(nearest-neighbour x2 upsampling of d_lo [B][h][w][C1], d_hi [B][2h][2w][C2]) along channels -> d_out
  * [B][2h][2w][C1+C2] (lo_first: the upsampled tensor's channels first), one pass (the detector neck). */
 int ss_op_upcat_f16(void* stream, const void* d_lo, const void* d_hi, void* d_out, int B, int h, int w, int C1, int C2, int lo_first);

@@ -1384,14 +1384,20 @@ __global__ __launch_bounds__(128) void k_gate_vec(const float* __restrict__ psum
     }
 }
 
-template <int MID, int C2, int N2>
+// C1 > 0: the block's shortcut is its `down` convolution (first block of a stage, C1 -> C2 channels, no activation): instead
+// of reading a [pixels][C2] tensor another launch wrote, the tail computes it from the block input `idn` = x [pixels][C1]
+// as one more MFMA product (weights wd [C2][C1], bias bd) and applies it in the accumulator layout — the `down` launch
+// (56 us at stage 1 / 512 crops) and 0.1 GB of shortcut reads disappear.  Same products, roundings and order as k_pw.
+template <int MID, int C2, int N2, int C1>
 __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __restrict__ gv,
                                                    const __half* __restrict__ w3, const __half* __restrict__ b3,
-                                                   const __half* __restrict__ idn, __half* __restrict__ out,
+                                                   const __half* __restrict__ idn, const __half* __restrict__ wd,
+                                                   const __half* __restrict__ bd, __half* __restrict__ out,
                                                    const __half* __restrict__ w4, const __half* __restrict__ b4,
                                                    __half* __restrict__ out2, int pool, int Nimg, int HW, int W)
 {
-    constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8, IT = 32 * CG / 64;
+    constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8;
+    constexpr int IT = C1 > 0 ? 1 : 32 * CG / 64, KS1 = C1 > 0 ? (C1 + 31) / 32 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
     __shared__ __attribute__((aligned(16))) _Float16 Et[128 * EP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
@@ -1407,16 +1413,26 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
         const float4* gp = reinterpret_cast<const float4*>(gv + ((size_t)img * 4 + t) * 32 + 8 * q);
         gq[t][0] = gp[0]; gq[t][1] = gp[1];
     }
-    h8 yv[2][4], a3[MT], rs[IT];
+    h8 yv[2][4], a3[MT], rs[IT], xb[2][KS1];
 #pragma unroll
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             yv[pt][t] = kval ? *reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q) : z8;
+    if constexpr (C1 > 0) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-        rs[it] = *reinterpret_cast<const h8*>(idn + (px0 + row) * C2 + cg * 8);
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int k = ks * 32 + 8 * q;
+                xb[pt][ks] = k < C1 ? *reinterpret_cast<const h8*>(idn + (px0 + pt * 16 + n) * C1 + k) : z8;
+            }
+    } else {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+            rs[it] = *reinterpret_cast<const h8*>(idn + (px0 + row) * C2 + cg * 8);
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
@@ -1457,32 +1473,75 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
         }
     }
     _Float16* tile = Et + wave * 32 * EP;
-#pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    if constexpr (C1 > 0) {
+        // shortcut = down(x): per 16-channel tile one more product, applied in the accumulator layout (lane (q, n): channels
+        // mt*16 + 4q .. +3 of pixel n), then the finished tile goes to LDS
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
-            *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
-        }
-    __builtin_amdgcn_wave_barrier();
+            f4 dd[2] = { f4{ 0.f, 0.f, 0.f, 0.f }, f4{ 0.f, 0.f, 0.f, 0.f } };
 #pragma unroll
-    for (int it = 0; it < 32 * CG / 64; ++it) {                              // + bias + shortcut, ReLU; 16-byte vectors
-        const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-        const size_t px = px0 + row;
-        const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
-        const h8 bb = *reinterpret_cast<const h8*>(b3 + cg * 8);
-        const h8 r = rs[it];
-        h8 o;
+            for (int ks = 0; ks < KS1; ++ks) {
+                const int k = ks * 32 + 8 * q;
+                const h8 a = k < C1 ? *reinterpret_cast<const h8*>(wd + (size_t)(mt * 16 + n) * C1 + k) : z8;
+                const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] + (float)bb[j];
-            f += (float)r[j];
-            o[j] = (_Float16)(f > 0.f ? f : 0.f);
+                for (int pt = 0; pt < 2; ++pt) {
+                    const h8 bv = xb[pt][ks];
+                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
+                    dd[pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, dd[pt], 0, 0, 0);
+                    dd[pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, dd[pt], 0, 0, 0);
+                }
+            }
+            const h4 bb3 = *reinterpret_cast<const h4*>(b3 + mt * 16 + 4 * q), bbd = *reinterpret_cast<const h4*>(bd + mt * 16 + 4 * q);
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const _Float16 sc = (_Float16)((float)(_Float16)dd[pt][j] + (float)bbd[j]);      // down: conv to half, + bias, to half
+                    float f = (float)(_Float16)acc[mt][pt][j] + (float)bb3[j];
+                    f += (float)sc;
+                    o[j] = (_Float16)(f > 0.f ? f : 0.f);
+                }
+                *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
+            }
         }
-        if (out) *reinterpret_cast<h8*>(out + px * C2 + cg * 8) = o;
-        *reinterpret_cast<h8*>(tile + row * EP + cg * 8) = o;
+        __builtin_amdgcn_wave_barrier();
+        if (out) {
+#pragma unroll
+            for (int it = 0; it < 32 * CG / 64; ++it) {                      // the block output, 16-byte vectors
+                const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+                *reinterpret_cast<h8*>(out + (px0 + row) * C2 + cg * 8) = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
+                *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 32 * CG / 64; ++it) {                          // + bias + shortcut, ReLU; 16-byte vectors
+            const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
+            const size_t px = px0 + row;
+            const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+            const h8 bb = *reinterpret_cast<const h8*>(b3 + cg * 8);
+            const h8 r = rs[it];
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j] + (float)bb[j];
+                f += (float)r[j];
+                o[j] = (_Float16)(f > 0.f ? f : 0.f);
+            }
+            if (out) *reinterpret_cast<h8*>(out + px * C2 + cg * 8) = o;
+            *reinterpret_cast<h8*>(tile + row * EP + cg * 8) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
 
     // second product: o (LDS tile) x w4 (LDS)
     f4 acc2[MT2][2];
@@ -1803,11 +1862,12 @@ extern "C" int ss_op_avgpool2_f16(void* stream, const void* x, void* y, int N, i
 
 extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const float* psum, int parts, float scale, const void* gw1,
                                     const void* gb1, const void* gw2, const void* gb2, int Cr, float* gates_ws, const void* w3,
-                                    const void* b3, const void* idn, void* out, const void* w4, const void* b4, void* out2, int pool,
-                                    int N, int H, int W, int MID, int C2, int N2)
+                                    const void* b3, const void* idn, int C1, const void* wd, const void* bd, void* out, const void* w4,
+                                    const void* b4, void* out2, int pool, int N, int H, int W, int MID, int C2, int N2)
 {
     if (!ys || !psum || !gw1 || !gb1 || !gw2 || !gb2 || !gates_ws || !w3 || !b3 || !idn || !w4 || !b4 || !out2 || parts < 1 || Cr < 1 ||
-        Cr > 16 || N < 1 || H < 1 || W < 2 || (H * W) % 128 || 128 % W || (pool && ((128 / W) % 2 || W % 2)) || MID > 32)
+        Cr > 16 || N < 1 || H < 1 || W < 2 || (H * W) % 128 || 128 % W || (pool && ((128 / W) % 2 || W % 2)) || MID > 32 ||
+        (C1 > 0 && (!wd || !bd)))
         return SS_ERR_INVALID;
     GatePtrs p;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; p.x[t] = (const __half*)ys[t]; }
@@ -1815,16 +1875,24 @@ extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const f
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_gate_vec, dim3(N), dim3(128), 0, st, psum, parts, scale, (const __half*)gw1, (const __half*)gb1,
                        (const __half*)gw2, (const __half*)gb2, Cr, MID, N, gates_ws);
-#define SS_TAIL(A, B, CC)                                                                                                       \
-    hipLaunchKernelGGL((k_osnet_tail<A, B, CC>), grid, block, 0, st, p, (const float*)gates_ws, (const __half*)w3, (const __half*)b3, \
-                       (const __half*)idn, (__half*)out, (const __half*)w4, (const __half*)b4, (__half*)out2, pool, N, H * W, W)
-    if (MID == 16 && C2 == 64 && N2 == 16) SS_TAIL(16, 64, 16);
-    else if (MID == 16 && C2 == 64 && N2 == 64) SS_TAIL(16, 64, 64);
-    else if (MID == 24 && C2 == 96 && N2 == 24) SS_TAIL(24, 96, 24);
-    else if (MID == 24 && C2 == 96 && N2 == 96) SS_TAIL(24, 96, 96);
-    else if (MID == 32 && C2 == 128 && N2 == 32) SS_TAIL(32, 128, 32);
-    else if (MID == 32 && C2 == 128 && N2 == 128) SS_TAIL(32, 128, 128);
-    else return SS_ERR_INVALID;
+#define SS_TAIL(A, B, CC, DD)                                                                                                   \
+    hipLaunchKernelGGL((k_osnet_tail<A, B, CC, DD>), grid, block, 0, st, p, (const float*)gates_ws, (const __half*)w3,          \
+                       (const __half*)b3, (const __half*)idn, (const __half*)wd, (const __half*)bd, (__half*)out, (const __half*)w4, \
+                       (const __half*)b4, (__half*)out2, pool, N, H * W, W)
+    if (C1 == 0) {
+        if (MID == 16 && C2 == 64 && N2 == 16) SS_TAIL(16, 64, 16, 0);
+        else if (MID == 16 && C2 == 64 && N2 == 64) SS_TAIL(16, 64, 64, 0);
+        else if (MID == 24 && C2 == 96 && N2 == 24) SS_TAIL(24, 96, 24, 0);
+        else if (MID == 24 && C2 == 96 && N2 == 96) SS_TAIL(24, 96, 96, 0);
+        else if (MID == 32 && C2 == 128 && N2 == 32) SS_TAIL(32, 128, 32, 0);
+        else if (MID == 32 && C2 == 128 && N2 == 128) SS_TAIL(32, 128, 128, 0);
+        else return SS_ERR_INVALID;
+    } else {                                                     // first block of a stage: shortcut = down(x), C1 -> C2
+        if (MID == 16 && C2 == 64 && N2 == 16 && C1 == 16) SS_TAIL(16, 64, 16, 16);
+        else if (MID == 24 && C2 == 96 && N2 == 24 && C1 == 64) SS_TAIL(24, 96, 24, 64);
+        else if (MID == 32 && C2 == 128 && N2 == 32 && C1 == 96) SS_TAIL(32, 128, 32, 96);
+        else return SS_ERR_INVALID;
+    }
 #undef SS_TAIL
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -307,20 +307,26 @@ def tail_ok(mid, c2, n2, h, w, pool) -> bool:
             and (h * w) % 128 == 0 and 128 % w == 0 and (not pool or ((128 // w) % 2 == 0 and w % 2 == 0)))
 
 
-def osnet_tail(ys, psum, gate_w, w3, b3, idn, want_out, w4, b4, pool):
+def tail_down_ok(c1, mid, c2, n2) -> bool:
+    return TAIL and (c1, mid, c2, n2) in ((16, 16, 64, 16), (64, 24, 96, 24), (96, 32, 128, 32))
+
+
+def osnet_tail(ys, psum, gate_w, w3, b3, idn, want_out, w4, b4, pool, down=None):
     """-> (o or None, o2): o = relu(conv3(sum_t ys[t]*gate_t) + b3 + idn), o2 = relu(conv4(o) + b4), 2x2-averaged when
-    `pool`; w3 [C2, MID], w4 [N2, C2] (out, in).  Bit-identical to gate_apply + pointwise + pointwise (+ avgpool2)."""
+    `pool`; w3 [C2, MID], w4 [N2, C2] (out, in).  down = (wd [C2, C1], bd): `idn` is the block input and the shortcut is its 1x1
+    convolution, computed inside (tail_down_ok).  Bit-identical to (pointwise +) gate_apply + pointwise + pointwise (+ avgpool2)."""
     n, mid, h, w = ys[0].shape
     idn = _cl(idn)
     c2, n2 = w3.shape[0], w4.shape[0]
-    out = torch.empty_like(idn, memory_format=torch.channels_last) if want_out else None
+    c1, wd, bd = (idn.shape[1], down[0], down[1]) if down is not None else (0, None, None)       # down: shortcut = conv1x1(idn, wd) + bd
+    out = torch.empty((n, c2, h, w), dtype=idn.dtype, device=idn.device, memory_format=torch.channels_last) if want_out else None
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     out2 = torch.empty((n, n2, oh, ow), dtype=idn.dtype, device=idn.device, memory_format=torch.channels_last)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
     gw1, gb1, gw2, gb2 = gate_w
     gates = torch.empty((n, 4, 32), dtype=torch.float32, device=idn.device)
     _ck(_lib.load().ss_op_osnet_tail_f16(_st(idn), arr, _p(psum), psum.shape[2], 1.0 / (h * w), _p(gw1), _p(gb1), _p(gw2), _p(gb2),
-                                         gw1.shape[0], _p(gates), _p(w3), _p(b3), _p(idn), _p(out), _p(w4), _p(b4),
+                                         gw1.shape[0], _p(gates), _p(w3), _p(b3), _p(idn), c1, _p(wd), _p(bd), _p(out), _p(w4), _p(b4),
                                          _p(out2), int(pool), n, h, w, mid, c2, n2))
     return out, out2
 

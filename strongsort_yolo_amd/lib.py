@@ -130,7 +130,7 @@ def load():
     L.ss_op_osnet_streams_f16.argtypes = [vp, vp, vp, vp, vp, C.POINTER(vp), vp, i, i, i, i]
     L.ss_op_osnet_streams_bands.argtypes = [i, i, i, i]
     L.ss_op_gate_apply_f16.argtypes = [vp, C.POINTER(vp), i, vp, vp, vp, vp, vp, i, f, vp, i, i, i, i]
-    L.ss_op_osnet_tail_f16.argtypes = [vp, C.POINTER(vp), vp, i, f, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i]
+    L.ss_op_osnet_tail_f16.argtypes = [vp, C.POINTER(vp), vp, i, f, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i]
     L.ss_op_upcat_f16.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i]
     L.ss_op_sppf_pools_f16.argtypes = [vp, vp, vp, i, i, i, i]
     L.ss_op_avgpool2_f16.argtypes = [vp, vp, vp, i, i, i, i]

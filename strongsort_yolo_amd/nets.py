@@ -432,13 +432,17 @@ class OSBlock(nn.Module):
     def forward_tail(self, x, x1, nxt, pool, want_out):
         """-> (block output or None, relu(nxt(block output)) [2x2-averaged when pool]); x1 = this block's conv1(x) if the previous
         block's tail already produced it."""
-        idn = x if self.down is None else self.down(x)
+        c3, c4 = self.conv3.conv, nxt.conv
+        down = None
+        if self.down is not None and fused.pointwise_ok(self.down.conv) and not self.down.relu and not pool and fused.tail_down_ok(
+                x.shape[1], c3.in_channels, c3.out_channels, c4.out_channels):
+            down = (fused.weight_nk(self.down, self.down.conv), self.down.conv.bias)      # the tail computes the shortcut from x itself
+        idn = x if (self.down is None or down is not None) else self.down(x)
         if x1 is None:
             x1 = self.conv1(x)
         ys, psum = fused.osnet_streams(x1, *self._stream_w(x1))
-        c3, c4 = self.conv3.conv, nxt.conv
         return fused.osnet_tail(ys, psum, self._gate_w(), fused.weight_nk(self.conv3, c3), c3.bias, idn, want_out,
-                                fused.weight_nk(nxt, c4), c4.bias, pool)
+                                fused.weight_nk(nxt, c4), c4.bias, pool, down)
 
     def forward(self, x, x1=None):
         idn = x if self.down is None else self.down(x)

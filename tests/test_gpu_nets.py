@@ -200,6 +200,31 @@ def test_osnet_tail_equals_separate_kernels(n, mid, c2, n2, h, w, pool, want):
     assert r2.float().abs().max().item() > 0.1                           # not a comparison of zeros
 
 
+@pytest.mark.parametrize("n,c1,mid,c2,h,w", [(3, 16, 16, 64, 64, 32), (2, 64, 24, 96, 32, 16), (5, 96, 32, 128, 16, 8)])
+def test_osnet_tail_with_down_shortcut_equals_separate_kernels(n, c1, mid, c2, h, w):
+    """First block of a stage: the tail computes the shortcut down(x) itself == pointwise(down) + gate_apply + pointwise + pointwise."""
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(c1 * 7 + h)
+    rnd = lambda *sh, s=1.0: (torch.randn(*sh, generator=g) * s).to(dev, torch.float16)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    ys = [cl(rnd(n, mid, h, w).relu_()) for _ in range(4)]
+    psum = torch.stack([y.float().sum((2, 3)).unsqueeze(1) for y in ys]).contiguous()          # one part per image
+    cr = max(mid // 16, 1)
+    gw = (rnd(cr, mid, s=mid ** -0.5), rnd(cr), rnd(mid, cr), rnd(mid))
+    x = cl(rnd(n, c1, h, w))
+    wd, bd = rnd(c2, c1, s=c1 ** -0.5), rnd(c2, s=0.5)
+    w3, b3 = rnd(c2, mid, s=mid ** -0.5), rnd(c2, s=0.5)
+    w4, b4 = rnd(mid, c2, s=c2 ** -0.5), rnd(mid, s=0.5)
+    assert fused.tail_ok(mid, c2, mid, h, w, False) and fused.tail_down_ok(c1, mid, c2, mid)
+    out, o2 = fused.osnet_tail(ys, psum, gw, w3, b3, x, True, w4, b4, False, down=(wd, bd))
+    idn = fused.pointwise(x, wd, bd, "none")
+    r1 = fused.pointwise(fused.gate_apply(ys, psum, *gw), w3, b3, "relu", res=idn)
+    r2 = fused.pointwise(r1, w4, b4, "relu")
+    assert torch.equal(out, r1) and torch.equal(o2, r2)
+    assert r2.float().abs().max().item() > 0.1
+
+
 @pytest.mark.parametrize("name,B", [("yolov8n", 16), ("yolov8n", 1), ("yolov8s", 2)])
 def test_detect_head_grouped_launches_equal_separate_launches(name, B):
     """The detect head's six branches as three grouped launches (one per depth) vs 18 separate launches: same kernels' bodies,
