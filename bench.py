@@ -545,7 +545,7 @@ def main():
     pipe.close()
     if rank == 0:
         if world == 1 and not args.no_batched:
-            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16) else (16 if FB > 16 else 8))
+            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16, 32) else (32 if FB > 32 else 8))
             res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=1, check=False)
         if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
             res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)

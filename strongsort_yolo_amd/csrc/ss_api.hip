@@ -344,6 +344,8 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     return SS_OK;
 }
 
+extern "C" int ss_max_group_frames(void) { return SS_FMAX; }
+
 extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndets, const float* d_feats,
                                const int* d_img_hw, float* d_out, int* d_nout)
 {

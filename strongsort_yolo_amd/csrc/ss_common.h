@@ -18,7 +18,7 @@
 #define SS_MAXD 128           // detections per stream per frame
 #define SS_NCT (SS_MAXD / SS_TILE)
 #define SS_COST_CAP 12288     // LDS-resident cost entries (f64) of the per-frame kernel; larger matrices spill to HBM
-#define SS_FMAX 16            // frames of a stream that one tracker call (group) may carry
+#define SS_FMAX 32            // frames of a stream that one tracker call (group) may carry
 #define SS_TLMAX (SS_MAXT * SS_NRT)          // gallery tiles of a stream
 #define SS_PLMAX (SS_FMAX * SS_NCT / 2)      // column-tile pairs of a stream's group
 #define SS_CHUNK 8            // gallery tiles per association work item (one per wave of the workgroup)

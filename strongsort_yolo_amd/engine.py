@@ -125,8 +125,12 @@ class TrackerEngine:
                                         _ptr(self.out), _ptr(self.nout)))
         return self.out, self.nout
 
+    @property
+    def max_group_frames(self) -> int:
+        return int(self.L.ss_max_group_frames())
+
     def update_group(self, n_frames, dets, ndets, feats, img_hw, out, nout):
-        """A group of n_frames (<= 16) consecutive frames of all streams: tensors [F,S,128,6] f32, [F,S] i32,
+        """A group of n_frames (<= max_group_frames) consecutive frames of all streams: tensors [F,S,128,6] f32, [F,S] i32,
         [F,S,128,512] f32, [S,2] i32 -> rows out [F,S,256,8], counts nout [F,S] (device tensors, asynchronous).
         Frames are associated in order; the galleries are read once for the whole group."""
         self._ck(self.L.ss_track_update_group(self.ctx, int(n_frames), _ptr(dets), _ptr(ndets), _ptr(feats), _ptr(img_hw),

@@ -426,7 +426,7 @@ class OverlappedPipeline(FramePipeline):
         frame (None while warming up / capturing: no callbacks)."""
         e = self.eng
         nv = self.F if n_valid is None else n_valid
-        G, S = 16, self.S                                       # the library takes up to 16 frames per call (SS_FMAX)
+        G, S = self.eng.max_group_frames, self.S             # frames per library call (SS_FMAX)
         for f0 in range(0, nv, G):
             n, v0, v1 = min(G, nv - f0), f0 * S, min(nv, f0 + G) * S
             if self.cmc:
