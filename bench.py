@@ -16,7 +16,7 @@ Throughput structure (all of it result-preserving — every frame runs every sta
 oracle): the stateless stages (letterbox, detector, NMS, crops, OSNet) take `--frame-batch` (default 32)
 consecutive frames of a stream at a time — a decoded video file or a capture queue supplies them; it costs
 frame_batch frame periods of latency on a live camera — and the tracker consumes them one by one in frame
-order (library calls of up to 16 frames: the galleries are read once per call); stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
+order (one library call per group of up to 32 frames: the galleries are read once per call); stage A of group k+1 (letterbox, detector, NMS, crops, first `--reid-split` parts of OSNet) overlaps
 stage B of group k (rest of OSNet, feature select, tracker) on a second HIP stream (`--overlap`).
 `--frame-batch 1 --overlap 0` is the strictly frame-at-a-time pipeline (profiles/ keeps these lines too).
 

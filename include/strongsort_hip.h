@@ -137,7 +137,7 @@ int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long lon
 /* Largest n_frames ss_track_update_group / ss_cmc_estimate accept (compile-time SS_FMAX). */
 int ss_max_group_frames(void);
 /* ---- a6..a10  tracker update  (tracker.update inside model.track, yolo_multi_model.py:41) -----
- * A GROUP of n_frames (1..16) consecutive frames for EVERY stream of the context in one batch of launches; the
+ * A GROUP of n_frames (1..ss_max_group_frames() = 32) consecutive frames for EVERY stream of the context in one batch of launches; the
  * frames are associated strictly in order (frame f sees the tracks, galleries and ids left by frame f-1), so the
  * rows are identical to n_frames single-frame calls — what the group buys is that the galleries are read from HBM
  * once per group instead of once per frame (the association kernel handles the detections of all frames at once).

@@ -142,7 +142,8 @@ def test_many_streams_per_launch(S, frames):
         assert conf[S - 2] == 0
 
 
-@pytest.mark.parametrize("S,F,frames,ids", [(1, 8, 124, 30), (1, 16, 120, 30), (2, 5, 63, 24), (4, 8, 112, 0), (1, 3, 30, 100)])
+@pytest.mark.parametrize("S,F,frames,ids", [(1, 8, 124, 30), (1, 16, 120, 30), (2, 5, 63, 24), (4, 8, 112, 0), (1, 3, 30, 100), (1, 32, 168, 30), (2, 21, 130, 24),
+                                            (1, 32, 150, 100)])
 def test_frame_groups_equal_frame_by_frame(S, F, frames, ids):
     """The group call (galleries read once for F frames: rows that leave the ring during the group are masked per
     frame in k_assoc, the rows appended during the group are added by k_newrow) == the oracle's frame-by-frame
