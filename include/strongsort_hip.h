@@ -136,6 +136,11 @@ int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long lon
 
 /* Largest n_frames ss_track_update_group / ss_cmc_estimate accept (compile-time SS_FMAX). */
 int ss_max_group_frames(void);
+/* hip_event (a hipEvent_t of the caller, NULL: none) is recorded on the tracker's stream right after the association launch
+ * of every following ss_track_update_group call: a pipeline can hold its other stream back for those ~40 us — the
+ * association kernel needs whole CUs (8 waves x 127 VGPRs + 64 KiB LDS per workgroup) and is starved by co-running network
+ * kernels otherwise — and let it run beside the per-frame chain that follows. */
+int ss_track_set_assoc_event(ss_ctx* ctx, void* hip_event);
 /* ---- a6..a10  tracker update  (tracker.update inside model.track, yolo_multi_model.py:41) -----
  * A GROUP of n_frames (1..ss_max_group_frames() = 32) consecutive frames for EVERY stream of the context in one batch of launches; the
  * frames are associated strictly in order (frame f sees the tracks, galleries and ids left by frame f-1), so the

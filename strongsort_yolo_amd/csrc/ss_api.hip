@@ -9,7 +9,7 @@
 
 // launchers implemented in ss_track.hip / ss_front.hip
 size_t ss_lsap_lds_bytes();
-void ss_launch_group(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t);
+void ss_launch_group(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t);
 void ss_launch_normalize(const float*, int, float*, hipStream_t);
 void ss_launch_ema(const float*, const float*, int, float, float, float*, hipStream_t);
 void ss_launch_kf(int, double*, double*, const double*, const double*, int, double, double, hipStream_t);
@@ -61,6 +61,7 @@ struct ss_ctx {
     int cmc_hw[2];              // frame size the buffer was made for
     int* cmc_prev_valid;        // [S]
     const double* cmc_warps;    // what ss_track_set_cmc installed
+    hipEvent_t assoc_event;     // what ss_track_set_assoc_event installed (recorded after every association launch)
     struct Back { void* p = nullptr; size_t cap = 0; } back;      // device -> host staging (ss_download)
     int cos_grid;               // persistent workgroups of the association kernel
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
@@ -111,7 +112,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
-    c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr;
+    c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr; c->assoc_event = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { int r = fail(nullptr, SS_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); delete c; return r; }
     SSParams& p = c->prm;
@@ -339,12 +340,19 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
-    ss_launch_group(dev, c->prm, c->stream, e0, e1);
+    ss_launch_group(dev, c->prm, c->stream, e0, e1, c->assoc_event);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }
 
 extern "C" int ss_max_group_frames(void) { return SS_FMAX; }
+
+extern "C" int ss_track_set_assoc_event(ss_ctx* c, void* hip_event)
+{
+    if (!c) return SS_ERR_INVALID;
+    c->assoc_event = (hipEvent_t)hip_event;
+    return SS_OK;
+}
 
 extern "C" int ss_track_update(ss_ctx* c, const float* d_dets, const int* d_ndets, const float* d_feats,
                                const int* d_img_hw, float* d_out, int* d_nout)

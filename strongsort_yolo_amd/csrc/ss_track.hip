@@ -1294,12 +1294,13 @@ extern "C" void ss_step_kernel_attr()
 }
 
 // One group of dev.F frames for every stream.  ev0/ev1 (optional) bracket the association kernel's dispatch.
-void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
     if (dev.ts_enable > 1) hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
     else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
     else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    if (ev_assoc) (void)hipEventRecord(ev_assoc, st);          // the caller's "association done" event (ss_track_set_assoc_event)
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);
         hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);

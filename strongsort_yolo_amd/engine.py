@@ -152,6 +152,12 @@ class TrackerEngine:
         self._cmc_keep = warps
         self._ck(self.L.ss_track_set_cmc(self.ctx, _ptr(warps)))
 
+    def set_assoc_event(self, event):
+        """`event` (torch.cuda.Event, recorded at least once, or None) is recorded on the tracker's stream right after the
+        association launch of every following update_group call."""
+        self._assoc_ev_keep = event
+        self._ck(self.L.ss_track_set_assoc_event(self.ctx, C.c_void_p(event.cuda_event if event is not None else 0)))
+
     def update_host(self, dets: np.ndarray, feats: np.ndarray, img_hw) -> np.ndarray:
         """Single-stream synchronous update with host arrays -> rows [M,8] float32."""
         dets = np.ascontiguousarray(dets, dtype=np.float32).reshape(-1, 6)

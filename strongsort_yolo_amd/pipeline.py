@@ -328,6 +328,15 @@ class OverlappedPipeline(FramePipeline):
         # register file) its launch took 50-83 us instead of 30.  Results arrive one group later; one more buffer set.
         self.defer = bool(defer_track) and self.sT is None and self.graph_mode == "front"
         self._pending_track = None
+        # ... and stage 0 of the next group waits for that call's association launch (not for the per-frame chain after it):
+        # for ~40 us the association kernel has the chip to itself (alone: 39.8 us for 32 frames, beside the detector's first
+        # layers: 61-65 us)
+        self.assoc_ev = None
+        if self.defer and _os.environ.get("SS_ASSOC_GATE", "1") == "1":
+            self.assoc_ev = torch.cuda.Event()
+            self.assoc_ev.record(torch.cuda.current_stream(self.dev))
+            self.eng.set_assoc_event(self.assoc_ev)
+        self._gate = False
         self.nb = self.n + (1 if (self.sT is not None or self.defer) else 0)              # buffer sets
         self.bufs = [_Bufs(self) for _ in range(self.nb)]
         self.ev = [[torch.cuda.Event() for _ in range(self.nb)] for _ in range(self.n)]   # ev[stage][set]
@@ -514,6 +523,7 @@ class OverlappedPipeline(FramePipeline):
             self._pending_track = None
             self._track_b(self.bufs[i], self.valid[i], self.base[i])
             self.ev[self.n - 1][i].record(st)
+            self._gate = self.assoc_ev is not None
 
     def submit(self, n_valid: int = None):
         """Stage 0 of the group of frames just filled (n_valid <= frame_batch of them are real), and stage j of
@@ -523,9 +533,12 @@ class OverlappedPipeline(FramePipeline):
         self.valid[k % self.nb] = nv
         self.base[k % self.nb] = self.frames_in                 # index of the group's first frame (partial groups allowed)
         self.frames_in += nv
-        for j in range(self.n):
+        for j in (range(self.n - 1, -1, -1) if self.defer else range(self.n)):     # deferred: the tracker call is enqueued first
             f = k - j
             if f >= 0 and self.stage_done[j] == f:
+                if j == 0 and self._gate:
+                    self.sA.wait_event(self.assoc_ev)           # the association launch just enqueued on the other stream
+                    self._gate = False
                 self._run_stage(j, f)
         self.k += 1
 
