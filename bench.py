@@ -251,7 +251,7 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, 
             "batched_id_match_rate": round(same / max(tot, 1), 6) if check else None, "rows_checked": tot}
 
 
-def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device=0, timed=192, batch=16):
+def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device=0, timed=192, batch=32):
     """The drop-in calls themselves (what the reference's loop does at yolo_multi_model.py:41 / :270-278): per-frame
     `model.track(frame)` with host frames in, Results out (replayed HIP graphs, one sync per call), and
     `model.track_stream(frames, batch)` (overlapped pipeline behind the same object).  Same synthetic head-tensor

@@ -233,38 +233,36 @@ class YOLO:
             if self._stream_pipe is not None:
                 self._stream_pipe.close()
             self._stream_pipe = self._build(OverlappedPipeline, first.shape[:2], device, graph="front", frame_batch=batch,
-                                            reid_split=2 if batch > 1 else None)
+                                            reid_split=2 if batch > 1 else None, defer_track=batch > 1)
             self._stream_key = key
         pipe = self._stream_pipe
         F, H, W = batch, first.shape[0], first.shape[1]
-        ring = 3                                                          # result slots: groups in flight + one
+        ring = 5                                                          # result slots: groups in flight (<= 3) + margin
         h_rows = torch.empty(ring, F, pipe.outs.shape[2], 8).pin_memory()
         h_dets = torch.empty(ring, F, pipe.bufs[0].dets.shape[1], pipe.bufs[0].dets.shape[2]).pin_memory()
         h_cnt = torch.zeros(ring, 2, F, dtype=torch.int32).pin_memory()
         done = [torch.cuda.Event() for _ in range(ring)]
         pending = []                                                      # (group index, frames of the group)
-        state = {"group": 0}
+        state = {"group": 0, "first": {}, "enqueued": -1}                 # first frame index of a group -> group index
 
-        def on_result(frame_idx, f):                                      # runs while the last stage is being enqueued
-            g, nv = state["cur"], state["nv"]
+        def on_result(frame_idx, f):                                      # runs while a tracker call is being enqueued
+            g = state["first"].get(frame_idx - f)
+            if g is None:                                                 # a group left over from an abandoned generator
+                return
+            b = pipe.bufs[g % pipe.nb]
+            nv = pipe.valid[g % pipe.nb]
             if f != nv - 1:
                 return
-            slot, b = g % ring, pipe.bufs[g % pipe.nb]
+            slot = g % ring
             h_rows[slot, :nv].copy_(pipe.outs[:nv, 0], non_blocking=True)
             h_cnt[slot, 1, :nv].copy_(pipe.nouts[:nv, 0], non_blocking=True)
             h_cnt[slot, 0, :nv].copy_(b.ndets[:nv], non_blocking=True)
             h_dets[slot, :nv].copy_(b.dets[:nv], non_blocking=True)
             done[slot].record(torch.cuda.current_stream(pipe.dev))
+            state["enqueued"] = g
+            del state["first"][frame_idx - f]
 
-        # the last stage of group g is enqueued during submit() of group g+1 (or flush()): remember which group that is
-        orig_run = pipe._run_stage
-
-        def run_stage(j, group_idx):
-            if j == pipe.n - 1:
-                state["cur"], state["nv"] = group_idx, pipe.valid[group_idx % pipe.nb]
-            return orig_run(j, group_idx)
-
-        pipe._run_stage, pipe.on_result = run_stage, on_result
+        pipe.on_result = on_result
 
         def finish(g, imgs):
             slot = g % ring
@@ -290,10 +288,11 @@ class YOLO:
                         for f in range(len(chunk)):
                             self._fill(b, f, self._frame_index + f)
                 self._frame_index += len(chunk)
+                state["first"][pipe.frames_in] = g                       # submit() numbers the group's frames from here
                 pipe.submit(len(chunk))
                 pending.append((g, chunk))
                 state["group"] = g + 1
-                while len(pending) > 2:                                   # results of group g-2 are certainly enqueued
+                while pending and pending[0][0] <= state["enqueued"] - 1:  # its results are enqueued, and so is a group after it
                     yield from finish(*pending.pop(0))
                 nxt = next(it, None)
                 chunk = [nxt] if nxt is not None else []
@@ -302,7 +301,7 @@ class YOLO:
                 yield from finish(*pending.pop(0))
             pipe.eng.check_errors()
         finally:
-            pipe._run_stage, pipe.on_result = orig_run, None
+            pipe.on_result = None
 
     def overlay(self):
         """Annotation overlay bound to this model's device context (drawing of yolo_multi_model.py:58-162 as a kernel)."""
