@@ -204,10 +204,7 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
 // CONV3: the same kernel as an implicit GEMM for 3x3 / pad 1 / stride 1|2 convolutions: K = 9*Cin with k = tap*Cin + c
 // (weights [N][3][3][Cin]), and a lane's eight k's — always inside one tap because Cin % 8 == 0 — come from the
 // input pixel shifted by that tap (zeros outside the image).  Replaces MIOpen's zero-fill + igemm + our epilogue pass.
-// cin_magic = ceil(2^32 / Cin): k / Cin == __umulhi(k, cin_magic) for k < 9 * Cin (the runtime division cost ~40 VALU
-// instructions per operand load in the im2col index arithmetic — more than the chunk's MFMAs for 16..32-channel layers)
-struct ConvGeom { int H, W, Cin, OH, OW, stride; unsigned cin_magic; };
-static inline unsigned ss_cin_magic(int cin) { return cin > 1 ? (unsigned)((0x100000000ull + (unsigned)cin - 1) / (unsigned)cin) : 0u; }
+struct ConvGeom { int H, W, Cin, OH, OW, stride; };
 
 // VEC_EPI: the accumulators (4 channels x 1 pixel per lane and tile) are transposed through a per-wave LDS tile so the
 // epilogue reads the shortcut and writes the output as 16-byte vectors, 128 contiguous bytes per 8 lanes, instead
@@ -272,7 +269,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
                 if (!CONV3) {
                     b[ks][pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
                 } else {
-                    const int tap = (int)__umulhi((unsigned)k, g.cin_magic), c = k - tap * g.Cin, dy = (tap * 11) >> 5, dx = tap - dy * 3;
+                    const int tap = k / g.Cin, c = k - tap * g.Cin, dy = tap / 3, dx = tap - dy * 3;
                     const int iy = iy0[pt] + dy, ix = ix0[pt] + dx;
                     const bool ok = px < (size_t)M && k < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
                     b[ks][pt] = ok ? *reinterpret_cast<const h8*>(x + (ibase[pt] + (size_t)iy * g.W + ix) * g.Cin + c) : z8;
@@ -431,7 +428,7 @@ __device__ __forceinline__ void pw_splitk_body(const PwArgs& A, const int bx, co
             if (!CONV3) {
                 b[ks] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
             } else {
-                const int tap = (int)__umulhi((unsigned)k, g.cin_magic), c = k - tap * g.Cin, dy = (tap * 11) >> 5, dx = tap - dy * 3;
+                const int tap = k / g.Cin, c = k - tap * g.Cin, dy = tap / 3, dx = tap - dy * 3;
                 const int iy = iy0 + dy, ix = ix0 + dx;
                 const bool ok = px < (size_t)M && k < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
                 b[ks] = ok ? *reinterpret_cast<const h8*>(x + (ibase + (size_t)iy * g.W + ix) * g.Cin + c) : z8;
@@ -1723,7 +1720,7 @@ extern "C" int ss_op_conv3x3_f16(void* stream, const void* x, const void* w, con
     if (!x || !w || !bias || !out || B < 1 || H < 1 || W < 1 || Cin < 8 || Cin % 8 || N < 8 || N % 8 || (conv_stride != 1 && conv_stride != 2) ||
         out_ld % 4 || out_ld < N || c0 % 4 || cn % 4 || (out2 && (cn < 4 || c0 + cn > N)))
         return SS_ERR_INVALID;
-    ConvGeom g{ H, W, Cin, (H - 1) / conv_stride + 1, (W - 1) / conv_stride + 1, conv_stride, ss_cin_magic(Cin) };
+    ConvGeom g{ H, W, Cin, (H - 1) / conv_stride + 1, (W - 1) / conv_stride + 1, conv_stride };
     const long long M = (long long)B * g.OH * g.OW;
     if (M > 0x7fffffffLL) return SS_ERR_INVALID;
     return launch_pw((hipStream_t)stream, true, x, w, bias, res, M, 9 * Cin, N, act, res_after, out, out_ld, out2, c0, cn, g);
@@ -1924,7 +1921,7 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
     int wgs = 0;
     for (int s = 0; s < n; ++s) {
         const ss_conv_desc& c = d[order[s]];
-        ConvGeom g{ c.H, c.W, c.Cin, (c.H - 1) / c.stride + 1, (c.W - 1) / c.stride + 1, c.stride, ss_cin_magic(c.Cin) };
+        ConvGeom g{ c.H, c.W, c.Cin, (c.H - 1) / c.stride + 1, (c.W - 1) / c.stride + 1, c.stride };
         const long long M = (long long)c.B * g.OH * g.OW;
         if (M > 0x7fffffffLL) return SS_ERR_INVALID;
         const int K = c.ksize * c.ksize * c.Cin;
