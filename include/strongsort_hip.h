@@ -133,6 +133,15 @@ int ss_crop_norm(ss_ctx* ctx, const uint8_t* d_frame, int h, int w, int row_stri
 int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long long frame_batch_stride,
                        int h, int w, int row_stride, const float* d_dets, int det_stride,
                        long long dets_batch_stride, int n, const int* d_counts, void* d_out, int out_flags);
+/* Packed form of ss_crop_norm_batch (channels-last output only): d_off [batch + 1] receives the exclusive prefix of
+ * min(count, n) (d_off[batch] = number of crops) and crop d of image i lands at slot d_off[i] + d, so the valid crops of
+ * a frame group are contiguous; ss_op_set_valid_images(d_off + batch, batch * n) then lets the ReID network skip the rest.
+ * ss_unpack_feats: d_feats[i][d][0..512) (float, image stride in floats) = d_emb[d_off[i] + d] for d < min(count, n). */
+int ss_crop_norm_packed(ss_ctx* ctx, const uint8_t* d_frames, int batch, long long frame_batch_stride, int h, int w, int stride,
+                        const float* d_dets, int det_stride, long long dets_batch_stride, int n, const int* d_counts,
+                        int* d_off, void* d_out, int out_flags);
+int ss_unpack_feats(ss_ctx* ctx, const void* d_emb, int emb_half, const int* d_off, const int* d_counts, int batch, int n,
+                    float* d_feats, long long feats_image_stride);
 
 /* Largest n_frames ss_track_update_group / ss_cmc_estimate accept (compile-time SS_FMAX). */
 int ss_max_group_frames(void);
@@ -260,6 +269,10 @@ int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const v
  * channel) the taps 3*kx+ch placed (6r + 5) % 8 halfs into a zero-padded 16-wide K window (fused.conv0_weight).  W % 128 == 0. */
 int ss_op_conv0_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int B, int H, int W, int Cout,
                     int act);
+/* Packed ReID batches: until the next call, the OSNet-side entry points (ss_op_osnet_stem_f16, ss_op_pointwise_f16,
+ * ss_op_osnet_streams_f16, ss_op_osnet_tail_f16) launched with `batch` images compute only the first *d_n of them (device
+ * int, read by the kernels; the grids stay fixed, so the launches can sit in a captured graph).  d_n == NULL: off. */
+int ss_op_set_valid_images(const int* d_n, int batch);
 /* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
  * half -> [N][H/4][32][16]; d_w_prep [4][7][16][32] = for conv columns c = 4n + r, per (ky, out channel) the taps 3*kx+ch
  * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0. */

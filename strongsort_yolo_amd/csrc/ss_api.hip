@@ -25,7 +25,9 @@ int  ss_launch_nms(const float*, int, long long, int, int, int, float, float, in
                    unsigned long long, hipStream_t);
 int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
-void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t);
+void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t, const int*);
+void ss_launch_crop_offsets(const int*, int, int, int*, hipStream_t);
+void ss_launch_unpack_feats(const void*, int, const int*, const int*, int, int, float*, long long, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
 void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, double*, hipStream_t);
 extern "C" void ss_step_kernel_attr();
@@ -554,7 +556,33 @@ extern "C" int ss_crop_norm_batch(ss_ctx* c, const uint8_t* frames, int batch, l
     if (!c || !frames || !dets || !out || batch < 0 || n < 0 || (long long)batch * n > 65535)
         return fail(c, SS_ERR_INVALID, "ss_crop_norm: bad argument (batch * n <= 65535)");
     ss_launch_crop(frames, batch, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_counts, out,
-                   out_flags, c->stream);
+                   out_flags, c->stream, nullptr);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+// Packed form: d_off[batch + 1] <- exclusive prefix of min(count, n) (d_off[batch] = crops in total), crop d of image i is
+// written at slot d_off[i] + d.  The network behind it then computes *(d_off + batch) crops (ss_op_set_valid_images) and
+// ss_unpack_feats puts the embeddings back at [image][d].
+extern "C" int ss_crop_norm_packed(ss_ctx* c, const uint8_t* frames, int batch, long long frame_batch_stride, int h, int w,
+                                   int stride, const float* dets, int det_stride, long long dets_batch_stride, int n,
+                                   const int* d_counts, int* d_off, void* out, int out_flags)
+{
+    if (!c || !frames || !dets || !out || !d_counts || !d_off || batch < 1 || n < 1 || (long long)batch * n > 65535 || !(out_flags & 2))
+        return fail(c, SS_ERR_INVALID, "ss_crop_norm_packed: bad argument (channels-last output, batch * n <= 65535)");
+    ss_launch_crop_offsets(d_counts, batch, n, d_off, c->stream);
+    ss_launch_crop(frames, batch, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_counts, out,
+                   out_flags, c->stream, d_off);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_unpack_feats(ss_ctx* c, const void* d_emb, int emb_half, const int* d_off, const int* d_counts, int batch, int n,
+                               float* d_feats, long long feats_image_stride)
+{
+    if (!c || !d_emb || !d_off || !d_counts || !d_feats || batch < 1 || n < 1 || n > 65535 || batch > 65535)
+        return fail(c, SS_ERR_INVALID, "ss_unpack_feats: bad argument");
+    ss_launch_unpack_feats(d_emb, emb_half, d_off, d_counts, batch, n, d_feats, feats_image_stride, c->stream);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }

@@ -145,7 +145,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ src, long long src_batch_stride, int H, int W,
                                                    int stride, const float* __restrict__ dets, int det_stride,
                                                    long long dets_batch_stride, int n, const int* __restrict__ d_count,
-                                                   T* __restrict__ dst)
+                                                   T* __restrict__ dst, const int* __restrict__ d_off)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char crop_smem[];
     T* lut = reinterpret_cast<T*>(crop_smem);                                  // [3][256]
@@ -230,22 +230,61 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
         }
     }
     constexpr int NV = 24 * sizeof(T) / 16;
-    uint4* out = reinterpret_cast<uint4*>(dst + ((size_t)blockIdx.z * out_h * out_w + (size_t)y * out_w + xg) * 3);
+    const size_t slot = d_off ? (size_t)d_off[img] + d : (size_t)blockIdx.z;     // packed: image i's crops follow image i-1's
+    uint4* out = reinterpret_cast<uint4*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);
     const uint4* ov = reinterpret_cast<const uint4*>(o);
 #pragma unroll
     for (int v = 0; v < NV; ++v) out[v] = ov[v];
 }
 
+// exclusive prefix of min(count, n) over the images of a batch -> off[batch + 1] (off[batch] = number of crops)
+__global__ __launch_bounds__(1024) void k_crop_offsets(const int* __restrict__ counts, int batch, int n, int* __restrict__ off)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, per = (batch + 1023) / 1024, i0 = tid * per;
+    int sum = 0;
+    for (int i = i0; i < i0 + per && i < batch; ++i) sum += min(counts[i], n);
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = a; a += v; } off[batch] = a; }
+    __syncthreads();
+    int a = part[tid];
+    for (int i = i0; i < i0 + per && i < batch; ++i) { off[i] = a; a += min(counts[i], n); }
+}
+
+// embeddings of a packed batch back to [image][slot]: feats[img][d][:] = emb[off[img] + d][:] for d < min(count, n)
+template <typename T>
+__global__ __launch_bounds__(128) void k_unpack_feats(const T* __restrict__ emb, const int* __restrict__ off, const int* __restrict__ counts,
+                                                     int n, float* __restrict__ feats, long long feats_img_stride)
+{
+    const int img = blockIdx.y, d = blockIdx.x;
+    if (d >= min(counts[img], n)) return;
+    const T* src = emb + ((size_t)off[img] + d) * 512;
+    float* dst = feats + (size_t)img * feats_img_stride + (size_t)d * 512;
+    for (int k = threadIdx.x; k < 512; k += 128) dst[k] = (float)src[k];
+}
+
+void ss_launch_crop_offsets(const int* counts, int batch, int n, int* off, hipStream_t st)
+{ hipLaunchKernelGGL(k_crop_offsets, dim3(1), dim3(1024), 0, st, counts, batch, n, off); }
+
+void ss_launch_unpack_feats(const void* emb, int half, const int* off, const int* counts, int batch, int n, float* feats,
+                            long long feats_img_stride, hipStream_t st)
+{
+    if (batch <= 0 || n <= 0) return;
+    if (half) hipLaunchKernelGGL(k_unpack_feats<__half>, dim3(n, batch), dim3(128), 0, st, (const __half*)emb, off, counts, n, feats, feats_img_stride);
+    else hipLaunchKernelGGL(k_unpack_feats<float>, dim3(n, batch), dim3(128), 0, st, (const float*)emb, off, counts, n, feats, feats_img_stride);
+}
+
 // flags: bit 0 = half output, bit 1 = channels-last output
 void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_stride, int h, int w, int stride,
                     const float* dets, int det_stride, long long dets_batch_stride, int n, const int* d_count,
-                    void* out, int flags, hipStream_t st)
+                    void* out, int flags, hipStream_t st, const int* d_off)
 {
     if (n <= 0 || batch <= 0) return;
     if (flags & 2) {
         dim3 grid(1, 16, n * batch), block(256);
-        if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 768 * sizeof(__half) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out);
-        else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 768 * sizeof(float) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out);
+        if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 768 * sizeof(__half) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out, d_off);
+        else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 768 * sizeof(float) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out, d_off);
         return;
     }
     dim3 grid(1, 256, n * batch), block(128);

@@ -12,6 +12,12 @@
 #include <stdlib.h>
 #include "../../include/strongsort_hip.h"
 
+// Valid-image count of the OSNet kernels (ss_op_set_valid_images): the ReID crops of a frame group are packed (frame f's
+// crops follow frame f-1's), the launches keep their fixed grids (graph replay) and the workgroups of images >= *g_nvalid
+// leave at once.  NULL: every image is valid.
+static const int* g_nvalid = nullptr;
+static int g_nvalid_batch = 0;
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -214,6 +220,7 @@ struct PwArgs {
     int M, K, N, act, res_after;
     __half* out; int out_ld; __half* out2; int c0, cn;
     ConvGeom g;
+    const int* n_img; int img_px;                  // optional: only the first *n_img images (img_px pixels each) are computed
 };
 
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
@@ -221,9 +228,12 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
 {
     const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
     const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
-    const int M = A.M, K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    const int K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    int M = A.M;
+    if (A.n_img) { const long long mv = (long long)(*A.n_img) * A.img_px; if (mv < M) M = (int)mv; }
     const ConvGeom g = A.g;
     constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT;
+    if ((long long)bx * BM >= M) return;                    // (only with n_img: the launch covers the full batch)
     __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
     const int n0 = by * BN;
@@ -396,7 +406,9 @@ __device__ __forceinline__ void pw_splitk_body(const PwArgs& A, const int bx, co
 {
     const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
     const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
-    const int M = A.M, K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    const int K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
+    int M = A.M;
+    if (A.n_img) { const long long mv = (long long)(*A.n_img) * A.img_px; if (mv < M) M = (int)mv; }
     const ConvGeom g = A.g;
     constexpr int MT = BN / 16, KC = 64, RP = 17;
     __shared__ float Red[4 * BN * RP];
@@ -529,8 +541,10 @@ __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
 #define STEM_CW 65          // conv columns + left pad
 
 __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x, const __half* __restrict__ wp /*[4][7][16][32]*/,
-                                                   const __half* __restrict__ bias, __half* __restrict__ y, int H, int tiles)
+                                                   const __half* __restrict__ bias, __half* __restrict__ y, int H, int tiles,
+                                                   const int* __restrict__ nvalid)
 {
+    if (nvalid && (int)(blockIdx.x / tiles) >= *nvalid) return;
     __shared__ __attribute__((aligned(16))) _Float16 In[STEM_IN_ROWS * STEM_PITCH];
     __shared__ __attribute__((aligned(16))) _Float16 Cv[STEM_CR * STEM_CW * 16];
     const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, q = lane >> 4, n = lane & 15;
@@ -770,8 +784,9 @@ template <int C>
 __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                       const __half* __restrict__ w9, const __half* __restrict__ bias,
                                                       StreamOut out, float* __restrict__ psum, int N, int H, int W,
-                                                      int bands)
+                                                      int bands, const int* __restrict__ nvalid)
 {
+    if (nvalid && (int)(blockIdx.x / bands) >= *nvalid) return;
     constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH, PXPAR = 256 / C8;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
     const int WP = W + 2;
@@ -1111,7 +1126,7 @@ template <int C, int NT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 16 ? 3 : 2, C == 16 ? 3 : 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                      const __half* __restrict__ w9, const __half* __restrict__ bias,
                                                      StreamOut out, float* __restrict__ psum, int N, int H, int TH, int bands,
-                                                     unsigned masks)
+                                                     unsigned masks, const int* __restrict__ nvalid)
 {
     constexpr int W = 16 * NT, MT = (C + 15) / 16, CP = MT * 16;
     __shared__ __attribute__((aligned(16))) _Float16 taps[10 * 9 * CP];
@@ -1124,6 +1139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 16 ? 3
     const int item = blockIdx.x * 4 + wave;
     if (item >= N * bands) return;
     const int img = item / bands, band = item - img * bands, y0 = band * TH;
+    if (nvalid && img >= *nvalid) return;
     const unsigned m = (masks >> (4 * blockIdx.y)) & 15u;
     const __half* xi = x + (size_t)img * H * W * C;
     const size_t io = (size_t)img * H * W * C;
@@ -1350,8 +1366,10 @@ __global__ __launch_bounds__(256) void k_gate_apply(GatePtrs in, int T, const fl
 // gates of every image: gv[img][t][32] = sigmoid(fc2(relu(fc1(mean_hw(y_t))))) from the band sums (k_gate_apply's arithmetic)
 __global__ __launch_bounds__(128) void k_gate_vec(const float* __restrict__ psum, int parts, float scale, const __half* __restrict__ gw1,
                                                  const __half* __restrict__ gb1, const __half* __restrict__ gw2,
-                                                 const __half* __restrict__ gb2, int Cr, int MID, int Nimg, float* __restrict__ gv)
+                                                 const __half* __restrict__ gb2, int Cr, int MID, int Nimg, float* __restrict__ gv,
+                                                 const int* __restrict__ nvalid)
 {
+    if (nvalid && (int)blockIdx.x >= *nvalid) return;
     __shared__ float g[4][32];
     __shared__ float hid[4][16];
     const int tid = threadIdx.x, img = blockIdx.x;
@@ -1394,8 +1412,10 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
                                                    const __half* __restrict__ idn, const __half* __restrict__ wd,
                                                    const __half* __restrict__ bd, __half* __restrict__ out,
                                                    const __half* __restrict__ w4, const __half* __restrict__ b4,
-                                                   __half* __restrict__ out2, int pool, int Nimg, int HW, int W)
+                                                   __half* __restrict__ out2, int pool, int Nimg, int HW, int W,
+                                                   const int* __restrict__ nvalid)
 {
+    if (nvalid && (long long)blockIdx.x * 128 >= (long long)(*nvalid) * HW) return;
     constexpr int MT = C2 / 16, MT2 = (N2 + 15) / 16, KS2 = C2 / 32, EP = C2 + 8, CG = C2 / 8, CG2 = N2 / 8, K8 = C2 / 8;
     constexpr int IT = C1 > 0 ? 1 : 32 * CG / 64, KS1 = C1 > 0 ? (C1 + 31) / 32 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
@@ -1672,8 +1692,9 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
     static const bool vec_allowed = [] { const char* e = getenv("SS_PW_EPILOGUE"); return !(e && e[0] == '0'); }();
     const bool vec = vec_allowed && out_ld % 8 == 0 && c0 % 8 == 0 && cn % 8 == 0 && ((uintptr_t)out % 16) == 0 &&
                      (!out2 || ((uintptr_t)out2 % 16) == 0) && (!res || ((uintptr_t)res % 16) == 0);
+    const bool nv = g_nvalid && !conv3 && g_nvalid_batch > 0 && M % g_nvalid_batch == 0;
     const PwArgs A{ (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act, res_after,
-                    (__half*)out, out_ld, (__half*)out2, c0, cn, g };
+                    (__half*)out, out_ld, (__half*)out2, c0, cn, g, nv ? g_nvalid : nullptr, nv ? (int)(M / g_nvalid_batch) : 0 };
 #define SS_PW(BN, PT, CV, VE)                                                                                           \
     hipLaunchKernelGGL((k_pw<BN, PT, CV, VE>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, A)
 #define SS_PW2(BN, PT)                                                                                                  \
@@ -1731,7 +1752,7 @@ extern "C" int ss_op_osnet_stem_f16(void* stream, const void* x, const void* w_p
     if (!x || !w_prep || !bias || !y || N < 1 || W != STEM_W || H < 16 || H % 16) return SS_ERR_INVALID;
     const int tiles = H / 16;                                   // 4 pooled rows = 16 input rows per tile
     hipLaunchKernelGGL(k_osnet_stem, dim3((unsigned)((size_t)N * tiles)), dim3(256), 0, (hipStream_t)stream, (const __half*)x,
-                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles);
+                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles, g_nvalid_batch == N ? g_nvalid : nullptr);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
@@ -1813,12 +1834,13 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
     hipStream_t st = (hipStream_t)stream;
+    const int* nv = g_nvalid_batch == N ? g_nvalid : nullptr;
     if (os_chain_form(N, W, C)) {
         // one wave per (image, band, chain group); groups {4,1} and {3,2}: five layers each
         const unsigned masks = 0x69u;
         dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), 2), block(256);
 #define SS_CHN(CC, NT) hipLaunchKernelGGL((k_osnet_chains<CC, NT>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
-                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, TH, bands, masks)
+                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, TH, bands, masks, nv)
         if (W == 32) SS_CHN(16, 2);                          // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
         else { if (C == 16) SS_CHN(16, 1); else if (C == 24) SS_CHN(24, 1); else SS_CHN(32, 1); }
 #undef SS_CHN
@@ -1828,7 +1850,7 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
     if (lds > 65536) return SS_ERR_INVALID;
     dim3 grid((unsigned)((size_t)N * bands), 4), block(256);
 #define SS_OS(CC) hipLaunchKernelGGL(k_osnet_streams<CC>, grid, block, lds, st, (const __half*)x, (const __half*)w1, \
-                                     (const __half*)w9, (const __half*)bias, o, psum, N, H, W, bands)
+                                     (const __half*)w9, (const __half*)bias, o, psum, N, H, W, bands, nv)
     if (C == 16) SS_OS(16);
     else if (C == 24) SS_OS(24);
     else if (C == 32) SS_OS(32);
@@ -1873,12 +1895,13 @@ extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const f
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; p.x[t] = (const __half*)ys[t]; }
     const dim3 grid((unsigned)((size_t)N * H * W / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    const int* nv = g_nvalid_batch == N ? g_nvalid : nullptr;
     hipLaunchKernelGGL(k_gate_vec, dim3(N), dim3(128), 0, st, psum, parts, scale, (const __half*)gw1, (const __half*)gb1,
-                       (const __half*)gw2, (const __half*)gb2, Cr, MID, N, gates_ws);
+                       (const __half*)gw2, (const __half*)gb2, Cr, MID, N, gates_ws, nv);
 #define SS_TAIL(A, B, CC, DD)                                                                                                   \
     hipLaunchKernelGGL((k_osnet_tail<A, B, CC, DD>), grid, block, 0, st, p, (const float*)gates_ws, (const __half*)w3,          \
                        (const __half*)b3, (const __half*)idn, (const __half*)wd, (const __half*)bd, (__half*)out, (const __half*)w4, \
-                       (const __half*)b4, (__half*)out2, pool, N, H * W, W)
+                       (const __half*)b4, (__half*)out2, pool, N, H * W, W, nv)
     if (C1 == 0) {
         if (MID == 16 && C2 == 64 && N2 == 16) SS_TAIL(16, 64, 16, 0);
         else if (MID == 16 && C2 == 64 && N2 == 64) SS_TAIL(16, 64, 64, 0);
@@ -1926,7 +1949,7 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
         if (M > 0x7fffffffLL) return SS_ERR_INVALID;
         const int K = c.ksize * c.ksize * c.Cin;
         G.p[s] = PwArgs{ (const __half*)c.x, (const __half*)c.w, (const __half*)c.bias, nullptr, (int)M, K, c.N, c.act, 0, (__half*)c.out,
-                         c.N, nullptr, 0, 0, g };
+                         c.N, nullptr, 0, 0, g, nullptr, 0 };
         G.split[s] = splitk_allowed && conv3 && K >= 512 && M <= 4096;
         G.start[s] = wgs;
         wgs += (int)(G.split[s] ? (M + 15) / 16 : (M + 63) / 64);
@@ -1973,4 +1996,12 @@ extern "C" int ss_op_conv0_f16(void* stream, const void* x, const void* w_prep, 
     if (Cout == 16) SS_C0(16); else if (Cout == 32) SS_C0(32); else SS_C0(48);
 #undef SS_C0
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+// The OSNet entry points above (stem, pointwise, streams, tail) compute only the first *d_n images of launches whose batch
+// is `batch` until the next call; d_n == NULL switches it off.  Host-side setting, read at launch time.
+extern "C" int ss_op_set_valid_images(const int* d_n, int batch)
+{
+    g_nvalid = d_n; g_nvalid_batch = d_n ? batch : 0;
+    return SS_OK;
 }

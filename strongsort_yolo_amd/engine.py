@@ -356,6 +356,22 @@ class TrackerEngine:
                                            dets.stride(1), dets.stride(0), n, _ptr(counts), _ptr(out), flags))
         return out
 
+    def crop_norm_packed(self, frames: torch.Tensor, dets: torch.Tensor, n: int, counts: torch.Tensor, offsets: torch.Tensor,
+                         out: torch.Tensor, half: bool = True):
+        """Packed crops (channels-last `out` [B*n,3,256,128]): offsets int32 [B+1] <- exclusive prefix of min(counts, n); crop d
+        of image i at slot offsets[i] + d; offsets[B] = crops in total."""
+        B, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        flags = (_lib.DST_F16 if half else 0) | _lib.DST_HWC
+        self._ck(self.L.ss_crop_norm_packed(self.ctx, _ptr(frames), B, frames.stride(0), H, W, frames.stride(1), _ptr(dets),
+                                            dets.stride(1), dets.stride(0), n, _ptr(counts), _ptr(offsets), _ptr(out), flags))
+        return out
+
+    def unpack_feats(self, emb: torch.Tensor, offsets: torch.Tensor, counts: torch.Tensor, n: int, feats: torch.Tensor):
+        """feats[i, d, :] = emb[offsets[i] + d, :] for d < min(counts[i], n); emb [*, 512] half or float, feats [B, cap, 512] f32."""
+        assert emb.is_contiguous() and feats.stride(2) == 1 and feats.stride(1) == 512
+        self._ck(self.L.ss_unpack_feats(self.ctx, _ptr(emb), int(emb.dtype == torch.float16), _ptr(offsets), _ptr(counts),
+                                        feats.shape[0], n, _ptr(feats), feats.stride(0)))
+
     def nms(self, pred: torch.Tensor, nc: int, dcfg: DetectConfig, gain: float, pad_x: float, pad_y: float,
             w0: int, h0: int, n_extra: int = 0, rows=None, keep=None, count=None):
         """pred: [(4+nc+n_extra), N] float32 on the device."""

@@ -44,6 +44,24 @@ def _ck(rc):
         raise _lib.SSError(rc, "fused op failed")
 
 
+class valid_images:
+    """`with valid_images(n_dev, batch):` — the OSNet-side launches of `batch` images inside compute only the first n_dev[0]
+    (device int32) of them (packed ReID batches; csrc ss_op_set_valid_images)."""
+
+    def __init__(self, n_dev, batch):
+        self.n_dev, self.batch = n_dev, int(batch)
+
+    def __enter__(self):
+        if self.n_dev is not None:
+            _ck(_lib.load().ss_op_set_valid_images(_p(self.n_dev), self.batch))
+        return self
+
+    def __exit__(self, *a):
+        if self.n_dev is not None:
+            _ck(_lib.load().ss_op_set_valid_images(None, 0))
+        return False
+
+
 def bias_act_(x, bias, act="none", res=None):
     """x <- act(x + bias[c] (+ res)) in place; x NCHW-shaped, channels-last memory."""
     x = _cl(x)

@@ -243,6 +243,7 @@ class _Bufs:
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads
+        self.crop_off = torch.zeros(S + 1, dtype=torch.int32, device=dev)                     # packed ReID batch: first crop of every image, total
         self.warps = torch.zeros(getattr(p, "F", 1), p.S, 8, dtype=torch.float64, device=dev) if getattr(p, "cmc", False) else None
 
 
@@ -282,6 +283,10 @@ class OverlappedPipeline(FramePipeline):
         if self.F > 1:
             self.graph_mode = "front"       # the per-frame tracker calls stay eager (partial last groups)
         self.Sv = self.S * self.F
+        # packed ReID batches: the group's valid crops contiguous, the OSNet kernels skip the unused slots of the fixed batch
+        # (~28 of 32 slots per frame are used at configs[1]); SS_PACK_CROPS=0: A/B switch
+        import os as _os0
+        self.pack = bool(self.half and self.run_nets and _os0.environ.get("SS_PACK_CROPS", "1") == "1")
         self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
@@ -392,27 +397,43 @@ class OverlappedPipeline(FramePipeline):
         if self.nk:
             b.dets6.copy_(b.dets[:, :, :6])
         if self.run_nets:
-            e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.half, out=b.crops, channels_last=True)
+            if self.pack:        # the group's valid crops contiguous; the ReID kernels skip the rest of the fixed-size batch
+                e.crop_norm_packed(b.frames, b.dets6, self.RB, b.ndets, b.crop_off, b.crops, half=True)
+            else:
+                e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.half, out=b.crops, channels_last=True)
+
+    def _valid(self, b):
+        from . import fused
+        return fused.valid_images(b.crop_off[self.Sv:] if self.pack else None, self.Sv * self.RB)
 
     def _select(self, b, emb):
         if emb is not None and self.feat_source == "reid":
-            b.feats_v[:, :self.RB].copy_(emb.view(self.Sv, self.RB, FEAT_DIM))
+            if self.pack:
+                self.eng.unpack_feats(emb.contiguous(), b.crop_off, b.ndets, self.RB, b.feats_v)
+            else:
+                b.feats_v[:, :self.RB].copy_(emb.view(self.Sv, self.RB, FEAT_DIM))
         if self.feat_source == "by_anchor":
             idx = b.anchor_gt.gather(1, b.keep.long().clamp_(0, self.n_anchors - 1))
             torch.gather(b.gt_feats, 1, idx.clamp_(min=0).unsqueeze(-1).expand(-1, -1, FEAT_DIM), out=b.feats_v)
 
     def _s_nms_crop_reid_a(self, b):
         self._nms_crop(b)
-        st = self.reid.forward_a(b.crops)                    # a tensor or a tuple of tensors (nets.OSNet._block_part)
+        with self._valid(b):
+            st = self.reid.forward_a(b.crops)                # a tensor or a tuple of tensors (nets.OSNet._block_part)
         b.mid_tuple = isinstance(st, tuple)
         self._keep(b, "mid", list(st) if b.mid_tuple else [st])
 
     def _s_reid_b_select(self, b):
-        self._select(b, self.reid.forward_b(tuple(b.mid) if b.mid_tuple else b.mid[0]))
+        with self._valid(b):
+            emb = self.reid.forward_b(tuple(b.mid) if b.mid_tuple else b.mid[0])
+        self._select(b, emb)
 
     def _s_nms_crop_reid_select(self, b):
         self._nms_crop(b)
-        emb = self.reid(b.crops) if self.run_nets else None
+        emb = None
+        if self.run_nets:
+            with self._valid(b):
+                emb = self.reid(b.crops)
         self._select(b, emb)
 
     def _s_front_split(self, b):
@@ -421,12 +442,14 @@ class OverlappedPipeline(FramePipeline):
         if self.run_nets and self.reid_split > 0:
             # no copy across the stage boundary: the tensor lives in this graph's private pool, keeps its address over
             # replays, and the next stage's graph (captured after this one, for the same buffer set) reads it there
-            b.mid = [self.reid.forward_a(b.crops, self.reid_split)]
+            with self._valid(b):
+                b.mid = [self.reid.forward_a(b.crops, self.reid_split)]
 
     def _s_back_split(self, b):
         emb = None
         if self.run_nets:
-            emb = self.reid.forward_b(b.mid[0] if self.reid_split > 0 else b.crops, self.reid_split)
+            with self._valid(b):
+                emb = self.reid.forward_b(b.mid[0] if self.reid_split > 0 else b.crops, self.reid_split)
         self._select(b, emb)
 
     def _track_b(self, b: _Bufs, n_valid: int = None, group: int = None):

@@ -131,3 +131,52 @@ def test_two_streams_in_one_pipeline_equal_their_oracles():
         for s in range(2):
             assert got[s].shape == refs[s].shape and got[s].tobytes() == refs[s].tobytes(), f"stream {s} frame {k}"
     pipe.close()
+
+
+def test_packed_reid_batches_give_the_same_embeddings_and_tracks(monkeypatch):
+    """feat_source="reid": the group's valid crops packed to the front of the fixed ReID batch (OSNet kernels skip the rest,
+    embeddings scattered back by offset) vs one slot range per frame: identical feature rows for the detections and identical
+    tracker output."""
+    from strongsort_yolo_amd.pipeline import OverlappedPipeline
+    res = {}
+    for pack in ("1", "0"):
+        monkeypatch.setenv("SS_PACK_CROPS", pack)
+        pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph="front", det_source="synthetic", feat_source="reid",
+                                  n_stages=2, frame_batch=4, reid_split=2, reid_batch=32, defer_track=True)
+        assert pipe.pack == (pack == "1")
+        gs, items = _workload(pipe)
+        rows, feats = [], []
+
+        def fetch(idx, f, pipe=pipe, rows=rows):
+            n = int(pipe.nouts[f][0].item())
+            rows.append((idx, pipe.outs[f][0, :n].cpu().numpy().copy()))
+
+        pipe.on_result = fetch
+        for g0 in range(0, FRAMES, 4):
+            n = min(4, FRAMES - g0)
+            b = pipe.begin_frame()
+            with torch.cuda.stream(pipe.sA):
+                for f in range(n):
+                    img, pred, agt, _ = items[g0 + f]
+                    b.frames[f].copy_(torch.from_numpy(img).to(pipe.dev))
+                    b.pred_in[f].copy_(torch.from_numpy(pred).to(pipe.dev))
+            pipe.submit(n)
+            if g0 == 4:                                       # one group's features, once its last stage has run
+                pipe.flush(); torch.cuda.synchronize()
+                bb = pipe.bufs[1 % pipe.nb]
+                nd = bb.ndets[:4].cpu().numpy()
+                feats = [bb.feats_v[f, :nd[f]].cpu().numpy().copy() for f in range(4)]
+                assert nd.sum() > 8 and nd.max() <= 32
+                if pack == "1":
+                    off = bb.crop_off.cpu().numpy()
+                    assert off[0] == 0 and (np.diff(off[:5]) == nd).all() and off[pipe.Sv] == nd.sum() + off[4] - off[4]
+        pipe.flush()
+        torch.cuda.synchronize()
+        pipe.eng.check_errors()
+        res[pack] = (sorted(rows, key=lambda t: t[0]), feats)
+        pipe.close()
+    assert [i for i, _ in res["1"][0]] == list(range(FRAMES))
+    for (i, a), (_, b) in zip(res["1"][0], res["0"][0]):
+        assert a.shape == b.shape and a.tobytes() == b.tobytes(), i
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert a.shape == b.shape and a.tobytes() == b.tobytes() and np.abs(a).max() > 0
