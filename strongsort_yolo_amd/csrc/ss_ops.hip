@@ -539,6 +539,11 @@ __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
 #define STEM_IN_ROWS 23
 #define STEM_CR 9           // conv rows per tile
 #define STEM_CW 65          // conv columns + left pad
+#define STEM_CP 18          // halfs per pixel of the conv-output tile: 9 dwords, so that the wave's 8-byte writes (pixels 4n + r:
+                            // 36-dword lane stride) and the pooling reads (2-pixel stride) spread over the LDS banks (16 halfs:
+                            // 128-byte lane stride, 16-way conflicts — 46 M conflict cycles per 1024 crops, PMC)
+typedef _Float16 h4a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef _Float16 h8a4 __attribute__((ext_vector_type(8), aligned(4)));
 
 __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x, const __half* __restrict__ wp /*[4][7][16][32]*/,
                                                    const __half* __restrict__ bias, __half* __restrict__ y, int H, int tiles,
@@ -546,7 +551,7 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
 {
     if (nvalid && (int)(blockIdx.x / tiles) >= *nvalid) return;
     __shared__ __attribute__((aligned(16))) _Float16 In[STEM_IN_ROWS * STEM_PITCH];
-    __shared__ __attribute__((aligned(16))) _Float16 Cv[STEM_CR * STEM_CW * 16];
+    __shared__ __attribute__((aligned(16))) _Float16 Cv[STEM_CR * STEM_CW * STEM_CP];
     const int tid = threadIdx.x, lane = tid & 63, r = tid >> 6, q = lane >> 4, n = lane & 15;
     const int img = blockIdx.x / tiles, j0 = (blockIdx.x - img * tiles) * 4;           // first pooled row of the tile
     const int OHc = H / 2, OHp = OHc / 2;
@@ -562,7 +567,7 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
         *reinterpret_cast<h8*>(In + rr * STEM_PITCH + ch * 8) =
             ok ? *reinterpret_cast<const h8*>(xi + (size_t)gr * STEM_W * 3 + (ch - STEM_M / 8) * 8) : z8;
     }
-    if (tid < STEM_CR * 2) *reinterpret_cast<h8*>(Cv + (tid >> 1) * STEM_CW * 16 + (tid & 1) * 8) = z8;      // left pad column
+    if (tid < STEM_CR * 2) *reinterpret_cast<h8a4*>(Cv + (tid >> 1) * STEM_CW * STEM_CP + (tid & 1) * 8) = z8;      // left pad column
     // weights of this wave's residue: A operand, lane (q, oc = n): k = 8q..8q+7 of every ky
     h8 a[7];
 #pragma unroll
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
             const float f = (float)(_Float16)d[j] + (float)bb[j];    // conv rounded to half, then the bias pass (as unfused)
             o[j] = (gr >= 0 && gr < OHc) ? (_Float16)(f > 0.f ? f : 0.f) : (_Float16)0.f;
         }
-        *reinterpret_cast<h4*>(Cv + ((size_t)(cr * STEM_CW + c + 1) * 16 + 4 * q)) = o;
+        *reinterpret_cast<h4a4*>(Cv + ((size_t)(cr * STEM_CW + c + 1) * STEM_CP + 4 * q)) = o;
     }
     __syncthreads();
 
@@ -594,12 +599,12 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
     {
         const int c8 = tid & 1, pc = (tid >> 1) & 31, pr = tid >> 6;
         if (j0 + pr < OHp) {
-            h8 m = *reinterpret_cast<const h8*>(Cv + ((size_t)((2 * pr) * STEM_CW + 2 * pc) * 16 + c8 * 8));
+            h8 m = *reinterpret_cast<const h8a4*>(Cv + ((size_t)((2 * pr) * STEM_CW + 2 * pc) * STEM_CP + c8 * 8));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const h8 v = *reinterpret_cast<const h8*>(Cv + ((size_t)((2 * pr + ky) * STEM_CW + 2 * pc + kx) * 16 + c8 * 8));
+                    const h8 v = *reinterpret_cast<const h8a4*>(Cv + ((size_t)((2 * pr + ky) * STEM_CW + 2 * pc + kx) * STEM_CP + c8 * 8));
 #pragma unroll
                     for (int k = 0; k < 8; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
                 }
