@@ -275,9 +275,11 @@ int ss_op_conv0_f16(void* stream, const void* d_x, const void* d_w_prep, const v
 int ss_op_set_valid_images(const int* d_n, int batch);
 /* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
  * half -> [N][H/4][32][16]; d_w_prep [4][7][16][32] = for conv columns c = 4n + r, per (ky, out channel) the taps 3*kx+ch
- * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0. */
+ * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0.  d_w1 != NULL:
+ * also d_y1 [N][H/4][32][16] = relu(conv1x1(d_y, d_w1 [16][16]) + d_b1) — the first OSBlock's conv1, bit-identical to
+ * ss_op_pointwise_f16 on d_y. */
 int ss_op_osnet_stem_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int N, int H,
-                         int W);
+                         int W, const void* d_w1 /*[16][16] or NULL*/, const void* d_b1, void* d_y1);
 /* The four LightConv3x3 chains of an OSNet block (1..4 layers deep, same input) in one launch; the intermediates stay in
  * registers (16- / 32-wide images: a wave streams the rows of a band through the layers) or in LDS:
  * d_w1 [10][C][C], d_w9 [10][9][C], d_bias [10][C] = the layers of the 1-, 2-, 3-, 4-deep chain in that order;

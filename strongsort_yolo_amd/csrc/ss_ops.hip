@@ -547,7 +547,8 @@ typedef _Float16 h8a4 __attribute__((ext_vector_type(8), aligned(4)));
 
 __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x, const __half* __restrict__ wp /*[4][7][16][32]*/,
                                                    const __half* __restrict__ bias, __half* __restrict__ y, int H, int tiles,
-                                                   const int* __restrict__ nvalid)
+                                                   const int* __restrict__ nvalid, const __half* __restrict__ w1c,
+                                                   const __half* __restrict__ b1c, __half* __restrict__ y1)
 {
     if (nvalid && (int)(blockIdx.x / tiles) >= *nvalid) return;
     __shared__ __attribute__((aligned(16))) _Float16 In[STEM_IN_ROWS * STEM_PITCH];
@@ -609,6 +610,32 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
                     for (int k = 0; k < 8; ++k) m[k] = v[k] > m[k] ? v[k] : m[k];
                 }
             reinterpret_cast<h8*>(y)[(((size_t)img * OHp + j0 + pr) * 32 + pc) * 2 + c8] = m;
+            if (w1c) *reinterpret_cast<h8*>(In + (size_t)(pr * 32 + pc) * 24 + c8 * 8) = m;       // In is free after the conv phase
+        }
+    }
+    if (!w1c) return;
+    // ---- the first OSBlock's conv1 (1x1, 16 -> 16, + bias, ReLU) on the pooled tile: k_pw's products for K = 16 (lane
+    // groups q = 0, 1 hold k = 8q..8q+7, two 16x16x16 MFMAs over elements 0-3 / 4-7), its rounding and epilogue ----
+    __syncthreads();
+    if (j0 + r < OHp) {                                              // wave r = pooled row r of the tile
+        const bool kv = q < 2;
+        const h8 aw = kv ? *reinterpret_cast<const h8*>(w1c + n * 16 + 8 * q) : z8;
+        const h4 a0 = { aw[0], aw[1], aw[2], aw[3] }, a1 = { aw[4], aw[5], aw[6], aw[7] };
+        const h4 b1 = *reinterpret_cast<const h4*>(b1c + 4 * q);
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const h8 bv = kv ? *reinterpret_cast<const h8*>(In + (size_t)(r * 32 + pt * 16 + n) * 24 + 8 * q) : z8;
+            const h4 v0 = { bv[0], bv[1], bv[2], bv[3] }, v1 = { bv[4], bv[5], bv[6], bv[7] };
+            f4 d = { 0.f, 0.f, 0.f, 0.f };
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, v0, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, v1, d, 0, 0, 0);
+            h4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float f = (float)(_Float16)d[j] + (float)b1[j];
+                o[j] = (_Float16)(f > 0.f ? f : 0.f);
+            }
+            *reinterpret_cast<h4*>(y1 + (((size_t)img * OHp + j0 + r) * 32 + pt * 16 + n) * 16 + 4 * q) = o;
         }
     }
 }
@@ -1752,12 +1779,14 @@ extern "C" int ss_op_conv3x3_f16(void* stream, const void* x, const void* w, con
     return launch_pw((hipStream_t)stream, true, x, w, bias, res, M, 9 * Cin, N, act, res_after, out, out_ld, out2, c0, cn, g);
 }
 
-extern "C" int ss_op_osnet_stem_f16(void* stream, const void* x, const void* w_prep, const void* bias, void* y, int N, int H, int W)
+extern "C" int ss_op_osnet_stem_f16(void* stream, const void* x, const void* w_prep, const void* bias, void* y, int N, int H, int W,
+                                    const void* w1, const void* b1, void* y1)
 {
-    if (!x || !w_prep || !bias || !y || N < 1 || W != STEM_W || H < 16 || H % 16) return SS_ERR_INVALID;
+    if (!x || !w_prep || !bias || !y || N < 1 || W != STEM_W || H < 16 || H % 16 || (w1 && (!b1 || !y1))) return SS_ERR_INVALID;
     const int tiles = H / 16;                                   // 4 pooled rows = 16 input rows per tile
     hipLaunchKernelGGL(k_osnet_stem, dim3((unsigned)((size_t)N * tiles)), dim3(256), 0, (hipStream_t)stream, (const __half*)x,
-                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles, g_nvalid_batch == N ? g_nvalid : nullptr);
+                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles, g_nvalid_batch == N ? g_nvalid : nullptr,
+                       (const __half*)w1, (const __half*)b1, (__half*)y1);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

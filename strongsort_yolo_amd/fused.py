@@ -275,12 +275,18 @@ def stem_weight(mod, conv):
     return w
 
 
-def osnet_stem(x, w_prep, bias):
+STEM_CONV1 = _flag("STEM_CONV1")        # the first OSBlock's conv1 (16 -> 16) on the stem's pooled tile
+
+
+def osnet_stem(x, w_prep, bias, conv1=None):
+    """conv1 = (w [16,16], b [16]): also returns relu(conv1x1(y, w) + b) (the first OSBlock's conv1) from the same launch."""
     x = _cl(x)
     n, c, h, w = x.shape
     y = torch.empty((n, 16, h // 4, w // 4), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    _ck(_lib.load().ss_op_osnet_stem_f16(_st(x), _p(x), _p(w_prep), _p(bias), _p(y), n, h, w))
-    return y
+    y1 = torch.empty_like(y, memory_format=torch.channels_last) if conv1 is not None else None
+    w1, b1 = conv1 if conv1 is not None else (None, None)
+    _ck(_lib.load().ss_op_osnet_stem_f16(_st(x), _p(x), _p(w_prep), _p(bias), _p(y), n, h, w, _p(w1), _p(b1), _p(y1)))
+    return y if conv1 is None else (y, y1)
 
 
 STREAMS = _flag("STREAMS")              # all four LightConv chains of an OSNet block in one launch (off: one launch per layer)

@@ -130,7 +130,7 @@ def load():
     L.ss_op_v8_decode_f16.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), hi, hi, hi, i, i, vp]
     L.ss_op_lightconv_f16.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i]
     L.ss_op_conv0_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i]
-    L.ss_op_osnet_stem_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i]
+    L.ss_op_osnet_stem_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp, vp, vp]
     L.ss_op_osnet_streams_f16.argtypes = [vp, vp, vp, vp, vp, C.POINTER(vp), vp, i, i, i, i]
     L.ss_op_osnet_streams_bands.argtypes = [i, i, i, i]
     L.ss_op_gate_apply_f16.argtypes = [vp, C.POINTER(vp), i, vp, vp, vp, vp, vp, i, f, vp, i, i, i, i]

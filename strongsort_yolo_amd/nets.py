@@ -496,6 +496,11 @@ class OSNet(nn.Module):
         between parts is a tensor or a tuple of tensors (see _block_part)."""
         if k == 0:
             if fused.usable(x) and fused.stem_ok(x, self.conv1.conv) and self.conv1.relu:      # conv + bias + ReLU + pool, one launch
+                c1 = self.conv2[0].conv1
+                if (fused.STEM_CONV1 and fused.TAIL and c1.relu and fused.pointwise_ok(c1.conv) and c1.conv.in_channels == 16
+                        and c1.conv.out_channels == 16):        # the first block's conv1 from the same launch: state (x0, x1)
+                    return fused.osnet_stem(x, fused.stem_weight(self.conv1, self.conv1.conv), self.conv1.conv.bias,
+                                            (fused.weight_nk(c1, c1.conv), c1.conv.bias))
                 return fused.osnet_stem(x, fused.stem_weight(self.conv1, self.conv1.conv), self.conv1.conv.bias)
             x = self.conv1(x)
             return fused.maxpool(x, 3, 2, 1) if fused.usable(x) else F.max_pool2d(x, 3, 2, 1)

@@ -261,7 +261,7 @@ def test_osnet_with_fused_tails_equals_blockwise_path():
         assert fused.TAIL
         for split in range(0, m.N_PARTS + 1):
             st = m.forward_a(x, split)
-            assert isinstance(st, tuple) == (split in (2, 3, 5, 6, 8, 9)), split
+            assert isinstance(st, tuple) == (split in (1, 2, 3, 5, 6, 8, 9)), split       # 1: (stem output, first block's conv1)
             assert torch.equal(m.forward_b(st, split), ref), split
 
 
@@ -316,6 +316,11 @@ def test_osnet_stem_matches_conv_relu_pool(N, H):
     assert got.shape == ref.shape == (N, 16, H // 4, 32)
     assert (got.float() - ref).abs().max().item() <= 4e-3 * (ref.abs().max().item() + 1.0)
     assert (got.float() != ref).float().mean().item() < 0.02
+    # the first OSBlock's conv1 from the same launch == the pointwise kernel on the stem output, bit for bit
+    w1 = (torch.randn(16, 16, generator=g) / 4).to(dev, torch.float16)
+    b1 = torch.randn(16, generator=g).to(dev, torch.float16)
+    y, y1 = fused.osnet_stem(x, fused.stem_weight(holder, conv), conv.bias, (w1, b1))
+    assert torch.equal(y, got) and torch.equal(y1, fused.pointwise(got, w1, b1, "relu"))
 
 
 @pytest.mark.parametrize("b,c1,c2,h,w,lo_first", [(16, 256, 128, 12, 20, True), (3, 128, 64, 24, 40, True), (2, 8, 24, 5, 7, False), (1, 64, 64, 1, 1, False)])
