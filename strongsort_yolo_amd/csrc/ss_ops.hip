@@ -392,120 +392,6 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
 __global__ __launch_bounds__(256) void k_pw(PwArgs A) { pw_body<BN, PT, CONV3, VEC_EPI>(A, blockIdx.x, blockIdx.y); }
 
-// Register-weight form of k_pw for narrow layers (N <= 32, K <= 288: the detector's 16- and 32-channel 3x3 convolutions at
-// strides 2-8, 9 launches per pass, 0.5-1 M pixels each).  There k_pw walks 3-5 K chunks with two workgroup barriers and an
-// LDS round trip of a 2-4 KB weight tile per chunk, and waits 41 % of its wave-cycles (PMC: MFMA busy 0.09, 0.95 TB/s).
-// The whole weight matrix of a wave's BN channels fits its registers (BN/16 x NB 16-byte vectors), so a wave keeps it
-// there, streams its 16*PT pixels' operands through a two-deep register pipeline and never synchronises.  Same MFMA
-// operands in the same order as k_pw (per accumulator: 32-wide blocks ascending, elements 0-3 then 4-7): bit-identical.
-template <int BN, int PT, int NB, bool CONV3>
-__global__ __launch_bounds__(256) void k_pw_reg(PwArgs A)
-{
-    const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
-    const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
-    const int K = A.K, N = A.N, act = A.act, res_after = A.res_after, out_ld = A.out_ld, c0 = A.c0, cn = A.cn;
-    int M = A.M;
-    if (A.n_img) { const long long mv = (long long)(*A.n_img) * A.img_px; if (mv < M) M = (int)mv; }
-    const ConvGeom g = A.g;
-    constexpr int MT = BN / 16, BM = 64 * PT;
-    if ((long long)blockIdx.x * BM >= M) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
-    const size_t px0 = (size_t)blockIdx.x * BM + wave * (16 * PT);
-    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    h8 a[MT][NB];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb) {
-            const int oc = mt * 16 + n, k = kb * 32 + 8 * q;
-            a[mt][kb] = (oc < N && k < K) ? *reinterpret_cast<const h8*>(w + (size_t)oc * K + k) : z8;
-        }
-    size_t ibase[PT];
-    int iy0[PT], ix0[PT];
-    if (CONV3) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const size_t px = px0 + pt * 16 + n;
-            const int ohw = g.OH * g.OW;
-            const int bimg = (int)(px / ohw), rem = (int)(px - (size_t)bimg * ohw), oy = rem / g.OW, ox = rem - oy * g.OW;
-            ibase[pt] = (size_t)bimg * g.H * g.W;
-            iy0[pt] = oy * g.stride - 1; ix0[pt] = ox * g.stride - 1;
-        }
-    }
-    auto load_b = [&](int kb, h8 (&b)[PT]) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const size_t px = px0 + pt * 16 + n;
-            const int k = kb * 32 + 8 * q;
-            if (!CONV3) {
-                b[pt] = (px < (size_t)M && k < K) ? *reinterpret_cast<const h8*>(x + px * K + k) : z8;
-            } else {
-                const int tap = k / g.Cin, c = k - tap * g.Cin, dy = tap / 3, dx = tap - dy * 3;
-                const int iy = iy0[pt] + dy, ix = ix0[pt] + dx;
-                const bool ok = px < (size_t)M && k < K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
-                b[pt] = ok ? *reinterpret_cast<const h8*>(x + (ibase[pt] + (size_t)iy * g.W + ix) * g.Cin + c) : z8;
-            }
-        }
-    };
-    f4 acc[MT][PT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
-    h8 b[NB][PT];
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) load_b(kb, b[kb]);               // all of the wave's operands in flight at once
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {                                  // (blocks beyond K hold zeros on both sides: k_pw skips them, + 0 is exact)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const h8 av = a[mt][kb];
-            const h4 a0 = { av[0], av[1], av[2], av[3] }, a1 = { av[4], av[5], av[6], av[7] };
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const h8 bv = b[kb][pt];
-                const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
-                acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
-                acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
-            }
-        }
-    }
-    // vector epilogue through a per-wave LDS tile (k_pw's)
-    constexpr int EP = BN + 8, CG = BN / 8;
-    __shared__ __attribute__((aligned(16))) _Float16 Et[4 * PT * 16 * EP];
-    _Float16* tile = Et + wave * (PT * 16 * EP);
-#pragma unroll
-    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const h4 o = { (_Float16)acc[mt][pt][0], (_Float16)acc[mt][pt][1], (_Float16)acc[mt][pt][2], (_Float16)acc[mt][pt][3] };
-            *reinterpret_cast<h4*>(tile + (pt * 16 + n) * EP + mt * 16 + 4 * q) = o;
-        }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int it = 0; it < (PT * 16 * CG + 63) / 64; ++it) {
-        const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-        const size_t px = px0 + row;
-        const int oc = cg * 8;
-        if (i >= PT * 16 * CG || px >= (size_t)M || oc >= N) continue;
-        const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
-        const h8 bb = *reinterpret_cast<const h8*>(bias + oc);
-        h8 r = z8;
-        if (res) r = *reinterpret_cast<const h8*>(res + px * N + oc);
-        h8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float f = (float)v[j] + (float)bb[j];
-            if (res && !res_after) f += (float)r[j];
-            f = act_apply(f, act);
-            if (res && res_after) f = (float)(_Float16)f + (float)r[j];
-            o[j] = (_Float16)f;
-        }
-        *reinterpret_cast<h8*>(out + px * out_ld + oc) = o;
-        if (out2 && oc >= c0 && oc < c0 + cn) *reinterpret_cast<h8*>(out2 + px * cn + (oc - c0)) = o;
-    }
-}
-
 // Split-K form of k_pw for layers whose pixel count cannot fill the chip with 64-pixel workgroups (the detector's
 // stride-32 level at batch 16: 60-120 workgroups for 256 CUs, each walking 18-36 K chunks with two barriers per chunk:
 // 17-31 us per layer, latency-bound).  Workgroup = 16 pixels x BN channels; the four waves take the 64-wide K
@@ -1859,16 +1745,6 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
         if (N <= 32) { if (conv3) SS_SK(32, true); else SS_SK(32, false); }
         else { if (conv3) SS_SK(64, true); else SS_SK(64, false); }
 #undef SS_SK
-        return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
-    }
-    // narrow layers with many pixels: the weights live in registers, no LDS / barriers in the K walk (SS_PW_REG=0: A/B switch)
-    static const bool reg_allowed = [] { const char* e = getenv("SS_PW_REG"); return !(e && e[0] == '0'); }();
-    if (reg_allowed && vec && N <= 32 && K <= 288 && M >= 32768) {
-        const dim3 grid((unsigned)((M + 127) / 128));
-#define SS_RG(NB, CV) hipLaunchKernelGGL((k_pw_reg<32, 2, NB, CV>), grid, dim3(256), 0, st, A)
-        if (K <= 160) { if (conv3) SS_RG(5, true); else SS_RG(5, false); }
-        else { if (conv3) SS_RG(9, true); else SS_RG(9, false); }
-#undef SS_RG
         return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
     }
     const bool big = M >= 32768;                 // enough pixels to fill the chip with 128-pixel workgroups

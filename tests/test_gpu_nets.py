@@ -351,42 +351,6 @@ def test_sppf_pools_equal_the_pool_cascade(b, c, h, w):
     assert torch.equal(fused.sppf_pools(x), torch.cat(y, 1))
 
 
-@pytest.mark.parametrize("B,cin,H,W,N,stride,k", [(12, 16, 96, 160, 16, 1, 3), (6, 32, 48, 80, 32, 1, 3), (8, 16, 192, 320, 32, 2, 3), (40, 24, 64, 32, 24, 1, 1),
-                                                  (9, 32, 97, 83, 24, 1, 3), (4, 64, 96, 160, 24, 1, 1)])
-def test_register_weight_form_equals_the_lds_form(B, cin, H, W, N, stride, k):
-    """Narrow layers with >= 32768 pixels take k_pw_reg (weights in registers, no barriers); the same layer on a sub-batch
-    below that size takes k_pw: identical bits per pixel (same products, same order) — and both match conv2d."""
-    import torch.nn.functional as F
-    from strongsort_yolo_amd import fused
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device="cpu").manual_seed(cin * 31 + N + k)
-    x = torch.randn(B, cin, H, W, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
-    res = None
-    if k == 3:
-        conv = torch.nn.Conv2d(cin, N, 3, stride, 1).to(dev, torch.float16)
-        wk = fused.weight_n9k(torch.nn.Module(), conv)
-        run = lambda t, r=None: fused.conv3x3(t, wk, conv.bias, stride, "silu", res=r, res_after=True)
-        oh, ow = (H - 1) // stride + 1, (W - 1) // stride + 1
-        if stride == 1 and cin == N:
-            res = torch.randn(B, N, oh, ow, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
-    else:
-        conv = torch.nn.Conv2d(cin, N, 1).to(dev, torch.float16)
-        wk = fused.weight_nk(torch.nn.Module(), conv)
-        run = lambda t, r=None: fused.pointwise(t, wk, conv.bias, "silu")
-        oh, ow = H, W
-    assert B * oh * ow >= 32768
-    full = run(x, res)
-    nb = max(1, 30000 // (oh * ow))                                    # a sub-batch below the threshold
-    assert nb * oh * ow < 32768
-    part = run(x[:nb].contiguous(memory_format=torch.channels_last), None if res is None else res[:nb].contiguous(memory_format=torch.channels_last))
-    assert torch.equal(full[:nb], part)
-    ref = F.silu(F.conv2d(x.float(), conv.weight.float(), None, stride if k == 3 else 1, 1 if k == 3 else 0).half().float()
-                 + conv.bias.float().view(1, N, 1, 1))
-    if res is not None:
-        ref = ref.half().float() + res.float()
-    assert (full.float() - ref).abs().max().item() <= 4e-3 * (ref.abs().max().item() + 1.0)
-
-
 @pytest.mark.parametrize("B,H,W,co", [(16, 384, 640, 16), (2, 384, 640, 32), (1, 30, 128, 48), (3, 17, 256, 16)])
 def test_conv0_matches_conv_bias_silu(B, H, W, co):
     import torch.nn.functional as F
