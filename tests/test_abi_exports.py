@@ -40,3 +40,26 @@ def test_error_without_gpu_is_loud():
     from strongsort_yolo_amd.engine import TrackerEngine
     with pytest.raises(lib.SSError):
         TrackerEngine()
+
+
+def test_host_side_entry_points_without_a_gpu():
+    """Entry points that only compute on the host or validate arguments: callable on a CPU-only box."""
+    lib.build()
+    L = lib.load()
+    assert L.ss_max_group_frames() == 32
+    # band count of the LightConv chain launches: LDS form (16-row bands) below 96 images, the row-stream form sizes its bands
+    # for one round of waves (32-wide: 3072 waves = images x bands x 2 chain groups), at least 8 rows per band
+    assert L.ss_op_osnet_streams_bands(32, 64, 32, 16) == 4
+    assert L.ss_op_osnet_streams_bands(512, 64, 32, 16) == 3
+    assert L.ss_op_osnet_streams_bands(1024, 64, 32, 16) == 1
+    assert L.ss_op_osnet_streams_bands(128, 64, 32, 16) == 8
+    assert L.ss_op_osnet_streams_bands(512, 32, 16, 24) == 2
+    assert L.ss_op_osnet_streams_bands(512, 16, 8, 32) == 1            # 8-wide maps stay on the LDS form
+    assert L.ss_op_osnet_streams_bands(0, 64, 32, 16) < 0
+    assert L.ss_op_set_valid_images(None, 0) == 0
+    assert L.ss_op_conv_group_f16(None, 0, None) < 0                    # n out of range / no descriptors
+    d = (lib.ss_conv_desc * 1)()
+    assert L.ss_op_conv_group_f16(None, 1, d) < 0                       # null tensors
+    assert L.ss_op_upcat_f16(None, None, None, None, 1, 4, 4, 8, 8, 1) < 0
+    assert L.ss_op_sppf_pools_f16(None, None, None, 1, 40, 40, 8) < 0   # H*W > 1024 (and null tensors)
+    assert L.ss_op_conv0_f16(None, None, None, None, None, 1, 8, 100, 16, 2) < 0
