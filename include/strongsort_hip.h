@@ -173,11 +173,13 @@ int ss_track_update(ss_ctx* ctx, const float* d_dets, const int* d_ndets, const 
  * the 0.1x grey images and align each with its predecessor (the stream's last frame of the previous call for f = 0) by
  * ECC, euclidean warp, <= 100 iterations: d_warps[f][s][8] = 2x3 matrix previous -> current in full-frame pixels,
  * [6] = iterations (>= 1) or -1 (no usable alignment / no predecessor: identity), [7] = 0.  Asynchronous on hip_stream;
- * stateless apart from the remembered last frames, so it can run beside the detector.
+ * stateless apart from the remembered last frames, so it can run beside the detector.  d_n_valid (device int, may be NULL =
+ * n_frames): only the first *d_n_valid frames of the buffer are real (a partial last group behind a captured graph): the
+ * others get -1 warps and the last REAL frame is what the next call aligns its first frame with.
  * ss_track_set_cmc: the following tracker calls move every track's box by warp [f][s] before predicting frame f
  * (NULL switches compensation off, the default). */
 int ss_cmc_estimate(ss_ctx* ctx, void* hip_stream, const uint8_t* d_frames, int n_frames, long long frame_stride, int h, int w,
-                    int row_stride, double* d_warps);
+                    int row_stride, const int* d_n_valid, double* d_warps);
 int ss_track_set_cmc(ss_ctx* ctx, const double* d_warps);
 
 /* Synchronous convenience for one stream with host buffers (used by StrongSORT.update). */

@@ -29,7 +29,7 @@ void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*,
 void ss_launch_crop_offsets(const int*, int, int, int*, hipStream_t);
 void ss_launch_unpack_feats(const void*, int, const int*, const int*, int, int, float*, long long, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
-void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, double*, hipStream_t);
+void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, const int*, double*, hipStream_t);
 extern "C" void ss_step_kernel_attr();
 
 static std::string g_last_error;
@@ -234,7 +234,7 @@ extern "C" int ss_download(ss_ctx* c, void* hip_stream, void* h_dst, const void*
 
 // ---- N4 camera-motion compensation ------------------------------------------------------------------------
 extern "C" int ss_cmc_estimate(ss_ctx* c, void* hip_stream, const uint8_t* d_frames, int n_frames, long long frame_stride, int h,
-                               int w, int row_stride, double* d_warps)
+                               int w, int row_stride, const int* d_n_valid, double* d_warps)
 {
     if (!c || !d_frames || !d_warps || n_frames < 1 || n_frames > SS_FMAX || h < 20 || w < 20 || row_stride < 3 * w)
         return fail(c, SS_ERR_INVALID, "ss_cmc_estimate: bad argument");
@@ -253,7 +253,7 @@ extern "C" int ss_cmc_estimate(ss_ctx* c, void* hip_stream, const uint8_t* d_fra
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     ss_launch_cmc(d_frames, n_frames * c->dev.S, frame_stride, h, w, row_stride, c->cmc_small, (long long)c->cmc_stride, c->dev.S,
-                  n_frames, hs, ws, 100, 1e-5, c->cmc_prev_valid, d_warps, (hipStream_t)hip_stream);
+                  n_frames, hs, ws, 100, 1e-5, c->cmc_prev_valid, d_n_valid, d_warps, (hipStream_t)hip_stream);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }

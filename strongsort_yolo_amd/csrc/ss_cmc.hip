@@ -134,7 +134,8 @@ __device__ inline void cm_reduce(double (&a)[NS], double (*red)[CM_NS], double (
 // [6] = iterations run, or -1: no usable alignment / no previous frame (identity stored, k_frame skips it).
 __global__ __launch_bounds__(1024) void k_ecc(const uint8_t* __restrict__ smalls, long long img_stride, int S, int hs, int ws,
                                               int max_iter, double eps, double scale_x, double scale_y,
-                                              const int* __restrict__ prev_valid, double* __restrict__ warps)
+                                              const int* __restrict__ prev_valid, const int* __restrict__ n_valid,
+                                              double* __restrict__ warps)
 {
     __shared__ double red[16][CM_NS];
     const int f = blockIdx.x / S, s = blockIdx.x - f * S, tid = threadIdx.x;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(1024) void k_ecc(const uint8_t* __restrict__ smalls
     double theta = 0.0, tx = 0.0, ty = 0.0, last_rho = -2.0;
     int it, status = 0;
     if (f == 0 && !prev_valid[s]) status = -1;
+    if (n_valid && f >= *n_valid) status = -1;            // frames past the real ones of a partial group
     for (it = 1; status == 0 && it <= max_iter; ++it) {
         double s_, c_;
         cm_sincos(theta, s_, c_);
@@ -209,8 +211,15 @@ __global__ __launch_bounds__(1024) void k_ecc(const uint8_t* __restrict__ smalls
 }
 
 // the group's last small images become "previous" for the next call (a kernel, not a memcpy node: graph-capture safe)
-__global__ __launch_bounds__(256) void k_cmc_roll(uint8_t* __restrict__ smalls, size_t last_off, size_t bytes, int* __restrict__ prev_valid, int S)
+// (n_valid: device count of real frames in the group, NULL = n_frames; the last REAL frame is the next call's predecessor,
+// and a group without real frames leaves the remembered one alone)
+__global__ __launch_bounds__(256) void k_cmc_roll(uint8_t* __restrict__ smalls, int n_frames, const int* __restrict__ n_valid, size_t bytes,
+                                                  int* __restrict__ prev_valid, int S)
 {
+    int n = n_valid ? *n_valid : n_frames;
+    if (n > n_frames) n = n_frames;
+    if (n <= 0) return;
+    const size_t last_off = (size_t)n * bytes;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i * 16 < bytes) reinterpret_cast<uint4*>(smalls)[i] = reinterpret_cast<const uint4*>(smalls + last_off)[i];
     if (i < (size_t)S) prev_valid[i] = 1;
@@ -218,14 +227,14 @@ __global__ __launch_bounds__(256) void k_cmc_roll(uint8_t* __restrict__ smalls, 
 
 void ss_launch_cmc(const uint8_t* frames, int n_images, long long frame_stride, int h, int w, int row_stride, uint8_t* smalls,
                    long long img_stride, int S, int n_frames, int hs, int ws, int max_iter, double eps, int* prev_valid,
-                   double* warps, hipStream_t st)
+                   const int* n_valid, double* warps, hipStream_t st)
 {
     // small images 1 .. n_frames of the buffer (index 0 holds the previous group's last frame)
     hipLaunchKernelGGL(k_gray_small, dim3((hs * ws + 255) / 256, n_images), dim3(256), 0, st, frames, frame_stride, h, w, row_stride,
                        smalls + (size_t)S * img_stride, img_stride, hs, ws);
     hipLaunchKernelGGL(k_ecc, dim3(n_frames * S), dim3(1024), 0, st, smalls, img_stride, S, hs, ws, max_iter, eps,
-                       (double)w / (double)ws, (double)h / (double)hs, prev_valid, warps);
+                       (double)w / (double)ws, (double)h / (double)hs, prev_valid, n_valid, warps);
     const size_t bytes = (size_t)S * img_stride;                       // img_stride is a multiple of 16
     hipLaunchKernelGGL(k_cmc_roll, dim3((unsigned)((bytes / 16 + 255) / 256 + (S + 255) / 256)), dim3(256), 0, st, smalls,
-                       (size_t)n_frames * S * img_stride, bytes, prev_valid, S);
+                       n_frames, n_valid, bytes, prev_valid, S);
 }

@@ -137,14 +137,15 @@ class TrackerEngine:
                                               _ptr(out), _ptr(nout)))
         return out, nout
 
-    def cmc_estimate(self, frames: torch.Tensor, n_frames: int, warps: torch.Tensor = None, stream=None):
+    def cmc_estimate(self, frames: torch.Tensor, n_frames: int, warps: torch.Tensor = None, stream=None, n_valid: torch.Tensor = None):
         """N4: ECC camera-motion warps of a group: frames uint8 [F*S,H,W,3] ([F][S] order) -> warps float64 [F,S,8]
-        (2x3 matrix previous -> current frame, [6] = iterations or -1).  Asynchronous."""
+        (2x3 matrix previous -> current frame, [6] = iterations or -1).  Asynchronous.  n_valid: device int32 [1], the real
+        frames of a partial group (the rest of the buffer is stale)."""
         if warps is None:
             warps = torch.zeros(n_frames, self.S, 8, dtype=torch.float64, device=self.device)
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         self._ck(self.L.ss_cmc_estimate(self.ctx, C.c_void_p(st.cuda_stream), _ptr(frames), int(n_frames), frames.stride(0),
-                                        frames.shape[1], frames.shape[2], frames.stride(1), _ptr(warps)))
+                                        frames.shape[1], frames.shape[2], frames.stride(1), _ptr(n_valid), _ptr(warps)))
         return warps
 
     def set_cmc(self, warps):

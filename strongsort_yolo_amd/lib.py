@@ -98,7 +98,7 @@ def load():
     L.ss_op_set_valid_images.argtypes = [vp, i]
     L.ss_track_update.argtypes = [vp, fp, ip, fp, ip, fp, ip]
     L.ss_track_update_group.argtypes = [vp, i, fp, ip, fp, ip, fp, ip]
-    L.ss_cmc_estimate.argtypes = [vp, vp, vp, i, C.c_longlong, i, i, i, vp]
+    L.ss_cmc_estimate.argtypes = [vp, vp, vp, i, C.c_longlong, i, i, i, ip, vp]
     L.ss_track_set_cmc.argtypes = [vp, vp]
     L.ss_track_set_assoc_event.argtypes = [vp, vp]
     hf, hi = C.POINTER(C.c_float), C.POINTER(C.c_int)

@@ -1,7 +1,7 @@
 """Per-frame tracking pipeline for the S streams owned by one GPU (one process per GPU).
 
-    frame (u8, HBM) -> letterbox [HIP] -> detector [PyTorch-ROCm] -> NMS [HIP] -> ReID crops [HIP]
-      -> OSNet [PyTorch-ROCm] -> StrongSORT update [HIP: k_pre / k_cosine / k_step]
+    frame (u8, HBM) -> letterbox [HIP] -> detector [own HIP conv kernels behind nets.py modules] -> NMS [HIP]
+      -> ReID crops [HIP] -> OSNet [own HIP kernels] -> StrongSORT update [HIP: k_group_prep / k_assoc / k_frame / k_post / k_newrow]
 
 This is what runs inside `model.track(frame, persist=True)` (/root/reference/yolo_multi_model.py:41).
 Everything between the frame and the output rows stays on the device: detection counts, track
@@ -245,6 +245,7 @@ class _Bufs:
         self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads
         self.crop_off = torch.zeros(S + 1, dtype=torch.int32, device=dev)                     # packed ReID batch: first crop of every image, total
         self.warps = torch.zeros(getattr(p, "F", 1), p.S, 8, dtype=torch.float64, device=dev) if getattr(p, "cmc", False) else None
+        self.nvalid = torch.full((1,), getattr(p, "F", 1), dtype=torch.int32, device=dev)    # real frames of the group in this set (device side: read by captured kernels)
 
 
 class OverlappedPipeline(FramePipeline):
@@ -359,7 +360,7 @@ class OverlappedPipeline(FramePipeline):
     # ---- stage bodies (b = the frame's buffer set) -------------------------------------------------------
     def _letterbox(self, b):
         if self.cmc:                                           # the group's F warps, beside the detector (stateless stage)
-            self.eng.cmc_estimate(b.frames, self.F, b.warps)
+            self.eng.cmc_estimate(b.frames, self.F, b.warps, n_valid=b.nvalid)    # a partial group: the last REAL frame becomes "previous"
         self.eng.letterbox_batch(b.frames, self.geom, half=self.half, pad_value=self.dcfg.pad_value, out=b.lb,
                                  channels_last=True)
 
@@ -465,6 +466,7 @@ class OverlappedPipeline(FramePipeline):
                 e.set_cmc(b.warps[f0:f0 + n])
             e.update_group(n, b.dets6[v0:v1], b.ndets[v0:v1], b.feats_v[v0:v1], self.img_hw, self.outs[f0:f0 + n], self.nouts[f0:f0 + n])
         if group is not None and self.on_result is not None:
+            self.cur_bufs, self.cur_valid = b, nv               # the buffer set / real-frame count the callbacks below refer to
             for f in range(nv):
                 self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
 
@@ -504,6 +506,7 @@ class OverlappedPipeline(FramePipeline):
 
     # ---- driver API --------------------------------------------------------------------------------------
     on_result = None
+    cur_bufs, cur_valid = None, 0
 
     def begin_frame(self) -> _Bufs:
         """Buffer set for the next frame.  Fill its inputs inside `with torch.cuda.stream(pipe.sA):`."""
@@ -556,6 +559,9 @@ class OverlappedPipeline(FramePipeline):
         self.valid[k % self.nb] = nv
         self.base[k % self.nb] = self.frames_in                 # index of the group's first frame (partial groups allowed)
         self.frames_in += nv
+        if self.cmc:
+            with torch.cuda.stream(self.sA):
+                self.bufs[k % self.nb].nvalid.fill_(nv)
         for j in (range(self.n - 1, -1, -1) if self.defer else range(self.n)):     # deferred: the tracker call is enqueued first
             f = k - j
             if f >= 0 and self.stage_done[j] == f:

@@ -86,8 +86,9 @@ class YOLO:
     `model.track(..., persist=False)` would."""
 
     def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128,
-                 camera_motion: bool = False):
+                 camera_motion: bool = False, reid_weights: Optional[str] = None):
         self.weights = weights
+        self.reid_weights = reid_weights          # OSNet-x0.25 state_dict; same policy as the detector's (raise unless random init is asked for)
         self.random_init_ok = random_init_ok
         self.arch = os.path.basename(weights).replace(".pt", "")
         self.overrides = {"conf": 0.25, "iou": 0.7, "agnostic_nms": False, "max_det": 300}
@@ -124,7 +125,10 @@ class YOLO:
         args.update(self._pipe_kw)
         args.update(kw)
         pipe = cls(self.arch, 1, shape, device=int(device or 0), **args)
+        # both networks, before the first forward (the fused weight-prep caches are built from the loaded tensors)
         nets.load_weights(pipe.detector, self.weights, f"detector {self.arch}", self.random_init_ok)
+        if pipe.feat_source == "reid" and pipe.det_rows == 128:      # the tracker consumes OSNet embeddings
+            nets.load_weights(pipe.reid, self.reid_weights, "OSNet-x0.25 ReID", self.random_init_ok)
         pipe.eng.nms_set_classes(self.overrides.get("classes"))
         return pipe
 
@@ -236,6 +240,8 @@ class YOLO:
                                             reid_split=2 if batch > 1 else None, defer_track=batch > 1)
             self._stream_key = key
         pipe = self._stream_pipe
+        pipe.on_result = None
+        pipe.flush()                                                      # groups an abandoned generator left in flight: tracked, results dropped
         F, H, W = batch, first.shape[0], first.shape[1]
         ring = 5                                                          # result slots: groups in flight (<= 3) + margin
         h_rows = torch.empty(ring, F, pipe.outs.shape[2], 8).pin_memory()
@@ -249,8 +255,7 @@ class YOLO:
             g = state["first"].get(frame_idx - f)
             if g is None:                                                 # a group left over from an abandoned generator
                 return
-            b = pipe.bufs[g % pipe.nb]
-            nv = pipe.valid[g % pipe.nb]
+            b, nv = pipe.cur_bufs, pipe.cur_valid                         # the set this tracker call read (the pipeline's own index, not g)
             if f != nv - 1:
                 return
             slot = g % ring

@@ -141,7 +141,7 @@ def test_yolo_track_graph_path_equals_oracle(weights, nk):
     model.close()
 
 
-@pytest.mark.parametrize("batch", [1, 4, 16])
+@pytest.mark.parametrize("batch", [1, 4, 16, 32])
 def test_yolo_track_stream_equals_oracle(batch):
     """the throughput form: groups of `batch` frames through the overlapped pipeline, partial last group included"""
     model, frames, ref = _synthetic_model()
@@ -149,6 +149,41 @@ def test_yolo_track_stream_equals_oracle(batch):
     for k, res in enumerate(model.track_stream(iter(frames), batch=batch, device=0)):
         _check_tracked(res, ref[k][1], ref[k][2], k)
         assert res[0].orig_img is frames[k]
+        n += 1
+    assert n == NF_
+    model.close()
+
+
+@pytest.mark.parametrize("batch,cmc", [(4, False), (32, False), (4, True), (3, True)])
+def test_yolo_track_stream_called_twice_and_after_an_abandoned_generator(batch, cmc):
+    """track_stream on the same model object again: the cached pipeline's buffer-set rotation does not restart
+    with the generator's group numbering, and a partial last group must leave the right 'previous frame' for the camera-motion
+    estimate of the next call.  17 frames = 4 full groups + 1 frame at batch 4 (5 groups: not a multiple of the 3 buffer sets);
+    then the rest of the clip; then a generator abandoned half way, and a third call picking up where it stopped."""
+    model, frames, ref = _synthetic_model(cmc=cmc)
+    n = 0
+    for part in (frames[:17], frames[17:26]):
+        for res in model.track_stream(iter(part), batch=batch, device=0):
+            _check_tracked(res, ref[n][1], ref[n][2], n)
+            assert res[0].orig_img is frames[n]
+            n += 1
+    assert n == 26
+    model.close()
+    # abandoned generator on one pipeline: consume a few results, drop it, go on from the frames it had taken in
+    model, frames, ref = _synthetic_model(cmc=cmc)
+    gen = model.track_stream(iter(frames[:20]), batch=batch, device=0)
+    got = 0
+    for res in gen:
+        _check_tracked(res, ref[got][1], ref[got][2], got)
+        got += 1
+        if got == 2:
+            break
+    gen.close()
+    k0 = model._frame_index                                   # frames the abandoned call had submitted: all tracked, in order
+    assert got <= k0 <= 20
+    n = k0
+    for res in model.track_stream(iter(frames[k0:]), batch=batch, device=0):
+        _check_tracked(res, ref[n][1], ref[n][2], n)
         n += 1
     assert n == NF_
     model.close()
