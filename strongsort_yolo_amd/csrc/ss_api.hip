@@ -139,8 +139,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(feat_unit, FM * S * D * SS_F); A(feat_frag, FM * S * SS_NCT * SS_TILE_FLOATS);
     A(tlwh, FM * S * D * 4); A(xyah, FM * S * D * 4);
     A(M, S * T * FM * D); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
-    d.items_cap = (int)(S * SS_PLMAX * (SS_TLMAX / SS_CHUNK / 8));
-    A(items, 8 * (size_t)d.items_cap * 4); A(n_items, 8);
+    d.items_cap = (int)(S * 4096);        // records per XCD list (<= F * max(cos_grid / (S F), pairs * ceil(tiles / SS_RECT)) per stream, spread over 8 lists)
+    A(items, 8 * (size_t)d.items_cap * 8); A(n_items, 8);
     A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4); A(timeline, 4096 * 16);
     if (cfg->debug) {
         A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);

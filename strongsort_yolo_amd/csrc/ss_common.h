@@ -21,7 +21,7 @@
 #define SS_FMAX 32            // frames of a stream that one tracker call (group) may carry
 #define SS_TLMAX (SS_MAXT * SS_NRT)          // gallery tiles of a stream
 #define SS_PLMAX (SS_FMAX * SS_NCT / 2)      // column-tile pairs of a stream's group
-#define SS_CHUNK 8            // gallery tiles per association work item (one per wave of the workgroup)
+#define SS_RECT 28            // gallery tiles per association work record at most (its 128-byte record carries their tile words)
 
 #define SS_TENTATIVE 1
 #define SS_CONFIRMED 2
@@ -79,8 +79,9 @@ struct SSDev {
     int2* pl;                   // [S][PLMAX] column-tile pairs of the group {frame, ct0 | two<<8 | D<<16}, by frame
     int* n_pl;                  // [S]
     int* pf;                    // [S][FMAX+1] first pair of frame f (pf[F] = n_pl)
-    int4* items;                // [8][items_cap][4] association work items per XCD: 64-byte records {stream, frame, pair word,
-                                //   tiles} + 8 packed tile words (slot | row tile<<8 | count<<12 | ring head<<20), snapshot at group start
+    int4* items;                // [8][items_cap][8] association work records per XCD: 128 bytes = {stream, frame, pair word,
+                                //   first tile | tiles<<16} + SS_RECT packed tile words (slot | row tile<<8 | count<<12 | ring head<<20),
+                                //   snapshot at group start
     int items_cap;
     int* n_items;               // [8] (re-armed by k_frame)
     // per-frame hand-off k_frame -> k_post -> k_newrow

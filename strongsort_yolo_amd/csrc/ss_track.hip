@@ -15,6 +15,14 @@
 #include <hip/hip_ext.h>
 #include "ss_common.h"
 
+// Memory operations without a return value as inline assembly: the compiler's wait-count pass does not see them, so they do
+// not mix a "store" event into the vector-memory counter — which would force s_waitcnt vmcnt(0) (i.e. the completion of the
+// store / atomic itself, and the end of every prefetch in flight) before each later use of a loaded value.
+__device__ __forceinline__ void ss_atomic_min_nr(int* p, int v) { asm volatile("global_atomic_smin %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ss_atomic_umin64_nr(unsigned long long* p, unsigned long long v) { asm volatile("global_atomic_umin_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ss_atomic_umax64_nr(unsigned long long* p, unsigned long long v) { asm volatile("global_atomic_umax_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ss_store_nr(long long* p, long long v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+
 // =================================================================================================
 // block / wave helpers
 // =================================================================================================
@@ -531,7 +539,7 @@ __device__ inline void gallery_append_wave(float* gal_track, int b, const float*
 __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 {
     __shared__ int wtot[4];
-    __shared__ int xcd_cnt[8], xcd_base[8];
+    __shared__ int lcnt[8], lbase[8], npf[SS_FMAX], roff[SS_PLMAX + 1];
     __shared__ int tlw[SS_TLMAX];             // packed gallery tiles of the stream (work-list block only)
     __shared__ int2 plw[SS_PLMAX];
     __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
@@ -566,31 +574,51 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
             }
         }
         if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_pl[s] = ptot; }
-        // Work items = (tile chunk, pair), one list per XCD: chunk c of stream s goes to list (c + s) % 8 with its pairs
-        // adjacent, and k_assoc's workgroup b serves list b % 8 (the dispatcher places block b on XCD b % 8), so the
-        // workgroups that need the same 256 KiB of gallery run on the same XCD at the same time: one of them pulls it
-        // from HBM, the others hit that XCD's L2.
-        const int nchunk = (ttot + SS_CHUNK - 1) / SS_CHUNK;
-        if (tid < 8) {
-            const int c0 = (tid - s) & 7;                              // first chunk of this stream on XCD tid
-            const int cnt = c0 < nchunk ? (nchunk - c0 + 7) / 8 : 0;
-            xcd_cnt[tid] = cnt;
-            xcd_base[tid] = cnt * ptot ? atomicAdd(dev.n_items + tid, cnt * ptot) : 0;
-        }
+        // Work records (one workgroup of k_assoc each) = (column-tile pair of one frame, range of <= SS_RECT gallery tiles).
+        // A pair is cut into n_g ranges of (almost) equal length: n_g = the workgroups a pair can have when the launch's
+        // cos_grid workgroups are shared evenly by the S*F frames and the frame's pairs, but ranges of at least 8 tiles (one
+        // whole tile per wave) and at most SS_RECT (the record carries its tile words).  Inside k_assoc the 8 waves of the
+        // workgroup split the range's 8*nt k-segments into 8 equal contiguous runs, so every wave of every workgroup of the
+        // launch has the same amount of matrix work (+-1 segment).  Range j of every frame of stream s goes to list
+        // (j + s) % 8 (n_g >= 8) and k_assoc's workgroup b serves list b % 8 (the dispatcher places block b on XCD b % 8):
+        // the workgroups that need the same part of the gallery run on the same XCD — one pulls it from HBM, the others hit
+        // that XCD's L2.
+        if (tid < F) npf[tid] = np;
+        if (tid < 8) lcnt[tid] = 0;
         __syncthreads();
-        // a work item is one self-contained 64-byte record: {stream, frame, pair word, tiles} + the 8 packed tile words
-        for (int x = 0; x < 8; ++x) {
-            const int nit = xcd_cnt[x] * ptot, c0 = (x - s) & 7;
-            int4* list = dev.items + ((size_t)x * dev.items_cap + xcd_base[x]) * 4;
-            for (int i = tid; i < nit; i += 256) {
-                const int ch = c0 + 8 * (i / ptot), pp = i % ptot;
-                const int t0 = ch * SS_CHUNK, nt = min(SS_CHUNK, ttot - t0);
-                int tw[8];
+        const int n_sf = max(1, dev.cos_grid / (S * F));
+        int ng = 0;
+        if (tid < ptot && ttot > 0) {
+            ng = min(n_sf / npf[plw[tid].x], max(1, ttot / 8));
+            ng = max(ng, (ttot + SS_RECT - 1) / SS_RECT);
+        }
+        int ro, NR;
+        block_scan_sum256(ng, wtot, ro, NR);
+        if (tid < ptot) roff[tid] = ro;
+        if (tid == 0) roff[ptot] = NR;
+        __syncthreads();
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int r = tid; r < NR; r += 256) {
+                int lo = 0, hi = ptot;                                 // pair of record r: roff[lo] <= r < roff[lo + 1]
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= r) lo = mid; else hi = mid; }
+                const int pp = lo, j = r - roff[pp], ngp = roff[pp + 1] - roff[pp];
+                const int x = (j + s + (ngp < 8 ? pp * ngp : 0)) & 7;
+                const int pos = atomicAdd(&lcnt[x], 1);
+                if (pass == 0) continue;
+                if (lbase[x] + pos >= dev.items_cap) { dev.err[s] = SS_ERR_CAPACITY; continue; }
+                const int t0 = (int)((long long)j * ttot / ngp), t1 = (int)((long long)(j + 1) * ttot / ngp), nt = t1 - t0;
+                int4* rec = dev.items + ((size_t)x * dev.items_cap + lbase[x] + pos) * 8;
+                int tw[SS_RECT];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
-                list[i * 4 + 0] = make_int4(s, plw[pp].x, plw[pp].y, nt);
-                list[i * 4 + 1] = make_int4(tw[0], tw[1], tw[2], tw[3]);
-                list[i * 4 + 2] = make_int4(tw[4], tw[5], tw[6], tw[7]);
+                for (int u = 0; u < SS_RECT; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
+                rec[0] = make_int4(s, plw[pp].x, plw[pp].y, t0 | (nt << 16));
+#pragma unroll
+                for (int u = 0; u < SS_RECT / 4; ++u) rec[1 + u] = make_int4(tw[4 * u], tw[4 * u + 1], tw[4 * u + 2], tw[4 * u + 3]);
+            }
+            __syncthreads();
+            if (pass == 0) {
+                if (tid < 8) { lbase[tid] = lcnt[tid] ? atomicAdd(dev.n_items + tid, lcnt[tid]) : 0; lcnt[tid] = 0; }
+                __syncthreads();
             }
         }
         return;
@@ -648,17 +676,22 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 // group, so frame f must not see the rows at head .. head + f - 1 (their replacements are added by k_newrow).
 // The gallery is therefore read ONCE per group, not once per frame.
 //
-// Work item = (stream, pair of 16-detection column tiles of one frame, chunk of <= 8 gallery tiles); one WAVE per
-// gallery tile: the wave walks the tile's 8 k-segments (8 x 16 v_mfma_f32_16x16x4_f32 per column tile, two
-// independent accumulation chains), adds the segment sums left to right in registers (oracle order) and reduces
-// min-over-rows with two shuffles; no LDS combine, no barriers while a tile is processed.  The tile arrives as 8
-// pieces of 4 KiB per wave, prefetched 3 pieces ahead through a 4-deep register ring (ordinary loads, so the counted
-// vmcnt keeps 3 pieces in flight); the pair's detection operand B (2 x 32 KiB fragment tiles) is staged once per
-// item in LDS and shared by the 8 waves; its global loads are issued together with the first gallery pieces.
-// Ragged last tile: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
-// profiling aid (ss_assoc_timeline): wall-clock stamps (100 MHz) of wave 0 of every workgroup's first item
+// Work record = (stream, pair of 16-detection column tiles of one frame, range of nt <= SS_RECT gallery tiles), one
+// workgroup of 8 waves per record (k_group_prep).  The pair's detection operand B (2 x 32 KiB fragment tiles) is staged once
+// in LDS; the range's 8*nt k-segments (a tile = 8 segments of 64 k, 4 KiB of gallery per segment and wave) are cut into 8
+// equal contiguous runs, one per wave, so all waves carry the same number of segments.  A segment = 8 x 16
+// v_mfma_f32_16x16x4_f32 per column tile into a fresh accumulator (two independent chains); a tile's segment sums are added
+// left to right (oracle order).  Where a run boundary cuts a tile, the wave that owns the tile's first segments computes them
+// FIRST and hands its running sum to the next wave through LDS (one 2 KiB slot per wave + a flag); that wave processes the
+// rest of the tile LAST, continues the sum in the same order and finishes the tile — bit-identical to one wave walking
+// the whole tile.  Finishing = rows not in the ring at frame f masked, min over the tile's 16 rows with two shuffles,
+// atomic min on an order-preserving key.  No barriers while a record is processed.  The gallery arrives as 4 KiB pieces
+// per wave, prefetched 3 pieces ahead through a 4-deep register ring (ordinary loads, so the counted vmcnt keeps 3 pieces
+// in flight); B's global loads are issued together with the first gallery pieces.  nt <= 8: one whole tile per wave.
+// Ragged last tile of a track: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
+// profiling aid (ss_assoc_timeline): wall-clock stamps (100 MHz) of wave 0 of every workgroup's first record
 // (a separate instantiation: the stamps cost registers, the production kernel must keep 2 workgroups per CU)
-#define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) dev.timeline[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) ss_store_nr(dev.timeline + blockIdx.x * 16 + (i), wall_clock64()); } while (0)
 
 template <bool TL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc(SSDev dev)
@@ -666,45 +699,63 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     bool first_item = true;
     SS_TL(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB
+    float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB: B of the record's pair
+    float4* hand = bl + 4096;                                      // [7][2][64] float4 = 14 KiB: running sums wave w -> wave w+1
+    int* hflag = reinterpret_cast<int*>(hand + 7 * 128);           // [8] record number whose sum is in the slot
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wu = __builtin_amdgcn_readfirstlane(w);
-    if (dev.ts_enable && threadIdx.x == 0) atomicMin(dev.tstamp, (unsigned long long)wall_clock64());
+    if (threadIdx.x < 8) hflag[threadIdx.x] = 0;                    // ordered before its first use by the staging barriers
+    if (dev.ts_enable && threadIdx.x == 0) ss_atomic_umin64_nr(dev.tstamp, (unsigned long long)wall_clock64());
     const int xcd = blockIdx.x & 7;                                  // this workgroup's list (see k_group_prep)
-    const int4* items = dev.items + (size_t)xcd * dev.items_cap * 4;
+    const int* items = reinterpret_cast<const int*>(dev.items) + (size_t)xcd * dev.items_cap * 32;
     int it = blockIdx.x >> 3;
-    // the first record is fetched together with the list length (one memory latency, not two)
-    int4 r0 = items[it * 4], r1 = items[it * 4 + 1], r2 = items[it * 4 + 2];
+    // the first record is fetched together with the list length (one memory latency, not two); lane i holds word i
+    int rec = items[(size_t)it * 32 + (l & 31)];
     const int n_items = dev.n_items[xcd];
     const int budget = dev.budget;
+    int seq = 0;
     for (; it < n_items; it += gridDim.x >> 3) {
-        const int s = __builtin_amdgcn_readfirstlane(r0.x), f = __builtin_amdgcn_readfirstlane(r0.y);
-        const int pw = __builtin_amdgcn_readfirstlane(r0.z), nt = __builtin_amdgcn_readfirstlane(r0.w);
+        ++seq;
+        const int cur = rec;                                         // words 4.. = the range's packed tile words
+        const int s = __builtin_amdgcn_readlane(cur, 0), f = __builtin_amdgcn_readlane(cur, 1);
+        const int pw = __builtin_amdgcn_readlane(cur, 2), nt = __builtin_amdgcn_readlane(cur, 3) >> 16;
         const int ct0 = pw & 0xff, D = pw >> 16;
         const bool two = (pw >> 8) & 1;
-        const int twv = wu == 0 ? r1.x : wu == 1 ? r1.y : wu == 2 ? r1.z : wu == 3 ? r1.w : wu == 4 ? r2.x : wu == 5 ? r2.y : wu == 6 ? r2.z : r2.w;
-        const int tword = __builtin_amdgcn_readfirstlane(twv);
         {   // next record (consumed at the end of the iteration; stale values past the end are never used)
             const int nx = it + (gridDim.x >> 3);
-            if (nx < n_items) { r0 = items[nx * 4]; r1 = items[nx * 4 + 1]; r2 = items[nx * 4 + 2]; }
+            if (nx < n_items) rec = items[(size_t)nx * 32 + (l & 31)];
         }
         SS_TL(1);                                                    // record in registers
-        const bool has = wu < nt;
-        int slot = 0, rt = 0, count = 0, head = 0;
-        const char* base = reinterpret_cast<const char*>(dev.gallery);
-        unsigned vo = 0;
-        auto ld = [&](int sg, float4 a[4]) {
+        // this wave's run of segments: [H] first nH segments of tile `last` (sum handed on), [M] nM whole tiles from
+        // mfirst, [T] segments a0..7 of tile `first` (sum received)
+        bool has = true;
+        int nsteps = nt, nH = 0, nM = 1, mfirst = wu, first = wu, a0 = 0, last = wu;
+        if (nt <= 8) { has = wu < nt; nsteps = 8; }
+        else {
+            const int g0 = wu * nt, g1 = g0 + nt;
+            first = g0 >> 3; a0 = g0 & 7; last = g1 >> 3; nH = g1 & 7;
+            mfirst = first + (a0 ? 1 : 0); nM = last - mfirst;
+        }
+        const int nHM = nH + 8 * nM;
+        auto where = [&](int i, int& q, int& sg) {                  // segment i of the run -> (tile of the record, k-segment); selects, no branches
+            const bool h = i < nH, m = i < nHM;
+            q = h ? last : m ? mfirst + ((i - nH) >> 3) : first;
+            sg = h ? i : m ? (i - nH) & 7 : a0 + (i - nHM);
+        };
+        const char* gbase = reinterpret_cast<const char*>(dev.gallery) + (size_t)s * SS_MAXT * SS_NRT * SS_TILE_FLOATS * 4;
+        auto ld = [&](int i, float4 a[4]) {
+            int q, sg;
+            where(i, q, sg);
+            const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
+            const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff;
+            const char* p = gbase + ((size_t)(slot * SS_NRT + rt) * SS_TILE_FLOATS + (size_t)sg * 1024) * 4;
+            const bool ok = (l & 15) < count - rt * SS_TILE;
+            const unsigned vo = (unsigned)((ok ? l : (l & ~15)) * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(base + vo + sg * 4096 + j * 1024);
+            for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(p + vo + j * 1024);
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
-        if (has) {
-            slot = tword & 0xff; rt = (tword >> 8) & 7; count = (tword >> 12) & 0xff; head = (tword >> 20) & 0x7f;
-            base += ((((size_t)s * SS_MAXT + slot) * SS_NRT + rt) * SS_TILE_FLOATS) * 4;
-            const bool ok = (l & 15) < count - rt * SS_TILE;
-            vo = (unsigned)((ok ? l : (l & ~15)) * 16);
-            ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]);                 // on the wire before the B staging
-        }
+        if (has) { ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]); }        // on the wire before the B staging (nsteps >= 8)
         // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
         const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
         // (a lone column tile is staged twice: branch-free, and the second copy's results are never stored)
@@ -712,7 +763,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int tx = threadIdx.x;
         const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
         const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
-        __syncthreads();                                             // the previous item's readers are done with bl
+        __syncthreads();                                             // the previous record's readers are done with bl / hand
         SS_TL(2);                                                    // first gallery pieces + B landed
         bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
         bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
@@ -720,21 +771,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         SS_TL(3);                                                    // B staged
         if (has) {
             const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
-            const char* bls1 = bls + 32768;
             f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
             // B fragments are read from LDS one step (8 MFMAs) ahead of their use, so the LDS latency never shows
-            float4 bq0 = *reinterpret_cast<const float4*>(bls), bq1 = *reinterpret_cast<const float4*>(bls1);
-#pragma unroll
-            for (int sg = 0; sg < 8; ++sg) {
-                if (sg + 3 < 8) ld(sg + 3, ra[(sg + 3) & 3]);       // prefetch piece sg+3 into ring slot (sg+3)%4
-                const float4* a = ra[sg & 3];
+            int q0, sg0;
+            where(0, q0, sg0);
+            float4 bq0 = *reinterpret_cast<const float4*>(bls + sg0 * 4096), bq1 = *reinterpret_cast<const float4*>(bls + sg0 * 4096 + 32768);
+            // one k-segment: prefetch (PF: piece i+3, clamped to the run's last piece so that the number of loads in flight
+            // does not depend on the path — the compiler's wait counts stay exact), 32 MFMAs, running sum, tile end / hand-over
+            auto step = [&](int i, float4* a, float4* anew, bool pf) {
+                if (pf) ld(min(i + 3, nsteps - 1), anew);
+                int q, sg, qn, sgn;
+                where(i, q, sg);
+                where(min(i + 1, nsteps - 1), qn, sgn);
+                const char* bcur = bls + sg * 4096;
+                const char* bnxt = bls + sgn * 4096;              // first fragments of the next segment (unused after the last)
                 f32x4 acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 b0 = bq0, b1 = bq1;
-                    const int nx = 4 * sg + j + 1;                   // next step's fragments (the last step re-reads step 0: unused)
-                    bq0 = *reinterpret_cast<const float4*>(bls + (nx & 31) * 1024);
-                    bq1 = *reinterpret_cast<const float4*>(bls1 + (nx & 31) * 1024);
+                    const char* bn = j < 3 ? bcur + (j + 1) * 1024 : bnxt;
+                    bq0 = *reinterpret_cast<const float4*>(bn);
+                    bq1 = *reinterpret_cast<const float4*>(bn + 32768);
                     acc0 = SS_MFMA16(a[j].x, b0.x, acc0); acc1 = SS_MFMA16(a[j].x, b1.x, acc1);
                     acc0 = SS_MFMA16(a[j].y, b0.y, acc0); acc1 = SS_MFMA16(a[j].y, b1.y, acc1);
                     acc0 = SS_MFMA16(a[j].z, b0.z, acc0); acc1 = SS_MFMA16(a[j].z, b1.z, acc1);
@@ -743,27 +800,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
                 if (sg == 0) { tot0 = acc0; tot1 = acc1; }
                 else {
+                    if (i == nHM && a0 != 0) {
+                        // the tile's first a0 segment sums, added up in order by the previous wave
+                        while (__hip_atomic_load(&hflag[wu - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seq) __builtin_amdgcn_s_sleep(1);
+                        const float4 h0 = hand[(wu - 1) * 128 + l], h1 = hand[(wu - 1) * 128 + 64 + l];
+                        tot0[0] = h0.x; tot0[1] = h0.y; tot0[2] = h0.z; tot0[3] = h0.w;
+                        tot1[0] = h1.x; tot1[1] = h1.y; tot1[2] = h1.z; tot1[3] = h1.w;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { tot0[r] = tot0[r] + acc0[r]; tot1[r] = tot1[r] + acc1[r]; }
                 }
-                SS_TL(4 + sg);
-            }
-            // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
-            float m0 = INFINITY, m1 = INFINITY;
+                if (TL && !(i & 1) && i < 16) SS_TL(4 + (i >> 1));      // stamps after segments 0, 2, 4, ..., 14 of the run
+                if (i == nH - 1) {
+                    // hand the running sum of tile `last` to the wave that owns the rest of it
+                    hand[wu * 128 + l] = make_float4(tot0[0], tot0[1], tot0[2], tot0[3]);
+                    hand[wu * 128 + 64 + l] = make_float4(tot1[0], tot1[1], tot1[2], tot1[3]);
+                    __hip_atomic_store(&hflag[wu], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if (sg == 7) {
+                    // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
+                    const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
+                    const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff, head = (tw >> 20) & 0x7f;
+                    float m0 = INFINITY, m1 = INFINITY;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int pos = rt * SS_TILE + 4 * (l >> 4) + r;
-                int jrel = pos - head;
-                if (jrel < 0) jrel += budget;
-                const bool valid = pos < count && jrel >= f;
-                m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
-                m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                    for (int r = 0; r < 4; ++r) {
+                        const int pos = rt * SS_TILE + 4 * (l >> 4) + r;
+                        int jrel = pos - head;
+                        if (jrel < 0) jrel += budget;
+                        const bool valid = pos < count && jrel >= f;
+                        m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
+                        m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                    }
+                    m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
+                    m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
+                    int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
+                    if (l < 16) { if (ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m0)); }
+                    else if (l < 32) { if (two && ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m1)); }
+                }
+            };
+            int i = 0;
+            for (; i + 4 <= nsteps; i += 4) {
+                step(i, ra[0], ra[3], true); step(i + 1, ra[1], ra[0], true); step(i + 2, ra[2], ra[1], true); step(i + 3, ra[3], ra[2], true);
             }
-            m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
-            m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
-            int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
-            if (l < 16) { if (ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m0)); }
-            else if (l < 32) { if (two && ct0 * SS_TILE + l < D) atomicMin(out + l, ss_fkey(m1)); }
+            if (i < nsteps) step(i, ra[0], nullptr, false);            // the run's last 0..3 segments: their pieces are on the way already
+            if (i + 1 < nsteps) step(i + 1, ra[1], nullptr, false);
+            if (i + 2 < nsteps) step(i + 2, ra[2], nullptr, false);
         }
         SS_TL(12);
         first_item = false;
@@ -771,7 +852,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (dev.ts_enable) {
         __builtin_amdgcn_s_waitcnt(0);                               // this wave's memory operations have completed
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(dev.tstamp + 1, (unsigned long long)wall_clock64());
+        if (threadIdx.x == 0) ss_atomic_umax64_nr(dev.tstamp + 1, (unsigned long long)wall_clock64());
     }
 }
 
@@ -1283,7 +1364,7 @@ __global__ void k_kat_iou(const double* ttlwh, int T, const double* dtlwh, int D
 
 // ---- launch helpers used by ss_api.hip -------------------------------------------------------------
 size_t ss_lsap_lds_bytes() { return 256 * 4; }
-size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4; }
+size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 7 * 2048 + 64; }
 
 extern "C" void ss_step_kernel_attr()
 {

@@ -30,9 +30,11 @@ us, n = eng.assoc_inkernel_timing(0)
 act = tl[:, 12] > 0
 t0 = tl[act, 0].min()
 rel = (tl[act] - t0) / 100.0
-names = ["entry", "record", "loads", "staged"] + [f"seg{i}" for i in range(8)] + ["done"]
+names = ["entry", "record", "loads", "staged"] + [f"seg{2 * i}" for i in range(8)] + ["done"]
 print(f"S={S} FB={FB}: in-kernel duration {us:.2f} us over {n} launch(es); {int(act.sum())} workgroups had work")
 print("stamp     min     median  max   (us from the first workgroup's entry)")
 for i, nm in enumerate(names):
     c = rel[:, i]
-    print(f"{nm:7s} {c.min():7.2f} {np.median(c):7.2f} {c.max():7.2f}")
+    c = c[tl[act][:, i] > 0]                     # runs shorter than 15 segments leave the later stamps empty
+    if len(c):
+        print(f"{nm:7s} {c.min():7.2f} {np.median(c):7.2f} {c.max():7.2f}   ({len(c)} workgroups)")
