@@ -28,6 +28,7 @@
 #define SS_DELETED 3
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // Fragment-major feature layout (16-row gallery tiles and 16-detection column tiles):
 //   float index = ((q*4 + ks)*16 + i)*4 + c   holds element k = 16q + 4c + ks of row i of the tile

@@ -629,6 +629,18 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         if (!dev.slot_used[sb + slot] || dev.state[sb + slot] != SS_CONFIRMED) return;
         int4* m = reinterpret_cast<int4*>(dev.M + (sb + slot) * SS_FMAX * SS_MAXD);
         for (int i = tid; i < F * SS_MAXD / 4; i += 256) m[i] = make_int4(SS_KEY_INF, SS_KEY_INF, SS_KEY_INF, SS_KEY_INF);
+        // ... and pull the track's gallery towards the chip: inside a frame pipeline the networks' kernels have pushed it out
+        // of the memory-side cache since the last group, and every workgroup of k_assoc would start on HBM misses (its launch
+        // was 3-7 us longer there than in a tracker-only loop).  One load per 128-byte line.
+        if (dev.F > 1) {
+            const int rows = dev.gal_count[sb + slot];
+            const char* g = reinterpret_cast<const char*>(dev.gallery + (sb + slot) * SS_NRT * SS_TILE_FLOATS);
+            const int lines = (rows + SS_TILE - 1) / SS_TILE * (SS_TILE_FLOATS * 4 / 128);
+            int acc = 0;
+#pragma unroll 8
+            for (int i = tid; i < lines; i += 256) acc |= *reinterpret_cast<const int*>(g + (size_t)i * 128);
+            asm volatile("" ::"v"(acc));                             // the loads stay, their values go nowhere
+        }
         return;
     }
     // ---- detection prep: one wave per detection of frame f ----
@@ -710,8 +722,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int* items = reinterpret_cast<const int*>(dev.items) + (size_t)xcd * dev.items_cap * 32;
     int it = blockIdx.x >> 3;
     // the first record is fetched together with the list length (one memory latency, not two); lane i holds word i
-    int rec = items[(size_t)it * 32 + (l & 31)];
-    const int n_items = dev.n_items[xcd];
+    // The first record comes through the SCALAR cache: at the start of a launch a vector load of these 128 bytes took 0.7 (first
+    // workgroup) to 6.4 us (median 3.8) while every workgroup of the chip issues its first vector access, a scalar load 0.85 us
+    // (timeline, r03).  Lane i of `rec` holds word i.  The following records are prefetched by an ordinary vector load.
+    int rec, n_items;
+    {
+        const int* rp = items + (size_t)it * 32;
+        const int* np = dev.n_items + xcd;
+        i32x16 lo, hi;
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(lo), "=&s"(hi), "=&s"(n_items) : "s"(rp), "s"(np) : "memory");
+        rec = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { rec = l == k ? lo[k] : rec; rec = l == 16 + k ? hi[k] : rec; }
+    }
     const int budget = dev.budget;
     int seq = 0;
     for (; it < n_items; it += gridDim.x >> 3) {
@@ -725,6 +749,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int nx = it + (gridDim.x >> 3);
             if (nx < n_items) rec = items[(size_t)nx * 32 + (l & 31)];
         }
+#if defined(SS_EXP_T13) || defined(SS_EXP_T14)
+        if (TL) {
+#ifdef SS_EXP_T13
+            if (wu == 0) { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 5); asm volatile("" ::"v"(x)); }
+#else
+            { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 5); asm volatile("" ::"v"(x)); }
+#endif
+            __builtin_amdgcn_s_waitcnt(0);
+            SS_TL(2);
+            { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 64 + 5); asm volatile("" ::"v"(x)); }
+            __builtin_amdgcn_s_waitcnt(0);
+            SS_TL(3);
+            return;
+        }
+#endif
         SS_TL(1);                                                    // record in registers
         // this wave's run of segments: [H] first nH segments of tile `last` (sum handed on), [M] nM whole tiles from
         // mfirst, [T] segments a0..7 of tile `first` (sum received)
@@ -755,6 +794,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(p + vo + j * 1024);
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
+#ifdef SS_EXP_T12
+        if (first_item) {
+            if (threadIdx.x == 0) {
+                const int tw0 = __builtin_amdgcn_readlane(cur, 4);
+                const float* g0p = reinterpret_cast<const float*>(gbase + ((size_t)((tw0 & 0xff) * SS_NRT + ((tw0 >> 8) & 7)) * SS_TILE_FLOATS) * 4);
+                const float* f0p = dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS;
+                float x = __builtin_nontemporal_load(g0p) + __builtin_nontemporal_load(f0p);
+                asm volatile("" ::"v"(x));
+            }
+            __syncthreads();
+        }
+#endif
         if (has) { ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]); }        // on the wire before the B staging (nsteps >= 8)
         // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
         const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
@@ -1378,7 +1429,12 @@ extern "C" void ss_step_kernel_attr()
 void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
-    if (dev.ts_enable > 1) hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    if (dev.ts_enable > 1) {
+        hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+#ifdef SS_EXP_TWICE
+        hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+#endif
+    }
     else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
     else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
     if (ev_assoc) (void)hipEventRecord(ev_assoc, st);          // the caller's "association done" event (ss_track_set_assoc_event)

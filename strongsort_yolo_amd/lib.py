@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libstrongsort_hip.so")
+SO_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_HERE, "libstrongsort_hip.so")     # SS_LIB_PATH: a differently built library (kernel experiments)
 CSRC = os.path.join(_HERE, "csrc")
 
 SS_OK, SS_ERR_INVALID, SS_ERR_CAPACITY, SS_ERR_HIP, SS_ERR_INFEASIBLE = 0, -1, -2, -3, -4

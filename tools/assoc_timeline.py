@@ -27,7 +27,7 @@ for k0 in range(0, frames, FB):
 torch.cuda.synchronize()
 tl = eng.assoc_timeline(512)
 us, n = eng.assoc_inkernel_timing(0)
-act = tl[:, 12] > 0
+act = tl[:, 0] > 0
 t0 = tl[act, 0].min()
 rel = (tl[act] - t0) / 100.0
 names = ["entry", "record", "loads", "staged"] + [f"seg{2 * i}" for i in range(8)] + ["done"]
@@ -38,3 +38,9 @@ for i, nm in enumerate(names):
     c = c[tl[act][:, i] > 0]                     # runs shorter than 15 segments leave the later stamps empty
     if len(c):
         print(f"{nm:7s} {c.min():7.2f} {np.median(c):7.2f} {c.max():7.2f}   ({len(c)} workgroups)")
+if os.environ.get("SS_TL_DUMP"):
+    i = int(os.environ["SS_TL_DUMP"])
+    d = (tl[:, i] - tl[:, 0]) / 100.0
+    print(f"stamp {i} - entry, by XCD (rows) x workgroup index within XCD (64 cols, us):")
+    for x in range(8):
+        print(x, " ".join(f"{v:4.1f}" for v in d[x::8][:64]))
