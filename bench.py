@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--defer-track", type=int, default=1, help="1: the tracker call of a group is enqueued after the last stage's stream has waited for stage 0 of the next group (it then runs beside the start of that group, away from the OSNet row-stream kernel)")
     ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
     ap.add_argument("--frame-batch", type=int, default=32, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (ss_set_option), e.g. --opt assoc_comp_rows=0")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -378,6 +379,8 @@ def main():
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
                    run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track)} if overlap else {}))
+    for kv in args.opt:
+        pipe.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     gs = scale_geometry(pipe.geom, H, W)
     nc, A = pipe.nc, pipe.n_anchors
     wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A, pipe.nk) for s in range(S)]

@@ -187,7 +187,9 @@ int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, co
                          int img_h, int img_w, float* h_out, int cap_rows, int* n_out);
 
 /* Tuning switches of a context (host state, read at the next tracker call):
- *   "cos_grid"     persistent workgroups of the association kernel, a multiple of 8 (default 512 = two per CU) */
+ *   "cos_grid"         persistent workgroups of the association kernel, a multiple of 8 (default 512 = two per CU)
+ *   "assoc_comp_rows"  a gallery's last 16-row tile with at most this many rows (0..12, default 12) is cut into 4-row groups
+ *                      and four groups of any tracks form one composite tile of the association kernel (0: off) */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */

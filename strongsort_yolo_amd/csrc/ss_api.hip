@@ -66,6 +66,7 @@ struct ss_ctx {
     hipEvent_t assoc_event;     // what ss_track_set_assoc_event installed (recorded after every association launch)
     struct Back { void* p = nullptr; size_t cap = 0; } back;      // device -> host staging (ss_download)
     int cos_grid;               // persistent workgroups of the association kernel
+    int comp_rows;              // ragged last tiles with at most this many rows travel as 4-row groups of composite tiles (0: never)
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
     bool timing;
@@ -112,6 +113,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->timing = false;
     c->ev_used = 0;
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
+    c->comp_rows = 12;
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
     c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr; c->assoc_event = nullptr;
@@ -140,7 +142,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(tlwh, FM * S * D * 4); A(xyah, FM * S * D * 4);
     A(M, S * T * FM * D); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
     d.items_cap = (int)(S * 4096);        // records per XCD list (<= F * max(cos_grid / (S F), pairs * ceil(tiles / SS_RECT)) per stream, spread over 8 lists)
-    A(items, 8 * (size_t)d.items_cap * 8); A(n_items, 8);
+    A(items, 8 * (size_t)d.items_cap * SS_RECI4); A(n_items, 8);
     A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4); A(timeline, 4096 * 16);
     if (cfg->debug) {
         A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);
@@ -330,7 +332,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     dev.out_rows = d_out; dev.n_out = d_nout;
     // Every launch dimension is fixed by (streams, n_frames): track and detection counts are device-side values read
     // from the work lists, so nothing here needs a host round trip and the sequence can be captured into a HIP graph.
-    dev.cos_grid = c->cos_grid;
+    dev.cos_grid = c->cos_grid; dev.comp_rows = c->comp_rows;
     dev.ts_enable = c->inkernel;
     dev.cmc = c->cmc_warps;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -396,6 +398,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     if (!c || !name) return fail(c, SS_ERR_INVALID, "ss_set_option: null argument");
     const std::string n(name);
     if (n == "cos_grid") { if (value < 8 || value > 4096 || value % 8) return fail(c, SS_ERR_INVALID, "cos_grid: a multiple of 8 in 8..4096"); c->cos_grid = value; }
+    else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;
 }

@@ -21,7 +21,9 @@
 #define SS_FMAX 32            // frames of a stream that one tracker call (group) may carry
 #define SS_TLMAX (SS_MAXT * SS_NRT)          // gallery tiles of a stream
 #define SS_PLMAX (SS_FMAX * SS_NCT / 2)      // column-tile pairs of a stream's group
-#define SS_RECT 28            // gallery tiles per association work record at most (its 128-byte record carries their tile words)
+#define SS_RECT 32            // gallery tiles per association work record at most (the record carries their tile words)
+#define SS_RECW (4 + SS_RECT) // ints per record: {stream, frame, pair word, tiles<<16 | composite<<31} + SS_RECT words (144 bytes)
+#define SS_RECI4 (SS_RECW / 4)
 
 #define SS_TENTATIVE 1
 #define SS_CONFIRMED 2
@@ -29,6 +31,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // Fragment-major feature layout (16-row gallery tiles and 16-detection column tiles):
 //   float index = ((q*4 + ks)*16 + i)*4 + c   holds element k = 16q + 4c + ks of row i of the tile
@@ -55,6 +58,7 @@ struct SSDev {
     int S, F;
     int budget;                 // nn_budget (ring length of a gallery)
     int cos_grid;               // workgroups of the persistent association kernel
+    int comp_rows;              // ragged last gallery tiles of <= comp_rows rows are cut into 4-row groups (composite tiles)
     // persistent per stream
     int *n_tracks, *next_id, *frame, *err;
     int* order;                 // [S][MAXT] slot ids in track-list order
@@ -80,8 +84,9 @@ struct SSDev {
     int2* pl;                   // [S][PLMAX] column-tile pairs of the group {frame, ct0 | two<<8 | D<<16}, by frame
     int* n_pl;                  // [S]
     int* pf;                    // [S][FMAX+1] first pair of frame f (pf[F] = n_pl)
-    int4* items;                // [8][items_cap][8] association work records per XCD: 128 bytes = {stream, frame, pair word,
-                                //   first tile | tiles<<16} + SS_RECT packed tile words (slot | row tile<<8 | count<<12 | ring head<<20),
+    int4* items;                // [8][items_cap][SS_RECI4] association work records per XCD: {stream, frame, pair word, tiles<<16 |
+                                //   composite<<31} + SS_RECT words: packed tiles (slot | row tile<<8 | count<<12 | ring head<<20) or, in a
+                                //   composite record, 4 packed row groups per tile (slot | row tile<<8 | r4<<11 | count<<13 | head<<21);
                                 //   snapshot at group start
     int items_cap;
     int* n_items;               // [8] (re-armed by k_frame)

@@ -541,6 +541,8 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
     __shared__ int wtot[4];
     __shared__ int lcnt[8], lbase[8], npf[SS_FMAX], roff[SS_PLMAX + 1];
     __shared__ int tlw[SS_TLMAX];             // packed gallery tiles of the stream (work-list block only)
+    __shared__ int cgw[SS_MAXT * 3 + 32];     // packed 4-row groups of the ragged last tiles
+    __shared__ int ngs[SS_PLMAX];             // ordinary records of every pair
     __shared__ int2 plw[SS_PLMAX];
     __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
     const int s = blockIdx.x, tid = threadIdx.x, F = dev.F, S = dev.S;
@@ -548,17 +550,27 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
     if (blockIdx.y == 0) {
         // gallery tiles of the tracks that are confirmed when the group starts (snapshot of count / ring head)
         const int nT = dev.n_tracks[s];
-        int ntile = 0, slot = 0, count = 0, head = 0;
+        // A track's last tile usually holds only a few rows (nn_budget 100 = 6 tiles + 4 rows): such rows travel as GROUPS of 4
+        // (rows 4*r4 .. 4*r4+3 of the tile), four groups of any tracks make one composite 16-row tile for k_assoc — 188 instead
+        // of 210 tiles per frame at 30 tracks x 100 rows.  Tiles with 13..15 rows stay ordinary tiles.
+        int ntile = 0, ngrp = 0, slot = 0, count = 0, head = 0;
         if (tid < nT) {
             slot = dev.order[sb + tid];
             if (dev.state[sb + slot] == SS_CONFIRMED) {
                 count = dev.gal_count[sb + slot]; head = dev.gal_head[sb + slot];
-                ntile = (count + SS_TILE - 1) / SS_TILE;
+                const int rem = count % SS_TILE;
+                ntile = count / SS_TILE;
+                if (rem > dev.comp_rows) ++ntile; else ngrp = (rem + 3) / 4;
             }
         }
-        int toff, ttot;
+        int toff, ttot, goff, gtot;
         block_scan_sum256(ntile, wtot, toff, ttot);
         for (int rt = 0; rt < ntile; ++rt) tlw[toff + rt] = slot | (rt << 8) | (count << 12) | (head << 20);   // 8+3+8+7 bits
+        block_scan_sum256(ngrp, wtot, goff, gtot);
+        for (int g = 0; g < ngrp; ++g) cgw[goff + g] = slot | ((count / SS_TILE) << 8) | (g << 11) | (count << 13) | (head << 21);   // 8+3+2+8+7 bits
+        __syncthreads();
+        for (int i = gtot + tid; i < (gtot + 31) / 32 * 32; i += 256) cgw[i] = 0;      // empty groups: count 0, every row masked
+        const int ncomp = (gtot + 3) / 4, ncrec = (ncomp + 7) / 8;                    // composite tiles, records of <= 8 of them
         // column-tile pairs of the group, frame by frame (a pair never spans two frames)
         int np = 0, D = 0;
         if (tid < F) { D = min(dev.n_dets[tid * S + s], SS_MAXD); np = ((D + SS_TILE - 1) / SS_TILE + 1) / 2; }
@@ -587,13 +599,17 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         if (tid < 8) lcnt[tid] = 0;
         __syncthreads();
         const int n_sf = max(1, dev.cos_grid / (S * F));
-        int ng = 0;
-        if (tid < ptot && ttot > 0) {
-            ng = min(n_sf / npf[plw[tid].x], max(1, ttot / 8));
-            ng = max(ng, (ttot + SS_RECT - 1) / SS_RECT);
+        int ng = 0, nr = 0;
+        if (tid < ptot) {
+            if (ttot > 0) {
+                ng = min(max(n_sf / npf[plw[tid].x] - ncrec, 1), max(1, ttot / 8));
+                ng = max(ng, (ttot + SS_RECT - 1) / SS_RECT);
+            }
+            ngs[tid] = ng;
+            nr = ng + ncrec;                                           // + the records of composite tiles (one tile per wave)
         }
         int ro, NR;
-        block_scan_sum256(ng, wtot, ro, NR);
+        block_scan_sum256(nr, wtot, ro, NR);
         if (tid < ptot) roff[tid] = ro;
         if (tid == 0) roff[ptot] = NR;
         __syncthreads();
@@ -601,17 +617,24 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
             for (int r = tid; r < NR; r += 256) {
                 int lo = 0, hi = ptot;                                 // pair of record r: roff[lo] <= r < roff[lo + 1]
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= r) lo = mid; else hi = mid; }
-                const int pp = lo, j = r - roff[pp], ngp = roff[pp + 1] - roff[pp];
-                const int x = (j + s + (ngp < 8 ? pp * ngp : 0)) & 7;
+                const int pp = lo, j = r - roff[pp], nrp = roff[pp + 1] - roff[pp], ngp = ngs[pp];
+                const int x = (j + s + (nrp < 8 ? pp * nrp : 0)) & 7;
                 const int pos = atomicAdd(&lcnt[x], 1);
                 if (pass == 0) continue;
                 if (lbase[x] + pos >= dev.items_cap) { dev.err[s] = SS_ERR_CAPACITY; continue; }
-                const int t0 = (int)((long long)j * ttot / ngp), t1 = (int)((long long)(j + 1) * ttot / ngp), nt = t1 - t0;
-                int4* rec = dev.items + ((size_t)x * dev.items_cap + lbase[x] + pos) * 8;
+                int4* rec = dev.items + ((size_t)x * dev.items_cap + lbase[x] + pos) * SS_RECI4;
                 int tw[SS_RECT];
+                if (j < ngp) {
+                    const int t0 = (int)((long long)j * ttot / ngp), t1 = (int)((long long)(j + 1) * ttot / ngp), nt = t1 - t0;
 #pragma unroll
-                for (int u = 0; u < SS_RECT; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
-                rec[0] = make_int4(s, plw[pp].x, plw[pp].y, t0 | (nt << 16));
+                    for (int u = 0; u < SS_RECT; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
+                    rec[0] = make_int4(s, plw[pp].x, plw[pp].y, nt << 16);
+                } else {
+                    const int c0 = (j - ngp) * 8, nc = min(8, ncomp - c0);             // composite tiles c0 .. c0+nc-1, 4 group words each
+#pragma unroll
+                    for (int u = 0; u < SS_RECT; ++u) tw[u] = cgw[c0 * 4 + u];
+                    rec[0] = make_int4(s, plw[pp].x, plw[pp].y, (nc << 16) | (int)0x80000000);
+                }
 #pragma unroll
                 for (int u = 0; u < SS_RECT / 4; ++u) rec[1 + u] = make_int4(tw[4 * u], tw[4 * u + 1], tw[4 * u + 2], tw[4 * u + 3]);
             }
@@ -703,7 +726,8 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 // Ragged last tile of a track: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
 // profiling aid (ss_assoc_timeline): wall-clock stamps (100 MHz) of wave 0 of every workgroup's first record
 // (a separate instantiation: the stamps cost registers, the production kernel must keep 2 workgroups per CU)
-#define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) ss_store_nr(dev.timeline + blockIdx.x * 16 + (i), wall_clock64()); } while (0)
+#define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) { ss_store_nr(dev.timeline + blockIdx.x * 16 + (i), wall_clock64()); \
+                                                                   if (blockIdx.x < 2048) ss_store_nr(dev.timeline + (blockIdx.x + 2048) * 16 + (i), clock64()); } } while (0)
 
 template <bool TL>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc(SSDev dev)
@@ -719,22 +743,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (threadIdx.x < 8) hflag[threadIdx.x] = 0;                    // ordered before its first use by the staging barriers
     if (dev.ts_enable && threadIdx.x == 0) ss_atomic_umin64_nr(dev.tstamp, (unsigned long long)wall_clock64());
     const int xcd = blockIdx.x & 7;                                  // this workgroup's list (see k_group_prep)
-    const int* items = reinterpret_cast<const int*>(dev.items) + (size_t)xcd * dev.items_cap * 32;
+    const int* items = reinterpret_cast<const int*>(dev.items) + (size_t)xcd * dev.items_cap * SS_RECW;
     int it = blockIdx.x >> 3;
-    // the first record is fetched together with the list length (one memory latency, not two); lane i holds word i
-    // The first record comes through the SCALAR cache: at the start of a launch a vector load of these 128 bytes took 0.7 (first
-    // workgroup) to 6.4 us (median 3.8) while every workgroup of the chip issues its first vector access, a scalar load 0.85 us
-    // (timeline, r03).  Lane i of `rec` holds word i.  The following records are prefetched by an ordinary vector load.
+    // The first record comes through the SCALAR cache: at the start of a launch the first vector load of a workgroup takes 0.7 to
+    // 6.4 us (median 3.8, staggered by XCD) whatever it asks for, a scalar load 0.85 us (timeline, r03); the vector path's start-up
+    // then overlaps the record fetch instead of following it.  Lane i of `rec` holds word i.  The following records are
+    // prefetched by an ordinary vector load.
     int rec, n_items;
     {
-        const int* rp = items + (size_t)it * 32;
+        const int* rp = items + (size_t)it * SS_RECW;
         const int* np = dev.n_items + xcd;
         i32x16 lo, hi;
-        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dword %2, %4, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(lo), "=&s"(hi), "=&s"(n_items) : "s"(rp), "s"(np) : "memory");
+        i32x4 top;
+        asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx4 %2, %4, 0x80\n\ts_load_dword %3, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(lo), "=&s"(hi), "=&s"(top), "=&s"(n_items) : "s"(rp), "s"(np) : "memory");
         rec = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) { rec = l == k ? lo[k] : rec; rec = l == 16 + k ? hi[k] : rec; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec = l == 32 + k ? top[k] : rec;
     }
     const int budget = dev.budget;
     int seq = 0;
@@ -742,28 +769,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         ++seq;
         const int cur = rec;                                         // words 4.. = the range's packed tile words
         const int s = __builtin_amdgcn_readlane(cur, 0), f = __builtin_amdgcn_readlane(cur, 1);
-        const int pw = __builtin_amdgcn_readlane(cur, 2), nt = __builtin_amdgcn_readlane(cur, 3) >> 16;
+        const int pw = __builtin_amdgcn_readlane(cur, 2), w3 = __builtin_amdgcn_readlane(cur, 3), nt = (w3 >> 16) & 0x7fff;
+        const bool comp = w3 < 0;                                    // a record of composite tiles (nt <= 8: one per wave)
         const int ct0 = pw & 0xff, D = pw >> 16;
         const bool two = (pw >> 8) & 1;
         {   // next record (consumed at the end of the iteration; stale values past the end are never used)
             const int nx = it + (gridDim.x >> 3);
-            if (nx < n_items) rec = items[(size_t)nx * 32 + (l & 31)];
+            if (nx < n_items) rec = items[(size_t)nx * SS_RECW + min(l, SS_RECW - 1)];
         }
-#if defined(SS_EXP_T13) || defined(SS_EXP_T14)
-        if (TL) {
-#ifdef SS_EXP_T13
-            if (wu == 0) { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 5); asm volatile("" ::"v"(x)); }
-#else
-            { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 5); asm volatile("" ::"v"(x)); }
-#endif
-            __builtin_amdgcn_s_waitcnt(0);
-            SS_TL(2);
-            { int x = __builtin_nontemporal_load(items + (size_t)it * 32 + 64 + 5); asm volatile("" ::"v"(x)); }
-            __builtin_amdgcn_s_waitcnt(0);
-            SS_TL(3);
-            return;
-        }
-#endif
         SS_TL(1);                                                    // record in registers
         // this wave's run of segments: [H] first nH segments of tile `last` (sum handed on), [M] nM whole tiles from
         // mfirst, [T] segments a0..7 of tile `first` (sum received)
@@ -776,36 +789,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             mfirst = first + (a0 ? 1 : 0); nM = last - mfirst;
         }
         const int nHM = nH + 8 * nM;
+        if (TL && threadIdx.x == 0 && first_item) { ss_store_nr(dev.timeline + blockIdx.x * 16 + 13, (long long)nt | ((long long)comp << 32)); ss_store_nr(dev.timeline + blockIdx.x * 16 + 14, (long long)n_items); }
         auto where = [&](int i, int& q, int& sg) {                  // segment i of the run -> (tile of the record, k-segment); selects, no branches
             const bool h = i < nH, m = i < nHM;
             q = h ? last : m ? mfirst + ((i - nH) >> 3) : first;
             sg = h ? i : m ? (i - nH) & 7 : a0 + (i - nHM);
         };
         const char* gbase = reinterpret_cast<const char*>(dev.gallery) + (size_t)s * SS_MAXT * SS_NRT * SS_TILE_FLOATS * 4;
+        // lane (ks, i) = l reads float4 #(q*64 + l) of an ordinary tile; in a composite tile its row i belongs to group i/4 =
+        // rows 4*r4 .. of tile (slot, rt) of that group's track
+        auto group_word = [&](int q, int g) {                       // word g (per lane) of composite tile q
+            const int b = 4 + 4 * q;
+            const int w0 = __builtin_amdgcn_readlane(cur, b), w1 = __builtin_amdgcn_readlane(cur, b + 1);
+            const int w2 = __builtin_amdgcn_readlane(cur, b + 2), w3g = __builtin_amdgcn_readlane(cur, b + 3);
+            return g == 0 ? w0 : g == 1 ? w1 : g == 2 ? w2 : w3g;
+        };
         auto ld = [&](int i, float4 a[4]) {
             int q, sg;
             where(i, q, sg);
-            const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
-            const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff;
-            const char* p = gbase + ((size_t)(slot * SS_NRT + rt) * SS_TILE_FLOATS + (size_t)sg * 1024) * 4;
-            const bool ok = (l & 15) < count - rt * SS_TILE;
-            const unsigned vo = (unsigned)((ok ? l : (l & ~15)) * 16);
+            unsigned vo;
+            if (comp) {
+                const int gw = group_word(q, (l >> 2) & 3);
+                vo = (unsigned)(((gw & 0xff) * SS_NRT + ((gw >> 8) & 7)) * (SS_TILE_FLOATS * 4) + ((l & 48) + 4 * ((gw >> 11) & 3) + (l & 3)) * 16);
+            } else {
+                const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
+                const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff;
+                const bool ok = (l & 15) < count - rt * SS_TILE;
+                vo = (unsigned)((slot * SS_NRT + rt) * (SS_TILE_FLOATS * 4) + (ok ? l : (l & ~15)) * 16);
+            }
+            const char* p = gbase + (size_t)sg * 4096;
 #pragma unroll
             for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(p + vo + j * 1024);
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
-#ifdef SS_EXP_T12
-        if (first_item) {
-            if (threadIdx.x == 0) {
-                const int tw0 = __builtin_amdgcn_readlane(cur, 4);
-                const float* g0p = reinterpret_cast<const float*>(gbase + ((size_t)((tw0 & 0xff) * SS_NRT + ((tw0 >> 8) & 7)) * SS_TILE_FLOATS) * 4);
-                const float* f0p = dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS;
-                float x = __builtin_nontemporal_load(g0p) + __builtin_nontemporal_load(f0p);
-                asm volatile("" ::"v"(x));
-            }
-            __syncthreads();
-        }
-#endif
         if (has) { ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]); }        // on the wire before the B staging (nsteps >= 8)
         // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
         const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
@@ -868,7 +884,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     hand[wu * 128 + 64 + l] = make_float4(tot1[0], tot1[1], tot1[2], tot1[3]);
                     __hip_atomic_store(&hflag[wu], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (sg == 7) {
+                if (sg == 7 && !comp) {
                     // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
                     const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
                     const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff, head = (tw >> 20) & 0x7f;
@@ -887,6 +903,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
                     if (l < 16) { if (ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m0)); }
                     else if (l < 32) { if (two && ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m1)); }
+                }
+                if (sg == 7 && comp) {
+                    // composite tile: this lane's four accumulator rows are the four rows of group l/16 — one track, no shuffles
+                    const int gw = group_word(q, l >> 4);
+                    const int slot = gw & 0xff, rt = (gw >> 8) & 7, r4 = (gw >> 11) & 3, count = (gw >> 13) & 0xff, head = (gw >> 21) & 0x7f;
+                    float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int pos = rt * SS_TILE + 4 * r4 + r;
+                        int jrel = pos - head;
+                        if (jrel < 0) jrel += budget;
+                        const bool valid = pos < count && jrel >= f;
+                        m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
+                        m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                    }
+                    int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE + (l & 15);
+                    if (count > 0 && ct0 * SS_TILE + (l & 15) < D) ss_atomic_min_nr(out, ss_fkey(m0));
+                    if (count > 0 && two && ct0 * SS_TILE + SS_TILE + (l & 15) < D) ss_atomic_min_nr(out + SS_TILE, ss_fkey(m1));
                 }
             };
             int i = 0;
@@ -1431,9 +1465,6 @@ void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipE
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
     if (dev.ts_enable > 1) {
         hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
-#ifdef SS_EXP_TWICE
-        hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
-#endif
     }
     else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
     else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);

@@ -9,7 +9,10 @@ from strongsort_yolo_amd.synth import make_stream
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 FB = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 frames = 128
-eng = TrackerEngine(StrongSortConfig(), S, 0)
+eng = TrackerEngine(StrongSortConfig(nn_budget=int(os.environ.get("SS_BUDGET", "100"))), S, 0)
+for kv in os.environ.get("SS_OPTS", "").split(","):
+    if kv:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev = eng.device
 hd, hf, hn = np.zeros((frames, S, 128, 6), np.float32), np.zeros((frames, S, 128, 512), np.float32), np.zeros((frames, S), np.int32)
 for s in range(S):
@@ -25,7 +28,8 @@ for k0 in range(0, frames, FB):
         torch.cuda.synchronize(); eng.assoc_inkernel_timing(2)
     eng.update_group(FB, dets[k0:k0 + FB], nd[k0:k0 + FB], feats[k0:k0 + FB], hw, out, nout)
 torch.cuda.synchronize()
-tl = eng.assoc_timeline(512)
+tl_all = eng.assoc_timeline(4096)
+tl, cy = tl_all[:512], tl_all[2048:2048 + 512]
 us, n = eng.assoc_inkernel_timing(0)
 act = tl[:, 0] > 0
 t0 = tl[act, 0].min()
@@ -40,7 +44,21 @@ for i, nm in enumerate(names):
         print(f"{nm:7s} {c.min():7.2f} {np.median(c):7.2f} {c.max():7.2f}   ({len(c)} workgroups)")
 if os.environ.get("SS_TL_DUMP"):
     i = int(os.environ["SS_TL_DUMP"])
-    d = (tl[:, i] - tl[:, 0]) / 100.0
+    j = int(os.environ.get("SS_TL_FROM", "0"))
+    d = (tl[:, i] - tl[:, j]) / 100.0
     print(f"stamp {i} - entry, by XCD (rows) x workgroup index within XCD (64 cols, us):")
     for x in range(8):
         print(x, " ".join(f"{v:4.1f}" for v in d[x::8][:64]))
+
+# shader-clock stamps (s_memtime) of the same points: cycles per interval and the clock they imply
+print("interval            us(median)  cycles(median)  GHz")
+a = act
+for i0, i1 in [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 12)]:
+    ok = a & (tl[:, i0] > 0) & (tl[:, i1] > 0)
+    if ok.any():
+        du = np.median((tl[ok, i1] - tl[ok, i0]) / 100.0); dc = np.median(cy[ok, i1] - cy[ok, i0])
+        print(f"{names[i0]:7s}->{names[i1]:7s} {du:9.2f} {dc:12.0f} {dc / max(du, 1e-9) / 1e3:8.2f}")
+
+nts = tl[act, 13] & 0xffff
+print("tiles per record (first record of every workgroup):", dict(zip(*np.unique(nts, return_counts=True))), " composite records:", int((tl[act, 13] >> 32).sum()),
+      " records per list:", sorted(set(tl[act, 14].tolist())))
