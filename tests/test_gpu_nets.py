@@ -269,7 +269,14 @@ def test_osnet_with_fused_tails_equals_blockwise_path():
                                                 ((3, 128, 12, 20), 128, 1, "relu"), ((1, 32, 7, 9), 64, 2, "none"), ((2, 64, 13, 11), 256, 2, "silu"),
                                                 ((1, 8, 5, 5), 8, 1, "sigmoid"), ((4, 24, 17, 16), 40, 1, "silu"),
                                                 # 80-channel tiles (class branch): 64- and 128-pixel workgroups, split-K
-                                                ((6, 64, 24, 40), 80, 1, "silu"), ((2, 64, 24, 40), 80, 1, "silu"), ((9, 80, 48, 80), 80, 1, "silu")])
+                                                ((6, 64, 24, 40), 80, 1, "silu"), ((2, 64, 24, 40), 80, 1, "silu"), ((9, 80, 48, 80), 80, 1, "silu"),
+                                                # the tiled form (k_cv: input tile in LDS): 256 / 128 / 64-pixel workgroups, every channel tile, 16-channel
+                                                # inputs (two taps per MFMA), stride 2 (space-to-depth tile), channel chunks, ragged tiles
+                                                ((32, 16, 96, 160), 16, 1, "silu"), ((32, 32, 96, 160), 64, 2, "silu"), ((32, 64, 48, 80), 64, 1, "silu"),
+                                                ((32, 64, 48, 80), 80, 1, "silu"), ((16, 128, 24, 40), 128, 1, "relu"), ((16, 128, 24, 40), 64, 1, "silu"),
+                                                ((5, 32, 37, 53), 48, 1, "none"), ((5, 32, 37, 53), 48, 2, "silu"), ((20, 256, 12, 20), 64, 1, "silu"),
+                                                ((32, 64, 48, 80), 128, 2, "silu"), ((32, 32, 96, 160), 32, 1, "silu"), ((12, 128, 24, 40), 256, 2, "silu"),
+                                                ((32, 80, 48, 80), 80, 1, "silu"), ((8, 48, 30, 44), 32, 2, "relu")])
 def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
     """Implicit-GEMM 3x3 kernel vs conv2d (pad 1) + bias + act, shortcut before/after, placement; odd sizes and stride 2."""
     import torch.nn.functional as F

@@ -4,7 +4,7 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 idx=[i for i,r in enumerate(rows) if 'k_v8_decode' in r['Kernel_Name']]
 e=idx[-1]
-s=max(i for i in range(e) if 'igemm' in rows[i]['Kernel_Name'])
+s=max(i for i in range(e) if 'k_conv0' in rows[i]['Kernel_Name'] or 'igemm' in rows[i]['Kernel_Name'])
 tot=0
 for r in rows[s:e+1]:
     n=r['Kernel_Name'].replace('void ','')
