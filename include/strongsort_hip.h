@@ -135,7 +135,7 @@ int ss_crop_norm_batch(ss_ctx* ctx, const uint8_t* d_frames, int batch, long lon
                        long long dets_batch_stride, int n, const int* d_counts, void* d_out, int out_flags);
 /* Packed form of ss_crop_norm_batch (channels-last output only): d_off [batch + 1] receives the exclusive prefix of
  * min(count, n) (d_off[batch] = number of crops) and crop d of image i lands at slot d_off[i] + d, so the valid crops of
- * a frame group are contiguous; ss_op_set_valid_images(d_off + batch, batch * n) then lets the ReID network skip the rest.
+ * a frame group are contiguous; ss_op_set_valid_images(stream, d_off + batch, batch * n) then lets the ReID network skip the rest.
  * ss_unpack_feats: d_feats[i][d][0..512) (float, image stride in floats) = d_emb[d_off[i] + d] for d < min(count, n). */
 int ss_crop_norm_packed(ss_ctx* ctx, const uint8_t* d_frames, int batch, long long frame_batch_stride, int h, int w, int stride,
                         const float* d_dets, int det_stride, long long dets_batch_stride, int n, const int* d_counts,
@@ -160,7 +160,9 @@ int ss_track_set_assoc_event(ss_ctx* ctx, void* hip_event);
  *   d_feats  [n_frames][n_streams][SS_MAX_DETS][512] raw ReID embeddings (normalised on device)
  *   d_img_hw [n_streams][2]                          frame height, width (device ints; output clipping)
  * Results stay on the device: d_out [n_frames][n_streams][SS_MAX_TRACKS][8], d_nout [n_frames][n_streams].
- * After a device-side error (ss_check_errors != SS_OK) the affected stream's state is undefined: ss_reset it. */
+ * Device-side capacity errors: detections of a frame that would need more than SS_MAX_TRACKS slots start no track (the
+ * frame is tracked as if they had not been there); the stream's tables stay consistent, SS_ERR_CAPACITY is reported by the
+ * next ss_check_errors and stays set until ss_reset. */
 int ss_track_update_group(ss_ctx* ctx, int n_frames, const float* d_dets, const int* d_ndets, const float* d_feats,
                           const int* d_img_hw, float* d_out, int* d_nout);
 /* One frame: ss_track_update_group with n_frames = 1. */
@@ -273,10 +275,15 @@ int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const v
  * channel) the taps 3*kx+ch placed (6r + 5) % 8 halfs into a zero-padded 16-wide K window (fused.conv0_weight).  W % 128 == 0. */
 int ss_op_conv0_f16(void* stream, const void* d_x, const void* d_w_prep, const void* d_bias, void* d_y, int B, int H, int W, int Cout,
                     int act);
-/* Packed ReID batches: until the next call, the OSNet-side entry points (ss_op_osnet_stem_f16, ss_op_pointwise_f16,
- * ss_op_osnet_streams_f16, ss_op_osnet_tail_f16) launched with `batch` images compute only the first *d_n of them (device
- * int, read by the kernels; the grids stay fixed, so the launches can sit in a captured graph).  d_n == NULL: off. */
-int ss_op_set_valid_images(const int* d_n, int batch);
+/* Packed ReID batches: until the next call for the same stream, the OSNet-side entry points (ss_op_osnet_stem_f16,
+ * ss_op_pointwise_f16, ss_op_osnet_streams_f16, ss_op_osnet_tail_f16) launched on `stream` BY THE CALLING THREAD with `batch`
+ * images compute only the first *d_n of them (device int, read by the kernels; the grids stay fixed, so the launches can sit
+ * in a captured graph).  d_n == NULL: off for that stream.  Per (host thread, stream): two pipelines in one process do not
+ * see each other's setting.  At most 8 streams of a thread hold a setting at once (SS_ERR_CAPACITY). */
+int ss_op_set_valid_images(void* stream, const int* d_n, int batch);
+/* Process-wide A/B switches of the stateless operators, for measurements (default 1 each): "pw_epilogue" (16-byte vector
+ * epilogue), "pw_splitk" (split-K form of small 3x3 layers), "osnet_chains" (register-resident LightConv row streams). */
+int ss_op_set_option(const char* name, int value);
 /* OSNet stem in one pass: conv 7x7/2 pad 3 (3 -> 16) + bias + ReLU + max pool 3x3/2 pad 1 on crops [N][H][128][3]
  * half -> [N][H/4][32][16]; d_w_prep [4][7][16][32] = for conv columns c = 4n + r, per (ky, out channel) the taps 3*kx+ch
  * placed (6r + 7) % 8 halfs into a zero-padded 32-wide K window (fused.stem_weight).  W == 128, H % 16 == 0.  d_w1 != NULL:

@@ -10,13 +10,28 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string>
 #include "../../include/strongsort_hip.h"
 
 // Valid-image count of the OSNet kernels (ss_op_set_valid_images): the ReID crops of a frame group are packed (frame f's
-// crops follow frame f-1's), the launches keep their fixed grids (graph replay) and the workgroups of images >= *g_nvalid
-// leave at once.  NULL: every image is valid.
-static const int* g_nvalid = nullptr;
-static int g_nvalid_batch = 0;
+// crops follow frame f-1's), the launches keep their fixed grids (graph replay) and the workgroups of images >= *n leave at
+// once.  The setting belongs to ONE HIP stream of ONE host thread (two pipelines in a process use different streams; a
+// stream that never set it computes every image): a small thread-local table keyed by the stream handle.
+struct NvEntry { void* stream; const int* n; int batch; };
+static thread_local NvEntry g_nv[8] = {};
+static inline const int* nv_for(void* stream, long long batch)
+{
+    for (const NvEntry& e : g_nv) if (e.n && e.stream == stream && e.batch == batch) return e.n;
+    return nullptr;
+}
+static inline int nv_batch(void* stream)
+{
+    for (const NvEntry& e : g_nv) if (e.n && e.stream == stream) return e.batch;
+    return 0;
+}
+
+// Process-wide A/B switches of the stateless operators (ss_op_set_option; all default to 1)
+static int g_opt_pw_epilogue = 1, g_opt_pw_splitk = 1, g_opt_osnet_chains = 1;
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -1724,12 +1739,14 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
                      int N, int act, int res_after, void* out, int out_ld, void* out2, int c0, int cn, ConvGeom g)
 {
     // vector epilogue needs 16-byte aligned rows and slices; SS_PW_EPILOGUE=0 forces the 8-byte form (A/B switch)
-    static const bool vec_allowed = [] { const char* e = getenv("SS_PW_EPILOGUE"); return !(e && e[0] == '0'); }();
+    const bool vec_allowed = g_opt_pw_epilogue != 0;
     const bool vec = vec_allowed && out_ld % 8 == 0 && c0 % 8 == 0 && cn % 8 == 0 && ((uintptr_t)out % 16) == 0 &&
                      (!out2 || ((uintptr_t)out2 % 16) == 0) && (!res || ((uintptr_t)res % 16) == 0);
-    const bool nv = g_nvalid && !conv3 && g_nvalid_batch > 0 && M % g_nvalid_batch == 0;
+    const int nvb = conv3 ? 0 : nv_batch((void*)st);
+    const int* nvp = (nvb > 0 && M % nvb == 0) ? nv_for((void*)st, nvb) : nullptr;
+    const bool nv = nvp != nullptr;
     const PwArgs A{ (const __half*)x, (const __half*)w, (const __half*)bias, (const __half*)res, (int)M, K, N, act, res_after,
-                    (__half*)out, out_ld, (__half*)out2, c0, cn, g, nv ? g_nvalid : nullptr, nv ? (int)(M / g_nvalid_batch) : 0 };
+                    (__half*)out, out_ld, (__half*)out2, c0, cn, g, nvp, nv ? (int)(M / nvb) : 0 };
 #define SS_PW(BN, PT, CV, VE)                                                                                           \
     hipLaunchKernelGGL((k_pw<BN, PT, CV, VE>), dim3((unsigned)((M + 64 * PT - 1) / (64 * PT)), (N + BN - 1) / BN), dim3(256), 0, st, A)
 #define SS_PW2(BN, PT)                                                                                                  \
@@ -1741,7 +1758,7 @@ static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, c
     // 16, every 3x3 layer at batch 1): 16-pixel workgroups, K split over the waves.  Measured at batch 16: M = 3840,
     // K = 1152..2304: 17.5 -> 14, 31 -> 15 us; M = 15360 (960 workgroups re-reading the weights from L2): 11 -> 17 us, so
     // those stay on k_pw.  (Needs the 16-byte epilogue; SS_PW_SPLITK=0: A/B switch)
-    static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
+    const bool splitk_allowed = g_opt_pw_splitk != 0;
     if (splitk_allowed && vec && conv3 && K >= 512 && M <= 4096) {
         const dim3 grid((unsigned)((M + 15) / 16), (N + ((N <= 32) ? 31 : 63)) / ((N <= 32) ? 32 : 64));
 #define SS_SK(BN, CV) hipLaunchKernelGGL((k_pw_splitk<BN, CV>), grid, dim3(256), 0, st, A)
@@ -1788,7 +1805,7 @@ extern "C" int ss_op_osnet_stem_f16(void* stream, const void* x, const void* w_p
     if (!x || !w_prep || !bias || !y || N < 1 || W != STEM_W || H < 16 || H % 16 || (w1 && (!b1 || !y1))) return SS_ERR_INVALID;
     const int tiles = H / 16;                                   // 4 pooled rows = 16 input rows per tile
     hipLaunchKernelGGL(k_osnet_stem, dim3((unsigned)((size_t)N * tiles)), dim3(256), 0, (hipStream_t)stream, (const __half*)x,
-                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles, g_nvalid_batch == N ? g_nvalid : nullptr,
+                       (const __half*)w_prep, (const __half*)bias, (__half*)y, H, tiles, nv_for(stream, N),
                        (const __half*)w1, (const __half*)b1, (__half*)y1);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
@@ -1841,7 +1858,7 @@ extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, co
 // chip with waves: below 96 images the LDS form (256 threads per band and chain) is the faster one.
 static bool os_chain_form(int N, int W, int C)
 {
-    static const bool chains = [] { const char* e = getenv("SS_OSNET_CHAINS"); return !(e && e[0] == '0'); }();
+    const bool chains = g_opt_osnet_chains != 0;
     return chains && N >= 96 && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)));
 }
 // band height of the stream form: as many bands as give one round of waves (32-wide: 3 waves per SIMD = 3072, 16-wide:
@@ -1871,7 +1888,7 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
     hipStream_t st = (hipStream_t)stream;
-    const int* nv = g_nvalid_batch == N ? g_nvalid : nullptr;
+    const int* nv = nv_for(stream, N);
     if (os_chain_form(N, W, C)) {
         // one wave per (image, band, chain group); groups {4,1} and {3,2}: five layers each
         const unsigned masks = 0x69u;
@@ -1932,7 +1949,7 @@ extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const f
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; p.x[t] = (const __half*)ys[t]; }
     const dim3 grid((unsigned)((size_t)N * H * W / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    const int* nv = g_nvalid_batch == N ? g_nvalid : nullptr;
+    const int* nv = nv_for(stream, N);
     hipLaunchKernelGGL(k_gate_vec, dim3(N), dim3(128), 0, st, psum, parts, scale, (const __half*)gw1, (const __half*)gb1,
                        (const __half*)gw2, (const __half*)gb2, Cr, MID, N, gates_ws, nv);
 #define SS_TAIL(A, B, CC, DD)                                                                                                   \
@@ -1961,7 +1978,7 @@ extern "C" int ss_op_osnet_tail_f16(void* stream, const void* const* ys, const f
 extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
 {
     if (!d || n < 1 || n > PW_GROUP_MAX) return SS_ERR_INVALID;
-    static const bool splitk_allowed = [] { const char* e = getenv("SS_PW_SPLITK"); return !(e && e[0] == '0'); }();
+    const bool splitk_allowed = g_opt_pw_splitk != 0;
     const bool conv3 = d[0].ksize == 3;
     int nmax = 0, order[PW_GROUP_MAX];
     long long cost[PW_GROUP_MAX];
@@ -2035,10 +2052,32 @@ extern "C" int ss_op_conv0_f16(void* stream, const void* x, const void* w_prep, 
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
-// The OSNet entry points above (stem, pointwise, streams, tail) compute only the first *d_n images of launches whose batch
-// is `batch` until the next call; d_n == NULL switches it off.  Host-side setting, read at launch time.
-extern "C" int ss_op_set_valid_images(const int* d_n, int batch)
+// The OSNet entry points above (stem, pointwise, streams, tail) launched on `stream` by this host thread compute only the first
+// *d_n images of launches whose batch is `batch`, until the next call for that stream; d_n == NULL switches it off.
+// Host-side setting, read at launch time (and baked into a HIP graph that captures the launches).
+extern "C" int ss_op_set_valid_images(void* stream, const int* d_n, int batch)
 {
-    g_nvalid = d_n; g_nvalid_batch = d_n ? batch : 0;
+    NvEntry* slot = nullptr;
+    for (NvEntry& e : g_nv) if (e.n && e.stream == stream) slot = &e;
+    if (!d_n) { if (slot) *slot = NvEntry{}; return SS_OK; }
+    if (batch < 1) return SS_ERR_INVALID;
+    if (!slot) for (NvEntry& e : g_nv) if (!e.n) { slot = &e; break; }
+    if (!slot) return SS_ERR_CAPACITY;                              // more than 8 streams of one thread with a valid count at once
+    *slot = NvEntry{ stream, d_n, batch };
+    return SS_OK;
+}
+
+// A/B switches of the operators (process-wide, for measurements; all 1 by default):
+//   "pw_epilogue"   16-byte vector epilogue of the pointwise / 3x3 kernels (0: the 8-byte form)
+//   "pw_splitk"     split-K form for 3x3 layers with few pixels and a long K walk
+//   "osnet_chains"  register-resident row-stream form of the OSNet LightConv chains (0: the LDS form)
+extern "C" int ss_op_set_option(const char* name, int value)
+{
+    if (!name) return SS_ERR_INVALID;
+    const std::string n(name);
+    if (n == "pw_epilogue") g_opt_pw_epilogue = value;
+    else if (n == "pw_splitk") g_opt_pw_splitk = value;
+    else if (n == "osnet_chains") g_opt_osnet_chains = value;
+    else return SS_ERR_INVALID;
     return SS_OK;
 }

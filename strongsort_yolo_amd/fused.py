@@ -45,21 +45,29 @@ def _ck(rc):
 
 
 class valid_images:
-    """`with valid_images(n_dev, batch):` — the OSNet-side launches of `batch` images inside compute only the first n_dev[0]
-    (device int32) of them (packed ReID batches; csrc ss_op_set_valid_images)."""
+    """`with valid_images(n_dev, batch):` — the OSNet-side launches of `batch` images made inside, on the current torch stream,
+    compute only the first n_dev[0] (device int32) of them (packed ReID batches; csrc ss_op_set_valid_images: the setting
+    belongs to this thread and this stream)."""
 
     def __init__(self, n_dev, batch):
         self.n_dev, self.batch = n_dev, int(batch)
+        self._stream = None
 
     def __enter__(self):
         if self.n_dev is not None:
-            _ck(_lib.load().ss_op_set_valid_images(_p(self.n_dev), self.batch))
+            self._stream = C.c_void_p(torch.cuda.current_stream(self.n_dev.device).cuda_stream)
+            _ck(_lib.load().ss_op_set_valid_images(self._stream, _p(self.n_dev), self.batch))
         return self
 
     def __exit__(self, *a):
         if self.n_dev is not None:
-            _ck(_lib.load().ss_op_set_valid_images(None, 0))
+            _ck(_lib.load().ss_op_set_valid_images(self._stream, None, 0))
         return False
+
+
+def set_option(name: str, value: int):
+    """Process-wide A/B switch of the operators: pw_epilogue, pw_splitk, osnet_chains (csrc ss_op_set_option)."""
+    _ck(_lib.load().ss_op_set_option(name.encode(), int(value)))
 
 
 def bias_act_(x, bias, act="none", res=None):

@@ -7,7 +7,7 @@ import pytest
 from oracle.strongsort_np import OracleStrongSort
 from strongsort_yolo_amd.config import StrongSortConfig
 from strongsort_yolo_amd.synth import make_stream
-from tests.gpu_util import engine, bits_equal
+from tests.gpu_util import engine, bits_equal, unit
 
 pytestmark = pytest.mark.gpu
 
@@ -252,4 +252,35 @@ def test_near_capacity_stream():
         got, ref = eng.update_host(fg.dets, fg.feats, (1080, 1920)), orc.update(fo.dets, fo.feats, (1080, 1920))
         assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), f"frame {k}"
     assert len(orc.tracks) >= 100
+    eng.close()
+
+
+def test_track_capacity_overflow_keeps_the_tables_consistent():
+    """More births than free slots (256 per stream): the detections that do not fit start no track, SS_ERR_CAPACITY is raised at
+    the next check and stays until ss_reset; the stream's tables stay consistent (unique ids, counts within capacity) —
+    the defined behaviour that include/strongsort_hip.h states."""
+    from strongsort_yolo_amd import lib
+    cfg = StrongSortConfig()
+    eng = engine(cfg, debug=False)
+    rng = np.random.default_rng(9)
+    feats = [unit(rng, 128) for _ in range(3)]
+    for k in range(7):                                   # three sets of 128 detections at disjoint places, three frames each: a set's
+        g = k // 3                                       # tracks are confirmed and then coast (max_age 30) while the next set is born
+        dets = np.zeros((128, 6), np.float32)
+        gx, gy = np.meshgrid(np.arange(16), np.arange(8))
+        dets[:, 0] = 10 + gx.ravel() * 110 + 36 * g; dets[:, 1] = 10 + gy.ravel() * 125 + 40 * g
+        dets[:, 2] = dets[:, 0] + 30; dets[:, 3] = dets[:, 1] + 60; dets[:, 4] = 0.9
+        try:
+            eng.update_host(dets, feats[g], (1080, 1920))
+            raised = False
+        except lib.SSError as e:
+            raised = e.code == lib.SS_ERR_CAPACITY
+        assert raised == (k == 6), k
+    t = eng.tracks(0)
+    assert len(t["track_id"]) == 256 and len(set(t["track_id"].tolist())) == 256 and t["next_id"] == 257
+    with pytest.raises(lib.SSError):
+        eng.check_errors()                                # sticky until reset
+    eng.reset(-1)
+    eng.check_errors()
+    assert len(eng.tracks(0)["track_id"]) == 0
     eng.close()

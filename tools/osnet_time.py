@@ -1,8 +1,11 @@
 """OSNet-x0.25 forward on 512 crops (16 frames x 32) and the detector on 16 frames, each as one replayed HIP graph:
-milliseconds per replay.  A/B switches: SS_FUSED_<NAME>=0 (fused.py).  usage: python tools/osnet_time.py [reps=20] [frames=16]"""
+milliseconds per replay.  A/B switches: SS_FUSED_<NAME>=0 (fused.py), SS_OP_OPTS=pw_splitk=0,... (ss_op_set_option).  usage: python tools/osnet_time.py [reps=20] [frames=16]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from strongsort_yolo_amd import nets
+from strongsort_yolo_amd import nets, fused
+for kv in os.environ.get("SS_OP_OPTS", "").split(","):          # e.g. SS_OP_OPTS=pw_splitk=0,osnet_chains=0
+    if kv:
+        fused.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 16
