@@ -55,6 +55,7 @@ PRESETS = {
     "c5": ("yolov8n-pose", 1280, 720, 30, 32), # configs[4] per GPU: pose head, keypoints carried by det_idx
 }
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}
+PMC_FILE = "r03_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by preset / streams / frames (tools/pmc_assoc.sh)
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
 
@@ -111,68 +112,113 @@ def oracle_rows(wl, n_frames, W, H, geom_scale, nc, cfg, dcfg):
     return rows
 
 
-def cpu_baseline(W, H, n_ids, geom, geom_scale, nc, n_anchors, cfg, dcfg, detector_name, budget_s=22.0,
-                 n_track=40, n_full=60):
-    """Reference-style CPU path on the host cores, bounded sample.  kind = "port".  Builds its own workload
-    (PREFILL warm-up frames + n_track tracker-only frames + up to n_full full-pipeline frames), so the sample does
-    not depend on --steps."""
+def _cpu_stream(job):
+    """One synthetic stream through the reference-style CPU path (oracle frame stages + CPU-torch fp32 networks + NumPy/SciPy
+    tracker) with `threads` torch threads: PREFILL tracker-only warm-up frames, then n_track tracker-only and up to n_full
+    full-pipeline frames with per-stage perf_counter sums.  Runs in this process or in a spawned worker (N processes x 1 thread)."""
     import torch
     from oracle import cexact
     from oracle.strongsort_np import OracleStrongSort
     from strongsort_yolo_amd import nets
+    from strongsort_yolo_amd.config import StrongSortConfig, DetectConfig
+    from strongsort_yolo_amd.engine import letterbox_geometry, scale_geometry
     try:
         from threadpoolctl import threadpool_limits
     except Exception:                                     # pragma: no cover
         threadpool_limits = None
-    gain, px, py = geom_scale
-    wl = make_workload(777, W, H, n_ids, PREFILL + n_track + n_full, geom_scale, nc, n_anchors)
-    ncores = os.cpu_count() or 1
-    nthr = min(ncores, 32)
-    torch.set_num_threads(nthr)
+    W, H, n_ids, nc, A, detector_name = job["W"], job["H"], job["n_ids"], job["nc"], job["A"], job["detector"]
+    cfg, dcfg = StrongSortConfig(), DetectConfig()
+    geom = letterbox_geometry(H, W, dcfg.imgsz, dcfg.stride)
+    gs = scale_geometry(geom, H, W)
+    gain, px, py = gs
+    n_track, n_full = job["n_track"], job["n_full"]
+    wl = make_workload(job["seed"], W, H, n_ids, PREFILL + n_track + n_full, gs, nc, A)
+    torch.set_num_threads(job["threads"])
     det = nets.build_detector(detector_name, 0).float()
     reid = nets.build_reid(1).float()
     orc = OracleStrongSort(cfg, "numpy")
     ctx = threadpool_limits(limits=1, user_api="blas") if threadpool_limits else None
     if ctx:
         ctx.__enter__()
+    st = {k: 0.0 for k in ("letterbox", "detector", "nms", "crop", "reid", "tracker")}
+    pc = time.perf_counter
 
-    def track_only(k):
+    def nms_rows(k):
         keep, r = cexact.nms(wl["preds"][k], nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, 128)
         r = cexact.scale_boxes(r, gain, px, py, W, H)
-        f = wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
-        return r, f
+        return r, wl["feats"][k][np.maximum(wl["agt"][k][keep], 0)]
 
     for k in range(PREFILL):                               # untimed: fill the galleries
-        r, f = track_only(k)
+        r, f = nms_rows(k)
         orc.update(r, f, (H, W))
     k = PREFILL
-    t0 = time.perf_counter(); n_t = 0                      # tracker-only timing
+    t0 = pc(); n_t = 0                                     # tracker-only timing (detections + features injected)
     while n_t < n_track:
-        r, f = track_only(k)
+        r, f = nms_rows(k)
         orc.update(r, f, (H, W)); n_t += 1; k += 1
-    t_track = (time.perf_counter() - t0) / n_t
-    t0 = time.perf_counter(); n_f = 0                      # full pipeline timing
+    t_track = pc() - t0
+    t0 = pc(); n_f = 0                                     # full pipeline timing, per stage
     with torch.no_grad():
-        while n_f < n_full and (n_f == 0 or time.perf_counter() - t0 < budget_s):
+        while n_f < n_full and (n_f == 0 or pc() - t0 < job["budget_s"]):
             img = wl["pixels"][k % len(wl["pixels"])]
-            lb = cexact.letterbox(img, geom.out_h, geom.out_w, geom.new_h, geom.new_w, geom.pad_top, geom.pad_left)
-            det(torch.from_numpy(lb)[None])                                    # random-init: output unused
-            r, f = track_only(k)
-            crops = cexact.crop_norm(img, r)
+            a = pc(); lb = cexact.letterbox(img, geom.out_h, geom.out_w, geom.new_h, geom.new_w, geom.pad_top, geom.pad_left)
+            b = pc(); det(torch.from_numpy(lb)[None])                             # random-init: output unused
+            c = pc(); r, f = nms_rows(k)
+            d = pc(); crops = cexact.crop_norm(img, r)
+            e = pc()
             if len(crops):
                 reid(torch.from_numpy(crops))
-            orc.update(r, f, (H, W)); n_f += 1; k += 1
-    t_full = (time.perf_counter() - t0) / max(n_f, 1)
+            g = pc(); orc.update(r, f, (H, W))
+            h = pc()
+            for name, dt in zip(st, (b - a, c - b, d - c, e - d, g - e, h - g)):
+                st[name] += dt
+            n_f += 1; k += 1
+    t_full = pc() - t0
     if ctx:
         ctx.__exit__(None, None, None)
-    return {"value": round(1.0 / t_full, 2) if n_f > 0 else None, "unit": "frames/s", "cores": nthr, "kind": "port",
-            "sample": f"{n_f} frames of one synthetic stream after {PREFILL} untimed warm-up frames: C-oracle letterbox/NMS/crop, "
-                      f"CPU-torch fp32 {detector_name}+OSNet-x0.25 ({nthr} threads), NumPy/SciPy StrongSORT update (1 BLAS thread)",
-            "sample_frames": n_f, "tracker_only_frames_per_s": round(1.0 / t_track, 1), "tracker_only_frames": n_t,
-            "host_cores": ncores}
+    return {"n_full": n_f, "t_full": t_full, "n_track": n_t, "t_track": t_track, "stage_s": st}
 
 
-def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, timed=40, device=0, frame_batch=8, check=True):
+def cpu_baseline(W, H, n_ids, nc, n_anchors, detector_name, budget_s=20.0, n_track=40, n_full=60):
+    """Reference-style CPU path on the host cores, bounded samples, SURVEY §8(d)'s two modes.  kind = "port".
+      (a) ONE stream, all BLAS / torch threads (<= 32): `value`, per-stage milliseconds;
+      (b) N = min(cores, 32) independent streams, one process each with ONE thread (a stream per core, as the reference's
+          Pool(len(sources)) does, /root/reference/yolo_multi_model.py:351-354): aggregate frames/s.
+    Each builds its own workload (PREFILL warm-up frames + tracker-only frames + full-pipeline frames), so the sample does not
+    depend on --steps."""
+    ncores = os.cpu_count() or 1
+    nthr = min(ncores, 32)
+    job = dict(W=W, H=H, n_ids=n_ids, nc=nc, A=n_anchors, detector=detector_name, n_track=n_track, n_full=n_full, budget_s=budget_s,
+               threads=nthr, seed=777)
+    one = _cpu_stream(job)
+    out = {"value": round(one["n_full"] / one["t_full"], 2) if one["n_full"] else None, "unit": "frames/s", "cores": nthr, "kind": "port",
+           "sample": f"{one['n_full']} frames of one synthetic stream after {PREFILL} untimed warm-up frames: C-oracle letterbox/NMS/crop, "
+                     f"CPU-torch fp32 {detector_name}+OSNet-x0.25 ({nthr} threads), NumPy/SciPy StrongSORT update (1 BLAS thread)",
+           "sample_frames": one["n_full"], "tracker_only_frames_per_s": round(one["n_track"] / one["t_track"], 1),
+           "tracker_only_frames": one["n_track"], "host_cores": ncores,
+           "stage_ms_per_frame": {k: round(v / max(one["n_full"], 1) * 1e3, 3) for k, v in one["stage_s"].items()}}
+    # (b) a stream per core
+    nproc = min(ncores, 32)
+    try:
+        import multiprocessing as mp
+        jobs = [dict(job, threads=1, seed=900 + i, n_track=20, n_full=4, budget_s=budget_s) for i in range(nproc)]
+        t0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_stream, jobs)
+        wall = time.perf_counter() - t0
+        nf = sum(r["n_full"] for r in res)
+        out["per_core_mode"] = {"processes": nproc, "threads_per_process": 1,
+                                "value": round(sum(r["n_full"] / r["t_full"] for r in res if r["n_full"]), 2), "unit": "frames/s (sum over the processes)",
+                                "sample": f"{nf} full-pipeline frames over {nproc} independent streams, one process x one thread each",
+                                "tracker_only_frames_per_s": round(sum(r["n_track"] / r["t_track"] for r in res), 1),
+                                "stage_ms_per_frame": {k: round(sum(r["stage_s"][k] for r in res) / max(nf, 1) * 1e3, 3) for k in res[0]["stage_s"]},
+                                "wall_s_incl_start_up": round(wall, 1)}
+    except Exception as e:                                    # pragma: no cover  (a box without fork/spawn headroom)
+        out["per_core_mode"] = {"error": repr(e)}
+    return out
+
+
+def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, timed=40, device=0, frame_batch=8, check=True, preset="c2"):
     """Association kernel at n_streams streams x frame_batch frames per launch (tracker path only, detections +
     features injected on the device): the regime in which the kernel can be compared with the HBM roofline."""
     import torch
@@ -235,20 +281,66 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, 
     eng.close()
     ach = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_assoc.json")
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"c2_b{n_streams}_f{FB}", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(f"{preset}_b{n_streams}_f{FB}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    return {"kernel": "k_assoc", "streams_per_launch": n_streams, "frames_per_launch": FB, "bound": "hbm", "achieved": round(ach, 1),
-            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+    return {"kernel": "k_assoc", "streams_per_launch": n_streams, "frames_per_launch": FB, "identities_per_stream": n_ids, "frame": f"{W}x{H}",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "note": "hbm-equivalent (algorithmic bytes / launch time); the kernel's binding resource at this size is the f32 MFMA pipe, see frac_of_f32_mfma_peak",
             "algorithmic_bytes_per_launch": int(alg), "flops_per_launch": int(flops),
             "f32_mfma_TFLOPs": round(flops / (ms * 1e-3) / 1e12, 2) if ms > 0 else None,
             "frac_of_f32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / 157.3, 4) if ms > 0 else None,
             "mean_launch_us": round(ms * 1e3, 2), "launches_timed": n, "inkernel_mean_us": round(ik_us, 2),
             "tracker_path_frames_per_s": round(n_streams * timed / dt, 1),
             "batched_id_match_rate": round(same / max(tot, 1), 6) if check else None, "rows_checked": tot}
+
+
+def front_rooflines(pipe, n_img, mean_dets, reps=20):
+    """a1 / a3 / a4 of SURVEY §8(a) on the pipeline's own buffers (one frame group = n_img images): mean duration of the
+    library call measured with HIP events on the stream it is launched on, algorithmic bytes of SURVEY §8(d) / that time /
+    8 TB/s.  Outside the timed region; the buffers hold the last group's data."""
+    import torch
+    e, b, g = pipe.eng, pipe.bufs[0], pipe.geom
+    st = torch.cuda.Stream(pipe.dev)
+    out = {}
+
+    def timed(fn):
+        with torch.cuda.stream(st):
+            e.use_current_stream()
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            st.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    esz = 2 if pipe.half else 4
+    t = timed(lambda: e.letterbox_batch(b.frames, g, half=pipe.half, pad_value=pipe.dcfg.pad_value, out=b.lb, channels_last=True))
+    by = n_img * (pipe.H * pipe.W * 3 + 3 * g.out_h * g.out_w * esz)
+    out["letterbox"] = {"kernel": "k_letterbox (a1)", "images": n_img, "algorithmic_bytes": by, "mean_call_us": round(t * 1e6, 2),
+                        "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4)}
+    t = timed(lambda: e.nms_batch(b.pred_in, pipe.nc, pipe.dcfg, pipe.geom_dev, n_extra=pipe.nk, rows=b.dets, keep=b.keep, count=b.ndets, max_det=pipe.max_det))
+    by = n_img * pipe.n_anchors * (4 + pipe.nc + pipe.nk) * 4
+    out["nms"] = {"kernel": "k_nms_filter + sort + mask + scan (a3), one call", "images": n_img, "algorithmic_bytes": by,
+                  "mean_call_us": round(t * 1e6, 2), "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4),
+                  "note": "the filter pass is the HBM-bound part; sort / IoU bit matrix / greedy scan are latency-bound on ~30 candidates per image"}
+    if pipe.pack:
+        t = timed(lambda: e.crop_norm_packed(b.frames, b.dets6, pipe.RB, b.ndets, b.crop_off, b.crops, half=True))
+    else:
+        t = timed(lambda: e.crop_norm_batch(b.frames, b.dets6, pipe.RB, counts=b.ndets, half=pipe.half, out=b.crops, channels_last=True))
+    ncrop = int(b.ndets.clamp(max=pipe.RB).sum().item())
+    by = ncrop * 3 * 256 * 128 * esz
+    out["crop"] = {"kernel": "k_crop_hwc8 (a4)", "crops": ncrop, "algorithmic_bytes": by, "mean_call_us": round(t * 1e6, 2),
+                   "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4),
+                   "note": "output bytes only (D x 3 x 256 x 128 halfs); the source boxes are read from L2"}
+    e._ck(e.L.ss_set_hip_stream(e.ctx, __import__("ctypes").c_void_p(pipe.sB.cuda_stream)))
+    return out
 
 
 def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device=0, timed=192, batch=32):
@@ -486,30 +578,51 @@ def main():
         frames_launch = KF / assoc_n                      # frames of a stream per association launch
         alg_bytes, flops = bytes_frame * frames_launch, flops_frame * frames_launch
         t_ev, t_ik = assoc_ms * 1e-3, assoc_ik_us * 1e-6
-        fp32_bound = args.preset == "c4"                  # a8 at C4 is FP32-bound (AI 49 flop/B > ridge 20)
         ach_b, ach_f = alg_bytes / t_ev / 1e9, flops / t_ev / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_assoc.json")
+        pmc = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}_f{int(round(frames_launch))}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # The bound is read off the data: the kernel reads a gallery once per frame GROUP, so its HBM traffic is a fraction of the
+        # algorithmic bytes (what a frame-by-frame implementation moves); when that fraction is below 0.5 (or the shape is
+        # FP32-bound by SURVEY §8(d): c4) the binding resource is the f32 MFMA pipe and `frac` is priced against its peak.  The
+        # contract's HBM-equivalent figure (algorithmic bytes / launch time / 8 TB/s) stays beside it.
+        fp32_bound = args.preset == "c4" or (traffic is not None and traffic / max(alg_bytes, 1) < 0.5) or (traffic is None and frames_launch >= 4)
+        # matrix work actually issued: 16-row tiles (full tiles + 4-row groups packed four to a tile) x 16-column tile pairs,
+        # 256 v_mfma_f32_16x16x4_f32 of 32 cycles per (tile, pair) on 1024 SIMDs at the 2.4 GHz peak clock
+        tiles = 0
+        for Tc, B in T_conf:
+            rows = int(round(B))
+            full, rem = rows // 16, rows % 16
+            groups = 0 if (rem == 0 or rem > 12) else -(-rem // 4)
+            tiles += Tc * (full + (1 if rem > 12 else 0)) + -(-(Tc * groups) // 4)
+        pairs = -(-int(-(-Dm // 16)) // 2)
+        mfma_floor_us = tiles * pairs * frames_launch * 256 * 32 / (1024 * 2.4e9) * 1e6
         roofline = {"kernel": "k_assoc (association: gallery stream x detections of the frame group, f32 MFMA, row min)",
                     "bound": "mfma" if fp32_bound else "hbm",
                     "achieved": round(ach_f if fp32_bound else ach_b, 2), "peak": 157.3 if fp32_bound else 8000.0,
                     "unit": "TFLOP/s" if fp32_bound else "GB/s",
                     "frac": round(ach_f / 157.3 if fp32_bound else ach_b / 8000.0, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r02_pmc_assoc.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                    "traffic_source": f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of the same workload; not measured in this run)" if traffic else None,
+                    "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
+                    "hbm_GBps_measured_traffic": round(traffic / t_ev / 1e9, 1) if traffic else None,
                     "frames_per_launch": round(frames_launch, 2), "algorithmic_bytes_per_frame": int(bytes_frame),
                     "algorithmic_bytes_per_launch": int(alg_bytes), "flops_per_launch": int(flops),
                     "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n,
                     "timing": "HIP start/stop events on the kernel's own dispatches inside the timed region",
+                    "hbm_equivalent": {"GBps": round(ach_b, 1), "frac_of_8TBps": round(ach_b / 8000.0, 4),
+                                       "note": "SURVEY §8(d) algorithmic bytes x frames per launch / launch time: what a frame-by-frame implementation would have to move"},
                     "hbm_equivalent_GBps": round(ach_b, 1), "frac_of_hbm_peak": round(ach_b / 8000.0, 4),
                     "f32_mfma_TFLOPs": round(ach_f, 2), "frac_of_f32_mfma_peak": round(ach_f / 157.3, 4),
+                    "mfma_floor_us": round(mfma_floor_us, 2), "mfma_tiles_per_frame": int(tiles * pairs),
                     "inkernel_mean_us": round(assoc_ik_us, 2), "inkernel_launches": assoc_ik_n,
                     "frac_inkernel": (round((flops / t_ik / 1e12 / 157.3) if fp32_bound else (alg_bytes / t_ik / 1e9 / 8000.0), 4) if t_ik > 0 else None),
                     "tracks_confirmed_per_stream": [t for t, _ in T_conf], "gallery_rows": [round(b, 1) for _, b in T_conf]}
+
+    roofline_front = front_rooflines(pipe, FB * S, Dm) if (rank == 0 and not args.no_nets and overlap) else None
 
     # ---- identical-ID rate vs the exact-order oracle: every rank checks ITS stream 0 over the WHOLE run (prefill, warm-up
     # and every timed frame: the oracle is a recurrence, so it has to see all of them anyway), rank 0 reports the minimum ----
@@ -549,19 +662,20 @@ def main():
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "id_match_rate": round(id_rate_min, 6), "frames_bit_exact": f"{exact_min}/{nchk}", "frames_bit_exact_timed": f"{exact_timed_min}/{n_timed}",
             "id_check": "every rank vs the oracle on its own stream 0 over prefill + warm-up + ALL timed frames, minimum over ranks",
-            "roofline": roofline,
+            "roofline": roofline, "roofline_front": roofline_front,
         }
         res["roofline_batched"] = None
         res["cpu_baseline"] = None
     pipe.close()
     if rank == 0:
         if world == 1 and not args.no_batched:
-            res["roofline_batched"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16, 32) else (32 if FB > 32 else 8))
-            res["roofline_batched_frame_at_a_time"] = batched_association(cfg, device=dev_index, frames=128, timed=32, frame_batch=1, check=False)
+            bkw = dict(device=dev_index, n_ids=n_ids, W=W, H=H, preset=args.preset, n_streams=32 if n_ids <= 30 else 8)
+            res["roofline_batched"] = batched_association(cfg, frames=160, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16, 32) else (32 if FB > 32 else 8), **bkw)
+            res["roofline_batched_frame_at_a_time"] = batched_association(cfg, frames=160, timed=32, frame_batch=1, check=False, **bkw)
         if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
             res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(W, H, n_ids, pipe.geom, gs, nc, A, cfg, dcfg, detector)
+            res["cpu_baseline"] = cpu_baseline(W, H, n_ids, nc, A, detector)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
