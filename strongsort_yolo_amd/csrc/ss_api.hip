@@ -27,6 +27,7 @@ int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
 void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t, const int*);
 void ss_launch_crop_offsets(const int*, int, int, int*, hipStream_t);
+extern int ss_nms_fused;
 void ss_launch_unpack_feats(const void*, int, const int*, const int*, int, int, float*, long long, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
 void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, const int*, double*, hipStream_t);
@@ -398,6 +399,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     if (!c || !name) return fail(c, SS_ERR_INVALID, "ss_set_option: null argument");
     const std::string n(name);
     if (n == "cos_grid") { if (value < 8 || value > 4096 || value % 8) return fail(c, SS_ERR_INVALID, "cos_grid: a multiple of 8 in 8..4096"); c->cos_grid = value; }
+    else if (n == "nms_fused") ss_nms_fused = value != 0;       // process-wide: one workgroup per image after the filter (1, default) or sort / mask / scan launches
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;

@@ -140,6 +140,8 @@ __global__ __launch_bounds__(128) void k_crop(const uint8_t* __restrict__ src, l
 //    pixel's three bytes come out of two LDS dwords + a 64-bit shift (the byte-wide global loads — 96 per thread — were the
 //    kernel's limit: 82 us per 512 crops).  Boxes whose row span does not fit the LDS budget take the global loads.
 #define CROP_LDS_BYTES 30720
+#define CROP_RPT 4            // output rows per thread: a workgroup covers a band of 64 rows of a crop (4 bands), so the fixed cost of a
+                              // workgroup (box read, table, staging latency) is paid 4x less often than with 16-row bands (113 -> us per ~880 crops)
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ src, long long src_batch_stride, int H, int W,
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     const int cnt = d_count ? d_count[img] : n;
     if (d >= cnt) return;
     src += (size_t)img * src_batch_stride;
-    const int tid = threadIdx.x, yb = blockIdx.y * 16, y = yb + (tid >> 4), xg = (tid & 15) * 8;
+    const int tid = threadIdx.x, yb = blockIdx.y * (16 * CROP_RPT), xg = (tid & 15) * 8;
     const float* b = dets + (size_t)img * dets_batch_stride + (size_t)d * det_stride;
     int x1 = (int)b[0], y1 = (int)b[1], x2 = (int)b[2], y2 = (int)b[3];
     if (x1 < 0) x1 = 0; if (y1 < 0) y1 = 0;
@@ -173,39 +175,65 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     // source rows of this band (uniform): first row's upper tap .. last row's lower tap
     int ra0, ra1, rb0, rb1; float fa, fb;
     ss_axis(yb, sy, ch, ra0, ra1, fa);
-    ss_axis(yb + 15, sy, ch, rb0, rb1, fb);
+    ss_axis(yb + 16 * CROP_RPT - 1, sy, ch, rb0, rb1, fb);
     const int nrows = rb1 - ra0 + 1;
     const size_t rowb = (size_t)x1 * 3;
     const int mis = (int)(rowb & 3), ndw = (mis + cw * 3 + 3) >> 2, pitch = ndw + 1;
     const bool staged = (stride & 3) == 0 && ((uintptr_t)src & 3) == 0 && (size_t)nrows * pitch * 4 <= CROP_LDS_BYTES;
     if (staged) {
         const size_t end = (size_t)H * stride;
-        for (int i = tid; i < nrows * ndw; i += 256) {
-            const int rr = i / ndw, dw = i - rr * ndw;
-            const size_t off = (size_t)(y1 + ra0 + rr) * stride + (rowb - mis) + (size_t)dw * 4;
-            uint32_t v;
-            if (off + 4 <= end) v = *reinterpret_cast<const uint32_t*>(src + off);
-            else { v = 0; for (int k = 0; k < 4 && off + k < end; ++k) v |= (uint32_t)src[off + k] << (8 * k); }
-            Ls[rr * pitch + dw] = v;
+        // eight loads in flight per thread before the first LDS store (a load -> store loop pays one memory latency per
+        // iteration: 22 iterations for a 64-row band of a 120-pixel box, the kernel's whole duration)
+        const int tot = nrows * ndw;
+        for (int i0 = tid; i0 < tot; i0 += 256 * 8) {
+            uint32_t v[8];
+            int la[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u;
+                v[u] = 0; la[u] = -1;
+                if (i < tot) {
+                    const int rr = i / ndw, dw = i - rr * ndw;
+                    const size_t off = (size_t)(y1 + ra0 + rr) * stride + (rowb - mis) + (size_t)dw * 4;
+                    la[u] = rr * pitch + dw;
+                    if (off + 4 <= end) v[u] = *reinterpret_cast<const uint32_t*>(src + off);
+                    else { for (int k = 0; k < 4 && off + k < end; ++k) v[u] |= (uint32_t)src[off + k] << (8 * k); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (la[u] >= 0) Ls[la[u]] = v[u];
         }
     }
     __syncthreads();
+    const size_t slot = d_off ? (size_t)d_off[img] + d : (size_t)blockIdx.z;     // packed: image i's crops follow image i-1's
+    // the column taps of this thread's 8 pixels are the same for every row of the band: byte offsets of the two taps in a staged
+    // row and the weight, once per workgroup instead of once per row
+    int hob0[8], hob1[8];
+    float hfx[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        int xx0, xx1;
+        ss_axis(xg + p, sx, cw, xx0, xx1, hfx[p]);
+        hob0[p] = mis + 3 * xx0; hob1[p] = mis + 3 * xx1;
+    }
+#pragma unroll 1
+    for (int rr = 0; rr < CROP_RPT; ++rr) {
+    const int y = yb + rr * 16 + (tid >> 4);
     int yy0, yy1; float fy;
     ss_axis(y, sy, ch, yy0, yy1, fy);
     __attribute__((aligned(16))) T o[24];
     if (staged) {
         const uint32_t* l0 = Ls + (yy0 - ra0) * pitch;
         const uint32_t* l1 = Ls + (yy1 - ra0) * pitch;
-        auto px = [&](const uint32_t* row, int xs) -> uint32_t {             // bytes 0..2 = B, G, R of source pixel xs
-            const int ob = mis + 3 * xs, dw = ob >> 2;
+        auto px = [&](const uint32_t* row, int ob) -> uint32_t {             // bytes 0..2 = B, G, R of the source pixel at byte ob
+            const int dw = ob >> 2;
             const uint64_t two = ((uint64_t)row[dw + 1] << 32) | row[dw];
             return (uint32_t)(two >> (8 * (ob & 3)));
         };
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            int xx0, xx1; float fx;
-            ss_axis(xg + p, sx, cw, xx0, xx1, fx);
-            const uint32_t v00 = px(l0, xx0), v01 = px(l0, xx1), v10 = px(l1, xx0), v11 = px(l1, xx1);
+            const float fx = hfx[p];
+            const uint32_t v00 = px(l0, hob0[p]), v01 = px(l0, hob1[p]), v10 = px(l1, hob0[p]), v11 = px(l1, hob1[p]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int sh = 8 * (2 - c);
@@ -230,25 +258,31 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
         }
     }
     constexpr int NV = 24 * sizeof(T) / 16;
-    const size_t slot = d_off ? (size_t)d_off[img] + d : (size_t)blockIdx.z;     // packed: image i's crops follow image i-1's
     uint4* out = reinterpret_cast<uint4*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);
     const uint4* ov = reinterpret_cast<const uint4*>(o);
 #pragma unroll
     for (int v = 0; v < NV; ++v) out[v] = ov[v];
+    }
 }
 
-// exclusive prefix of min(count, n) over the images of a batch -> off[batch + 1] (off[batch] = number of crops)
+// exclusive prefix of min(count, n) over the images of a batch -> off[batch + 1] (off[batch] = number of crops).
+// Wave shuffles + one LDS hop (a single thread walking 1024 partial sums in LDS was ~50 us of the packed crop call, r03).
 __global__ __launch_bounds__(1024) void k_crop_offsets(const int* __restrict__ counts, int batch, int n, int* __restrict__ off)
 {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x, per = (batch + 1023) / 1024, i0 = tid * per;
+    __shared__ int wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, per = (batch + 1023) / 1024, i0 = tid * per;
     int sum = 0;
     for (int i = i0; i < i0 + per && i < batch; ++i) sum += min(counts[i], n);
-    part[tid] = sum;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wtot[wv] = inc;
     __syncthreads();
-    if (tid == 0) { int a = 0; for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = a; a += v; } off[batch] = a; }
-    __syncthreads();
-    int a = part[tid];
+    int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = wtot[i]; if (i < wv) base += c; total += c; }
+    int a = base + inc - sum;
+    if (tid == 0) off[batch] = total;
     for (int i = i0; i < i0 + per && i < batch; ++i) { off[i] = a; a += min(counts[i], n); }
 }
 
@@ -282,7 +316,7 @@ void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_strid
 {
     if (n <= 0 || batch <= 0) return;
     if (flags & 2) {
-        dim3 grid(1, 16, n * batch), block(256);
+        dim3 grid(1, 16 / CROP_RPT, n * batch), block(256);
         if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 768 * sizeof(__half) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out, d_off);
         else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 768 * sizeof(float) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out, d_off);
         return;
@@ -528,14 +562,168 @@ __global__ __launch_bounds__(64) void k_nms_scan(NmsBatch nb, int N, int nc, int
     }
 }
 
+// Sort + suppression matrix + greedy scan + output rows of ONE image in ONE workgroup (1024 threads): the three kernels above
+// run back to back for a few dozen candidates per image (each launch costs more than its work: 75 us per 32 images for four
+// launches, r03 roofline_front), so the batched entry point launches k_nms_filter and this.  Same arithmetic, same order:
+// phase A = k_nms_sort's body, phase B = k_nms_mask's body with one WAVE per 64x64 block pair (per-wave LDS tiles),
+// phase C = k_nms_scan's greedy pass on wave 0, then all threads write the rows.
+__global__ __launch_bounds__(1024) void k_nms_rest(NmsBatch nb, int N, int nc, int n_extra, int agnostic, float max_wh, float iou_thres,
+                                                   int max_det, float gain, float pad_x, float pad_y, float w0, float h0,
+                                                   const float* __restrict__ geom, float* __restrict__ rows, int row_stride,
+                                                   long long rows_batch_stride, int* __restrict__ keep, long long keep_batch_stride,
+                                                   int* __restrict__ count)
+{
+    const int img = blockIdx.x;
+    const float* __restrict__ pred = nb.pred + (size_t)img * nb.pred_stride;
+    const NmsWs w = nms_unit(nb, img);
+    rows += (size_t)img * rows_batch_stride; keep += (size_t)img * keep_batch_stride; count += img;
+    if (geom) { const float* g = geom + img * 5; gain = g[0]; pad_x = g[1]; pad_y = g[2]; w0 = g[3]; h0 = g[4]; }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long* k = (unsigned long long*)smem;                         // [NMS_MAX_CAND] sort keys
+    float* sbw = (float*)(smem + (size_t)NMS_MAX_CAND * 8);                     // [16 waves][64][4] boxes of a column block
+    float* saw = sbw + 16 * 64 * 4;                                            // [16][64] areas
+    int* kept_sorted = (int*)(saw + 16 * 64);                                  // [1024]
+    __shared__ int s_kept;
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+    // ---- phase A: sort, offset boxes, areas ----
+    int n = w.counters[0];
+    __syncthreads();
+    if (n > NMS_MAX_CAND) {
+        if (tid == 0) { w.counters[1] = SS_ERR_CAPACITY; w.counters[0] = 0; }
+        n = 0;
+    }
+    int np = 1; while (np < n) np <<= 1;
+    for (int i = tid; i < np; i += 1024) k[i] = i < n ? w.keys[i] : ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= np; size <<= 1)
+        for (int strd = size >> 1; strd > 0; strd >>= 1) {
+            for (int i = tid; i < np / 2; i += 1024) {
+                int lo = 2 * i - (i & (strd - 1)), hi = lo + strd;
+                bool up = (lo & size) == 0;
+                unsigned long long a = k[lo], b = k[hi];
+                if ((a > b) == up) { k[lo] = b; k[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < n; i += 1024) {
+        unsigned long long key = k[i];
+        w.keys[i] = key;
+        const int a = (int)(key & 0xffffffffu);
+        float cx = pred[a], cy = pred[(size_t)N + a], bw = pred[(size_t)2 * N + a], bh = pred[(size_t)3 * N + a];
+        float hw = bw / 2.0f, hh = bh / 2.0f;
+        float off = agnostic ? 0.0f : (float)w.cand_cls[a] * max_wh;
+        float x1 = (cx - hw) + off, y1 = (cy - hh) + off, x2 = (cx + hw) + off, y2 = (cy + hh) + off;
+        w.box[i * 4 + 0] = x1; w.box[i * 4 + 1] = y1; w.box[i * 4 + 2] = x2; w.box[i * 4 + 3] = y2;
+        w.area[i] = (x2 - x1) * (y2 - y1);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase B: suppression bit matrix, one wave per (ib <= jb) block pair ----
+    {
+        float* sb = sbw + wv * 256;
+        float* sa = saw + wv * 64;
+        const int nblk = (n + 63) / 64, npair = nblk * (nblk + 1) / 2, t = l;
+        for (int pr = wv; pr < npair; pr += 16) {
+            int ib = 0, rem = pr;
+            while (rem >= nblk - ib) { rem -= nblk - ib; ++ib; }
+            const int jb = ib + rem;
+            const int j = jb * 64 + t;
+            SS_WAVE_SYNC();                                          // the previous pair's reads of sb / sa are done
+            if (j < n) { sb[t * 4] = w.box[j * 4]; sb[t * 4 + 1] = w.box[j * 4 + 1]; sb[t * 4 + 2] = w.box[j * 4 + 2]; sb[t * 4 + 3] = w.box[j * 4 + 3]; sa[t] = w.area[j]; }
+            SS_WAVE_SYNC();
+            const int i = ib * 64 + t;
+            if (i >= n) continue;
+            const float x1 = w.box[i * 4], y1 = w.box[i * 4 + 1], x2 = w.box[i * 4 + 2], y2 = w.box[i * 4 + 3], ai = w.area[i];
+            unsigned long long bits = 0;
+            const int jn = min(64, n - jb * 64);
+            for (int q = 0; q < jn; ++q) {
+                if (jb * 64 + q <= i) continue;
+                float xx1 = fmaxf(x1, sb[q * 4]), yy1 = fmaxf(y1, sb[q * 4 + 1]);
+                float xx2 = fminf(x2, sb[q * 4 + 2]), yy2 = fminf(y2, sb[q * 4 + 3]);
+                float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
+                float inter = iw * ih;
+                float iou = inter / (ai + sa[q] - inter);
+                if (iou > iou_thres) bits |= 1ull << q;
+            }
+            w.mask[(size_t)i * NMS_WORDS + jb] = bits;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase C: greedy scan on wave 0 ----
+    if (wv == 0) {
+        const int nw = (n + 63) / 64;
+        unsigned long long rem0 = 0, rem1 = 0;
+        int kept = 0;
+        const int cap = min(max_det, 1024);
+        for (int ib = 0; ib < nw && kept < cap; ++ib) {
+            unsigned long long rw = __shfl((ib < 64) ? rem0 : rem1, ib & 63);
+            const int i0 = ib * 64;
+            const int cnt = min(64, n - i0);
+            unsigned long long diag = (l < cnt) ? w.mask[(size_t)(i0 + l) * NMS_WORDS + ib] : 0ull;
+            unsigned long long keptbits = 0;
+            for (int q = 0; q < cnt && kept < cap; ++q) {
+                if (!((rw >> q) & 1ull)) {
+                    keptbits |= 1ull << q;
+                    if (l == 0) kept_sorted[kept] = i0 + q;
+                    ++kept;
+                    rw |= __shfl(diag, q);
+                }
+            }
+            unsigned long long kb = keptbits;
+            while (kb) {
+                int q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { q[u] = kb ? __builtin_ctzll(kb) : -1; if (kb) kb &= kb - 1; }
+                unsigned long long a0[4], a1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a0[u] = a1[u] = 0ull;
+                    if (q[u] >= 0) {
+                        const unsigned long long* mr = w.mask + (size_t)(i0 + q[u]) * NMS_WORDS;
+                        if (l > ib && l < nw) a0[u] = mr[l];
+                        if (l + 64 > ib && l + 64 < nw) a1[u] = mr[l + 64];
+                    }
+                }
+                rem0 |= (a0[0] | a0[1]) | (a0[2] | a0[3]);
+                rem1 |= (a1[0] | a1[1]) | (a1[2] | a1[3]);
+            }
+        }
+        if (l == 0) { s_kept = kept; *count = kept; w.counters[0] = 0; }     // re-arm the candidate counter for the next call
+    }
+    __syncthreads();
+    const int kept = s_kept;
+    for (int kk = tid; kk < kept; kk += 1024) {
+        const int i = kept_sorted[kk];
+        const unsigned long long key = w.keys[i];
+        const int a = (int)(key & 0xffffffffu);
+        const float score = __uint_as_float(~(unsigned)(key >> 32));
+        float cx = pred[a], cy = pred[(size_t)N + a], bw = pred[(size_t)2 * N + a], bh = pred[(size_t)3 * N + a];
+        float hw = bw / 2.0f, hh = bh / 2.0f;
+        float x1 = ((cx - hw) - pad_x) / gain, y1 = ((cy - hh) - pad_y) / gain;
+        float x2 = ((cx + hw) - pad_x) / gain, y2 = ((cy + hh) - pad_y) / gain;
+        float* r = rows + (size_t)kk * row_stride;
+        r[0] = fminf(fmaxf(x1, 0.0f), w0); r[1] = fminf(fmaxf(y1, 0.0f), h0);
+        r[2] = fminf(fmaxf(x2, 0.0f), w0); r[3] = fminf(fmaxf(y2, 0.0f), h0);
+        r[4] = score; r[5] = (float)w.cand_cls[a];
+        for (int e = 0; e < n_extra; ++e) r[6 + e] = pred[(size_t)(4 + nc + e) * N + a];
+        keep[kk] = a;
+    }
+}
+
+#define NMS_REST_LDS (NMS_MAX_CAND * 8 + 16 * 64 * 4 * 4 + 16 * 64 * 4 + 1024 * 4)
+
 int ss_front_init()
 {
     hipError_t e = hipFuncSetAttribute((const void*)k_nms_sort, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_CAND * 8);
-    return e == hipSuccess ? 0 : 1;
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_nms_rest, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_REST_LDS);
+    return (e == hipSuccess && e2 == hipSuccess) ? 0 : 1;
 }
 
 // error flags (counters[1]) of the first `units` workspace units, for ss_check_errors
 int* ss_nms_error_flag(void* ws, int unit) { return carve_nms((char*)ws + (size_t)unit * ss_nms_workspace_bytes()).counters + 1; }
+
+int ss_nms_fused = 1;      // 1: filter + one workgroup per image for the rest; 0: filter, sort, mask, scan as four launches (ss_set_option "nms_fused")
 
 int ss_launch_nms(const float* pred, int batch, long long pred_stride, int N, int nc, int n_extra, float conf, float iou,
                   int agnostic, float max_wh, int max_det, float gain, float pad_x, float pad_y, float w0, float h0,
@@ -548,9 +736,14 @@ int ss_launch_nms(const float* pred, int batch, long long pred_stride, int N, in
     NmsBatch nb{ pred, pred_stride, (char*)ws, (long long)ss_nms_workspace_bytes() };
     // the candidate counter is re-armed by k_nms_scan itself (no memset node: graph-capture safe)
     hipLaunchKernelGGL(k_nms_filter, dim3((N + 63) / 64, batch), dim3(512), 0, st, nb, N, nc, conf, cm0, cm1);
-    hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(1024), NMS_MAX_CAND * 8, st, nb, N, agnostic, max_wh);
-    hipLaunchKernelGGL(k_nms_mask, dim3(NMS_MASK_WG, batch), dim3(64), 0, st, nb, iou);
-    hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), 0, st, nb, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
-                       geom, rows, row_stride, rows_batch_stride, keep, keep_batch_stride, count);
+    if (ss_nms_fused) {
+        hipLaunchKernelGGL(k_nms_rest, dim3(batch), dim3(1024), NMS_REST_LDS, st, nb, N, nc, n_extra, agnostic, max_wh, iou, max_det, gain,
+                           pad_x, pad_y, w0, h0, geom, rows, row_stride, rows_batch_stride, keep, keep_batch_stride, count);
+    } else {
+        hipLaunchKernelGGL(k_nms_sort, dim3(batch), dim3(1024), NMS_MAX_CAND * 8, st, nb, N, agnostic, max_wh);
+        hipLaunchKernelGGL(k_nms_mask, dim3(NMS_MASK_WG, batch), dim3(64), 0, st, nb, iou);
+        hipLaunchKernelGGL(k_nms_scan, dim3(batch), dim3(64), 0, st, nb, N, nc, n_extra, max_det, gain, pad_x, pad_y, w0, h0,
+                           geom, rows, row_stride, rows_batch_stride, keep, keep_batch_stride, count);
+    }
     return 0;
 }
