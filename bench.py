@@ -559,7 +559,11 @@ def main():
     assoc_ik_us, assoc_ik_n = pipe.eng.assoc_inkernel_timing(False)
     pipe.eng.check_errors()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    per_rank_dt = [dt]
     if world > 1:
+        gathered = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(gathered, tmax)                     # every rank's own time between the barriers (rank 0 reports them)
+        per_rank_dt = [float(t.item()) for t in gathered]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -660,6 +664,9 @@ def main():
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
+            "per_rank_value": [round(S * KF / t, 2) for t in per_rank_dt], "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
+            "backend": (backend + ("=RCCL" if backend == "nccl" else "")) if world > 1 else None,
+            "devices": "one GPU shared by all ranks (SS_BENCH_SINGLE_DEVICE=1: control-flow run)" if (one_dev and world > 1) else "one GPU per rank",
             "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "id_match_rate": round(id_rate_min, 6), "frames_bit_exact": f"{exact_min}/{nchk}", "frames_bit_exact_timed": f"{exact_timed_min}/{n_timed}",
             "id_check": "every rank vs the oracle on its own stream 0 over prefill + warm-up + ALL timed frames, minimum over ranks",
             "roofline": roofline, "roofline_front": roofline_front,

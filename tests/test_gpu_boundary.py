@@ -294,3 +294,24 @@ def test_predict_keeps_more_than_128_detections():
     r = cexact.scale_boxes(r, gs[0], gs[1], gs[2], W, H)
     assert len(r) > 128 and np.array_equal(res.boxes.xyxy.numpy(), r[:, :4]) and np.array_equal(res.boxes.conf.numpy(), r[:, 4])
     model.close()
+
+
+def test_two_ranks_on_one_gpu_each_identical_to_its_oracle():
+    """The multi-rank path of bench.py with the PRODUCT pipeline in every rank (VERDICT r2 'next' item 6): two processes
+    started exactly as the driver starts them (torch.distributed.run, 127.0.0.1 rendezvous), gloo for the barrier / max /
+    gather because both ranks share this box's single GPU; every rank checks its own stream against its own oracle over all
+    frames and rank 0 reports the minimum.  Stands for /root/reference/yolo_multi_model.py:351-354 (one process per source)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SS_BENCH_BACKEND="gloo", SS_BENCH_SINGLE_DEVICE="1", SS_RANDOM_INIT="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-api-path", "--no-batched"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_in_process_group"] == 2 and len(d["per_rank_value"]) == 2 and d["scaling"] == "weak"
+    assert d["id_match_rate"] == 1.0
+    n, m = d["frames_bit_exact_timed"].split("/")
+    assert n == m and int(m) == 2 * 32
+    assert abs(d["value"] - 2 * min(d["per_rank_value"])) / d["value"] < 1e-6          # whole job = ranks x frames / max-rank time
