@@ -618,7 +618,11 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
                 int lo = 0, hi = ptot;                                 // pair of record r: roff[lo] <= r < roff[lo + 1]
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= r) lo = mid; else hi = mid; }
                 const int pp = lo, j = r - roff[pp], nrp = roff[pp + 1] - roff[pp], ngp = ngs[pp];
-                const int x = (j + s + (nrp < 8 ? pp * nrp : 0)) & 7;
+                // list = XCD: range j of stream s always on the same XCD (its part of the gallery stays in that XCD's L2 for every
+                // frame); with fewer than 8 ranges per pair, ceil(8 / ranges) consecutive pairs share the 8 XCDs between them, so a
+                // range lives on that many XCDs (not on all 8: at 32 streams x 7 ranges that was 4.1 GB of HBM traffic per launch
+                // instead of ~1 GB, L2 hit rate 0.33)
+                const int x = (j + s * nrp + (nrp < 8 ? (pp % ((8 + nrp - 1) / nrp)) * nrp : 0)) & 7;
                 const int pos = atomicAdd(&lcnt[x], 1);
                 if (pass == 0) continue;
                 if (lbase[x] + pos >= dev.items_cap) { dev.err[s] = SS_ERR_CAPACITY; continue; }

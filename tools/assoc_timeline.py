@@ -8,7 +8,7 @@ from strongsort_yolo_amd.engine import TrackerEngine
 from strongsort_yolo_amd.synth import make_stream
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 FB = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-frames = 128
+frames = 160                      # galleries full (nn_budget rows) from frame ~103 on
 eng = TrackerEngine(StrongSortConfig(nn_budget=int(os.environ.get("SS_BUDGET", "100"))), S, 0)
 for kv in os.environ.get("SS_OPTS", "").split(","):
     if kv:

@@ -1,9 +1,10 @@
-"""The multi-stream association-kernel measurement of bench.py on its own (for rocprofv3 PMC passes).
-usage: python tools/batched_assoc.py [streams=32] [frame_batch=8]"""
+"""The multi-stream association-kernel measurement of bench.py on its own (for rocprofv3 PMC passes / kernel traces).
+usage: python tools/batched_assoc.py [streams=32] [frame_batch=8] [identities=30] [W=1280] [H=720]
+160 frames (galleries reach nn_budget = 100 rows at frame ~103), the last 32 timed."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from strongsort_yolo_amd.config import StrongSortConfig
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-fb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-print(json.dumps(bench.batched_association(StrongSortConfig(), n_streams=n, frames=128, timed=32, frame_batch=fb, check=False)))
+a = [int(v) for v in sys.argv[1:]]
+n, fb, ids, W, H = (a + [32, 8, 30, 1280, 720][len(a):])[:5]
+print(json.dumps(bench.batched_association(StrongSortConfig(), n_streams=n, n_ids=ids, W=W, H=H, frames=160, timed=32, frame_batch=fb, check=False)))
