@@ -202,6 +202,10 @@ int ss_feat_normalize(ss_ctx* ctx, const float* d_raw, int n, float* d_unit);
 int ss_ema(ss_ctx* ctx, const float* d_smooth, const float* d_feat, int n, float* d_out);
 int ss_kf_predict(ss_ctx* ctx, double* d_mean, double* d_cov, int n);
 int ss_kf_update(ss_ctx* ctx, double* d_mean, double* d_cov, const double* d_z, const double* d_conf, int n);
+/* a7 KalmanFilter.project with the NSA noise: d_zmean[n][4] = H x, d_S[n][4][4] = H P H^T + R(x, conf), R's deviations scaled
+ * by (1 - conf); d_conf == NULL: conf = 0 (the form the gating distance uses).  The tracker runs it fused into the gate and
+ * the update; this entry point exists for known-answer tests. */
+int ss_kf_project(ss_ctx* ctx, const double* d_mean, const double* d_cov, const double* d_conf, int n, double* d_zmean, double* d_S);
 int ss_kf_initiate(ss_ctx* ctx, const double* d_z, int n, double* d_mean, double* d_cov);
 /* gallery rows natural [T][B][512] -> fragment-major [T][4][16384] used by ss_assoc_cost */
 int ss_gallery_pack(ss_ctx* ctx, const float* d_gallery, int T, int B, float* d_frag);

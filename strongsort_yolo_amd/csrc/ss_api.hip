@@ -27,6 +27,7 @@ int* ss_nms_error_flag(void*, int);
 size_t ss_nms_workspace_bytes();
 void ss_launch_crop(const uint8_t*, int, long long, int, int, int, const float*, int, long long, int, const int*, void*, int, hipStream_t, const int*);
 void ss_launch_crop_offsets(const int*, int, int, int*, hipStream_t);
+void ss_launch_project(const double*, const double*, const double*, int, double, double*, double*, hipStream_t);
 extern int ss_nms_fused;
 void ss_launch_unpack_feats(const void*, int, const int*, const int*, int, int, float*, long long, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
@@ -433,6 +434,12 @@ extern "C" int ss_kf_predict(ss_ctx* c, double* mean, double* cov, int n)
 
 extern "C" int ss_kf_update(ss_ctx* c, double* mean, double* cov, const double* z, const double* conf, int n)
 { if (!c) return SS_ERR_INVALID; ss_launch_kf(1, mean, cov, z, conf, n, c->prm.wp, c->prm.wv, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }
+
+extern "C" int ss_kf_project(ss_ctx* c, const double* mean, const double* cov, const double* conf, int n, double* zmean, double* S)
+{
+    if (!c || !mean || !cov || !zmean || !S || n < 0) return fail(c, SS_ERR_INVALID, "ss_kf_project: bad argument");
+    ss_launch_project(mean, cov, conf, n, c->prm.wp, zmean, S, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK;
+}
 
 extern "C" int ss_kf_initiate(ss_ctx* c, const double* z, int n, double* mean, double* cov)
 { if (!c) return SS_ERR_INVALID; ss_launch_kf(2, mean, cov, z, nullptr, n, c->prm.wp, c->prm.wv, c->stream); HIPCHK(c, hipGetLastError()); return SS_OK; }

@@ -1400,6 +1400,19 @@ __global__ void k_kat_kf(int op, double* mean, double* cov, const double* z, con
     for (int k = 0; k < 64; ++k) cov[(size_t)i * 64 + k] = c[k];
 }
 
+// a7 on its own: projected mean z = Hx [n][4] and innovation covariance S = H P H^T + R(x, conf) [n][16] (NSA noise)
+__global__ void k_kat_project(const double* mean, const double* cov, const double* conf, int n, double wp, double* zmean, double* S)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double m[8], c[64], m4[4], s16[16];
+    for (int k = 0; k < 8; ++k) m[k] = mean[(size_t)i * 8 + k];
+    for (int k = 0; k < 64; ++k) c[k] = cov[(size_t)i * 64 + k];
+    ss_kf_project(m, c, conf ? conf[i] : 0.0, wp, m4, s16);
+    for (int k = 0; k < 4; ++k) zmean[(size_t)i * 4 + k] = m4[k];
+    for (int k = 0; k < 16; ++k) S[(size_t)i * 16 + k] = s16[k];
+}
+
 __global__ void k_kat_pack(const float* nat, int T, int B, float* frag)
 {
     // nat [T][B][512] -> frag [T][NRT][TILE_FLOATS]; one wave per gallery row
@@ -1486,6 +1499,8 @@ void ss_launch_ema(const float* s, const float* f, int n, float a, float b, floa
 { if (n) hipLaunchKernelGGL(k_kat_ema, dim3((n + 3) / 4), dim3(256), 0, st, s, f, n, a, b, o); }
 void ss_launch_kf(int op, double* mean, double* cov, const double* z, const double* conf, int n, double wp, double wv, hipStream_t st)
 { if (n) hipLaunchKernelGGL(k_kat_kf, dim3((n + 63) / 64), dim3(64), 0, st, op, mean, cov, z, conf, n, wp, wv); }
+void ss_launch_project(const double* mean, const double* cov, const double* conf, int n, double wp, double* zmean, double* S, hipStream_t st)
+{ if (n) hipLaunchKernelGGL(k_kat_project, dim3((n + 63) / 64), dim3(64), 0, st, mean, cov, conf, n, wp, zmean, S); }
 void ss_launch_pack(const float* nat, int T, int B, float* frag, hipStream_t st)
 { if (T * B) hipLaunchKernelGGL(k_kat_pack, dim3((T * B + 3) / 4), dim3(256), 0, st, nat, T, B, frag); }
 void ss_launch_assoc(const float* gal_frag, const int* counts, int T, const float* feats, int D,

@@ -259,6 +259,16 @@ class TrackerEngine:
         self._ck(self.L.ss_kf_update(self.ctx, _ptr(m), _ptr(c), _ptr(z), _ptr(cf), m.shape[0]))
         return m, c
 
+    def kf_project(self, mean, cov, conf=None):
+        """a7: (projected mean [n,4], innovation covariance [n,4,4]) of the states, NSA noise for `conf` (None: 0)."""
+        m, c = self._dev(mean, torch.float64), self._dev(cov, torch.float64)
+        cf = self._dev(conf, torch.float64) if conf is not None else None
+        n = m.shape[0]
+        z = torch.empty(n, 4, dtype=torch.float64, device=self.device)
+        S = torch.empty(n, 4, 4, dtype=torch.float64, device=self.device)
+        self._ck(self.L.ss_kf_project(self.ctx, _ptr(m), _ptr(c), _ptr(cf), n, _ptr(z), _ptr(S)))
+        return z, S
+
     def kf_initiate(self, z):
         z = self._dev(z, torch.float64)
         n = z.shape[0]

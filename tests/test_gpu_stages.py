@@ -66,6 +66,12 @@ def test_kalman_bit_exact(eng):
     ref = [cexact.kf_update(means[i], covs[i], z[i], conf[i], wp) for i in range(70)]
     assert bits_equal(m.cpu().numpy(), np.array([r[0] for r in ref]))
     assert bits_equal(c.cpu().numpy(), np.array([r[1] for r in ref]))
+    # a7 on its own (ss_kf_project): projected mean + innovation covariance with the NSA noise, and with conf = 0
+    for cf in (conf, None):
+        zm, S = eng.kf_project(means, covs, cf)
+        ref = [cexact.kf_project(means[i], covs[i], 0.0 if cf is None else cf[i], wp) for i in range(70)]
+        assert bits_equal(zm.cpu().numpy(), np.array([r[0] for r in ref]))
+        assert bits_equal(S.cpu().numpy().reshape(70, 16), np.array([np.asarray(r[1]).reshape(16) for r in ref]))
 
 
 @pytest.mark.parametrize("T,D,B", [(30, 30, 100), (100, 100, 100), (5, 1, 1), (3, 33, 37), (1, 128, 128), (17, 64, 32)])
