@@ -183,8 +183,12 @@ class Detect(nn.Module):
                 bb, cb = [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3]
             return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)],
                                    [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, self.strides, self.nc)
-        box = torch.cat([self.cv2[i](f).view(B, 64, -1) for i, f in enumerate(feats)], 2)
-        cls = torch.cat([self.cv3[i](f).view(B, self.nc, -1) for i, f in enumerate(feats)], 2)
+        return self._forward_torch(feats)
+
+    def _forward_torch(self, feats):
+        B = feats[0].shape[0]
+        box = torch.cat([self.cv2[i](f).reshape(B, 64, -1) for i, f in enumerate(feats)], 2)
+        cls = torch.cat([self.cv3[i](f).reshape(B, self.nc, -1) for i, f in enumerate(feats)], 2)
         if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:
             self._anchors = self._make_anchors(feats)
         anchors, strides = self._anchors
@@ -195,7 +199,7 @@ class Detect(nn.Module):
         out = [torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * strides, cls.sigmoid()]
         if self.nk:
             # keypoint decode (Ultralytics Pose.kpts_decode): xy = (2 k + anchor - 0.5) * stride, visibility = sigmoid
-            k = torch.cat([self.cv4[i](f).view(B, self.nk, -1) for i, f in enumerate(feats)], 2).view(B, self.nk // 3, 3, -1)
+            k = torch.cat([self.cv4[i](f).reshape(B, self.nk, -1) for i, f in enumerate(feats)], 2).view(B, self.nk // 3, 3, -1)
             xy = (k[:, :, :2] * 2.0 + (anchors - 0.5).unsqueeze(1)) * strides.unsqueeze(1)
             out.append(torch.cat((xy, k[:, :, 2:].sigmoid()), 2).view(B, self.nk, -1))
         return torch.cat(out, 1)
@@ -238,6 +242,149 @@ class YOLOv8(nn.Module):
 
     def forward(self, x):
         return self.forward_head(*self.forward_backbone(x))
+
+
+# --------------------------------------------------------------------------------------------------
+# YOLO11 (the reference's default weights file: `YOLO("yolo11n-pose.pt")`, /root/reference/yolo_multi_model.py:17)
+# --------------------------------------------------------------------------------------------------
+# Block structure restated from the published Ultralytics yolo11.yaml / modules (C3k2, C3k, C2PSA, PSABlock, Attention, the
+# depthwise-separable class branch of the v11 Detect head); nothing of it is in the reference snapshot, and no weights exist
+# offline, so the only check available here is structural (strict state_dict key / shape match through
+# `convert_ultralytics_state_dict`).  Module attribute names follow the Ultralytics layer indices (b0..b10, h13.., detect = 23).
+class C3k(nn.Module):
+    """C3 with n Bottlenecks of two k x k convolutions (e = 1.0 inside)."""
+
+    def __init__(self, c1, c2, n=2, shortcut=True, k=3):
+        super().__init__()
+        c_ = c2 // 2
+        self.cv1, self.cv2, self.cv3 = Conv(c1, c_, 1), Conv(c1, c_, 1), Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, k=(k, k), e=1.0) for _ in range(n)))
+
+    def forward(self, x):
+        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+
+class C3k2(nn.Module):
+    """C2f whose inner blocks are C3k (c3k=True) or plain Bottlenecks with e = 0.5; hidden width c = int(c2 * e)."""
+
+    def __init__(self, c1, c2, n=1, c3k=False, e=0.5, shortcut=True):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(C3k(self.c, self.c, 2, shortcut) if c3k else Bottleneck(self.c, self.c, shortcut) for _ in range(n))
+
+    def forward(self, x):
+        y = list(self.cv1(x).chunk(2, 1))
+        for m in self.m:
+            y.append(m(y[-1]))
+        return self.cv2(torch.cat(y, 1))
+
+
+class Attention(nn.Module):
+    """Multi-head self-attention over the H*W positions of a feature map (key_dim = head_dim * attn_ratio) + a depthwise 3x3
+    positional term on v."""
+
+    def __init__(self, dim, num_heads=8, attn_ratio=0.5):
+        super().__init__()
+        self.num_heads, self.head_dim = num_heads, dim // num_heads
+        self.key_dim = int(self.head_dim * attn_ratio)
+        self.scale = self.key_dim ** -0.5
+        h = dim + self.key_dim * num_heads * 2
+        self.qkv, self.proj = Conv(dim, h, 1, act=False), Conv(dim, dim, 1, act=False)
+        self.pe = Conv(dim, dim, 3, 1, g=dim, act=False)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        N = H * W
+        qkv = self.qkv(x).contiguous().view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N)
+        q, k, v = qkv.split([self.key_dim, self.key_dim, self.head_dim], dim=2)
+        attn = ((q.transpose(-2, -1) @ k) * self.scale).softmax(dim=-1)
+        cl = x.is_contiguous(memory_format=torch.channels_last)
+        vv = v.reshape(B, C, H, W)
+        y = (v @ attn.transpose(-2, -1)).reshape(B, C, H, W) + self.pe(vv.contiguous(memory_format=torch.channels_last) if cl else vv)
+        if cl:
+            y = y.contiguous(memory_format=torch.channels_last)
+        return self.proj(y)
+
+
+class PSABlock(nn.Module):
+    def __init__(self, c, attn_ratio=0.5, num_heads=4):
+        super().__init__()
+        self.attn = Attention(c, num_heads, attn_ratio)
+        self.ffn = nn.Sequential(Conv(c, c * 2, 1), Conv(c * 2, c, 1, act=False))
+
+    def forward(self, x):
+        x = x + self.attn(x)
+        return x + self.ffn(x)
+
+
+class C2PSA(nn.Module):
+    def __init__(self, c1, n=1, e=0.5):
+        super().__init__()
+        self.c = int(c1 * e)
+        self.cv1, self.cv2 = Conv(c1, 2 * self.c, 1), Conv(2 * self.c, c1, 1)
+        self.m = nn.Sequential(*(PSABlock(self.c, 0.5, max(self.c // 64, 1)) for _ in range(n)))
+
+    def forward(self, x):
+        a, b = self.cv1(x).split((self.c, self.c), 1)
+        if x.is_contiguous(memory_format=torch.channels_last):
+            b = b.contiguous(memory_format=torch.channels_last)
+        return self.cv2(torch.cat((a, self.m(b)), 1))
+
+
+class Detect11(Detect):
+    """v11 head: the class branch is depthwise-separable (DWConv 3x3 -> Conv 1x1, twice) before the final 1x1."""
+
+    def __init__(self, nc, ch, nk=0):
+        super().__init__(nc, ch, nk)
+        c3 = max(ch[0], min(nc, 100))
+        self.cv3 = nn.ModuleList(nn.Sequential(nn.Sequential(Conv(x, x, 3, g=x), Conv(x, c3, 1)),
+                                               nn.Sequential(Conv(c3, c3, 3, g=c3), Conv(c3, c3, 1)), nn.Conv2d(c3, nc, 1)) for x in ch)
+
+    def forward(self, feats):
+        if fused.usable(feats[0]) and self.nk == 0 and all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
+            last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)
+            z = getattr(self, "_zeros", None)
+            if z is None or z.device != feats[0].device:
+                z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
+            return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)], [last(self.cv3[i], f) for i, f in enumerate(feats)],
+                                   [z] * 3, [z] * 3, self.strides, self.nc)
+        return self._forward_torch(feats)
+
+
+_V11_SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.00, 512)}
+
+
+class YOLO11(nn.Module):
+    def __init__(self, scale="n", nc=80, nk=0):
+        super().__init__()
+        d, w, mc = _V11_SCALES[scale]
+        c = lambda x: int(math.ceil(min(x, mc) * w / 8) * 8)
+        n = lambda x: max(round(x * d), 1)
+        k3 = scale in "mlx"                                       # the larger scales use C3k inner blocks everywhere
+        self.b0, self.b1 = Conv(3, c(64), 3, 2), Conv(c(64), c(128), 3, 2)
+        self.b2 = C3k2(c(128), c(256), n(2), k3, 0.25)
+        self.b3, self.b4 = Conv(c(256), c(256), 3, 2), C3k2(c(256), c(512), n(2), k3, 0.25)
+        self.b5, self.b6 = Conv(c(512), c(512), 3, 2), C3k2(c(512), c(512), n(2), True)
+        self.b7, self.b8 = Conv(c(512), c(1024), 3, 2), C3k2(c(1024), c(1024), n(2), True)
+        self.b9, self.b10 = SPPF(c(1024), c(1024)), C2PSA(c(1024), n(2))
+        self.h13 = C3k2(c(1024) + c(512), c(512), n(2), k3)
+        self.h16 = C3k2(c(512) + c(512), c(256), n(2), k3)
+        self.h17, self.h19 = Conv(c(256), c(256), 3, 2), C3k2(c(256) + c(512), c(512), n(2), k3)
+        self.h20, self.h22 = Conv(c(512), c(512), 3, 2), C3k2(c(512) + c(1024), c(1024), n(2), True)
+        self.detect = Detect11(nc, (c(256), c(512), c(1024)), nk)
+        self.nc, self.nk = nc, nk
+
+    def forward(self, x):
+        p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
+        p4 = self.b6(self.b5(p3))
+        p5 = self.b10(self.b9(self.b8(self.b7(p4))))
+        h13 = self.h13(_upcat(p5, p4))
+        h16 = self.h16(_upcat(h13, p3))
+        h19 = self.h19(torch.cat((self.h17(h16), h13), 1))
+        h22 = self.h22(torch.cat((self.h20(h19), p5), 1))
+        return self.detect([h16, h19, h22])
 
 
 class YOLOv5u(nn.Module):
@@ -547,8 +694,8 @@ def osnet_x0_25():
 
 DETECTORS = {
     "yolov8n": lambda: YOLOv8("n"), "yolov8s": lambda: YOLOv8("s"), "yolov8m": lambda: YOLOv8("m"),
-    "yolov8n-pose": lambda: YOLOv8("n", nc=1, nk=51), "yolo11n-pose": lambda: YOLOv8("n", nc=1, nk=51),
-    "yolov8n-seg": lambda: YOLOv8("n"), "yolo11n": lambda: YOLOv8("n"),
+    "yolov8n-pose": lambda: YOLOv8("n", nc=1, nk=51), "yolo11n-pose": lambda: YOLO11("n", nc=1, nk=51),
+    "yolov8n-seg": lambda: YOLOv8("n"), "yolo11n": lambda: YOLO11("n"), "yolo11s": lambda: YOLO11("s"), "yolo11s-pose": lambda: YOLO11("s", nc=1, nk=51),
     "yolov5n": lambda: YOLOv5u("n"), "yolov5s": lambda: YOLOv5u("s"),
     "yolov7": lambda: YOLOv7(),
 }
@@ -588,8 +735,53 @@ def load_weights(module: nn.Module, path, what: str, random_init_ok: bool = Fals
             ck = ck[key]
     if not isinstance(ck, dict) or not all(isinstance(v, torch.Tensor) for v in ck.values()):
         raise ValueError(f"{what}: {path} is not a plain state_dict; export one with torch.save(model.state_dict(), ...)")
+    if any(k.startswith("model.") for k in ck):                 # an Ultralytics DetectionModel state_dict: layer indices + Conv/BN pairs
+        ck = convert_ultralytics_state_dict(module, ck)
     module.load_state_dict(ck, strict=True)
     return True
+
+
+def convert_ultralytics_state_dict(module: nn.Module, sd: dict, bn_eps: float = 1e-3) -> dict:
+    """Keys of an Ultralytics model's `model.model.state_dict()` (exported where `ultralytics` is installed:
+    `torch.save(YOLO("yolo11n-pose.pt").model.state_dict(), "yolo11n-pose.pt")`) -> this module's keys:
+      * `model.<i>.` -> the attribute that stands for layer i here (`b<i>` / `h<i>`, the last indexed layer = `detect`);
+      * every Conv + BatchNorm pair (`X.conv.weight`, `X.bn.{weight,bias,running_mean,running_var}`; Ultralytics uses
+        eps = 1e-3) folded into the biased convolution the networks here are built with;
+      * the fixed DFL projection (`dfl.conv.weight` = arange(16)) and `num_batches_tracked` dropped.
+    The result is loaded strictly, so a layer that does not line up raises instead of running on wrong weights."""
+    idx = {}
+    for name, _ in module.named_children():
+        if name[:1] in "bh" and name[1:].isdigit():
+            idx[int(name[1:])] = name
+    layers = sorted({int(k.split(".")[1]) for k in sd if k.startswith("model.") and k.split(".")[1].isdigit()})
+    if hasattr(module, "detect") and layers:
+        idx.setdefault(layers[-1], "detect")
+    out, bn = {}, {}
+    for k, v in sd.items():
+        parts = k.split(".")
+        if parts[0] != "model" or not parts[1].isdigit():
+            raise ValueError(f"unexpected key {k!r} in an Ultralytics state_dict")
+        i = int(parts[1])
+        if i not in idx:
+            raise ValueError(f"layer {i} of the checkpoint has no counterpart in {type(module).__name__} ({k!r})")
+        rest = parts[2:]
+        if rest[-1] == "num_batches_tracked" or rest[:2] == ["dfl", "conv"]:
+            continue
+        name = ".".join([idx[i]] + rest)
+        if len(rest) >= 2 and rest[-2] == "bn":
+            bn.setdefault(".".join([idx[i]] + rest[:-2]), {})[rest[-1]] = v.float()
+        else:
+            out[name] = v
+    for prefix, p in bn.items():
+        wk = prefix + ".conv.weight"
+        if wk not in out or not {"weight", "bias", "running_mean", "running_var"} <= set(p):
+            raise ValueError(f"incomplete Conv/BatchNorm pair at {prefix!r}")
+        w = out[wk].float()
+        scale = p["weight"] / torch.sqrt(p["running_var"] + bn_eps)
+        out[wk] = (w * scale.view(-1, 1, 1, 1)).to(out[wk].dtype)
+        b0 = out.get(prefix + ".conv.bias")
+        out[prefix + ".conv.bias"] = (p["bias"] - p["running_mean"] * scale + (b0.float() * scale if b0 is not None else 0)).to(out[wk].dtype)
+    return out
 
 
 def build_reid(seed: int = 1) -> nn.Module:

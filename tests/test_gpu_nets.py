@@ -6,7 +6,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name,shape", [("yolov8n", (1, 3, 384, 640)), ("osnet", (8, 3, 256, 128)), ("yolov8n-pose", (2, 3, 128, 160)),
-                                        ("yolov8s", (2, 3, 192, 320)), ("yolov5n", (2, 3, 128, 160)), ("yolov7", (1, 3, 192, 320))])
+                                        ("yolov8s", (2, 3, 192, 320)), ("yolov5n", (2, 3, 128, 160)), ("yolov7", (1, 3, 192, 320)),
+                                        ("yolo11n", (2, 3, 192, 320)), ("yolo11n-pose", (1, 3, 384, 640))])
 def test_fused_ops_match_torch_modules(name, shape):
     from strongsort_yolo_amd import fused, nets
     dev = torch.device("cuda", 0)

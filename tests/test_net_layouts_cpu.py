@@ -3,6 +3,7 @@ torch's own operators in fp32.  They pin the host-side weight layouts (`fused.we
 the stacked LightConv weights of an OSNet block) and the kernels' addressing schemes independent of a GPU; the GPU
 tests (`tests/test_gpu_nets.py`) then check the kernels themselves."""
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -142,3 +143,52 @@ def test_avgpool_and_place_guards():
     assert fused.lightconv_ok(x) and fused.streams_ok(x)
     assert not fused.streams_ok(torch.zeros(1, 16, 64, 100))                 # W % 8 != 0
     assert not fused.streams_ok(torch.zeros(1, 32, 64, 64))                  # LDS budget
+
+
+@pytest.mark.parametrize("name,last", [("yolov8n", 22), ("yolov5n", 24), ("yolo11n-pose", 23), ("yolo11n", 23)])
+def test_ultralytics_state_dict_is_folded_and_mapped(name, last, tmp_path):
+    """An Ultralytics-style state_dict (layer indices, Conv + BatchNorm pairs, DFL projection, num_batches_tracked) built from
+    one of the networks here loads — strictly — into a fresh one and reproduces its forward pass: the layer-index map and the
+    BatchNorm folding of nets.convert_ultralytics_state_dict (what `YOLO("yolo11n-pose.pt")` of
+    /root/reference/yolo_multi_model.py:17 needs once a real exported file is there)."""
+    from strongsort_yolo_amd import nets
+    src = nets.build_detector(name, 3).float()
+    g = torch.Generator().manual_seed(11)
+    fake, convs = {}, {n for n, m in src.named_modules() if isinstance(m, nets.Conv)}
+    eps = 1e-3
+
+    def uname(key):                                               # b3.cv1.conv.weight -> model.3.cv1.conv.weight
+        head, rest = key.split(".", 1)
+        return f"model.{last if head == 'detect' else int(head[1:])}.{rest}"
+
+    sd = src.state_dict()
+    for key, v in sd.items():
+        mod = key.rsplit(".", 2)[0]
+        if mod in convs and key.endswith(".conv.weight"):
+            gamma, var = torch.rand(v.shape[0], generator=g) + 0.5, torch.rand(v.shape[0], generator=g) + 0.5
+            mean, beta = torch.randn(v.shape[0], generator=g), sd[mod + ".conv.bias"]
+            scale = gamma / torch.sqrt(var + eps)
+            fake[uname(key)] = v / scale.view(-1, 1, 1, 1)                        # folds back to v
+            pre = uname(mod + ".bn.")
+            fake[pre + "weight"], fake[pre + "running_var"], fake[pre + "running_mean"] = gamma, var, mean
+            fake[pre + "bias"] = beta + mean * scale                             # folds back to beta
+            fake[pre + "num_batches_tracked"] = torch.tensor(7)
+        elif mod in convs and key.endswith(".conv.bias"):
+            continue
+        else:
+            fake[uname(key)] = v
+    fake[f"model.{last}.dfl.conv.weight"] = torch.arange(16.0).view(1, 16, 1, 1)
+    path = tmp_path / (name + ".pt")
+    torch.save(fake, path)
+    dst = nets.build_detector(name, 99).float()
+    assert nets.load_weights(dst, str(path), name)
+    for k, v in sd.items():
+        assert torch.allclose(dst.state_dict()[k], v, rtol=1e-4, atol=1e-5), k
+    x = torch.randn(1, 3, 64, 96, generator=g)
+    with torch.no_grad():
+        assert torch.allclose(dst(x), src(x), rtol=1e-3, atol=1e-3)
+    # a layer that does not line up is an error, not a silently wrong network
+    bad = dict(fake); bad["model.40.conv.weight"] = torch.zeros(1)
+    torch.save(bad, path)
+    with pytest.raises(ValueError):
+        nets.load_weights(nets.build_detector(name, 1).float(), str(path), name)
