@@ -520,7 +520,7 @@ def main():
                 n = min(FB, k1 - g0)
                 seg_last.add(g0 + n - 1)
                 b = pipe.begin_frame()
-                with torch.cuda.stream(pipe.sA):
+                with torch.cuda.stream(pipe.s_in):
                     feed_group(g0, n, b)
                 pipe.submit(n)
 

@@ -348,7 +348,14 @@ class OverlappedPipeline(FramePipeline):
         self.ev = [[torch.cuda.Event() for _ in range(self.nb)] for _ in range(self.n)]   # ev[stage][set]
         self.ev_graph = [torch.cuda.Event() for _ in range(self.nb)]                      # last stage's graph done (tracker may start)
         self.graphs = [[None] * self.nb for _ in range(self.n)]                           # graphs[stage][set]
-        self.sA = self.streams[0]                                  # input stream
+        self.sA = self.streams[0]                                  # first stage's stream
+        # input stream: the caller fills a buffer set's inputs here (`with torch.cuda.stream(pipe.s_in)`).  Its own stream, so
+        # that the copies of group k+1 run as soon as their buffer set is free — beside the networks' kernels of the groups in
+        # flight — instead of at the head of stage 0's stream, which is exactly when the deferred tracker call of an older group
+        # launches its association kernel (the copies' blit kernels and k_assoc then share the chip: on some boxes / runs the
+        # association launch took 86 us instead of 38).  Filling on `sA` stays correct (it is ordered before stage 0).
+        self.s_in = torch.cuda.Stream(self.dev)
+        self.ev_in = [torch.cuda.Event() for _ in range(self.nb)]
         self.sB = self.sT if self.sT is not None else self.streams[-1]                    # tracker + result stream
         self.k = 0                          # groups (of frame_batch frames) submitted
         self.stage_done = [0] * self.n      # groups enqueued per stage
@@ -514,6 +521,7 @@ class OverlappedPipeline(FramePipeline):
             self._capture()
         i = self.k % self.nb
         self.sA.wait_event(self.ev[self.n - 1][i])               # the group that used this set has left the tracker
+        self.s_in.wait_event(self.ev[self.n - 1][i])
         return self.bufs[i]
 
     @torch.no_grad()
@@ -559,6 +567,8 @@ class OverlappedPipeline(FramePipeline):
         self.valid[k % self.nb] = nv
         self.base[k % self.nb] = self.frames_in                 # index of the group's first frame (partial groups allowed)
         self.frames_in += nv
+        self.ev_in[k % self.nb].record(self.s_in)               # inputs filled on the input stream: stage 0 waits for them
+        self.sA.wait_event(self.ev_in[k % self.nb])
         if self.cmc:
             with torch.cuda.stream(self.sA):
                 self.bufs[k % self.nb].nvalid.fill_(nv)

@@ -286,9 +286,9 @@ class YOLO:
                     chunk.append(nxt)
                 g = state["group"]
                 b = pipe.begin_frame()                                    # waits until this buffer set's last group left the tracker
-                with torch.cuda.stream(pipe.sA):
+                with torch.cuda.stream(pipe.s_in):
                     for f, img in enumerate(chunk):
-                        pipe.eng.upload(b.frames[f], img, pipe.sA)
+                        pipe.eng.upload(b.frames[f], img, pipe.s_in)
                     if self._fill is not None:
                         for f in range(len(chunk)):
                             self._fill(b, f, self._frame_index + f)
