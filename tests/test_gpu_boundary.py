@@ -314,4 +314,4 @@ def test_two_ranks_on_one_gpu_each_identical_to_its_oracle():
     assert d["id_match_rate"] == 1.0
     n, m = d["frames_bit_exact_timed"].split("/")
     assert n == m and int(m) == 2 * 32
-    assert abs(d["value"] - 2 * min(d["per_rank_value"])) / d["value"] < 1e-6          # whole job = ranks x frames / max-rank time
+    assert abs(d["value"] - 2 * min(d["per_rank_value"])) <= 0.03                       # whole job = ranks x frames / max-rank time (each rounded to 2 decimals)
