@@ -725,8 +725,8 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 // rest of the tile LAST, continues the sum in the same order and finishes the tile — bit-identical to one wave walking
 // the whole tile.  Finishing = rows not in the ring at frame f masked, min over the tile's 16 rows with two shuffles,
 // atomic min on an order-preserving key.  No barriers while a record is processed.  The gallery arrives as 4 KiB pieces
-// per wave, prefetched 3 pieces ahead through a 4-deep register ring (ordinary loads, so the counted vmcnt keeps 3 pieces
-// in flight); B's global loads are issued together with the first gallery pieces.  nt <= 8: one whole tile per wave.
+// per wave, prefetched 2 pieces ahead through a register ring (ordinary loads, so the counted vmcnt keeps 2 pieces in flight;
+// 3 ahead made every CU pull 64 KB more through its vector L1 before the first MFMA and bought nothing at 4 waves per SIMD); B's global loads are issued together with the first gallery pieces.  nt <= 8: one whole tile per wave.
 // Ragged last tile of a track: lanes of rows past the gallery count re-read row 0 (same cache lines, no extra HBM traffic).
 // profiling aid (ss_assoc_timeline): wall-clock stamps (100 MHz) of wave 0 of every workgroup's first record
 // (a separate instantiation: the stamps cost registers, the production kernel must keep 2 workgroups per CU)
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(p + vo + j * 1024);
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
-        if (has) { ld(0, ra[0]); ld(1, ra[1]); ld(2, ra[2]); }        // on the wire before the B staging (nsteps >= 8)
+        if (has) { ld(0, ra[0]); ld(1, ra[1]); }                      // on the wire before the B staging (nsteps >= 8)
         // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
         const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
         // (a lone column tile is staged twice: branch-free, and the second copy's results are never stored)
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             // one k-segment: prefetch (PF: piece i+3, clamped to the run's last piece so that the number of loads in flight
             // does not depend on the path — the compiler's wait counts stay exact), 32 MFMAs, running sum, tile end / hand-over
             auto step = [&](int i, float4* a, float4* anew, bool pf) {
-                if (pf) ld(min(i + 3, nsteps - 1), anew);
+                if (pf) ld(min(i + 2, nsteps - 1), anew);
                 int q, sg, qn, sgn;
                 where(i, q, sg);
                 where(min(i + 1, nsteps - 1), qn, sgn);
@@ -929,9 +929,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             };
             int i = 0;
             for (; i + 4 <= nsteps; i += 4) {
-                step(i, ra[0], ra[3], true); step(i + 1, ra[1], ra[0], true); step(i + 2, ra[2], ra[1], true); step(i + 3, ra[3], ra[2], true);
+                step(i, ra[0], ra[2], true); step(i + 1, ra[1], ra[3], true); step(i + 2, ra[2], ra[0], true); step(i + 3, ra[3], ra[1], true);
             }
-            if (i < nsteps) step(i, ra[0], nullptr, false);            // the run's last 0..3 segments: their pieces are on the way already
+            if (i < nsteps) step(i, ra[0], ra[2], true);               // the run's last 0..3 segments; the third one's piece is requested here
             if (i + 1 < nsteps) step(i + 1, ra[1], nullptr, false);
             if (i + 2 < nsteps) step(i + 2, ra[2], nullptr, false);
         }
