@@ -254,6 +254,13 @@ int ss_op_pointwise_f16(void* stream, const void* d_x, const void* d_w, const vo
 int ss_op_conv3x3_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, int B, int H,
                       int W, int Cin, int N, int conv_stride, int act, int res_after, void* d_out, int out_ld,
                       void* d_out2, int c0, int cn);
+/* A C2f bottleneck in ONE launch (nets.Bottleneck with 3x3 + 3x3, e = 1.0; reference: ultralytics' Bottleneck as the detector
+ * checkpoints the reference loads define it): out = [x +] silu(conv3x3(silu(conv3x3(x, w1) + b1), w2) + b2), the intermediate kept
+ * in LDS and rounded to half exactly where the two ss_op_conv3x3_f16 launches round it (the results are bit-identical to them).
+ * x dense [B][H][W][C], C in {16, 32, 64}; w1, w2 [C][3][3][C]; d_out points at the block's channel slice of a wider NHWC tensor
+ * (out_ld halfs per pixel), d_out2 (or NULL) receives a dense [B][H][W][C] copy. */
+int ss_op_bottleneck_f16(void* stream, const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
+                         int B, int H, int W, int C, int add, void* d_out, int out_ld, void* d_out2);
 /* Several independent convolutions in ONE launch (the detect head's branches: nets.Detect): every entry is a 3x3 / pad 1
  * (stride 1|2) or 1x1 convolution + bias + activation on NHWC half, dense output [B][OH][OW][N]; all entries of a call have
  * the same ksize; N <= 80, n <= 8.  Weights as ss_op_conv3x3_f16 ([N][3][3][Cin]) / ss_op_pointwise_f16 ([N][Cin]). */

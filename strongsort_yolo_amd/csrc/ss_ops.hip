@@ -539,6 +539,208 @@ __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
     else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_bneck — a C2f bottleneck (3x3 conv + SiLU -> 3x3 conv + SiLU (+ shortcut)) in ONE launch, the intermediate in LDS.
+// As two k_pw launches each of these layers is a chain of dependent round trips to data the previous launch has just written
+// (13-17 us per launch for 0.5 us of matrix work).  Here a workgroup owns a TH x TW tile of the block's output:
+// the input tile with a 2-pixel halo is staged once (pixel pitch C + 8 halfs: the 16 pixels of an MFMA column tile spread over
+// all LDS banks), the first convolution is evaluated on the tile + 1-pixel ring and written to LDS as half exactly as the
+// separate launch rounds it (accumulator -> half, + bias, SiLU, -> half; ZERO outside the image: it is the second convolution's
+// padding), the second convolution reads it from there, and the epilogue adds the shortcut from the staged input.  Weights:
+// 64-wide slices of k = tap * C + c, double-buffered in LDS, one barrier per slice, every LDS operand of a slice requested
+// before its first MFMA (v_mfma_f32_16x16x16_f16 pairs, as k_pw).  Output: a channel slice of the C2f concat buffer (+ the dense copy the next
+// bottleneck reads), as ss_op_conv3x3_f16 places it.
+struct BnArgs {
+    const __half* x; const __half* w1; const __half* b1; const __half* w2; const __half* b2;
+    __half* out; int out_ld; __half* out2;
+    int B, H, W, add, TW, TH, tiles_x, tiles_y;
+};
+
+template <int C, int PT>
+__device__ __forceinline__ void bn_conv(const _Float16* __restrict__ In, const int (&pbase)[PT], const int* __restrict__ tapoff,
+                                        const __half* __restrict__ w, _Float16* __restrict__ Ws, f4 (&acc)[C / 16][PT], const int tid)
+{
+    constexpr int MT = C / 16, WP = 72, K = 9 * C, WV = (C * 8 + 255) / 256;
+    const int lane = tid & 63, q = lane >> 4, n = lane & 15;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    auto load_w = [&](int k0, h8 (&wr)[WV]) {
+#pragma unroll
+        for (int j = 0; j < WV; ++j) {
+            const int i = tid + j * 256, r = i >> 3, c8 = i & 7, kk = k0 + c8 * 8;
+            wr[j] = (i < C * 8 && kk < K) ? *reinterpret_cast<const h8*>(w + (size_t)r * K + kk) : z8;
+        }
+    };
+    h8 wr[WV], wn[WV];
+    load_w(0, wr);
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += 64, buf ^= 1) {
+        _Float16* wb = Ws + buf * (C * WP);
+#pragma unroll
+        for (int j = 0; j < WV; ++j) {
+            const int i = tid + j * 256, r = i >> 3, c8 = i & 7;
+            if (i < C * 8) *reinterpret_cast<h8*>(wb + r * WP + c8 * 8) = wr[j];
+        }
+        if (k0 + 64 < K) load_w(k0 + 64, wn);
+        __syncthreads();                                           // slice k0 (and whatever the caller wrote to LDS before) is visible
+        h8 b[2][PT], a[2][MT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kk = k0 + ks * 32 + 8 * q, tap = kk / C, c = kk % C;
+            const bool kv = kk < K;
+            const int boff = kv ? tapoff[tap] + c : 0;
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                b[ks][pt] = *reinterpret_cast<const h8*>(In + pbase[pt] + boff);
+                if (!kv) b[ks][pt] = z8;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[ks][mt] = *reinterpret_cast<const h8*>(wb + (mt * 16 + n) * WP + ks * 32 + 8 * q);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (k0 + ks * 32 >= K) break;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {          // the two 16x16x16 steps of k_pw, in its order: the same bits as the separate launches
+                    const h8 av = a[ks][mt], bv = b[ks][pt];
+                    const h4 a0 = { av[0], av[1], av[2], av[3] }, a1 = { av[4], av[5], av[6], av[7] };
+                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
+                }
+        }
+        if (k0 + 64 < K) {
+#pragma unroll
+            for (int j = 0; j < WV; ++j) wr[j] = wn[j];
+        }
+    }
+}
+
+template <int C, int PT1, int PT2>
+__global__ __launch_bounds__(256) void k_bneck(BnArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char bn_smem[];
+    constexpr int MT = C / 16, P = C + 8, WP = 72;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int TW = A.TW, TH = A.TH, XW = TW + 4, XH = TH + 4, RW = TW + 2, RH = TH + 2;
+    _Float16* Xs = reinterpret_cast<_Float16*>(bn_smem);                               // [XH][XW][P]   input, origin (oy0-2, ox0-2)
+    _Float16* Ts = Xs + XH * XW * P;                                                   // [RH][RW][P]   first conv's output, origin (oy0-1, ox0-1)
+    _Float16* Ws = Ts + ((RH * RW * P + 7) & ~7);                                      // [2][C][WP]
+    int* tap1 = reinterpret_cast<int*>(Ws + 2 * C * WP);                               // [16] tap offsets in Xs / Ts
+    int* tap2 = tap1 + 16;
+    const int tpi = A.tiles_x * A.tiles_y;
+    const int img = blockIdx.x / tpi, trm = blockIdx.x - img * tpi, tyi = trm / A.tiles_x, txi = trm - tyi * A.tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW, H = A.H, W = A.W;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (tid < 9) { const int ky = tid / 3, kx = tid - ky * 3; tap1[tid] = (ky * XW + kx) * P; tap2[tid] = (ky * RW + kx) * P; }
+    // ---- stage the input tile (halo 2): a wave per row, 8 loads in flight per lane ----
+    const __half* xi = A.x + (size_t)img * H * W * C;
+    constexpr int VPC = C / 8;
+    const int rowv = XW * VPC;
+    for (int r = wave; r < XH; r += 4) {
+        const int iy = oy0 - 2 + r;
+        const bool rok = iy >= 0 && iy < H;
+        const __half* src = xi + (size_t)(rok ? iy : 0) * W * C;
+        _Float16* dst = Xs + r * XW * P;
+        for (int i0 = lane; i0 < rowv; i0 += 512) {
+            h8 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u, c = i / VPC, v = i % VPC, ix = ox0 - 2 + c;
+                const bool ok = rok && i < rowv && ix >= 0 && ix < W;
+                tmp[u] = ok ? *reinterpret_cast<const h8*>(src + (size_t)ix * C + v * 8) : z8;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u, c = i / VPC, v = i % VPC;
+                if (i < rowv) *reinterpret_cast<h8*>(dst + c * P + v * 8) = tmp[u];
+            }
+        }
+    }
+    // ---- first convolution on the tile + 1-pixel ring -> Ts ----
+    {
+        int pb[PT1], tpix[PT1];
+        bool inimg[PT1];
+#pragma unroll
+        for (int pt = 0; pt < PT1; ++pt) {
+            const int p = (wave * PT1 + pt) * 16 + n;
+            int ry = p / RW, rx = p - ry * RW;
+            const bool ok = p < RH * RW;
+            if (!ok) { ry = 0; rx = 0; }
+            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            inimg[pt] = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            tpix[pt] = ok ? p : -1;
+            pb[pt] = (ry * XW + rx) * P;
+        }
+        f4 acc[MT][PT1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT1; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+        bn_conv<C, PT1>(Xs, pb, tap1, A.w1, Ws, acc, tid);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 bb = *reinterpret_cast<const h4*>(A.b1 + mt * 16 + 4 * q);
+#pragma unroll
+            for (int pt = 0; pt < PT1; ++pt) {
+                if (tpix[pt] < 0) continue;
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = act_apply((float)(_Float16)acc[mt][pt][j] + (float)bb[j], 2);
+                    asm volatile("" : "+v"(f));                    // product rounded to f32 THEN to half, as k_pw (no v_fma_mixlo_f16: one rounding)
+                    o[j] = inimg[pt] ? (_Float16)f : (_Float16)0.f;
+                }
+                *reinterpret_cast<h4*>(Ts + tpix[pt] * P + mt * 16 + 4 * q) = o;
+            }
+        }
+    }
+    // (the first barrier inside bn_conv orders the Ts writes before the second convolution's reads; its weight buffers are free:
+    //  every wave has left the first K walk's last slice before it writes Ts ... and the slice written next is the OTHER buffer only
+    //  if the slice count is odd, so: one explicit barrier)
+    __syncthreads();
+    // ---- second convolution on the tile, shortcut from the staged input ----
+    {
+        int pb[PT2], opix[PT2], xoff[PT2];
+#pragma unroll
+        for (int pt = 0; pt < PT2; ++pt) {
+            const int p = (wave * PT2 + pt) * 16 + n;
+            int ty = p / TW, tx = p - ty * TW;
+            const bool ok = p < TH * TW && oy0 + ty < H && ox0 + tx < W;
+            if (!ok) { ty = 0; tx = 0; }
+            pb[pt] = (ty * RW + tx) * P;
+            xoff[pt] = ((ty + 2) * XW + tx + 2) * P;
+            opix[pt] = ok ? (img * H + oy0 + ty) * W + ox0 + tx : -1;
+        }
+        f4 acc[MT][PT2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+        bn_conv<C, PT2>(Ts, pb, tap2, A.w2, Ws, acc, tid);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 bb = *reinterpret_cast<const h4*>(A.b2 + mt * 16 + 4 * q);
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) {
+                if (opix[pt] < 0) continue;
+                const h4 xr = *reinterpret_cast<const h4*>(Xs + xoff[pt] + mt * 16 + 4 * q);
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = act_apply((float)(_Float16)acc[mt][pt][j] + (float)bb[j], 2);
+                    asm volatile("" : "+v"(f));
+                    if (A.add) f = (float)(_Float16)f + (float)xr[j];
+                    o[j] = (_Float16)f;
+                }
+                *reinterpret_cast<h4*>(A.out + (size_t)opix[pt] * A.out_ld + mt * 16 + 4 * q) = o;
+                if (A.out2) *reinterpret_cast<h4*>(A.out2 + (size_t)opix[pt] * C + mt * 16 + 4 * q) = o;
+            }
+        }
+    }
+}
+
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
 // pad 1, crops [N][H][128][3] half -> [N][H/4][32][16] half.  MIOpen runs the C_in = 3 convolution at 186 us for 256
 // crops (5% of its data rate) and bias, ReLU and pooling are three more passes over the 67 MB conv output.
@@ -2049,6 +2251,32 @@ extern "C" int ss_op_conv0_f16(void* stream, const void* x, const void* w_prep, 
 #define SS_C0(CO) hipLaunchKernelGGL(k_conv0<CO>, grid, block, 0, st, (const __half*)x, (const __half*)w_prep, (const __half*)bias, (__half*)y, H, W, act)
     if (Cout == 16) SS_C0(16); else if (Cout == 32) SS_C0(32); else SS_C0(48);
 #undef SS_C0
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+// C2f bottleneck in one launch (k_bneck).  x dense [B][H][W][C] half, C in {16, 32, 64}; w1 / w2 [C][3][3][C]; out = a channel slice
+// of a wider NHWC tensor (out_ld elements per pixel, pointer already at the slice), out2 = dense [B][H][W][C] copy or NULL.
+extern "C" int ss_op_bottleneck_f16(void* stream, const void* x, const void* w1, const void* b1, const void* w2, const void* b2, int B, int H,
+                                    int W, int C, int add, void* out, int out_ld, void* out2)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !out || B < 1 || H < 1 || W < 1 || (C != 16 && C != 32 && C != 64) || out_ld < C || out_ld % 4 ||
+        ((uintptr_t)out % 8) || ((uintptr_t)x % 16) || ((uintptr_t)w1 % 16) || ((uintptr_t)w2 % 16) || (out2 && ((uintptr_t)out2 % 8)))
+        return SS_ERR_INVALID;
+    // 128-pixel tiles (8 x 16) while they still give >= 2 workgroups per CU, else 64-pixel tiles (8 x 8)
+    const long long M = (long long)B * H * W;
+    const bool big = M / 128 >= 512;
+    BnArgs A{ (const __half*)x, (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2, (__half*)out, out_ld, (__half*)out2,
+              B, H, W, add, big ? 16 : 8, 8, 0, 0 };
+    A.tiles_x = (W + A.TW - 1) / A.TW; A.tiles_y = (H + A.TH - 1) / A.TH;
+    const int P = C + 8;
+    const size_t lds = ((size_t)(A.TH + 4) * (A.TW + 4) * P + (((size_t)(A.TH + 2) * (A.TW + 2) * P + 7) & ~(size_t)7) + 2 * (size_t)C * 72) * 2 + 128;
+    const dim3 grid((unsigned)(B * A.tiles_x * A.tiles_y));
+    hipStream_t st = (hipStream_t)stream;
+#define SS_BN(CC, P1, P2) do { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k_bneck<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
+                               hipLaunchKernelGGL((k_bneck<CC, P1, P2>), grid, dim3(256), lds, st, A); } while (0)
+    if (big) { if (C == 16) SS_BN(16, 3, 2); else if (C == 32) SS_BN(32, 3, 2); else SS_BN(64, 3, 2); }
+    else { if (C == 16) SS_BN(16, 2, 1); else if (C == 32) SS_BN(32, 2, 1); else SS_BN(64, 2, 1); }
+#undef SS_BN
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

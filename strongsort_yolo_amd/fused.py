@@ -162,6 +162,26 @@ def conv3x3(x, w_n9k, bias, stride=1, act="none", res=None, res_after=False, out
     return ret
 
 
+BNECK = _flag("BNECK")                  # a C2f bottleneck (3x3 + 3x3 + shortcut) in one launch, the intermediate in LDS
+
+
+def bottleneck_ok(m) -> bool:
+    a, b = m.cv1.conv, m.cv2.conv
+    silu = all(type(cv.act).__name__ == "SiLU" for cv in (m.cv1, m.cv2))
+    return (BNECK and silu and conv3x3_ok(a) and conv3x3_ok(b) and a.stride == (1, 1) and b.stride == (1, 1)
+            and a.in_channels == a.out_channels == b.out_channels and a.in_channels in (16, 32, 64))
+
+
+def bottleneck(x, m, out, c_off, out2=None):
+    """out[:, c_off:c_off+C] (= out2) = [x +] silu(conv3x3(silu(conv3x3(x)))) of nets.Bottleneck `m`; x dense channels-last."""
+    x = _cl(x)
+    b, c, h, w = x.shape
+    a, bb = m.cv1.conv, m.cv2.conv
+    _ck(_lib.load().ss_op_bottleneck_f16(_st(x), _p(x), _p(weight_n9k(m.cv1, a)), _p(a.bias), _p(weight_n9k(m.cv2, bb)), _p(bb.bias),
+                                         b, h, w, c, int(m.add), C.c_void_p(out.data_ptr() + 2 * c_off), out.shape[1], _p(out2)))
+    return out
+
+
 GROUP = _flag("GROUP")                  # independent convolutions of the detect head in one launch per depth
 
 

@@ -90,7 +90,9 @@ class C2f(nn.Module):
         for i, m in enumerate(self.m):
             cv = m.cv2.conv
             nxt = dense() if i + 1 < n else None
-            if fused.conv3x3_ok(cv):         # conv + bias + SiLU + shortcut + placement in one launch
+            if fused.bottleneck_ok(m):       # both convolutions + shortcut + placement in one launch (csrc k_bneck)
+                fused.bottleneck(cur, m, cat, (2 + i) * c, out2=nxt)
+            elif fused.conv3x3_ok(cv):       # conv + bias + SiLU + shortcut + placement in one launch
                 fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, cv.stride[0], "silu", res=cur if m.add else None,
                               res_after=True, out=cat, c_off=(2 + i) * c, out2=nxt, c0=0)
             else:

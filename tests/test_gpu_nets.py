@@ -308,6 +308,32 @@ def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
         assert (cat[:, :16] == 3.0).all()
 
 
+@pytest.mark.parametrize("B,C,H,W,add", [(32, 16, 96, 160, True), (32, 32, 48, 80, True), (32, 64, 24, 40, True), (3, 32, 48, 80, False),
+                                          (2, 64, 13, 21, True), (1, 16, 7, 5, False), (5, 16, 37, 53, True), (32, 64, 24, 40, False)])
+def test_bottleneck_launch_is_bit_identical_to_its_two_convolutions(B, C, H, W, add):
+    """k_bneck (3x3 + SiLU -> LDS -> 3x3 + SiLU + shortcut, placed into a concat slice) == the two ss_op_conv3x3_f16 launches,
+    every bit; tiles that hang over the right / bottom edge, images smaller than a tile, both tile sizes."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(C * 1000 + H)
+    m = nets.Bottleneck(C, C, shortcut=add, e=1.0).to(dev, torch.float16)
+    assert fused.bottleneck_ok(m) and m.add == add
+    x = torch.randn(B, C, H, W).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    a, b = m.cv1.conv, m.cv2.conv
+    fused.set_option("pw_splitk", 0)                                 # (the split-K form of small 64-channel layers sums in another order)
+    try:
+        t = fused.conv3x3(x, fused.weight_n9k(m.cv1, a), a.bias, 1, "silu")
+        ref = fused.conv3x3(t, fused.weight_n9k(m.cv2, b), b.bias, 1, "silu", res=x if add else None, res_after=True)
+    finally:
+        fused.set_option("pw_splitk", 1)
+    cat = torch.full((B, 3 * C, H, W), 3.0, dtype=torch.float16, device=dev).contiguous(memory_format=torch.channels_last)
+    out2 = torch.empty_like(x)
+    fused.bottleneck(x, m, cat, 2 * C, out2=out2)
+    assert torch.equal(cat[:, 2 * C:], ref) and torch.equal(out2, ref) and (cat[:, :2 * C] == 3.0).all()
+    fused.bottleneck(x, m, cat, C)                                   # no dense copy, another slice
+    assert torch.equal(cat[:, C:2 * C], ref) and (cat[:, :C] == 3.0).all()
+
+
 @pytest.mark.parametrize("N,H", [(3, 256), (2, 64), (1, 16)])
 def test_osnet_stem_matches_conv_relu_pool(N, H):
     import torch.nn.functional as F
