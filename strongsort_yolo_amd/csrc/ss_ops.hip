@@ -241,8 +241,13 @@ struct PwArgs {
     const int* n_img; int img_px;                  // optional: only the first *n_img images (img_px pixels each) are computed
 };
 
+// LDS of pw_body<BN, PT, ., VEC_EPI> in halfs: the weight slice, then the four waves' epilogue tiles.  The caller owns the array
+// (a kernel that inlines several instantiations - k_pw_group - would otherwise get the SUM of their static arrays).
+template <int BN, int PT, bool VEC_EPI>
+constexpr int pw_lds_halfs() { return BN * 72 + (VEC_EPI ? 4 * PT * 16 * (BN + 8) : 0); }
+
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
-__device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int by)
+__device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int by, _Float16* __restrict__ pw_lds)
 {
     const __half* __restrict__ x = A.x; const __half* __restrict__ w = A.w; const __half* __restrict__ bias = A.bias;
     const __half* __restrict__ res = A.res; __half* __restrict__ out = A.out; __half* __restrict__ out2 = A.out2;
@@ -252,7 +257,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
     const ConvGeom g = A.g;
     constexpr int MT = BN / 16, KC = 64, PITCH = KC + 8, BM = 64 * PT;
     if ((long long)bx * BM >= M) return;                    // (only with n_img: the launch covers the full batch)
-    __shared__ __attribute__((aligned(16))) _Float16 Ws[BN * PITCH];
+    _Float16* __restrict__ Ws = pw_lds;                     // [BN][PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
     const int n0 = by * BN;
     const size_t px0 = (size_t)bx * BM + wave * (16 * PT);
@@ -344,8 +349,7 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
 
     if (VEC_EPI) {
         constexpr int EP = BN + 8;                                           // tile pitch (halfs)
-        __shared__ __attribute__((aligned(16))) _Float16 Et[4 * PT * 16 * EP];
-        _Float16* tile = Et + wave * (PT * 16 * EP);
+        _Float16* tile = pw_lds + BN * PITCH + wave * (PT * 16 * EP);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
@@ -408,7 +412,11 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
 }
 
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
-__global__ __launch_bounds__(256) void k_pw(PwArgs A) { pw_body<BN, PT, CONV3, VEC_EPI>(A, blockIdx.x, blockIdx.y); }
+__global__ __launch_bounds__(256) void k_pw(PwArgs A)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 pw_lds[pw_lds_halfs<BN, PT, VEC_EPI>()];
+    pw_body<BN, PT, CONV3, VEC_EPI>(A, blockIdx.x, blockIdx.y, pw_lds);
+}
 
 // Split-K form of k_pw for layers whose pixel count cannot fill the chip with 64-pixel workgroups (the detector's
 // stride-32 level at batch 16: 60-120 workgroups for 256 CUs, each walking 18-36 K chunks with two barriers per chunk:
@@ -527,16 +535,22 @@ __global__ __launch_bounds__(256) void k_pw_splitk(PwArgs A) { pw_splitk_body<BN
 // small levels fill the CUs the stride-8 level leaves idle.  blockIdx.x walks the problems' workgroup ranges; a problem is
 // either in k_pw's form (64 pixels per workgroup) or in the split-K form (16 pixels, long K walk, few pixels).
 #define PW_GROUP_MAX 8
-struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int split[PW_GROUP_MAX]; int n; };
+// form[p]: 0 = 64 pixels per workgroup, 1 = split-K.  A problem with N <= 64 in a BN = 80 group (the box branches next to the class
+// branches) runs 4, not 5, channel tiles.  (128-pixel workgroups for the stride-8 level were measured too: the 148 VGPRs of that form
+// set the occupancy of EVERY problem in the launch to 2 waves per SIMD - detector 1.03 -> 1.05 ms.)
+struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int form[PW_GROUP_MAX]; int n; };
 
 template <int BN, bool CONV3>
 __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
 {
+    __shared__ __attribute__((aligned(16))) _Float16 pw_lds[pw_lds_halfs<BN, 1, true>()];
     int bx = blockIdx.x, p = 0;
     for (int i = 1; i < G.n; ++i) if (bx >= G.start[i]) p = i;
     bx -= G.start[p];
-    if (G.split[p]) pw_splitk_body<BN, CONV3>(G.p[p], bx, 0);
-    else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0);
+    const int form = G.form[p];
+    if (form == 1) { pw_splitk_body<BN, CONV3>(G.p[p], bx, 0); return; }
+    if (BN == 80 && G.p[p].N <= 64) pw_body<64, 1, CONV3, true>(G.p[p], bx, 0, pw_lds);      // (dead code in the narrower groups)
+    else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0, pw_lds);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2206,11 +2220,11 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
         const int K = c.ksize * c.ksize * c.Cin;
         G.p[s] = PwArgs{ (const __half*)c.x, (const __half*)c.w, (const __half*)c.bias, nullptr, (int)M, K, c.N, c.act, 0, (__half*)c.out,
                          c.N, nullptr, 0, 0, g, nullptr, 0 };
-        G.split[s] = splitk_allowed && conv3 && K >= 512 && M <= 4096;
+        G.form[s] = (splitk_allowed && conv3 && K >= 512 && M <= 4096) ? 1 : 0;
         G.start[s] = wgs;
-        wgs += (int)(G.split[s] ? (M + 15) / 16 : (M + 63) / 64);
+        wgs += (int)(G.form[s] == 1 ? (M + 15) / 16 : (M + 63) / 64);
     }
-    for (int s = n; s < PW_GROUP_MAX; ++s) { G.p[s] = G.p[0]; G.split[s] = 0; G.start[s] = wgs; }
+    for (int s = n; s < PW_GROUP_MAX; ++s) { G.p[s] = G.p[0]; G.form[s] = 0; G.start[s] = wgs; }
     G.start[PW_GROUP_MAX] = wgs;
     G.n = n;
     hipStream_t st = (hipStream_t)stream;
