@@ -257,7 +257,7 @@ int ss_op_conv3x3_f16(void* stream, const void* d_x, const void* d_w, const void
 /* A C2f bottleneck in ONE launch (nets.Bottleneck with 3x3 + 3x3, e = 1.0; reference: ultralytics' Bottleneck as the detector
  * checkpoints the reference loads define it): out = [x +] silu(conv3x3(silu(conv3x3(x, w1) + b1), w2) + b2), the intermediate kept
  * in LDS and rounded to half exactly where the two ss_op_conv3x3_f16 launches round it (the results are bit-identical to them).
- * x dense [B][H][W][C], C in {16, 32, 64}; w1, w2 [C][3][3][C]; d_out points at the block's channel slice of a wider NHWC tensor
+ * x dense [B][H][W][C], C in {16, 32, 64, 128}; w1, w2 [C][3][3][C]; d_out points at the block's channel slice of a wider NHWC tensor
  * (out_ld halfs per pixel), d_out2 (or NULL) receives a dense [B][H][W][C] copy. */
 int ss_op_bottleneck_f16(void* stream, const void* d_x, const void* d_w1, const void* d_b1, const void* d_w2, const void* d_b2,
                          int B, int H, int W, int C, int add, void* d_out, int out_ld, void* d_out2);

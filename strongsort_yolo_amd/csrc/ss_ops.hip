@@ -2268,17 +2268,17 @@ extern "C" int ss_op_conv0_f16(void* stream, const void* x, const void* w_prep, 
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
-// C2f bottleneck in one launch (k_bneck).  x dense [B][H][W][C] half, C in {16, 32, 64}; w1 / w2 [C][3][3][C]; out = a channel slice
+// C2f bottleneck in one launch (k_bneck).  x dense [B][H][W][C] half, C in {16, 32, 64, 128}; w1 / w2 [C][3][3][C]; out = a channel slice
 // of a wider NHWC tensor (out_ld elements per pixel, pointer already at the slice), out2 = dense [B][H][W][C] copy or NULL.
 extern "C" int ss_op_bottleneck_f16(void* stream, const void* x, const void* w1, const void* b1, const void* w2, const void* b2, int B, int H,
                                     int W, int C, int add, void* out, int out_ld, void* out2)
 {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !out || B < 1 || H < 1 || W < 1 || (C != 16 && C != 32 && C != 64) || out_ld < C || out_ld % 4 ||
+    if (!x || !w1 || !b1 || !w2 || !b2 || !out || B < 1 || H < 1 || W < 1 || (C != 16 && C != 32 && C != 64 && C != 128) || out_ld < C || out_ld % 4 ||
         ((uintptr_t)out % 8) || ((uintptr_t)x % 16) || ((uintptr_t)w1 % 16) || ((uintptr_t)w2 % 16) || (out2 && ((uintptr_t)out2 % 8)))
         return SS_ERR_INVALID;
     // 128-pixel tiles (8 x 16) while they still give >= 2 workgroups per CU, else 64-pixel tiles (8 x 8)
     const long long M = (long long)B * H * W;
-    const bool big = M / 128 >= 512;
+    const bool big = M / 128 >= 512 && C <= 64;                    // (C = 128: the 8 x 16 tile's input + intermediate + weights exceed the LDS)
     BnArgs A{ (const __half*)x, (const __half*)w1, (const __half*)b1, (const __half*)w2, (const __half*)b2, (__half*)out, out_ld, (__half*)out2,
               B, H, W, add, big ? 16 : 8, 8, 0, 0 };
     A.tiles_x = (W + A.TW - 1) / A.TW; A.tiles_y = (H + A.TH - 1) / A.TH;
@@ -2289,7 +2289,7 @@ extern "C" int ss_op_bottleneck_f16(void* stream, const void* x, const void* w1,
 #define SS_BN(CC, P1, P2) do { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k_bneck<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
                                hipLaunchKernelGGL((k_bneck<CC, P1, P2>), grid, dim3(256), lds, st, A); } while (0)
     if (big) { if (C == 16) SS_BN(16, 3, 2); else if (C == 32) SS_BN(32, 3, 2); else SS_BN(64, 3, 2); }
-    else { if (C == 16) SS_BN(16, 2, 1); else if (C == 32) SS_BN(32, 2, 1); else SS_BN(64, 2, 1); }
+    else { if (C == 16) SS_BN(16, 2, 1); else if (C == 32) SS_BN(32, 2, 1); else if (C == 64) SS_BN(64, 2, 1); else SS_BN(128, 2, 1); }
 #undef SS_BN
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

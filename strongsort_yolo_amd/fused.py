@@ -162,6 +162,7 @@ def conv3x3(x, w_n9k, bias, stride=1, act="none", res=None, res_after=False, out
     return ret
 
 
+BNECK_C = tuple(int(c) for c in _os.environ.get("SS_BNECK_C", "16,32,64,128").split(","))     # A/B: channel counts that take the fused kernel
 BNECK = _flag("BNECK")                  # a C2f bottleneck (3x3 + 3x3 + shortcut) in one launch, the intermediate in LDS
 
 
@@ -169,7 +170,7 @@ def bottleneck_ok(m) -> bool:
     a, b = m.cv1.conv, m.cv2.conv
     silu = all(type(cv.act).__name__ == "SiLU" for cv in (m.cv1, m.cv2))
     return (BNECK and silu and conv3x3_ok(a) and conv3x3_ok(b) and a.stride == (1, 1) and b.stride == (1, 1)
-            and a.in_channels == a.out_channels == b.out_channels and a.in_channels in (16, 32, 64))
+            and a.in_channels == a.out_channels == b.out_channels and a.in_channels in BNECK_C)
 
 
 def bottleneck(x, m, out, c_off, out2=None):

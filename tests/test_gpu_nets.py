@@ -309,7 +309,8 @@ def test_conv3x3_matches_conv2d_bias_act(shape, N, stride, act):
 
 
 @pytest.mark.parametrize("B,C,H,W,add", [(32, 16, 96, 160, True), (32, 32, 48, 80, True), (32, 64, 24, 40, True), (3, 32, 48, 80, False),
-                                          (2, 64, 13, 21, True), (1, 16, 7, 5, False), (5, 16, 37, 53, True), (32, 64, 24, 40, False)])
+                                          (2, 64, 13, 21, True), (1, 16, 7, 5, False), (5, 16, 37, 53, True), (32, 64, 24, 40, False),
+                                          (32, 128, 12, 20, True), (3, 128, 9, 11, False)])
 def test_bottleneck_launch_is_bit_identical_to_its_two_convolutions(B, C, H, W, add):
     """k_bneck (3x3 + SiLU -> LDS -> 3x3 + SiLU + shortcut, placed into a concat slice) == the two ss_op_conv3x3_f16 launches,
     every bit; tiles that hang over the right / bottom edge, images smaller than a tile, both tile sizes."""
