@@ -331,9 +331,13 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
                     const h8 bv = b[ks][pt];
-                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
+                    if (CONV3) {                               // 3x3 layers (detector only): the double-K form, half the matrix-core issue cycles
+                        acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bv, acc[mt][pt], 0, 0, 0);
+                    } else {                                   // 1x1 layers keep the two 16x16x16 steps: OSNet's fused kernels reproduce their bits
+                        const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
+                        acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
+                        acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
 // separate launch rounds it (accumulator -> half, + bias, SiLU, -> half; ZERO outside the image: it is the second convolution's
 // padding), the second convolution reads it from there, and the epilogue adds the shortcut from the staged input.  Weights:
 // 64-wide slices of k = tap * C + c, double-buffered in LDS, one barrier per slice, every LDS operand of a slice requested
-// before its first MFMA (v_mfma_f32_16x16x16_f16 pairs, as k_pw).  Output: a channel slice of the C2f concat buffer (+ the dense copy the next
+// before its first MFMA (v_mfma_f32_16x16x32_f16, as k_pw's 3x3 form).  Output: a channel slice of the C2f concat buffer (+ the dense copy the next
 // bottleneck reads), as ss_op_conv3x3_f16 places it.
 struct BnArgs {
     const __half* x; const __half* w1; const __half* b1; const __half* w2; const __half* b2;
@@ -616,13 +620,8 @@ __device__ __forceinline__ void bn_conv(const _Float16* __restrict__ In, const i
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {          // the two 16x16x16 steps of k_pw, in its order: the same bits as the separate launches
-                    const h8 av = a[ks][mt], bv = b[ks][pt];
-                    const h4 a0 = { av[0], av[1], av[2], av[3] }, a1 = { av[4], av[5], av[6], av[7] };
-                    const h4 b0 = { bv[0], bv[1], bv[2], bv[3] }, b1 = { bv[4], bv[5], bv[6], bv[7] };
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
-                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
-                }
+                for (int pt = 0; pt < PT; ++pt)            // k_pw's 3x3 form (v_mfma_f32_16x16x32_f16 on the same operands): the same bits as the separate launches
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks][mt], b[ks][pt], acc[mt][pt], 0, 0, 0);
         }
         if (k0 + 64 < K) {
 #pragma unroll
