@@ -55,6 +55,9 @@ PRESETS = {
     "c5": ("yolov8n-pose", 1280, 720, 30, 32), # configs[4] per GPU: pose head, keypoints carried by det_idx
 }
 CONFIG_INDEX = {"c2": 1, "c3": 2, "c4": 3, "c5": 4}
+# where the two HIP streams' stages are cut inside OSNet.  c2, r03 sweep after the detector got faster (40 steps, two runs each): split 2:
+# 11 232 / 11 244, 4: 11 701 / 11 531, 5: 11 720 / 11 785, 6: 11 509 / 11 014 frames/s; c4 (yolov7: the detector is the long stage) was only measured at 2
+REID_SPLIT = {"c2": 5, "c3": 5, "c4": 2, "c5": 5}
 PMC_FILE = "r03_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by preset / streams / frames (tools/pmc_assoc.sh)
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
@@ -416,7 +419,7 @@ def main():
     ap.add_argument("--check-frames", type=int, default=-1, help="frames (from the start of the run) compared with the oracle; -1: all of them, the timed ones included")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--defer-track", type=int, default=1, help="1: the tracker call of a group is enqueued after the last stage's stream has waited for stage 0 of the next group (it then runs beside the start of that group, away from the OSNet row-stream kernel)")
-    ap.add_argument("--reid-split", type=int, default=2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS)")
+    ap.add_argument("--reid-split", type=int, default=-2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS; -2: the preset's measured best, REID_SPLIT)")
     ap.add_argument("--frame-batch", type=int, default=32, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (ss_set_option), e.g. --opt assoc_comp_rows=0")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
@@ -460,6 +463,8 @@ def main():
         return
 
     detector, W, H, n_ids, rb = PRESETS[args.preset]
+    if args.reid_split == -2:
+        args.reid_split = REID_SPLIT[args.preset]
     cfg, dcfg = StrongSortConfig(), DetectConfig()
     overlap = args.overlap > 1 and args.graph != "none" and not args.no_nets
     FB = args.frame_batch if overlap else 1
