@@ -192,3 +192,22 @@ def test_ultralytics_state_dict_is_folded_and_mapped(name, last, tmp_path):
     torch.save(bad, path)
     with pytest.raises(ValueError):
         nets.load_weights(nets.build_detector(name, 1).float(), str(path), name)
+
+
+def test_bottleneck_launch_eligibility():
+    """Host-side rule for the one-launch C2f bottleneck (csrc k_bneck): two 3x3 / stride 1 SiLU convolutions of one width in
+    {16, 32, 64, 128}; everything else (e = 0.5 bottlenecks of C3k2, 1x1 + 3x3 pairs of C3, other widths) takes the per-layer path."""
+    assert fused.bottleneck_ok(nets.Bottleneck(32, 32, True, e=1.0)) and fused.bottleneck_ok(nets.Bottleneck(128, 128, False, e=1.0))
+    assert not fused.bottleneck_ok(nets.Bottleneck(32, 32, True, e=0.5))            # hidden width 16 != 32
+    assert not fused.bottleneck_ok(nets.Bottleneck(48, 48, True, e=1.0))            # width without a kernel instance
+    assert not fused.bottleneck_ok(nets.Bottleneck(32, 32, True, k=(1, 3), e=1.0))  # C3's 1x1 -> 3x3 pair
+    m = nets.Bottleneck(64, 64, True, e=1.0)
+    m.cv2.act = torch.nn.Identity()
+    assert not fused.bottleneck_ok(m)                                               # the kernel's activation is SiLU on both layers
+    c2f = nets.C2f(64, 64, n=2, shortcut=True)
+    assert all(fused.bottleneck_ok(b) and b.add for b in c2f.m) and c2f.c == 32
+
+
+def test_bench_stage_cut_defaults_cover_every_preset():
+    import bench
+    assert set(bench.REID_SPLIT) == set(bench.PRESETS) and all(0 <= v <= nets.OSNet.N_PARTS for v in bench.REID_SPLIT.values())
