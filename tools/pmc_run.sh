@@ -11,6 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM" \
            "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   out=$root/p$i; mkdir -p $out
+  if [ -n "$PMC_GROUPS" ] && [[ ",$PMC_GROUPS," != *",$i,"* ]]; then i=$((i+1)); continue; fi     # PMC_GROUPS=0,3,4: only those passes
   (cd $GRAFT_REPO_ROOT && rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out -o run -- "$@" > $out/log.txt 2>&1)
   i=$((i+1))
 done
