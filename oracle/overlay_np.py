@@ -83,3 +83,45 @@ def rasterise(frame, prims, chars, font):
     if in_grp.any():
         out[in_grp] = _mix(grp[in_grp], out[in_grp])
     return out
+
+
+# ---- mask fills (the reference's fillPoly + addWeighted 0.5, /root/reference/yolo_multi_model.py:112-121) ------------------------
+def polygon_mask_np(poly, H, W):
+    """Even-odd interior of the closed integer polygon [k, 2] on the H x W pixel grid: a pixel is inside when an odd number of
+    edges straddle its y (exactly one end point with y <= the pixel's) strictly to its right, in exact rational arithmetic.
+    Written per pixel and edge, the slow way (the product side vectorises over both)."""
+    from fractions import Fraction
+    q = [(int(x), int(y)) for x, y in np.asarray(poly).reshape(-1, 2)]
+    m = np.zeros((H, W), bool)
+    if len(q) < 3:
+        return m
+    ys = [p[1] for p in q]
+    for py in range(max(min(ys), 0), min(max(ys), H - 1) + 1):
+        xs = []
+        for (ax, ay), (bx, by) in zip(q, q[1:] + q[:1]):
+            if (ay <= py) != (by <= py):
+                xs.append(ax + Fraction((py - ay) * (bx - ax), by - ay))
+        for px in range(W):
+            m[py, px] = sum(px < x for x in xs) % 2 == 1
+    return m
+
+
+def blend_polygon_np(frame, poly, color):
+    """frame uint8 [H, W, 3] copied; inside the polygon (frame + color) / 2 rounded half to even."""
+    out = frame.copy()
+    m = polygon_mask_np(poly, *frame.shape[:2])
+    mixed = np.rint((out[m].astype(np.float64) + np.asarray(color, np.float64)) / 2.0)
+    out[m] = mixed.astype(np.uint8)
+    return out
+
+
+def rasterise_with_blends(frame, prims, chars, font, blends):
+    """Primitive stretches and mask fills in painter's order: blends = [(primitives drawn before it, polygon, colour)]."""
+    out, at = frame, 0
+    for pos, poly, color in list(blends) + [(len(prims), None, None)]:
+        if pos > at:
+            out = rasterise(out, prims[at:pos], chars, font)
+        at = pos
+        if poly is not None:
+            out = blend_polygon_np(out, poly, color)
+    return out if out is not frame else frame.copy()

@@ -130,18 +130,37 @@ class SPPF(nn.Module):
         return self.cv2(torch.cat(y, 1))
 
 
-class Detect(nn.Module):
-    """Anchor-free v8 head with DFL decode.  Output [B, 4+nc(+nk), A] (xywh in input pixels)."""
+class Proto(nn.Module):
+    """Mask prototypes of the segmentation head (Ultralytics `Proto`): 3x3 -> 2x transposed convolution -> 3x3 -> 1x1 on the
+    stride-8 map, [B, nm, H/4, W/4]."""
 
-    def __init__(self, nc, ch, nk=0):
+    def __init__(self, c1, c_=256, c2=32):
         super().__init__()
-        self.nc, self.nk, self.reg_max = nc, nk, 16
+        self.cv1, self.upsample = Conv(c1, c_, 3), nn.ConvTranspose2d(c_, c_, 2, 2, 0, bias=True)
+        self.cv2, self.cv3 = Conv(c_, c_, 3), Conv(c_, c2, 1)
+
+    def forward(self, x):
+        return self.cv3(self.cv2(self.upsample(self.cv1(x))))
+
+
+class Detect(nn.Module):
+    """Anchor-free v8 head with DFL decode.  Output [B, 4+nc(+nk | +nm), A] (xywh in input pixels); with nm > 0 (the
+    segmentation head, Ultralytics `Segment`: /root/reference/yolo_multi_model.py:14 names 'yolov8n-seg.pt') the rows end in
+    the nm raw mask coefficients and forward returns (rows, prototypes [B, nm, H/4, W/4])."""
+
+    def __init__(self, nc, ch, nk=0, nm=0, npr=256):
+        super().__init__()
+        if nk and nm:
+            raise ValueError("a head carries keypoints or mask coefficients, not both")
+        self.nc, self.nk, self.nm, self.reg_max = nc, nk, nm, 16
         c2, c3 = max(16, ch[0] // 4, 64), max(ch[0], min(nc, 100))
         self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 64, 1)) for x in ch)
         self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, nc, 1)) for x in ch)
-        if nk:
-            c4 = max(ch[0] // 4, nk)
-            self.cv4 = nn.ModuleList(nn.Sequential(Conv(x, c4, 3), Conv(c4, c4, 3), nn.Conv2d(c4, nk, 1)) for x in ch)
+        if nk or nm:
+            c4 = max(ch[0] // 4, nk or nm)
+            self.cv4 = nn.ModuleList(nn.Sequential(Conv(x, c4, 3), Conv(c4, c4, 3), nn.Conv2d(c4, nk or nm, 1)) for x in ch)
+        if nm:
+            self.proto = Proto(ch[0], npr, nm)
         self.strides = (8, 16, 32)
         self.register_buffer("proj", torch.arange(16, dtype=torch.float32).view(1, 1, 16, 1), persistent=False)
         self._anchors = None
@@ -159,7 +178,7 @@ class Detect(nn.Module):
 
     def forward(self, feats):
         B = feats[0].shape[0]
-        if fused.usable(feats[0]) and self.nk == 0:          # six branch tensors -> [B,4+nc,A] float in one launch
+        if fused.usable(feats[0]) and self.nk == 0 and self.nm == 0:     # six branch tensors -> [B,4+nc,A] float in one launch
             seqs = list(self.cv2) + list(self.cv3)
             if (fused.GROUP and len(feats) == 3 and all(fused.pointwise_ok(s[2]) and fused.conv3x3_ok(s[0].conv) and
                                                          fused.conv3x3_ok(s[1].conv) and isinstance(s[0].act, nn.SiLU) and
@@ -204,6 +223,11 @@ class Detect(nn.Module):
             k = torch.cat([self.cv4[i](f).reshape(B, self.nk, -1) for i, f in enumerate(feats)], 2).view(B, self.nk // 3, 3, -1)
             xy = (k[:, :, :2] * 2.0 + (anchors - 0.5).unsqueeze(1)) * strides.unsqueeze(1)
             out.append(torch.cat((xy, k[:, :, 2:].sigmoid()), 2).view(B, self.nk, -1))
+        if self.nm:
+            # mask coefficients stay raw (Ultralytics Segment: `torch.cat([x, mc], 1), p`); the masks are assembled from them
+            # and the prototypes after NMS (yolo.Masks)
+            out.append(torch.cat([self.cv4[i](f).reshape(B, self.nm, -1) for i, f in enumerate(feats)], 2))
+            return torch.cat(out, 1), self.proto(feats[0])
         return torch.cat(out, 1)
 
 
@@ -211,7 +235,7 @@ _V8_SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75
 
 
 class YOLOv8(nn.Module):
-    def __init__(self, scale="n", nc=80, nk=0):
+    def __init__(self, scale="n", nc=80, nk=0, nm=0):
         super().__init__()
         d, w, mc = _V8_SCALES[scale]
         c = lambda x: int(math.ceil(min(x, mc) * w / 8) * 8)
@@ -226,8 +250,8 @@ class YOLOv8(nn.Module):
         self.h15 = C2f(c(512) + c(256), c(256), n(3))
         self.h16, self.h18 = Conv(c(256), c(256), 3, 2), C2f(c(256) + c(512), c(512), n(3))
         self.h19, self.h21 = Conv(c(512), c(512), 3, 2), C2f(c(512) + c(1024), c(1024), n(3))
-        self.detect = Detect(nc, (c(256), c(512), c(1024)), nk)
-        self.nc, self.nk = nc, nk
+        self.detect = Detect(nc, (c(256), c(512), c(1024)), nk, nm, c(256))
+        self.nc, self.nk, self.nm = nc, nk, nm
 
     def forward_backbone(self, x):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
@@ -338,14 +362,14 @@ class C2PSA(nn.Module):
 class Detect11(Detect):
     """v11 head: the class branch is depthwise-separable (DWConv 3x3 -> Conv 1x1, twice) before the final 1x1."""
 
-    def __init__(self, nc, ch, nk=0):
-        super().__init__(nc, ch, nk)
+    def __init__(self, nc, ch, nk=0, nm=0, npr=256):
+        super().__init__(nc, ch, nk, nm, npr)
         c3 = max(ch[0], min(nc, 100))
         self.cv3 = nn.ModuleList(nn.Sequential(nn.Sequential(Conv(x, x, 3, g=x), Conv(x, c3, 1)),
                                                nn.Sequential(Conv(c3, c3, 3, g=c3), Conv(c3, c3, 1)), nn.Conv2d(c3, nc, 1)) for x in ch)
 
     def forward(self, feats):
-        if fused.usable(feats[0]) and self.nk == 0 and all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
+        if fused.usable(feats[0]) and self.nk == 0 and self.nm == 0 and all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
             last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)
             z = getattr(self, "_zeros", None)
             if z is None or z.device != feats[0].device:
@@ -359,7 +383,7 @@ _V11_SCALES = {"n": (0.50, 0.25, 1024), "s": (0.50, 0.50, 1024), "m": (0.50, 1.0
 
 
 class YOLO11(nn.Module):
-    def __init__(self, scale="n", nc=80, nk=0):
+    def __init__(self, scale="n", nc=80, nk=0, nm=0):
         super().__init__()
         d, w, mc = _V11_SCALES[scale]
         c = lambda x: int(math.ceil(min(x, mc) * w / 8) * 8)
@@ -375,8 +399,8 @@ class YOLO11(nn.Module):
         self.h16 = C3k2(c(512) + c(512), c(256), n(2), k3)
         self.h17, self.h19 = Conv(c(256), c(256), 3, 2), C3k2(c(256) + c(512), c(512), n(2), k3)
         self.h20, self.h22 = Conv(c(512), c(512), 3, 2), C3k2(c(512) + c(1024), c(1024), n(2), True)
-        self.detect = Detect11(nc, (c(256), c(512), c(1024)), nk)
-        self.nc, self.nk = nc, nk
+        self.detect = Detect11(nc, (c(256), c(512), c(1024)), nk, nm, c(256))
+        self.nc, self.nk, self.nm = nc, nk, nm
 
     def forward(self, x):
         p3 = self.b4(self.b3(self.b2(self.b1(self.b0(x)))))
@@ -697,7 +721,8 @@ def osnet_x0_25():
 DETECTORS = {
     "yolov8n": lambda: YOLOv8("n"), "yolov8s": lambda: YOLOv8("s"), "yolov8m": lambda: YOLOv8("m"),
     "yolov8n-pose": lambda: YOLOv8("n", nc=1, nk=51), "yolo11n-pose": lambda: YOLO11("n", nc=1, nk=51),
-    "yolov8n-seg": lambda: YOLOv8("n"), "yolo11n": lambda: YOLO11("n"), "yolo11s": lambda: YOLO11("s"), "yolo11s-pose": lambda: YOLO11("s", nc=1, nk=51),
+    "yolov8n-seg": lambda: YOLOv8("n", nm=32), "yolov8s-seg": lambda: YOLOv8("s", nm=32), "yolo11n-seg": lambda: YOLO11("n", nm=32),
+    "yolo11n": lambda: YOLO11("n"), "yolo11s": lambda: YOLO11("s"), "yolo11s-pose": lambda: YOLO11("s", nc=1, nk=51),
     "yolov5n": lambda: YOLOv5u("n"), "yolov5s": lambda: YOLOv5u("s"),
     "yolov7": lambda: YOLOv7(),
 }

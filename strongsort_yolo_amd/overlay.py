@@ -25,11 +25,62 @@ def bgr(b, g, r):
     return int(b) | int(g) << 8 | int(r) << 16
 
 
+# per-class fill colours of the mask blend; the reference draws 80 random ones at import (yolo_multi_model.py:25, unseeded) — here a fixed table
+CLASS_COLORS = np.random.default_rng(25).integers(0, 255, size=(80, 3), dtype=np.uint8)
+
+
+def polygon_mask(poly: torch.Tensor, x0: int, y0: int, h: int, w: int) -> torch.Tensor:
+    """Even-odd interior of the closed integer polygon `poly` [k, 2] (x, y) on the pixel grid x0..x0+w-1 x y0..y0+h-1, in exact
+    integer arithmetic (an edge is crossed when exactly one end point has y <= the pixel's y and the pixel is strictly left of
+    the crossing).  Stands for cv2.fillPoly's interior (yolo_multi_model.py:118); cv2's rasteriser — which also paints the
+    boundary pixels — is not restated, the boundary is the polyline drawn just before.  -> bool [h, w] on poly's device."""
+    dev = poly.device
+    p0 = poly.to(torch.int64)
+    p1 = torch.roll(p0, -1, 0)
+    px = (torch.arange(w, device=dev, dtype=torch.int64) + x0).view(1, 1, w)
+    py = (torch.arange(h, device=dev, dtype=torch.int64) + y0).view(1, h, 1)
+    ax, ay, bx, by = (t.view(-1, 1, 1) for t in (p0[:, 0], p0[:, 1], p1[:, 0], p1[:, 1]))
+    straddle = (ay <= py) != (by <= py)
+    dy = by - ay
+    lhs, rhs = (px - ax) * dy, (py - ay) * (bx - ax)                     # px < ax + (py - ay) (bx - ax) / dy, cross-multiplied
+    left = torch.where(dy > 0, lhs < rhs, lhs > rhs)
+    return ((straddle & left).sum(0) & 1).bool()
+
+
+def blend_polygon_(frame: torch.Tensor, poly: np.ndarray, color, alpha_num: int = 1, alpha_den: int = 2) -> torch.Tensor:
+    """frame uint8 [H, W, 3] (any device), in place: inside the polygon round_half_even((frame + color) / 2) — what
+    cv2.addWeighted(image, 0.5, filled_copy, 0.5, 0) leaves there (:119-121); outside nothing changes."""
+    H, W = frame.shape[:2]
+    q = np.asarray(poly, np.int64).reshape(-1, 2)
+    if len(q) < 3:
+        return frame
+    x0, y0 = max(int(q[:, 0].min()), 0), max(int(q[:, 1].min()), 0)
+    x1, y1 = min(int(q[:, 0].max()), W - 1), min(int(q[:, 1].max()), H - 1)
+    if x0 > x1 or y0 > y1:
+        return frame
+    m = polygon_mask(torch.from_numpy(q).to(frame.device), x0, y0, y1 - y0 + 1, x1 - x0 + 1)
+    reg = frame[y0:y1 + 1, x0:x1 + 1]
+    c = torch.tensor([int(v) for v in color], dtype=torch.int32, device=frame.device).view(1, 1, 3)
+    tot = reg.to(torch.int32) + c                                        # (a + b) / 2, ties to even
+    half = (tot >> 1) + ((tot & 1) & ((tot >> 1) & 1))
+    reg.copy_(torch.where(m.unsqueeze(-1), half.to(torch.uint8), reg))
+    return frame
+
+
 class CommandList:
     """Ordered primitives of one frame: int32 [n,8] rows + the characters of its text primitives."""
 
     def __init__(self):
         self.rows, self.chars = [], bytearray()
+        self.blends = []                       # (primitives drawn before it, int32 polygon [k, 2], BGR colour): mask fills, in painter's order
+
+    def blend(self, poly, color):
+        self.blends.append((len(self.rows), np.asarray(poly, np.int32).reshape(-1, 2), tuple(int(c) for c in color)))
+
+    def polyline(self, poly, color, thickness=2):
+        q = np.asarray(poly, np.int32).reshape(-1, 2)
+        for a, b in zip(q, np.roll(q, -1, 0)) if len(q) > 1 else ():
+            self.line(a[0], a[1], b[0], b[1], color, thickness)
 
     def rect(self, x0, y0, x1, y1, color, thickness=2, group=False):
         self.rows.append((RECT, int(x0), int(y0), int(x1), int(y1), color, int(thickness), int(group)))
@@ -81,6 +132,23 @@ class Overlay:
                             if (x, y) != (0.0, 0.0):
                                 cl.circle(x, y, 5, bgr(0, 255, 0)); cl.circle(x, y, 2, bgr(0, 0, 0))
                                 cl.text(str(idx), int(x) + 5, int(y) - 5, bgr(0, 0, 255))
+            if getattr(r, "masks", None) is not None:                                         # :71-121 / :195-221: box, (trails,) mask, per pair
+                ids = r.boxes.id if tracked else [None] * len(r.boxes)
+                for conf, cls, xyxy, id_, polys in zip(r.boxes.conf, r.boxes.cls, r.boxes.xyxy, ids, r.masks.xy):
+                    name = f"{self.names.get(int(cls), int(cls))} {round(float(conf) * 100, 1)}%"
+                    self._box(cl, xyxy, f" ID: {int(id_)} {name}" if tracked else f" {name}")
+                    if tracked:
+                        t = self.trails.setdefault(int(id_), deque(maxlen=self.trail_len))
+                        t.append(((float(xyxy[0]) + float(xyxy[2])) / 2, (float(xyxy[1]) + float(xyxy[3])) / 2))
+                        for t in self.trails.values():
+                            for i in range(1, len(t)):
+                                cl.line(int(t[i - 1][0]), int(t[i - 1][1]), int(t[i][0]), int(t[i][1]), bgr(255, 255, 255), 2)
+                    for poly in (polys if isinstance(polys, (list, tuple)) else [polys]):
+                        q = np.int32(poly)                                                       # np.int32(polygon), :114
+                        if len(q):
+                            cl.polyline(q, bgr(255, 0, 0), 2)                                    # :114
+                            cl.blend(q, CLASS_COLORS[int(cls) % len(CLASS_COLORS)])              # :116-121
+                continue
             if not tracked:
                 for conf, cls, xyxy in zip(r.boxes.conf, r.boxes.cls, r.boxes.xyxy):          # detection only, :193-237
                     self._box(cl, xyxy, f" {self.names.get(int(cls), int(cls))} {round(float(conf) * 100, 1)}%")
@@ -114,6 +182,22 @@ class Overlay:
         fr = frames if frames.dim() == 4 else frames.unsqueeze(0)
         if len(command_lists) != fr.shape[0]:
             raise ValueError("one command list per frame")
+        if any(c.blends for c in command_lists):
+            # mask fills sit BETWEEN primitives (a later box is drawn over an earlier mask): such a frame is drawn as
+            # [primitives up to the fill] -> fill -> ..., one launch per stretch
+            for i, c in enumerate(command_lists):
+                at = 0
+                for pos, poly, color in c.blends + [(len(c.rows), None, None)]:
+                    if pos > at:
+                        part = CommandList()
+                        part.rows, part.chars = c.rows[at:pos], c.chars
+                        self.draw_device(fr[i], [part], stream)
+                    at = pos
+                    if poly is not None:
+                        st = torch.cuda.current_stream(fr.device) if stream is None else stream
+                        with torch.cuda.stream(st):
+                            blend_polygon_(fr[i], poly, color)
+            return frames
         arr = [c.arrays() for c in command_lists]
         off = np.zeros(len(arr) + 1, np.int32)
         coff = 0

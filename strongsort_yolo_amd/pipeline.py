@@ -64,8 +64,10 @@ class FramePipeline:
             self.detector = nets.build_detector(detector, seed).to(dev, self.dtype).to(memory_format=torch.channels_last)
             self.reid = nets.build_reid(seed + 1).to(dev, self.dtype).to(memory_format=torch.channels_last)
             self.nc, self.nk = self.detector.nc, self.detector.nk
+            self.nm = getattr(self.detector, "nm", 0)           # mask coefficients of a segmentation head (after the keypoints' place)
         else:
-            self.nc, self.nk = 80, 0
+            self.nc, self.nk, self.nm = 80, 0, 0
+        self.nx = self.nk + self.nm                             # extra columns NMS carries along with every kept row
         g, S = self.geom, n_streams
         self.n_anchors = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
         # ---- static buffers (addresses are baked into the graph) ----
@@ -73,9 +75,11 @@ class FramePipeline:
         self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.geom_dev = torch.tensor([[self.gain, self.pad_x, self.pad_y, float(self.W), float(self.H)]] * S,
                                      dtype=torch.float32, device=dev)      # per-image scale_boxes geometry for ss_nms_batch
-        self.pred_in = torch.zeros(S, 4 + self.nc + self.nk, self.n_anchors, dtype=torch.float32, device=dev)
-        self.dets = torch.zeros(S, self.det_rows, 6 + self.nk, dtype=torch.float32, device=dev)
-        self.dets6 = self.dets if self.nk == 0 else torch.zeros(S, self.det_rows, 6, dtype=torch.float32, device=dev)
+        self.pred_in = torch.zeros(S, 4 + self.nc + self.nx, self.n_anchors, dtype=torch.float32, device=dev)
+        self.dets = torch.zeros(S, self.det_rows, 6 + self.nx, dtype=torch.float32, device=dev)
+        self.dets6 = self.dets if self.nx == 0 else torch.zeros(S, self.det_rows, 6, dtype=torch.float32, device=dev)
+        # segmentation: the frame's mask prototypes [nm, out_h/4, out_w/4] stay here until the caller has built its Results
+        self.proto = torch.zeros(S, self.nm, g.out_h // 4, g.out_w // 4, dtype=self.dtype, device=dev) if self.nm else None
         self.keep = torch.zeros(S, self.det_rows, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
         self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
@@ -103,13 +107,21 @@ class FramePipeline:
             e.cmc_estimate(self.frames, 1, self.warps)
         if self.run_nets:
             e.letterbox_batch(self.frames, g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb, channels_last=True)
-            pred = self.detector(self.lb)                       # [S, 4+nc+nk, A]
+            pred = self._pred(self.detector(self.lb), self.proto)    # [S, 4+nc+nk+nm, A]
             if self.det_source == "detector":
                 self.pred_in.copy_(pred)
-        e.nms_batch(self.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=self.dets, keep=self.keep,
+        e.nms_batch(self.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nx, rows=self.dets, keep=self.keep,
                     count=self.ndets, max_det=self.max_det)
-        if self.nk:
+        if self.nx:
             self.dets6.copy_(self.dets[:, :, :6])
+
+    @staticmethod
+    def _pred(out, proto_dst):
+        """Detector output -> the row tensor; a segmentation head's prototypes go to their static buffer."""
+        if isinstance(out, tuple):
+            out, proto = out
+            proto_dst.copy_(proto)
+        return out
 
     def _reid_impl(self):
         e, S = self.eng, self.S
@@ -234,9 +246,10 @@ class _Bufs:
         dev, S, g = p.dev, getattr(p, "Sv", p.S), p.geom
         self.frames = torch.zeros(S, p.H, p.W, 3, dtype=torch.uint8, device=dev)
         self.lb = torch.zeros(S, 3, g.out_h, g.out_w, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
-        self.pred_in = torch.zeros(S, 4 + p.nc + p.nk, p.n_anchors, dtype=torch.float32, device=dev)
-        self.dets = torch.zeros(S, MAX_DETS, 6 + p.nk, dtype=torch.float32, device=dev)
-        self.dets6 = self.dets if p.nk == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
+        self.pred_in = torch.zeros(S, 4 + p.nc + p.nx, p.n_anchors, dtype=torch.float32, device=dev)
+        self.dets = torch.zeros(S, MAX_DETS, 6 + p.nx, dtype=torch.float32, device=dev)
+        self.dets6 = self.dets if p.nx == 0 else torch.zeros(S, MAX_DETS, 6, dtype=torch.float32, device=dev)
+        self.proto = torch.zeros(S, p.nm, p.geom.out_h // 4, p.geom.out_w // 4, dtype=p.dtype, device=dev) if p.nm else None
         self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
         self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
@@ -387,22 +400,22 @@ class OverlappedPipeline(FramePipeline):
             self._keep(b, "pyr", self.detector.forward_backbone(b.lb))
 
     def _s_head(self, b):
-        pred = self.detector.forward_head(*b.pyr)
+        pred = self._pred(self.detector.forward_head(*b.pyr), b.proto)
         if self.det_source == "detector":
             b.pred_in.copy_(pred)
 
     def _s_detector(self, b):
         if self.run_nets:
             self._letterbox(b)
-            pred = self.detector(b.lb)
+            pred = self._pred(self.detector(b.lb), b.proto)
             if self.det_source == "detector":
                 b.pred_in.copy_(pred)
 
     def _nms_crop(self, b):
         e = self.eng                       # one launch set over all S*F virtual streams
-        e.nms_batch(b.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nk, rows=b.dets, keep=b.keep,
+        e.nms_batch(b.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nx, rows=b.dets, keep=b.keep,
                     count=b.ndets, max_det=self.max_det)
-        if self.nk:
+        if self.nx:
             b.dets6.copy_(b.dets[:, :, :6])
         if self.run_nets:
             if self.pack:        # the group's valid crops contiguous; the ReID kernels skip the rest of the fixed-size batch

@@ -7,7 +7,7 @@ Mirrors exactly what /root/reference/yolo_multi_model.py touches:
   :41     model.track(image, verbose=False, device=0, persist=True, tracker="botsort.yaml") -> [Results]
   :173    model.predict(image, verbose=False, device=0)                                       -> [Results]
 and the Results duck type consumed at :45-169 / :175-237 (boxes.id/.conf/.cls/.xyxy as 1-row tensors
-per box, keypoints[i].xy, masks, names).  The frame -> rows path runs on the MI355X
+per box, keypoints[i].xy, masks[i].xy, names).  The frame -> rows path runs on the MI355X
 (pipeline.FramePipeline); this file is host glue only.
 """
 from __future__ import annotations
@@ -67,9 +67,132 @@ class Keypoints:
         return (self[i] for i in range(len(self)))
 
 
+def assemble_masks(proto, coef, boxes_in, in_hw):
+    """Instance masks at the network-input resolution from a frame's prototypes [nm, mh, mw], the kept rows' coefficients [n, nm]
+    and their DETECTION boxes in input pixels [n, 4] (the published Ultralytics recipe `process_mask(..., upsample=True)`: linear
+    combination, cropped to the box on the prototype grid, bilinear up to the input size, > 0).  Host arithmetic in float32:
+    the device hands over prototypes and coefficients, nothing of this is on the timed path.  -> bool [n, ih, iw]"""
+    import torch.nn.functional as F
+    c, mh, mw = proto.shape
+    ih, iw = in_hw
+    n = coef.shape[0]
+    if n == 0:
+        return torch.zeros(0, ih, iw, dtype=torch.bool)
+    m = (coef.float() @ proto.float().reshape(c, -1)).view(n, mh, mw)
+    b = boxes_in.float().clone()
+    b[:, [0, 2]] *= mw / iw
+    b[:, [1, 3]] *= mh / ih
+    x1, y1, x2, y2 = (b[:, i].view(n, 1, 1) for i in range(4))
+    col = torch.arange(mw, dtype=torch.float32).view(1, 1, mw)
+    row = torch.arange(mh, dtype=torch.float32).view(1, mh, 1)
+    m = m * ((col >= x1) & (col < x2) & (row >= y1) & (row < y2))
+    return F.interpolate(m[None], (ih, iw), mode="bilinear", align_corners=False)[0] > 0.0
+
+
+_RING = ((-1, 0), (-1, -1), (0, -1), (1, -1), (1, 0), (1, 1), (0, 1), (-1, 1))      # (dx, dy) clockwise from west, y down
+
+
+def trace_outline(comp: np.ndarray) -> np.ndarray:
+    """Outer boundary of ONE 8-connected component (bool [h, w]) by Moore-neighbour tracing, clockwise from its first pixel in
+    raster order, runs of equal chain direction reduced to their end points (what cv2.CHAIN_APPROX_SIMPLE keeps).  cv2 is not
+    installed and its border-following order is not restated: the polygon is the same closed pixel chain, the start point
+    and orientation are this function's.  -> int32 [k, 2] (x, y)"""
+    h, w = comp.shape
+    ys, xs = np.nonzero(comp)
+    if len(ys) == 0:
+        return np.zeros((0, 2), np.int32)
+    sx, sy = int(xs[0]), int(ys[0])                       # np.nonzero is row-major: top-most row, left-most pixel
+    inside = lambda x, y: 0 <= x < w and 0 <= y < h and comp[y, x]
+    pts, x, y, back = [(sx, sy)], sx, sy, 0               # back: ring index of a background neighbour (west of the start pixel)
+    first = None
+    for _ in range(4 * (h * w + 4)):
+        nxt = None
+        for k in range(1, 9):
+            j = (back + k) % 8
+            qx, qy = x + _RING[j][0], y + _RING[j][1]
+            if inside(qx, qy):
+                bx, by = x + _RING[(j - 1) % 8][0], y + _RING[(j - 1) % 8][1]      # the background pixel scanned just before
+                nxt = (qx, qy, _RING.index((bx - qx, by - qy)))
+                break
+        if nxt is None:                                   # an isolated pixel
+            break
+        if (x, y) == (sx, sy) and first is not None and nxt[:2] == first:          # back at the start, leaving as the first time
+            pts.pop()
+            break
+        if first is None:
+            first = nxt[:2]
+        x, y, back = nxt
+        pts.append((x, y))
+    p = np.asarray(pts, np.int32)
+    if len(p) < 3:
+        return p
+    d_in, d_out = p - np.roll(p, 1, 0), np.roll(p, -1, 0) - p
+    return p[(d_in != d_out).any(1)]
+
+
+def mask_polygon(mask: np.ndarray) -> np.ndarray:
+    """The polygon Ultralytics' `masks2segments(strategy="largest")` stands for: the outline with the most points among the
+    mask's 8-connected components (the 16 largest are traced).  -> float32 [k, 2] in the mask's pixel coordinates."""
+    from scipy import ndimage
+    lab, n = ndimage.label(mask, structure=np.ones((3, 3), np.int8))
+    if n == 0:
+        return np.zeros((0, 2), np.float32)
+    order = np.argsort(-np.bincount(lab.ravel(), minlength=n + 1)[1:], kind="stable")[:16] + 1
+    best = max((trace_outline(lab == int(i)) for i in order), key=len)
+    return best.astype(np.float32)
+
+
+class Masks:
+    """Instance masks of one frame: the part of Ultralytics' `Masks` the reference touches (/root/reference/yolo_multi_model.py
+    :71-72 iterates them in step with the boxes, :112-121 draws `masks.xy`).  `data`: bool [n, ih, iw] at the network-input size,
+    `xy`: one float32 [k, 2] polygon per mask in ORIGINAL-image pixels, `xyn`: the same normalised.  Assembled lazily on the host
+    from the frame's prototypes and the kept rows' coefficients (`assemble_masks`)."""
+
+    def __init__(self, proto, coef, boxes_in, in_hw, orig_shape, gain, pad_xy, _data=None):
+        self._proto, self._coef, self._boxes, self._in_hw = proto, coef, boxes_in, tuple(int(v) for v in in_hw)
+        self.orig_shape, self._gain, self._pad = tuple(int(v) for v in orig_shape[:2]), float(gain), (float(pad_xy[0]), float(pad_xy[1]))
+        self._data, self._xy = _data, None
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = assemble_masks(self._proto, self._coef, self._boxes, self._in_hw)
+        return self._data
+
+    @property
+    def xy(self):
+        if self._xy is None:
+            H, W = self.orig_shape
+            out = []
+            for m in self.data.numpy():
+                p = mask_polygon(m)
+                if len(p):
+                    p = (p - np.float32(self._pad)) / np.float32(self._gain)       # scale_coords: un-pad, un-scale, clip
+                    p[:, 0], p[:, 1] = p[:, 0].clip(0, W), p[:, 1].clip(0, H)
+                out.append(p.astype(np.float32))
+            self._xy = out
+        return self._xy
+
+    @property
+    def xyn(self):
+        H, W = self.orig_shape
+        return [p / np.float32((W, H)) for p in self.xy]
+
+    def __len__(self):
+        return self._coef.shape[0]
+
+    def __getitem__(self, i):
+        i = slice(i, i + 1) if isinstance(i, int) else i
+        return Masks(self._proto, self._coef[i], self._boxes[i], self._in_hw, self.orig_shape, self._gain, self._pad,
+                     None if self._data is None else self._data[i])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class Results:
-    def __init__(self, orig_img, names, boxes: Optional[Boxes], keypoints: Optional[Keypoints] = None):
-        self.orig_img, self.names, self.boxes, self.keypoints, self.masks = orig_img, names, boxes, keypoints, None
+    def __init__(self, orig_img, names, boxes: Optional[Boxes], keypoints: Optional[Keypoints] = None, masks: Optional[Masks] = None):
+        self.orig_img, self.names, self.boxes, self.keypoints, self.masks = orig_img, names, boxes, keypoints, masks
 
     def __len__(self):
         return 0 if self.boxes is None else len(self.boxes)
@@ -147,6 +270,7 @@ class YOLO:
             self._h_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
             self._h_cnt = torch.zeros(2, dtype=torch.int32).pin_memory()
             self._d_cnt = torch.zeros(2, dtype=torch.int32, device=p.dev)
+            self._h_proto = torch.empty(p.proto.shape[1:], dtype=p.proto.dtype).pin_memory() if p.nm else None
         return self._pipe
 
     def _run(self, image, device, track):
@@ -163,11 +287,14 @@ class YOLO:
             self._d_cnt[1:2].copy_(pipe.nout)
             self._h_rows.copy_(pipe.out[0], non_blocking=True)
         self._h_cnt.copy_(self._d_cnt, non_blocking=True)
+        if pipe.nm:
+            self._h_proto.copy_(pipe.proto[0], non_blocking=True)
         torch.cuda.current_stream(pipe.dev).synchronize()            # the one synchronisation of the call
         pipe.eng.check_errors()
         self._frame_index += 1
         n, m = int(self._h_cnt[0]), int(self._h_cnt[1])
-        return self._results(image, pipe, self._h_dets[:n].clone(), self._h_rows[:m].clone() if track else None)
+        return self._results(image, pipe, self._h_dets[:n].clone(), self._h_rows[:m].clone() if track else None,
+                             self._h_proto.clone() if pipe.nm else None)
 
     def _run_predict_wide(self, image, device):
         """model.predict with max_det > 128 (the reference sets 1000, yolo_multi_model.py:21): a detection-only pipeline
@@ -181,6 +308,7 @@ class YOLO:
             self._pred_key = key
             self._hp_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
             self._hp_cnt = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._hp_proto = torch.empty(p.proto.shape[1:], dtype=p.proto.dtype).pin_memory() if p.nm else None
         pipe = self._pred_pipe
         pipe.eng.upload(pipe.frames[0], image)
         if self._fill is not None:
@@ -188,26 +316,37 @@ class YOLO:
         pipe.step(track=False)
         self._hp_dets.copy_(pipe.dets[0], non_blocking=True)
         self._hp_cnt.copy_(pipe.ndets, non_blocking=True)
+        if pipe.nm:
+            self._hp_proto.copy_(pipe.proto[0], non_blocking=True)
         torch.cuda.current_stream(pipe.dev).synchronize()
         pipe.eng.check_errors()
-        return self._results(image, pipe, self._hp_dets[:int(self._hp_cnt[0])].clone(), None)
+        return self._results(image, pipe, self._hp_dets[:int(self._hp_cnt[0])].clone(), None,
+                             self._hp_proto.clone() if pipe.nm else None)
 
-    def _results(self, image, pipe, dets, rows):
-        kpts = None
+    def _results(self, image, pipe, dets, rows, proto=None):
+        kpts = masks = None
         if pipe.nk:
-            k = dets[:, 6:].reshape(dets.shape[0], pipe.nk // 3, 3).clone()
+            k = dets[:, 6:6 + pipe.nk].reshape(dets.shape[0], pipe.nk // 3, 3).clone()
             k[..., 0] = (k[..., 0] - pipe.pad_x) / pipe.gain
             k[..., 1] = (k[..., 1] - pipe.pad_y) / pipe.gain
             kpts = k
+        if pipe.nm and proto is not None:
+            # masks are cut with the DETECTION boxes (as upstream: assembled at predict time, before the tracker replaces the boxes),
+            # brought back to the network-input frame: x * gain + pad
+            b = dets[:, :4].clone()
+            b[:, [0, 2]] = b[:, [0, 2]] * pipe.gain + pipe.pad_x
+            b[:, [1, 3]] = b[:, [1, 3]] * pipe.gain + pipe.pad_y
+            masks = Masks(proto, dets[:, 6 + pipe.nk:6 + pipe.nk + pipe.nm].clone(), b, (pipe.geom.out_h, pipe.geom.out_w),
+                          image.shape, pipe.gain, (pipe.pad_x, pipe.pad_y))
         if rows is None:
             return [Results(image, self.names, Boxes(dets[:, :4], dets[:, 4], dets[:, 5]),
-                            None if kpts is None else Keypoints(kpts))]
+                            None if kpts is None else Keypoints(kpts), masks)]
         rows = rows[rows[:, 7] >= 0]                   # ultralytics semantics: results[i] = results[i][det_idx]
         if rows.shape[0] == 0:
             return [Results(image, self.names, Boxes(torch.zeros(0, 4), torch.zeros(0), torch.zeros(0), None))]
         di = rows[:, 7].long()
         return [Results(image, self.names, Boxes(rows[:, :4], rows[:, 6], rows[:, 5], rows[:, 4]),
-                        None if kpts is None else Keypoints(kpts[di]))]
+                        None if kpts is None else Keypoints(kpts[di]), None if masks is None else masks[di])]
 
     @torch.no_grad()
     def track(self, image, verbose=False, device=0, persist=True, tracker="strongsort.yaml", **kw) -> List[Results]:
@@ -247,6 +386,7 @@ class YOLO:
         h_rows = torch.empty(ring, F, pipe.outs.shape[2], 8).pin_memory()
         h_dets = torch.empty(ring, F, pipe.bufs[0].dets.shape[1], pipe.bufs[0].dets.shape[2]).pin_memory()
         h_cnt = torch.zeros(ring, 2, F, dtype=torch.int32).pin_memory()
+        h_proto = torch.empty((ring, F) + tuple(pipe.bufs[0].proto.shape[1:]), dtype=pipe.bufs[0].proto.dtype).pin_memory() if pipe.nm else None
         done = [torch.cuda.Event() for _ in range(ring)]
         pending = []                                                      # (group index, frames of the group)
         state = {"group": 0, "first": {}, "enqueued": -1}                 # first frame index of a group -> group index
@@ -263,6 +403,8 @@ class YOLO:
             h_cnt[slot, 1, :nv].copy_(pipe.nouts[:nv, 0], non_blocking=True)
             h_cnt[slot, 0, :nv].copy_(b.ndets[:nv], non_blocking=True)
             h_dets[slot, :nv].copy_(b.dets[:nv], non_blocking=True)
+            if h_proto is not None:
+                h_proto[slot, :nv].copy_(b.proto[:nv], non_blocking=True)
             done[slot].record(torch.cuda.current_stream(pipe.dev))
             state["enqueued"] = g
             del state["first"][frame_idx - f]
@@ -274,7 +416,8 @@ class YOLO:
             done[slot].synchronize()
             for f, img in enumerate(imgs):
                 n, m = int(h_cnt[slot, 0, f]), int(h_cnt[slot, 1, f])
-                yield self._results(img, pipe, h_dets[slot, f, :n].clone(), h_rows[slot, f, :m].clone())
+                yield self._results(img, pipe, h_dets[slot, f, :n].clone(), h_rows[slot, f, :m].clone(),
+                                    None if h_proto is None else h_proto[slot, f].clone())
 
         try:
             chunk = [first]

@@ -315,3 +315,51 @@ def test_two_ranks_on_one_gpu_each_identical_to_its_oracle():
     n, m = d["frames_bit_exact_timed"].split("/")
     assert n == m and int(m) == 2 * 32
     assert abs(d["value"] - 2 * min(d["per_rank_value"])) <= 0.03                       # whole job = ranks x frames / max-rank time (each rounded to 2 decimals)
+
+
+def test_yolo_segmentation_masks_follow_the_boxes():
+    """YOLO("yolov8n-seg.pt") (yolo_multi_model.py:14): `Results.masks` built from the prototypes and mask coefficients the device
+    holds for the frame — predict (detection order), track (tracker rows, `det_idx`), and the throughput form's host ring."""
+    from strongsort_yolo_amd.yolo import YOLO, assemble_masks
+    rng = np.random.default_rng(3)
+    frames = [rng.integers(0, 256, (480, 640, 3), dtype=np.uint8) for _ in range(6)]
+    model = YOLO("yolov8n-seg.pt")
+    model.overrides.update(conf=0.5, iou=0.4, agnostic_nms=False, max_det=20)       # random-init head: about half the anchors pass
+    det = model.predict(frames[0], verbose=False, device=0)[0]
+    pipe = model._pipe
+    ih, iw = pipe.geom.out_h, pipe.geom.out_w
+    assert pipe.nm == 32 and pipe.nk == 0 and tuple(pipe.proto.shape[1:]) == (32, ih // 4, iw // 4)
+    n = len(det.boxes)
+    assert det.masks is not None and len(det.masks) == n and tuple(det.masks.data.shape) == (n, ih, iw)
+
+    def from_device(idx):
+        d = pipe.dets[0].cpu()[idx]
+        b = d[:, :4].clone()
+        b[:, [0, 2]] = b[:, [0, 2]] * pipe.gain + pipe.pad_x
+        b[:, [1, 3]] = b[:, [1, 3]] * pipe.gain + pipe.pad_y
+        return assemble_masks(pipe.proto[0].cpu(), d[:, 6:38], b, (ih, iw))
+
+    assert torch.equal(det.masks.data, from_device(torch.arange(n)))
+    for box, mk in zip(det.boxes, det.masks):                                        # the reference's loop (:196)
+        assert len(mk.xy) == 1 and mk.xy[0].dtype == np.float32
+        if len(mk.xy[0]):
+            assert mk.xy[0][:, 0].min() >= 0 and mk.xy[0][:, 0].max() <= 640 and mk.xy[0][:, 1].min() >= 0 and mk.xy[0][:, 1].max() <= 480
+    for _ in range(4):                                                               # the same frame: tracks confirm on the third call
+        r = model.track(frames[0], verbose=False, device=0, persist=True)[0]
+    if r.boxes.id is not None:
+        rows = pipe.out[0].cpu()[:int(pipe.nout[0])]
+        di = rows[rows[:, 7] >= 0][:, 7].long()
+        assert len(r.masks) == len(r.boxes) == len(di) and torch.equal(r.masks.data, from_device(di))
+    model.close()
+    outs = []
+    for _ in range(2):                                                               # throughput form, twice from scratch: same results
+        m2 = YOLO("yolov8n-seg.pt")
+        m2.overrides.update(conf=0.5, iou=0.4, agnostic_nms=False, max_det=20)
+        res = [r[0] for r in m2.track_stream(iter(frames), batch=2, device=0)]
+        assert len(res) == len(frames)
+        for r in res:
+            assert (r.masks is None and len(r.boxes) == 0) or len(r.masks) == len(r.boxes)
+        outs.append([(r.boxes.xyxy.numpy().copy(), [] if r.masks is None else [p.copy() for p in r.masks.xy]) for r in res])
+        m2.close()
+    for (b0, p0), (b1, p1) in zip(*outs):
+        assert np.array_equal(b0, b1) and len(p0) == len(p1) and all(np.array_equal(u, v) for u, v in zip(p0, p1))

@@ -24,6 +24,29 @@ def test_fused_ops_match_torch_modules(name, shape):
     assert (a - b).abs().max().item() <= 2e-2 * scale, ((a - b).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("name,shape", [("yolov8n-seg", (2, 3, 192, 320)), ("yolo11n-seg", (1, 3, 128, 160))])
+def test_segmentation_head_fused_matches_torch_modules(name, shape):
+    """Segment head (yolo_multi_model.py:14 names 'yolov8n-seg.pt'): rows [B, 4+nc+32, A] with the raw mask coefficients last,
+    prototypes [B, 32, H/4, W/4]; the fused convolutions under it against the plain torch modules."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    m = nets.build_detector(name).to(dev, torch.float16).to(memory_format=torch.channels_last)
+    x = torch.randn(*shape, device=dev, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        fused.ENABLED = True
+        a = m(x)
+        fused.ENABLED = False
+        b = m(x)
+        fused.ENABLED = True
+    B, _, H, W = shape
+    A = sum((H // s) * (W // s) for s in (8, 16, 32))
+    assert a[0].shape == b[0].shape == (B, 4 + 80 + 32, A) and a[1].shape == b[1].shape == (B, 32, H // 4, W // 4)
+    for u, v in zip(a, b):
+        u, v = u.float(), v.float()
+        scale = v.abs().max().item() + 1e-6
+        assert torch.isfinite(u).all() and (u - v).abs().max().item() <= 2e-2 * scale, ((u - v).abs().max().item(), scale)
+
+
 @pytest.mark.parametrize("shape", [(3, 16, 64, 32), (2, 24, 32, 16), (5, 32, 16, 8), (1, 16, 20, 24), (2, 32, 7, 8)])
 def test_lightconv_matches_pointwise_plus_depthwise(shape):
     """Fused LightConv3x3 (MFMA pointwise -> LDS -> depthwise+bias+ReLU) vs the two-step form: the pointwise

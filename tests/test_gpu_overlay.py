@@ -58,3 +58,21 @@ def test_overlay_draw_results_round_trip():
         ref = rasterise(frame, *ov_ref.commands(_results(), {"person": 1, "car": 1}, "FPS: 12.50").arrays(), font)
         assert np.array_equal(got, ref) and not np.array_equal(got, frame)
     eng.close()
+
+
+def test_overlay_mask_fills_equal_the_oracle():
+    """Segmentation overlay (yolo_multi_model.py:112-121): polygon outlines as line primitives, fills as exact even-odd blends between
+    the primitive stretches — device result == oracle.overlay_np.rasterise_with_blends, pixel for pixel; tracked and detect-only."""
+    from oracle.overlay_np import rasterise_with_blends
+    from tests.test_overlay_cpu import _seg_results
+    eng = engine(debug=False)
+    frame = np.random.default_rng(2).integers(0, 256, (240, 320, 3), dtype=np.uint8)
+    font = font_table()
+    for tracked in (True, False):
+        ov, ov_ref = Overlay({0: "person", 2: "car"}, eng), Overlay({0: "person", 2: "car"})
+        for k in range(2):
+            got = ov.draw(frame, _seg_results(tracked), fps_text="FPS: 9.00")
+            cl = ov_ref.commands(_seg_results(tracked), None, "FPS: 9.00")
+            ref = rasterise_with_blends(frame, *cl.arrays(), font, cl.blends)
+            assert len(cl.blends) == 2 and np.array_equal(got, ref), f"tracked={tracked} frame {k}: {int((got != ref).any(axis=2).sum())} pixels differ"
+    eng.close()

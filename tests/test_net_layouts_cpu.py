@@ -145,7 +145,7 @@ def test_avgpool_and_place_guards():
     assert not fused.streams_ok(torch.zeros(1, 32, 64, 64))                  # LDS budget
 
 
-@pytest.mark.parametrize("name,last", [("yolov8n", 22), ("yolov5n", 24), ("yolo11n-pose", 23), ("yolo11n", 23)])
+@pytest.mark.parametrize("name,last", [("yolov8n", 22), ("yolov5n", 24), ("yolo11n-pose", 23), ("yolo11n", 23), ("yolov8n-seg", 22), ("yolo11n-seg", 23)])
 def test_ultralytics_state_dict_is_folded_and_mapped(name, last, tmp_path):
     """An Ultralytics-style state_dict (layer indices, Conv + BatchNorm pairs, DFL projection, num_batches_tracked) built from
     one of the networks here loads — strictly — into a fresh one and reproduces its forward pass: the layer-index map and the
@@ -186,7 +186,12 @@ def test_ultralytics_state_dict_is_folded_and_mapped(name, last, tmp_path):
         assert torch.allclose(dst.state_dict()[k], v, rtol=1e-4, atol=1e-5), k
     x = torch.randn(1, 3, 64, 96, generator=g)
     with torch.no_grad():
-        assert torch.allclose(dst(x), src(x), rtol=1e-3, atol=1e-3)
+        a, b = dst(x), src(x)
+        if name.endswith("-seg"):                                 # (rows with 32 mask coefficients, prototypes at stride 4)
+            assert a[0].shape == (1, 4 + 80 + 32, 126) and a[1].shape == (1, 32, 16, 24)
+            assert any(k.startswith("detect.proto.upsample") for k in sd) and f"model.{last}.proto.cv3.bn.weight" in fake
+            a, b = torch.cat([t.flatten() for t in a]), torch.cat([t.flatten() for t in b])
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-3)
     # a layer that does not line up is an error, not a silently wrong network
     bad = dict(fake); bad["model.40.conv.weight"] = torch.zeros(1)
     torch.save(bad, path)

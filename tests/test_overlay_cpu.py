@@ -77,3 +77,67 @@ def test_frame_sinks(tmp_path):
     assert json.load(open(tmp_path / "b.bgr.json")) == {"width": 8, "height": 6, "fps": 15, "frames": 3, "pix_fmt": "bgr24"}
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(tmp_path / "dir" / "frame_000002.png"))[:, :, ::-1], frames[2])
+
+
+# ---- segmentation overlay (/root/reference/yolo_multi_model.py:71-121, :195-221) ------------------------------------------------
+def _seg_results(tracked=True):
+    from strongsort_yolo_amd.yolo import Masks
+    xyxy = torch.tensor([[40., 60., 120., 200.], [150., 30., 210., 180.]])
+    proto = torch.zeros(2, 60, 80)
+    proto[0, 20:45, 12:28] = 1.0
+    proto[1, 10:40, 40:50] = 1.0
+    mk = Masks(proto, torch.eye(2), torch.tensor([[0., 0., 320., 240.]] * 2), (240, 320), (240, 320, 3), 1.0, (0.0, 0.0))
+    ids = torch.tensor([7., 9.]) if tracked else None
+    return [Results(np.zeros((240, 320, 3), np.uint8), {0: "person", 2: "car"}, Boxes(xyxy, torch.tensor([0.91, 0.5]), torch.tensor([0., 2.]), ids), None, mk)]
+
+
+def test_polygon_fill_equals_the_exact_oracle():
+    from oracle.overlay_np import blend_polygon_np, polygon_mask_np
+    from strongsort_yolo_amd.overlay import blend_polygon_, polygon_mask
+    rng = np.random.default_rng(4)
+    polys = [np.array([[2, 2], [12, 2], [12, 9], [7, 5], [2, 9]]), np.array([[5, 5], [30, 25], [5, 25], [30, 5]]),        # concave, bow tie
+             np.array([[-6, 3], [20, -4], [44, 18], [10, 40]]), np.array([[3, 3], [9, 3]]), np.array([[4, 4], [4, 4], [4, 4]])]
+    polys += [rng.integers(-5, 45, (int(rng.integers(3, 12)), 2)) for _ in range(12)]
+    for q in polys:
+        ref = polygon_mask_np(q, 36, 40)
+        got = polygon_mask(torch.from_numpy(np.asarray(q, np.int64)), 0, 0, 36, 40).numpy() if len(q) >= 3 else np.zeros((36, 40), bool)
+        assert np.array_equal(got, ref), q.tolist()
+        frame = rng.integers(0, 256, (36, 40, 3), dtype=np.uint8)
+        color = tuple(int(c) for c in rng.integers(0, 256, 3))
+        out = blend_polygon_(torch.from_numpy(frame.copy()), q, color).numpy()
+        assert np.array_equal(out, blend_polygon_np(frame, q, color))
+        assert np.array_equal(out[~ref], frame[~ref])                     # outside: addWeighted(x, .5, x, .5) = x
+
+
+def test_mask_commands_interleave_boxes_and_fills():
+    from strongsort_yolo_amd.overlay import CLASS_COLORS
+    ov = Overlay({0: "person", 2: "car"})
+    cl = ov.commands(_seg_results())
+    prims = cl.arrays()[0]
+    assert len(cl.blends) == 2
+    (p0, q0, c0), (p1, q1, c1) = cl.blends
+    # pair 0: box (outline, plate, text), its polygon's edges, THEN its fill; pair 1's box comes after that fill (drawn over it)
+    assert prims[:3, 0].tolist() == [RECT, FILL, TEXT] and (prims[3:p0, 0] == LINE).all() and p0 - 3 == len(q0)
+    assert prims[p0:p0 + 3, 0].tolist() == [RECT, FILL, TEXT] and prims[p0, 1:5].tolist() == [150, 30, 210, 180]
+    assert (prims[3:p0, 5] == bgr(255, 0, 0)).all() and c0 == tuple(int(v) for v in CLASS_COLORS[0]) and c1 == tuple(int(v) for v in CLASS_COLORS[2])
+    assert q0[:, 0].min() >= 40 and q0[:, 0].max() <= 120 and p1 == len(prims)
+    n_lines_first = int((prims[:, 0] == LINE).sum())
+    cl2 = ov.commands(_seg_results())                                    # second frame: one trail segment per id, drawn per pair (:101-110)
+    assert int((cl2.arrays()[0][:, 0] == LINE).sum()) == n_lines_first + 1 + 2
+    det = Overlay({0: "person", 2: "car"}).commands(_seg_results(tracked=False))
+    lab = det.arrays()
+    assert len(det.blends) == 2 and bytes(lab[1][lab[0][2, 6]:lab[0][2, 6] + lab[0][2, 3]]).decode() == " person 91.0%"
+
+
+def test_rasterise_with_blends_is_painters_order():
+    from oracle.overlay_np import rasterise_with_blends
+    font = font_table()
+    frame = np.full((240, 320, 3), 90, np.uint8)
+    cl = Overlay({0: "person", 2: "car"}).commands(_seg_results())
+    prims, chars = cl.arrays()
+    out = rasterise_with_blends(frame, prims, chars, font, cl.blends)
+    (p0, q0, c0), _ = cl.blends
+    cx, cy = int(q0[:, 0].mean()), int(q0[:, 1].mean())
+    assert tuple(out[cy, cx]) == tuple(int(np.rint((90 + c) / 2)) for c in c0)                   # inside mask 0: blended once
+    assert tuple(out[130, 40]) == (0, 0, 225) and tuple(out[100, 150]) == (0, 0, 225)            # both box outlines (left edges) survive
+    assert np.array_equal(rasterise_with_blends(frame, prims, chars, font, []), rasterise(frame, prims, chars, font))
