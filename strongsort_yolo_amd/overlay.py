@@ -140,9 +140,9 @@ class Overlay:
                     if tracked:
                         t = self.trails.setdefault(int(id_), deque(maxlen=self.trail_len))
                         t.append(((float(xyxy[0]) + float(xyxy[2])) / 2, (float(xyxy[1]) + float(xyxy[3])) / 2))
-                        for t in self.trails.values():
-                            for i in range(1, len(t)):
-                                cl.line(int(t[i - 1][0]), int(t[i - 1][1]), int(t[i][0]), int(t[i][1]), bgr(255, 255, 255), 2)
+                        for tr in self.trails.values():                                          # :106-110, inside the pair loop
+                            for i in range(1, len(tr)):
+                                cl.line(int(tr[i - 1][0]), int(tr[i - 1][1]), int(tr[i][0]), int(tr[i][1]), bgr(255, 255, 255), 2)
                     for poly in (polys if isinstance(polys, (list, tuple)) else [polys]):
                         q = np.int32(poly)                                                       # np.int32(polygon), :114
                         if len(q):
