@@ -376,7 +376,7 @@ class YOLO:
             if self._stream_pipe is not None:
                 self._stream_pipe.close()
             self._stream_pipe = self._build(OverlappedPipeline, first.shape[:2], device, graph="front", frame_batch=batch,
-                                            reid_split=5 if batch > 1 else None, defer_track=batch > 1)
+                                            reid_split=(5 if self.arch == "yolov8n" else 2) if batch > 1 else None, defer_track=batch > 1)     # stage cut: bench.REID_SPLIT's sweep
             self._stream_key = key
         pipe = self._stream_pipe
         pipe.on_result = None
