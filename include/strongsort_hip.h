@@ -191,7 +191,13 @@ int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, co
 /* Tuning switches of a context (host state, read at the next tracker call):
  *   "cos_grid"         persistent workgroups of the association kernel, a multiple of 8 (default 512 = two per CU)
  *   "assoc_comp_rows"  a gallery's last 16-row tile with at most this many rows (0..12, default 12) is cut into 4-row groups
- *                      and four groups of any tracks form one composite tile of the association kernel (0: off) */
+ *                      and four groups of any tracks form one composite tile of the association kernel (0: off)
+ *   "assoc_stage"      how the association kernel brings a work record's detection operand (2 x 32 KiB) into the LDS:
+ *                      0 through registers behind one barrier; 1 / 2 / 4 by LDS-DMA in that many pieces, each awaited
+ *                      right before the first k-segment that reads it; 5 = 4 with only the first piece requested before
+ *                      the first barrier.  Same bits in every form.
+ *   "assoc_xcd_map"    0 (default): a gallery range lives on one XCD (every XCD stages all detection operands);
+ *                      1: a detection column-tile pair lives on one XCD (every XCD streams the whole gallery) */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
@@ -346,6 +352,9 @@ int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void*
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
  * call, measured with HIP events on the context stream; also returns the launch count. */
 int ss_assoc_timing(ss_ctx* ctx, int enable, float* mean_ms, int* launches);
+/* The individual durations (ms, launch order) behind the mean the LAST ss_assoc_timing call returned: up to `cap` values into
+ * out_ms, *n = how many there were.  For distributions (p50 / p95 / max) instead of a mean. */
+int ss_assoc_timing_values(ss_ctx* ctx, float* out_ms, int cap, int* n);
 /* The same kernel timed from inside: first workgroup start -> last workgroup end (100 MHz wall clock, written by the
  * kernel itself), i.e. without the time a dispatch waits for compute units behind other streams' kernels.  Returns
  * the mean over the launches since the last call (microseconds) and re-arms / disarms the stamps. */

@@ -69,11 +69,14 @@ struct ss_ctx {
     struct Back { void* p = nullptr; size_t cap = 0; } back;      // device -> host staging (ss_download)
     int cos_grid;               // persistent workgroups of the association kernel
     int comp_rows;              // ragged last tiles with at most this many rows travel as 4-row groups of composite tiles (0: never)
+    int assoc_stage;            // staging of the association kernel's detection operand (SSDev.assoc_stage)
+    int xcd_map;                // SSDev.xcd_map
     int inkernel;               // in-kernel timing of the association kernel: 0 off, 1 duration, 2 + timeline
     // association-kernel timing
     bool timing;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t ev_used;
+    std::vector<float> ev_ms;   // the durations behind the last ss_assoc_timing mean
 };
 
 static int fail(ss_ctx* c, int code, const std::string& msg)
@@ -116,6 +119,8 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->ev_used = 0;
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
     c->comp_rows = 12;
+    c->assoc_stage = 0;
+    c->xcd_map = 0;
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
     c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr; c->assoc_event = nullptr;
@@ -334,7 +339,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     dev.out_rows = d_out; dev.n_out = d_nout;
     // Every launch dimension is fixed by (streams, n_frames): track and detection counts are device-side values read
     // from the work lists, so nothing here needs a host round trip and the sequence can be captured into a HIP graph.
-    dev.cos_grid = c->cos_grid; dev.comp_rows = c->comp_rows;
+    dev.cos_grid = c->cos_grid; dev.comp_rows = c->comp_rows; dev.assoc_stage = c->assoc_stage; dev.xcd_map = c->xcd_map;
     dev.ts_enable = c->inkernel;
     dev.cmc = c->cmc_warps;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -402,6 +407,8 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     if (n == "cos_grid") { if (value < 8 || value > 4096 || value % 8) return fail(c, SS_ERR_INVALID, "cos_grid: a multiple of 8 in 8..4096"); c->cos_grid = value; }
     else if (n == "nms_fused") ss_nms_fused = value != 0;       // process-wide: one workgroup per image after the filter (1, default) or sort / mask / scan launches
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
+    else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
+    else if (n == "assoc_xcd_map") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "assoc_xcd_map: 0 or 1"); c->xcd_map = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;
 }
@@ -712,14 +719,24 @@ extern "C" int ss_assoc_timing(ss_ctx* c, int enable, float* mean_ms, int* launc
     if (!c) return SS_ERR_INVALID;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double tot = 0;
+    c->ev_ms.clear();
     for (size_t i = 0; i < c->ev_used; ++i) {
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i].first, c->ev[i].second));
         tot += ms;
+        c->ev_ms.push_back(ms);
     }
     if (mean_ms) *mean_ms = c->ev_used ? (float)(tot / c->ev_used) : 0.f;
     if (launches) *launches = (int)c->ev_used;
     c->ev_used = 0;
     c->timing = enable != 0;
+    return SS_OK;
+}
+
+extern "C" int ss_assoc_timing_values(ss_ctx* c, float* out_ms, int cap, int* n)
+{
+    if (!c || !n || cap < 0 || (cap > 0 && !out_ms)) return SS_ERR_INVALID;
+    *n = (int)c->ev_ms.size();
+    for (int i = 0; i < cap && i < *n; ++i) out_ms[i] = c->ev_ms[i];
     return SS_OK;
 }

@@ -59,6 +59,8 @@ struct SSDev {
     int budget;                 // nn_budget (ring length of a gallery)
     int cos_grid;               // workgroups of the persistent association kernel
     int comp_rows;              // ragged last gallery tiles of <= comp_rows rows are cut into 4-row groups (composite tiles)
+    int xcd_map;                // work-list placement: 0 a gallery range per XCD, 1 a detection column-tile pair per XCD
+    int assoc_stage;            // how k_assoc stages a record's detection operand: 0 registers, 1 / 2 / 4 LDS-DMA in that many pieces
     // persistent per stream
     int *n_tracks, *next_id, *frame, *err;
     int* order;                 // [S][MAXT] slot ids in track-list order

@@ -622,7 +622,9 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
                 // frame); with fewer than 8 ranges per pair, ceil(8 / ranges) consecutive pairs share the 8 XCDs between them, so a
                 // range lives on that many XCDs (not on all 8: at 32 streams x 7 ranges that was 4.1 GB of HBM traffic per launch
                 // instead of ~1 GB, L2 hit rate 0.33)
-                const int x = (j + s * nrp + (nrp < 8 ? (pp % ((8 + nrp - 1) / nrp)) * nrp : 0)) & 7;
+                // (assoc_xcd_map 1: all ranges of a pair on ONE XCD instead — each XCD then stages 1/8 of the detection operands and
+                // streams the whole gallery; for launches of few pairs, where the operands' fabric traffic is the start-up burst)
+                const int x = dev.xcd_map ? ((pp + s) & 7) : ((j + s * nrp + (nrp < 8 ? (pp % ((8 + nrp - 1) / nrp)) * nrp : 0)) & 7);
                 const int pos = atomicAdd(&lcnt[x], 1);
                 if (pass == 0) continue;
                 if (lbase[x] + pos >= dev.items_cap) { dev.err[s] = SS_ERR_CAPACITY; continue; }
@@ -733,8 +735,28 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
 #define SS_TL(i) do { if (TL && threadIdx.x == 0 && first_item) { ss_store_nr(dev.timeline + blockIdx.x * 16 + (i), wall_clock64()); \
                                                                    if (blockIdx.x < 2048) ss_store_nr(dev.timeline + (blockIdx.x + 2048) * 16 + (i), clock64()); } } while (0)
 
-template <bool TL>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc(SSDev dev)
+// LDS-DMA of one 1 KiB row of a fragment tile: lane l's 16 bytes land at lds_dst + 16 l (wave-uniform base in M0), no VGPRs hold
+// the data.  Inline assembly: the compiler's wait-count pass does not see the load, so the gallery ring keeps its counted
+// vmcnt; its completion is awaited with the explicit counts of the staging schedule below (loads return in order, so a
+// wait that allows N younger operations guarantees everything issued before them).
+__device__ __forceinline__ void ss_glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+#define SS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+// NP: how the record's detection operand B (2 x 32 KiB) reaches the LDS.  0: through registers, one barrier (round 3).
+// 1 / 2 / 4: LDS-DMA in NP pieces of 8 / 4 / 2 k-segments (5: four pieces, only the first requested before the first barrier); a piece is awaited (counted vmcnt + barrier) right before the first
+// step that can read it — every wave's run starts at k-segment 0 and advances at most one k-segment per step, and the
+// first fragment of a step is fetched during the step before it.  The first MFMAs then wait for 16 + 32 KiB per workgroup
+// instead of 64 + 64 KiB, and no staging registers / ds_write pass exist.
+// The three leading scalars are what the first record's address needs: with -amdgpu-kernarg-preload-count they are in SGPRs
+// when the wave starts (no dependent scalar load of the kernel-argument segment before the record fetch).
+template <bool TL, int NP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc(const int* items_all, const int* n_items_all, int items_cap_arg, SSDev dev)
 {
     bool first_item = true;
     SS_TL(0);
@@ -747,7 +769,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (threadIdx.x < 8) hflag[threadIdx.x] = 0;                    // ordered before its first use by the staging barriers
     if (dev.ts_enable && threadIdx.x == 0) ss_atomic_umin64_nr(dev.tstamp, (unsigned long long)wall_clock64());
     const int xcd = blockIdx.x & 7;                                  // this workgroup's list (see k_group_prep)
-    const int* items = reinterpret_cast<const int*>(dev.items) + (size_t)xcd * dev.items_cap * SS_RECW;
+    const int* items = items_all + (size_t)xcd * items_cap_arg * SS_RECW;
     int it = blockIdx.x >> 3;
     // The first record comes through the SCALAR cache: at the start of a launch the first vector load of a workgroup takes 0.7 to
     // 6.4 us (median 3.8, staggered by XCD) whatever it asks for, a scalar load 0.85 us (timeline, r03); the vector path's start-up
@@ -756,7 +778,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int rec, n_items;
     {
         const int* rp = items + (size_t)it * SS_RECW;
-        const int* np = dev.n_items + xcd;
+        const int* np = n_items_all + xcd;
         i32x16 lo, hi;
         i32x4 top;
         asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx4 %2, %4, 0x80\n\ts_load_dword %3, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
@@ -767,6 +789,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) rec = l == 32 + k ? top[k] : rec;
     }
+    n_items = min(n_items, items_cap_arg);                             // k_group_prep drops records past the capacity (SS_ERR_CAPACITY)
     const int budget = dev.budget;
     int seq = 0;
     for (; it < n_items; it += gridDim.x >> 3) {
@@ -794,7 +817,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const int nHM = nH + 8 * nM;
         if (TL && threadIdx.x == 0 && first_item) { ss_store_nr(dev.timeline + blockIdx.x * 16 + 13, (long long)nt | ((long long)comp << 32)); ss_store_nr(dev.timeline + blockIdx.x * 16 + 14, (long long)n_items); }
-        auto where = [&](int i, int& q, int& sg) {                  // segment i of the run -> (tile of the record, k-segment); selects, no branches
+        auto where = [&](int i, int& q, int& sg) __attribute__((always_inline)) {                  // segment i of the run -> (tile of the record, k-segment); selects, no branches
             const bool h = i < nH, m = i < nHM;
             q = h ? last : m ? mfirst + ((i - nH) >> 3) : first;
             sg = h ? i : m ? (i - nH) & 7 : a0 + (i - nHM);
@@ -802,13 +825,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const char* gbase = reinterpret_cast<const char*>(dev.gallery) + (size_t)s * SS_MAXT * SS_NRT * SS_TILE_FLOATS * 4;
         // lane (ks, i) = l reads float4 #(q*64 + l) of an ordinary tile; in a composite tile its row i belongs to group i/4 =
         // rows 4*r4 .. of tile (slot, rt) of that group's track
-        auto group_word = [&](int q, int g) {                       // word g (per lane) of composite tile q
+        auto group_word = [&](int q, int g) __attribute__((always_inline)) {                       // word g (per lane) of composite tile q
             const int b = 4 + 4 * q;
             const int w0 = __builtin_amdgcn_readlane(cur, b), w1 = __builtin_amdgcn_readlane(cur, b + 1);
             const int w2 = __builtin_amdgcn_readlane(cur, b + 2), w3g = __builtin_amdgcn_readlane(cur, b + 3);
             return g == 0 ? w0 : g == 1 ? w1 : g == 2 ? w2 : w3g;
         };
-        auto ld = [&](int i, float4 a[4]) {
+        auto ld = [&](int i, float4 a[4]) __attribute__((always_inline)) {
             int q, sg;
             where(i, q, sg);
             unsigned vo;
@@ -826,21 +849,62 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const float4*>(p + vo + j * 1024);
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
-        if (has) { ld(0, ra[0]); ld(1, ra[1]); }                      // on the wire before the B staging (nsteps >= 8)
-        // B of (frame f, stream s, column tiles ct0, ct0+1): global loads now, LDS writes after the barrier
+        // B of (frame f, stream s, column tiles ct0, ct0+1)
         const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
         // (a lone column tile is staged twice: branch-free, and the second copy's results are never stored)
         const float4* ff1 = two ? ff + 4 * 512 : ff;
         const int tx = threadIdx.x;
-        const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
-        const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
-        __syncthreads();                                             // the previous record's readers are done with bl / hand
-        SS_TL(2);                                                    // first gallery pieces + B landed
-        bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
-        bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
-        __syncthreads();
-        SS_TL(3);                                                    // B staged
+        // piece m (k-segments 2m, 2m+1 of both column tiles): this wave's two 1 KiB rows of it, straight into bl
+        auto dma = [&](int m) __attribute__((always_inline)) {
+            ss_glds16(ff + tx + 512 * m, (unsigned)(m * 8192 + wu * 1024));
+            ss_glds16(ff1 + tx + 512 * m, (unsigned)(32768 + m * 8192 + wu * 1024));
+        };
+        if constexpr (NP == 0) {
+            if (has) { ld(0, ra[0]); ld(1, ra[1]); }                  // on the wire before the B staging (nsteps >= 8)
+            const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
+            const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
+            __syncthreads();                                         // the previous record's readers are done with bl / hand
+            SS_TL(2);                                                // first gallery pieces + B landed
+            bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
+            bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
+            __syncthreads();
+            SS_TL(3);                                                // B staged
+        } else {
+            if (seq > 1) SS_LDS_BARRIER();                           // the previous record's readers are done with bl / hand
+            if (!has) {
+                // a wave without a run (records of fewer than 8 tiles) only moves its rows of B and takes part in the barriers —
+                // the same number of them as the waves with a run execute (the hardware barrier counts arrivals, not places)
+                if constexpr (NP == 5) {
+                    dma(0); SS_VMCNT(0); __builtin_amdgcn_s_barrier();
+                    dma(1); dma(2); SS_VMCNT(2); __builtin_amdgcn_s_barrier();
+                    dma(3); SS_VMCNT(2); __builtin_amdgcn_s_barrier();
+                    SS_VMCNT(0); __builtin_amdgcn_s_barrier();
+                } else if constexpr (NP == 4) {
+                    dma(0); dma(1); SS_VMCNT(2); __builtin_amdgcn_s_barrier();
+                    dma(2); SS_VMCNT(2); __builtin_amdgcn_s_barrier();
+                    dma(3); SS_VMCNT(2); __builtin_amdgcn_s_barrier();
+                    SS_VMCNT(0); __builtin_amdgcn_s_barrier();
+                } else if constexpr (NP == 2) {
+                    dma(0); dma(1); dma(2); dma(3); SS_VMCNT(4); __builtin_amdgcn_s_barrier();
+                    SS_VMCNT(0); __builtin_amdgcn_s_barrier();
+                } else {
+                    dma(0); dma(1); dma(2); dma(3); SS_VMCNT(0); __builtin_amdgcn_s_barrier();
+                }
+            }
+        }
         if (has) {
+            // issue order with LDS-DMA staging: NP 4: m0, ld 0, m1, ld 1 | NP 2: m0 m1, ld 0, ld 1, m2 m3 | NP 1: m0..m3, ld 0, ld 1.
+            // Every explicit wait admits exactly the operations issued after the awaited piece.
+            if constexpr (NP == 4) { dma(0); ld(0, ra[0]); dma(1); ld(1, ra[1]); SS_VMCNT(10); }
+            else if constexpr (NP == 5) { dma(0); ld(0, ra[0]); SS_VMCNT(4); }       // the start-up burst is 16 + 32 KiB per workgroup; the rest follows the barrier
+            else if constexpr (NP == 2) { dma(0); dma(1); ld(0, ra[0]); ld(1, ra[1]); dma(2); dma(3); SS_VMCNT(12); }
+            else if constexpr (NP == 1) { dma(0); dma(1); dma(2); dma(3); ld(0, ra[0]); ld(1, ra[1]); SS_VMCNT(8); }
+            if constexpr (NP != 0) {
+                SS_TL(2);                                            // first piece of B landed (this wave's rows)
+                __builtin_amdgcn_s_barrier();
+                SS_TL(3);                                            // first piece of B staged
+                if constexpr (NP == 5) { dma(1); ld(1, ra[1]); }
+            }
             const char* bls = reinterpret_cast<const char*>(bl) + l * 16;
             f32x4 tot0 = { 0.f, 0.f, 0.f, 0.f }, tot1 = { 0.f, 0.f, 0.f, 0.f };
             // B fragments are read from LDS one step (8 MFMAs) ahead of their use, so the LDS latency never shows
@@ -849,7 +913,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float4 bq0 = *reinterpret_cast<const float4*>(bls + sg0 * 4096), bq1 = *reinterpret_cast<const float4*>(bls + sg0 * 4096 + 32768);
             // one k-segment: prefetch (PF: piece i+3, clamped to the run's last piece so that the number of loads in flight
             // does not depend on the path — the compiler's wait counts stay exact), 32 MFMAs, running sum, tile end / hand-over
-            auto step = [&](int i, float4* a, float4* anew, bool pf) {
+            auto step = [&](int i, float4* a, float4* anew, bool pf) __attribute__((always_inline)) {
                 if (pf) ld(min(i + 2, nsteps - 1), anew);
                 int q, sg, qn, sgn;
                 where(i, q, sg);
@@ -928,6 +992,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 }
             };
             int i = 0;
+            if constexpr (NP == 4 || NP == 5 || NP == 2) {
+                // The first eight steps (nsteps >= 8 always) with the remaining pieces of B awaited on the way: step i reads
+                // k-segments <= i and requests the first fragment of a k-segment <= i + 1.
+#define SS_S1(k) step((k), ra[(k) & 3], ra[((k) + 2) & 3], true)
+                if constexpr (NP == 4 || NP == 5) {
+                    SS_S1(0);
+                    dma(2);
+                    SS_VMCNT(10); __builtin_amdgcn_s_barrier();     // piece 1 (before step 1); after it: ld 1, ld 2, m2
+                    SS_S1(1); SS_S1(2);
+                    dma(3);
+                    SS_VMCNT(10); __builtin_amdgcn_s_barrier();     // piece 2 (before step 3); after it: ld 3, ld 4, m3
+                    SS_S1(3); SS_S1(4);
+                    SS_VMCNT(8); __builtin_amdgcn_s_barrier();      // piece 3 (before step 5); after it: ld 5, ld 6
+                    SS_S1(5); SS_S1(6); SS_S1(7);
+                } else {
+                    SS_S1(0); SS_S1(1); SS_S1(2);
+                    SS_VMCNT(12); __builtin_amdgcn_s_barrier();     // pieces 2, 3 (before step 3); after them: ld 2, ld 3, ld 4
+                    SS_S1(3); SS_S1(4); SS_S1(5); SS_S1(6); SS_S1(7);
+                }
+#undef SS_S1
+                i = 8;
+            }
             for (; i + 4 <= nsteps; i += 4) {
                 step(i, ra[0], ra[2], true); step(i + 1, ra[1], ra[3], true); step(i + 2, ra[2], ra[0], true); step(i + 3, ra[3], ra[1], true);
             }
@@ -1472,19 +1558,32 @@ extern "C" void ss_step_kernel_attr()
 {
     // a failure here surfaces as a launch error on first use (checked with hipGetLastError after every launch)
     (void)hipFuncSetAttribute((const void*)k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_frame_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_assoc<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
-    (void)hipFuncSetAttribute((const void*)k_assoc<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
+    for (const void* k : { (const void*)k_assoc<false, 0>, (const void*)k_assoc<true, 0>, (const void*)k_assoc<false, 1>, (const void*)k_assoc<true, 1>,
+                           (const void*)k_assoc<false, 2>, (const void*)k_assoc<true, 2>, (const void*)k_assoc<false, 4>, (const void*)k_assoc<true, 4>,
+                           (const void*)k_assoc<false, 5>, (const void*)k_assoc<true, 5> })
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_assoc_lds_bytes());
+}
+
+template <bool TL, int NP>
+static void launch_assoc(const SSDev& dev, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const int* items = reinterpret_cast<const int*>(dev.items);
+    if (ev0) hipExtLaunchKernelGGL((k_assoc<TL, NP>), dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, items, (const int*)dev.n_items, dev.items_cap, dev);
+    else hipLaunchKernelGGL((k_assoc<TL, NP>), dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, items, (const int*)dev.n_items, dev.items_cap, dev);
 }
 
 // One group of dev.F frames for every stream.  ev0/ev1 (optional) bracket the association kernel's dispatch.
 void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
-    if (dev.ts_enable > 1) {
-        hipLaunchKernelGGL(k_assoc<true>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
+    const bool tl = dev.ts_enable > 1;                          // the timeline instantiation (stamps cost registers)
+    switch (dev.assoc_stage) {
+    case 1: tl ? launch_assoc<true, 1>(dev, st, nullptr, nullptr) : launch_assoc<false, 1>(dev, st, ev0, ev1); break;
+    case 2: tl ? launch_assoc<true, 2>(dev, st, nullptr, nullptr) : launch_assoc<false, 2>(dev, st, ev0, ev1); break;
+    case 4: tl ? launch_assoc<true, 4>(dev, st, nullptr, nullptr) : launch_assoc<false, 4>(dev, st, ev0, ev1); break;
+    case 5: tl ? launch_assoc<true, 5>(dev, st, nullptr, nullptr) : launch_assoc<false, 5>(dev, st, ev0, ev1); break;
+    default: tl ? launch_assoc<true, 0>(dev, st, nullptr, nullptr) : launch_assoc<false, 0>(dev, st, ev0, ev1); break;
     }
-    else if (ev0) hipExtLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, ev0, ev1, 0, dev);
-    else hipLaunchKernelGGL(k_assoc<false>, dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, dev);
     if (ev_assoc) (void)hipEventRecord(ev_assoc, st);          // the caller's "association done" event (ss_track_set_assoc_event)
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);

@@ -232,6 +232,14 @@ class TrackerEngine:
         self._ck(self.L.ss_assoc_timing(self.ctx, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def assoc_timing_values(self) -> np.ndarray:
+        """Per-launch durations (ms) behind the mean the last assoc_timing() call returned."""
+        n = C.c_int()
+        self._ck(self.L.ss_assoc_timing_values(self.ctx, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float32)
+        self._ck(self.L.ss_assoc_timing_values(self.ctx, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
+        return out[: n.value]
+
     # ---- stage entry points (device tensors in, device tensors out) ---------------------------------
     def _dev(self, a, dtype):
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=self.device).contiguous()

@@ -75,6 +75,28 @@ class SynthStream:
                 0, 256, (self.cfg.frame_pool, self.cfg.height, self.cfg.width, 3), dtype=np.uint8)
         return self._frames[index % self.cfg.frame_pool]
 
+    def render(self, frame: "SynthFrame") -> np.ndarray:
+        """uint8 BGR [H,W,3] with every visible identity DRAWN into its box: an identity-specific seeded 8 x 4 colour field,
+        bilinearly interpolated over the box, on a flat background; identities are painted in ascending id order, so an
+        overlap looks the same in every frame.  For the legs that put the real ReID network in the loop (SURVEY §8d:
+        "rendered boxes when the real ReID net is in the loop"): crops of one identity look alike from frame to frame (box
+        jitter and occlusion aside), crops of different identities do not."""
+        cfg = self.cfg
+        img = np.full((cfg.height, cfg.width, 3), 96, np.uint8)
+        if not hasattr(self, "_tex"):
+            self._tex = np.random.default_rng(cfg.seed + 15485863).integers(0, 256, (cfg.n_ids, 9, 5, 3)).astype(np.float32)
+        for i in np.argsort(frame.gt_ids, kind="stable"):
+            x1, y1, x2, y2 = (int(v) for v in frame.dets[i, :4])
+            w, h = max(x2 - x1, 1), max(y2 - y1, 1)
+            t = self._tex[int(frame.gt_ids[i])]
+            fy, fx = (np.arange(h) + 0.5) / h * 8, (np.arange(w) + 0.5) / w * 4
+            y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+            ay, ax = (fy - y0)[:, None, None], (fx - x0)[None, :, None]
+            p = (t[y0][:, x0] * (1 - ay) * (1 - ax) + t[y0 + 1][:, x0] * ay * (1 - ax) + t[y0][:, x0 + 1] * (1 - ay) * ax
+                 + t[y0 + 1][:, x0 + 1] * ay * ax)
+            img[y1:y1 + h, x1:x1 + w] = p.astype(np.uint8)[:img.shape[0] - y1, :img.shape[1] - x1]
+        return img
+
     # -- detections -----------------------------------------------------------------------------
     def next_frame(self) -> SynthFrame:
         cfg, rng = self.cfg, self.rng

@@ -82,7 +82,7 @@ def test_births_deaths_and_empty_frames():
     eng.close()
 
 
-def _run_streams(S, ids_of, frames, F=1, mute=(), late=(), cfg=None, wh=(1280, 720), stream_kw=None, empty_every=0):
+def _run_streams(S, ids_of, frames, F=1, mute=(), late=(), cfg=None, wh=(1280, 720), stream_kw=None, empty_every=0, opts=None):
     """S streams in one context, fed in groups of F frames (one ss_track_update_group call per group: the
     association kernel sees the detections of all F frames at once), against S single-stream oracles that run frame by
     frame; rows and every stage intermediate of every frame and stream are compared (rows a6-a10).
@@ -92,6 +92,8 @@ def _run_streams(S, ids_of, frames, F=1, mute=(), late=(), cfg=None, wh=(1280, 7
     cfg = cfg or StrongSortConfig()
     W, H = wh
     eng = engine(cfg, n_streams=S, debug=True)
+    for name, value in (opts or {}).items():
+        eng.set_option(name, value)
     orcs = [OracleStrongSort(cfg, "c") for _ in range(S)]
     streams = [make_stream(10 + s, W, H, ids_of(s), **(stream_kw or {})) for s in range(S)]
     dev = eng.device
@@ -155,6 +157,18 @@ def test_frame_groups_equal_frame_by_frame(S, F, frames, ids):
     assert max(conf) >= (90 if ids == 100 else 20)
     if frames > 110:
         assert max(len(t.gallery) for t in orcs[0].tracks) == 100           # the ring wrapped
+
+
+@pytest.mark.parametrize("stage", [0, 1, 2, 4, 5, 104])
+@pytest.mark.parametrize("S,F,frames,ids", [(1, 32, 136, 30), (32, 8, 24, 0), (2, 5, 25, 5), (1, 32, 64, 100)])
+def test_assoc_operand_staging_variants(stage, S, F, frames, ids):
+    """Every staging form of k_assoc's detection operand (`assoc_stage`: registers, or LDS-DMA in 1 / 2 / 4 pieces awaited
+    step by step) gives the same bits: full galleries with split tiles and composite tiles (1 x 32 frames), workgroups that
+    process several records (32 streams), records of fewer than 8 tiles (waves without a run that only take part in the
+    barriers) and four column-tile pairs per frame."""
+    mixed = [10, 24, 40, 30]
+    wh = (1920, 1080) if ids == 100 else (1280, 720)
+    _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + s), frames, F=F, wh=wh, opts={"assoc_stage": stage % 100, "assoc_xcd_map": stage // 100})
 
 
 def test_frame_groups_with_births_deaths_and_empty_frames():
