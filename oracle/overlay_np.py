@@ -6,7 +6,7 @@ restated; this file fixes the coverage rules of the primitives (integer arithmet
 must reproduce bit for bit."""
 import numpy as np
 
-RECT, FILL, CIRCLE, LINE, TEXT = 0, 1, 2, 3, 4
+RECT, FILL, CIRCLE, LINE, TEXT, POLY = 0, 1, 2, 3, 4, 5
 
 
 def _coverage(p, chars, font, H, W):
@@ -22,6 +22,8 @@ def _coverage(p, chars, font, H, W):
     elif t == LINE:
         o = (a + 1) >> 1
         bx0, by0, bx1, by1 = min(x0, x1) - o, min(y0, y1) - o, max(x0, x1) + o, max(y0, y1) + o
+    elif t == POLY:
+        bx0, by0, bx1, by1 = x0, y0, x1, y1
     else:
         sc = max(b >> 1, 1)
         bx0, bx1, by1, by0 = x0, x0 + x1 * 6 * sc - 1, y0, y0 - 7 * sc + 1
@@ -42,6 +44,10 @@ def _coverage(p, chars, font, H, W):
         cr = px * dy - py * dx
         m = np.where(tt <= 0, 4 * (px * px + py * py) <= a2,
                      np.where(tt >= L, 4 * ((xs - x1) ** 2 + (ys - y1) ** 2) <= a2, 4 * cr * cr <= a2 * L))
+    elif t == POLY:
+        pts = np.frombuffer(chars[a:a + 8 * (b >> 1)].tobytes(), np.int32).reshape(-1, 2)
+        full = polygon_mask_np(pts, H, W)
+        m = full[cy0:cy1 + 1, cx0:cx1 + 1]
     else:
         sc = max(b >> 1, 1)
         cx, cy = xs - x0, ys - (y0 - 7 * sc + 1)
@@ -57,13 +63,22 @@ def _mix(top, under):
     return ((179 * top.astype(np.int64) + 77 * under.astype(np.int64) + 128) >> 8).astype(np.uint8)
 
 
-def rasterise(frame, prims, chars, font):
-    """frame uint8 [H,W,3] BGR (copied), prims int32 [n,8], chars uint8, font uint8 [95,5] -> annotated frame."""
+def _half_even(a, b):
+    t = a.astype(np.int64) + b.astype(np.int64)
+    return ((t >> 1) + ((t & 1) & ((t >> 1) & 1))).astype(np.uint8)
+
+
+def rasterise(frame, prims, chars, font, skip_poly=False):
+    """frame uint8 [H,W,3] BGR (copied), prims int32 [n,8], chars uint8, font uint8 [95,5] -> annotated frame.  A POLY
+    primitive blends its even-odd interior half and half (ties to even) with what is there; like every non-group primitive
+    it first closes a blended group pending under the pixels it covers."""
     out = frame.copy()
     H, W = frame.shape[:2]
     grp = np.zeros_like(out)
     in_grp = np.zeros((H, W), bool)
     for p in prims:
+        if skip_poly and int(p[0]) == POLY:
+            continue
         cov = _coverage(p, chars, font, H, W)
         if cov is None:
             continue
@@ -79,14 +94,18 @@ def rasterise(frame, prims, chars, font):
                 o, g = out[sl], grp[sl]
                 o[close] = _mix(g[close], o[close])
                 in_grp[sl] &= ~m
-            out[sl][m] = color
+            if int(p[0]) == POLY:
+                o = out[sl]
+                o[m] = _half_even(o[m], color[None, :])
+            else:
+                out[sl][m] = color
     if in_grp.any():
         out[in_grp] = _mix(grp[in_grp], out[in_grp])
     return out
 
 
 # ---- mask fills (the reference's fillPoly + addWeighted 0.5, /root/reference/yolo_multi_model.py:112-121) ------------------------
-def polygon_mask_np(poly, H, W):
+def polygon_mask_np(poly, H, W):  # noqa: E302
     """Even-odd interior of the closed integer polygon [k, 2] on the H x W pixel grid: a pixel is inside when an odd number of
     edges straddle its y (exactly one end point with y <= the pixel's) strictly to its right, in exact rational arithmetic.
     Written per pixel and edge, the slow way (the product side vectorises over both)."""
@@ -120,7 +139,7 @@ def rasterise_with_blends(frame, prims, chars, font, blends):
     out, at = frame, 0
     for pos, poly, color in list(blends) + [(len(prims), None, None)]:
         if pos > at:
-            out = rasterise(out, prims[at:pos], chars, font)
+            out = rasterise(out, prims[at:pos], chars, font, skip_poly=True)     # the list's own POLY rows are what `blends` restates
         at = pos
         if poly is not None:
             out = blend_polygon_np(out, poly, color)

@@ -3,9 +3,11 @@
 What is kept is the per-stream loop (:244-339), the labels file (:34-39, :165-169), the class-count analytics
 (:284-305) — as an incremental per-id majority-class counter instead of re-reading the whole CSV every frame
  — and, with `--save`, the annotated output (:58-162, :311-331): the drawing runs as an overlay kernel
-on the device (overlay.py, N2) and the frames go to a sink (N3).  Frame sources (N3): `synthetic[:N]`, a `.npy` stack
-[T,H,W,3], or a directory of images (Pillow); sinks: `.npy`, raw BGR24 or a PNG directory.  There is no video
-decoder / encoder and no GUI in this environment (imshow / VideoWriter are out of scope).
+on the device (overlay.py, N2) on the frame that is ALREADY there (the throughput path keeps a device copy of every frame
+of a group: one upload and one download per frame) and the frames go to a sink (N3).  Frame sources (N3): `synthetic[:N]`,
+a `.npy` stack [T,H,W,3], a directory of images (Pillow) and — when OpenCV is importable — a video file or a camera index
+through `cv2.VideoCapture` (:252); sinks: `.npy`, raw BGR24, a PNG directory and — with OpenCV — `cv2.VideoWriter` (:256-260).
+OpenCV is optional: this environment has none, there the video branches raise a clear error (no GUI: imshow is out of scope).
 """
 from __future__ import annotations
 
@@ -38,7 +40,45 @@ def frame_source(spec: str, limit: Optional[int] = None) -> Iterator[np.ndarray]
                 break
             yield np.asarray(Image.open(os.path.join(spec, f)).convert("RGB"))[:, :, ::-1].copy()   # BGR like cv2
     else:
-        raise ValueError(f"cannot open source '{spec}' (synthetic[:N] | stack.npy | image directory)")
+        yield from _video_source(spec, limit)
+
+
+VIDEO_EXT = (".mp4", ".avi", ".mov", ".mkv", ".m4v", ".webm", ".mpg", ".mpeg", ".wmv")
+
+
+def _cv2():
+    """OpenCV, if this interpreter has it (it is not a dependency: decoding / encoding video is the only use)."""
+    try:
+        import cv2
+        return cv2
+    except ImportError:
+        return None
+
+
+def _video_source(spec: str, limit: Optional[int]) -> Iterator[np.ndarray]:
+    """A video file, a stream URL or a camera index through cv2.VideoCapture — the reference's only source kind
+    (`cv2.VideoCapture(int(source) if source == '0' else source)`, yolo_multi_model.py:252; here every all-digit source is a
+    camera index, App. C notes that the reference's '1' stays a path)."""
+    is_cam = spec.isdigit()
+    if not (is_cam or "://" in spec or spec.lower().endswith(VIDEO_EXT)):
+        raise ValueError(f"cannot open source '{spec}' (synthetic[:N] | stack.npy | image directory | video file / camera index with OpenCV)")
+    cv2 = _cv2()
+    if cv2 is None:
+        raise RuntimeError(f"source '{spec}' is a video / camera: that needs OpenCV (`import cv2` failed in this interpreter); "
+                           f"decode it to a .npy stack or an image directory instead")
+    cap = cv2.VideoCapture(int(spec) if is_cam else spec)
+    try:
+        if not cap.isOpened():                               # the reference checks this after creating its writer (:262)
+            raise RuntimeError(f"cv2.VideoCapture could not open '{spec}'")
+        k = 0
+        while limit is None or k < limit:
+            ok, frame = cap.read()                           # BGR uint8 [H,W,3], :272
+            if not ok:
+                break
+            yield np.ascontiguousarray(frame)
+            k += 1
+    finally:
+        cap.release()
 
 
 # ---- frame sink (N3) ------------------------------------------------------------------------------------------
@@ -52,7 +92,11 @@ class FrameSink:
 
     def __init__(self, path: str, fps: int = 15):
         self.path, self.fps, self.n, self.shape = path, fps, 0, None
-        self.kind = "npy" if path.endswith(".npy") else "bgr" if path.endswith((".bgr", ".raw")) else "dir"
+        self.kind = ("npy" if path.endswith(".npy") else "bgr" if path.endswith((".bgr", ".raw")) else
+                     "video" if path.lower().endswith(VIDEO_EXT) else "dir")
+        self._writer = None
+        if self.kind == "video" and _cv2() is None:
+            raise RuntimeError(f"sink '{path}' is a video file: that needs OpenCV (`import cv2` failed); use .bgr (raw BGR24 + .json), .npy or a directory")
         if self.kind == "dir":
             os.makedirs(path, exist_ok=True)
         else:
@@ -67,12 +111,19 @@ class FrameSink:
             self._frames.append(frame.copy())
         elif self.kind == "bgr":
             self._f.write(frame.tobytes())
+        elif self.kind == "video":
+            if self._writer is None:                         # cv2.VideoWriter(path, mp4v, 15 fps, (w, h)), yolo_multi_model.py:258-260
+                cv2 = _cv2()
+                self._writer = cv2.VideoWriter(self.path, cv2.VideoWriter_fourcc(*"mp4v"), self.fps, (frame.shape[1], frame.shape[0]))
+            self._writer.write(frame)
         else:
             from PIL import Image
             Image.fromarray(frame[:, :, ::-1]).save(os.path.join(self.path, f"frame_{self.n:06d}.png"))
         self.n += 1
 
     def close(self):
+        if self.kind == "video" and self._writer is not None:
+            self._writer.release()
         if self.kind == "npy":
             np.save(self.path, np.stack(self._frames) if self._frames else np.zeros((0, 0, 0, 3), np.uint8))
         elif self.kind == "bgr":
@@ -165,12 +216,18 @@ def process_video(args: dict, model=None) -> dict:
         if sink is not None:
             if overlay is None:
                 overlay = model.overlay()
-            sink.write(overlay.draw(frame, res, counter.counts() if (count and track) else None, fps_str))
+            cnt = counter.counts() if (count and track) else None
+            dev_frame = getattr(res[0], "orig_img_device", None) if res else None
+            if dev_frame is not None:                # the frame is still on the device: draw there, ONE download, no second upload
+                sink.write(overlay.draw_resident(dev_frame, res, cnt, fps_str))
+            else:
+                sink.write(overlay.draw(frame, res, cnt, fps_str))
 
     if track and batch > 1 and hasattr(model, "track_stream"):
         # a file / synthetic source can supply frames ahead: groups of `batch` frames through the overlapped pipeline
         # (same rows as frame-by-frame model.track; --batch 1 keeps the reference's per-frame call, :41)
-        for res in model.track_stream(src, batch=batch, device=args.get("device", 0)):
+        kw = {"keep_device_frames": True} if sink is not None else {}
+        for res in model.track_stream(src, batch=batch, device=args.get("device", 0), **kw):
             emit(res[0].orig_img, res)
         src = ()
     for frame in src:
@@ -197,7 +254,7 @@ def main(argv=None):
     p.add_argument("--weights", default="yolov8n.pt")
     p.add_argument("--reid-weights", default=None, help="OSNet-x0.25 state_dict for the tracker's appearance features (required with --track unless --random-init)")
     p.add_argument("--limit", type=int, default=None)
-    p.add_argument("--save", default=None, help="write annotated frames: stack.npy | video.bgr (raw BGR24 + .json) | directory of PNGs")
+    p.add_argument("--save", default=None, help="write annotated frames: stack.npy | video.bgr (raw BGR24 + .json) | directory of PNGs | video.mp4 (needs OpenCV)")
     p.add_argument("--batch", type=int, default=16, help="frames per group on the throughput path (1: per-frame model.track calls as in the reference)")
     p.add_argument("--random-init", action="store_true", help="run seeded random-init networks when the weights file is missing")
     a = p.parse_args(argv)

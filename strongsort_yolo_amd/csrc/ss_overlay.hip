@@ -15,6 +15,9 @@
 #define OV_CIRCLE 2    // filled circle, centre (x0,y0), radius a
 #define OV_LINE 3      // segment (x0,y0)-(x1,y1), thickness a (round caps)
 #define OV_TEXT 4      // 5x7 raster text: baseline-left origin (x0,y0), x1 = characters, a = offset into the character buffer, b>>1 = scale
+#define OV_POLY 5      // even-odd interior of a closed integer polygon, BLENDED half and half (ties to even) with what is there — the
+                       // reference's fillPoly + addWeighted(0.5, 0.5) per mask (yolo_multi_model.py:116-121): (x0,y0)-(x1,y1) = bounding box,
+                       // a = byte offset (multiple of 4) of the b>>1 vertices (int32 x, y pairs) in the character buffer
 // b bit 0: the primitive belongs to a blended group: consecutive group primitives are composited opaquely among
 // themselves and the result is mixed 179:77 (0.7 : 0.3) over what was there before the group (cv2.addWeighted plate)
 
@@ -27,6 +30,7 @@ __device__ __forceinline__ void ov_bbox(const OvPrim& p, int& bx0, int& by0, int
     case OV_FILL: bx0 = min(p.x0, p.x1); by0 = min(p.y0, p.y1); bx1 = max(p.x0, p.x1); by1 = max(p.y0, p.y1); break;
     case OV_CIRCLE: bx0 = p.x0 - p.a; by0 = p.y0 - p.a; bx1 = p.x0 + p.a; by1 = p.y0 + p.a; break;
     case OV_LINE: { const int o = (p.a + 1) >> 1; bx0 = min(p.x0, p.x1) - o; by0 = min(p.y0, p.y1) - o; bx1 = max(p.x0, p.x1) + o; by1 = max(p.y0, p.y1) + o; break; }
+    case OV_POLY: bx0 = p.x0; by0 = p.y0; bx1 = p.x1; by1 = p.y1; break;
     default: { const int sc = max(p.b >> 1, 1); bx0 = p.x0; bx1 = p.x0 + p.x1 * 6 * sc - 1; by1 = p.y0; by0 = p.y0 - 7 * sc + 1; break; }
     }
 }
@@ -56,6 +60,23 @@ __device__ __forceinline__ bool ov_covers(const OvPrim& p, int x, int y, const u
         const long long cr = px * dy - py * dx;
         return 4 * cr * cr <= a2 * L;
     }
+    case OV_POLY: {
+        // a pixel is inside when an odd number of edges straddle its row (exactly one end point with y <= the pixel's) strictly to
+        // its right: x < ax + (y - ay)(bx - ax) / (by - ay), cross-multiplied in 64-bit integers (oracle polygon_mask_np)
+        if (x < p.x0 || x > p.x1 || y < p.y0 || y > p.y1) return false;
+        const int n = p.b >> 1;
+        const int* pts = reinterpret_cast<const int*>(chars + p.a);
+        int cnt = 0, ax = pts[2 * (n - 1)], ay = pts[2 * (n - 1) + 1];
+        for (int i = 0; i < n; ++i) {
+            const int bx = pts[2 * i], by = pts[2 * i + 1];
+            if ((ay <= y) != (by <= y)) {
+                const long long dy = (long long)by - ay, lhs = ((long long)x - ax) * dy, rhs = ((long long)y - ay) * ((long long)bx - ax);
+                cnt += (dy > 0) ? (lhs < rhs) : (lhs > rhs);
+            }
+            ax = bx; ay = by;
+        }
+        return cnt & 1;
+    }
     default: {
         const int sc = max(p.b >> 1, 1);
         const int cx = x - p.x0, cy = y - (p.y0 - 7 * sc + 1);
@@ -76,6 +97,17 @@ __device__ __forceinline__ int ov_mix(int top, int under)        // 0.7 : 0.3 in
     for (int c = 0; c < 3; ++c) {
         const int t = (top >> (8 * c)) & 255, u = (under >> (8 * c)) & 255;
         out |= ((179 * t + 77 * u + 128) >> 8) << (8 * c);
+    }
+    return out;
+}
+
+__device__ __forceinline__ int ov_half(int a, int b)             // (a + b) / 2 per channel, ties to even (cv2.addWeighted 0.5 / 0.5 + saturate_cast)
+{
+    int out = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int t = ((a >> (8 * c)) & 255) + ((b >> (8 * c)) & 255);
+        out |= ((t >> 1) + ((t & 1) & ((t >> 1) & 1))) << (8 * c);
     }
     return out;
 }
@@ -119,7 +151,8 @@ __global__ __launch_bounds__(256) void k_overlay(uint8_t* __restrict__ frames, l
                 const OvPrim& q = hits[i];
                 if (!ov_covers(q, x, y, chars, font)) continue;
                 if (!loaded) { cur = px[0] | (px[1] << 8) | (px[2] << 16); loaded = true; }
-                if (q.b & 1) { grp = q.color; in_grp = true; }
+                if (q.type == OV_POLY) { if (in_grp) { cur = ov_mix(grp, cur); in_grp = false; } cur = ov_half(cur, q.color); }
+                else if (q.b & 1) { grp = q.color; in_grp = true; }
                 else { if (in_grp) { cur = ov_mix(grp, cur); in_grp = false; } cur = q.color; }
                 touched = true;
             }

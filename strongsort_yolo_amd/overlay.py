@@ -18,7 +18,7 @@ import torch
 
 from .overlay_font import ADVANCE, font_table
 
-RECT, FILL, CIRCLE, LINE, TEXT = 0, 1, 2, 3, 4
+RECT, FILL, CIRCLE, LINE, TEXT, POLY = 0, 1, 2, 3, 4, 5
 
 
 def bgr(b, g, r):
@@ -75,7 +75,18 @@ class CommandList:
         self.blends = []                       # (primitives drawn before it, int32 polygon [k, 2], BGR colour): mask fills, in painter's order
 
     def blend(self, poly, color):
-        self.blends.append((len(self.rows), np.asarray(poly, np.int32).reshape(-1, 2), tuple(int(c) for c in color)))
+        """Mask fill: the polygon's even-odd interior mixed half and half with the frame — an ordered primitive like the others
+        (POLY: bounding box + the vertices, stored 4-byte aligned in the character buffer), so a frame with masks is still ONE
+        launch in painter's order.  `blends` restates the fills for the two-pass checker (oracle rasterise_with_blends)."""
+        q = np.ascontiguousarray(np.asarray(poly, np.int32).reshape(-1, 2))
+        col = tuple(int(c) for c in color)
+        self.blends.append((len(self.rows), q, col))
+        if len(q) < 3:
+            self.rows.append((FILL, 1, 1, 0, 0, 0, 0, 0) if False else (POLY, 1, 1, 0, 0, 0, 0, 0))       # empty box: covers nothing, keeps positions
+            return
+        self.chars += b"\0" * (-len(self.chars) % 4)
+        self.rows.append((POLY, int(q[:, 0].min()), int(q[:, 1].min()), int(q[:, 0].max()), int(q[:, 1].max()), bgr(*col), len(self.chars), len(q) << 1))
+        self.chars += q.tobytes()
 
     def polyline(self, poly, color, thickness=2):
         q = np.asarray(poly, np.int32).reshape(-1, 2)
@@ -100,7 +111,8 @@ class CommandList:
         self.chars += s
 
     def arrays(self):
-        return (np.asarray(self.rows, dtype=np.int32).reshape(-1, 8), np.frombuffer(bytes(self.chars) or b"\0", dtype=np.uint8).copy())
+        ch = bytes(self.chars) + b"\0" * (-len(self.chars) % 4)       # a multiple of 4 bytes: frames are concatenated, vertex offsets stay aligned
+        return (np.asarray(self.rows, dtype=np.int32).reshape(-1, 8), np.frombuffer(ch or b"\0\0\0\0", dtype=np.uint8).copy())
 
 
 class Overlay:
@@ -177,48 +189,46 @@ class Overlay:
 
     # ---- device -------------------------------------------------------------------------------------------
     def draw_device(self, frames: torch.Tensor, command_lists, stream=None) -> torch.Tensor:
-        """frames: uint8 [B,H,W,3] (or [H,W,3]) on the device, annotated in place with one CommandList per frame."""
+        """frames: uint8 [B,H,W,3] (or [H,W,3]) on the device, annotated in place with one CommandList per frame: ONE launch for the
+        batch, mask fills included (POLY primitives).  The command upload and the launch are enqueued on `stream` (default: the
+        current torch stream)."""
         e = self.eng
         fr = frames if frames.dim() == 4 else frames.unsqueeze(0)
         if len(command_lists) != fr.shape[0]:
             raise ValueError("one command list per frame")
-        if any(c.blends for c in command_lists):
-            # mask fills sit BETWEEN primitives (a later box is drawn over an earlier mask): such a frame is drawn as
-            # [primitives up to the fill] -> fill -> ..., one launch per stretch
-            for i, c in enumerate(command_lists):
-                at = 0
-                for pos, poly, color in c.blends + [(len(c.rows), None, None)]:
-                    if pos > at:
-                        part = CommandList()
-                        part.rows, part.chars = c.rows[at:pos], c.chars
-                        self.draw_device(fr[i], [part], stream)
-                    at = pos
-                    if poly is not None:
-                        st = torch.cuda.current_stream(fr.device) if stream is None else stream
-                        with torch.cuda.stream(st):
-                            blend_polygon_(fr[i], poly, color)
-            return frames
+        st = torch.cuda.current_stream(fr.device) if stream is None else stream
+        self._keep = []                                                 # command buffers of this call's launch, alive until the next call
         arr = [c.arrays() for c in command_lists]
         off = np.zeros(len(arr) + 1, np.int32)
         coff = 0
         prims = []
         for i, (p, ch) in enumerate(arr):
             p = p.copy()
-            p[p[:, 0] == TEXT, 6] += coff                              # character offsets into the concatenated buffer
+            p[(p[:, 0] == TEXT) | (p[:, 0] == POLY), 6] += coff        # character / vertex offsets into the concatenated buffer
             prims.append(p)
             off[i + 1] = off[i] + len(p)
             coff += len(ch)
         prims = np.concatenate(prims) if prims else np.zeros((0, 8), np.int32)
         chars = np.concatenate([ch for _, ch in arr])
         dev = fr.device
-        d_prims = torch.from_numpy(prims if len(prims) else np.zeros((1, 8), np.int32)).to(dev)
-        d_off, d_chars = torch.from_numpy(off).to(dev), torch.from_numpy(chars).to(dev)
-        st = torch.cuda.current_stream(dev) if stream is None else stream
+        with torch.cuda.stream(st):                                     # the copies are ordered on the stream the kernel runs on
+            d_prims = torch.from_numpy(prims if len(prims) else np.zeros((1, 8), np.int32)).to(dev)
+            d_off, d_chars = torch.from_numpy(off).to(dev), torch.from_numpy(chars).to(dev)
         e._ck(e.L.ss_overlay(e.ctx, C.c_void_p(st.cuda_stream), C.c_void_p(fr.data_ptr()), fr.shape[0], fr.stride(0), fr.shape[1],
                              fr.shape[2], fr.stride(1), C.c_void_p(d_prims.data_ptr()), C.c_void_p(d_off.data_ptr()),
                              C.c_void_p(d_chars.data_ptr())))
-        self._keep = (d_prims, d_off, d_chars)                          # alive until the launch has run
+        for t in (d_prims, d_off, d_chars):
+            t.record_stream(st)                                         # the allocator must not hand the block out under the pending launch
+        self._keep.append((d_prims, d_off, d_chars))
         return frames
+
+    def draw_resident(self, dev_frame: torch.Tensor, results, counts: Optional[dict] = None, fps_text: str = "") -> np.ndarray:
+        """A frame that is ALREADY on the device (uint8 [H,W,3], e.g. `Results.orig_img_device` of track_stream) -> annotated
+        host frame: ss_overlay in place, one download, no upload of the frame."""
+        self.draw_device(dev_frame, [self.commands(results, counts, fps_text)])
+        out = np.empty(tuple(dev_frame.shape), np.uint8)
+        self.eng.download(out, dev_frame)
+        return out
 
     def draw(self, frame: np.ndarray, results, counts: Optional[dict] = None, fps_text: str = "") -> np.ndarray:
         """Host frame in, annotated host frame out (upload -> ss_overlay -> download)."""

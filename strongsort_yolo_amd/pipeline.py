@@ -38,12 +38,18 @@ class FramePipeline:
     def __init__(self, detector: str = "yolov8n", n_streams: int = 1, frame_hw=(720, 1280), device: int = 0,
                  half: bool = True, reid_batch: int = 32, cfg: Optional[StrongSortConfig] = None,
                  dcfg: Optional[DetectConfig] = None, det_source: str = "detector", feat_source: str = "reid",
-                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0, cmc: bool = False):
+                 graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0, cmc: bool = False,
+                 reid_half: Optional[bool] = None):
         self.cfg, self.dcfg = cfg or StrongSortConfig(), dcfg or DetectConfig()
         self.S, (self.H, self.W) = n_streams, frame_hw
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
         dev = self.dev = self.eng.device
         self.half, self.dtype = half, torch.float16 if half else torch.float32
+        # reid_half=False: the ReID crops and OSNet in fp32 (PyTorch-ROCm's library convolutions; the fused kernels are half-only)
+        # beside a half detector — the accuracy mode: appearance distances then agree with a CPU fp32 OSNet to ~1e-6, which f16
+        # activations do not (bench.py reid_f16_vs_f32; north_star's 1e-4 bound on float distances).  Default: as the detector.
+        self.reid_half = half if reid_half is None else bool(reid_half)
+        self.reid_dtype = torch.float16 if self.reid_half else torch.float32
         self.det_source, self.feat_source, self.run_nets = det_source, feat_source, run_nets
         self.RB = reid_batch
         if reid_batch > MAX_DETS:
@@ -62,7 +68,7 @@ class FramePipeline:
         self.detector = self.reid = None
         if run_nets:
             self.detector = nets.build_detector(detector, seed).to(dev, self.dtype).to(memory_format=torch.channels_last)
-            self.reid = nets.build_reid(seed + 1).to(dev, self.dtype).to(memory_format=torch.channels_last)
+            self.reid = nets.build_reid(seed + 1).to(dev, self.reid_dtype).to(memory_format=torch.channels_last)
             self.nc, self.nk = self.detector.nc, self.detector.nk
             self.nm = getattr(self.detector, "nm", 0)           # mask coefficients of a segmentation head (after the keypoints' place)
         else:
@@ -82,7 +88,7 @@ class FramePipeline:
         self.proto = torch.zeros(S, self.nm, g.out_h // 4, g.out_w // 4, dtype=self.dtype, device=dev) if self.nm else None
         self.keep = torch.zeros(S, self.det_rows, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.dtype, device=dev).contiguous(memory_format=torch.channels_last)
+        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.reid_dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.feats_in = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.img_hw = torch.tensor([[self.H, self.W]] * S, dtype=torch.int32, device=dev)
         self.out, self.nout = self.eng.out, self.eng.nout
@@ -126,7 +132,7 @@ class FramePipeline:
     def _reid_impl(self):
         e, S = self.eng, self.S
         if self.run_nets:
-            e.crop_norm_batch(self.frames, self.dets6, self.RB, counts=self.ndets, half=self.half, out=self.crops,
+            e.crop_norm_batch(self.frames, self.dets6, self.RB, counts=self.ndets, half=self.reid_half, out=self.crops,
                               channels_last=True)
             emb = self.reid(self.crops)                         # [S*RB, 512]
             if self.feat_source == "reid":
@@ -252,7 +258,7 @@ class _Bufs:
         self.proto = torch.zeros(S, p.nm, p.geom.out_h // 4, p.geom.out_w // 4, dtype=p.dtype, device=dev) if p.nm else None
         self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.dtype, device=dev).contiguous(memory_format=torch.channels_last)
+        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.reid_dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads
@@ -304,7 +310,7 @@ class OverlappedPipeline(FramePipeline):
         # packed ReID batches: the group's valid crops contiguous, the OSNet kernels skip the unused slots of the fixed batch
         # (~28 of 32 slots per frame are used at configs[1]); SS_PACK_CROPS=0: A/B switch
         import os as _os0
-        self.pack = bool(self.half and self.run_nets and _os0.environ.get("SS_PACK_CROPS", "1") == "1")
+        self.pack = bool(self.reid_half and self.run_nets and _os0.environ.get("SS_PACK_CROPS", "1") == "1")
         self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
@@ -429,7 +435,7 @@ class OverlappedPipeline(FramePipeline):
             if self.pack:        # the group's valid crops contiguous; the ReID kernels skip the rest of the fixed-size batch
                 e.crop_norm_packed(b.frames, b.dets6, self.RB, b.ndets, b.crop_off, b.crops, half=True)
             else:
-                e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.half, out=b.crops, channels_last=True)
+                e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.reid_half, out=b.crops, channels_last=True)
 
     def _valid(self, b):
         from . import fused

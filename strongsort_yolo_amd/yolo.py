@@ -29,6 +29,17 @@ COCO_NAMES = ("person bicycle car motorcycle airplane bus train truck boat traff
               "toothbrush").split()
 
 
+def _row(i, n):
+    """An int index as a one-row slice (negative indices count from the end, as on a tensor); anything else unchanged."""
+    if isinstance(i, (int, np.integer)):
+        i = int(i)
+        if not -n <= i < n:
+            raise IndexError(f"index {i} out of range for {n} rows")
+        i %= n
+        return slice(i, i + 1)
+    return i
+
+
 class Boxes:
     """Rows of [x1,y1,x2,y2,(id),conf,cls]; iterating yields 1-row Boxes (yolo_multi_model.py:73,126)."""
 
@@ -39,7 +50,7 @@ class Boxes:
         return self.xyxy.shape[0]
 
     def __getitem__(self, i):
-        i = slice(i, i + 1) if isinstance(i, int) else i
+        i = _row(i, len(self))
         return Boxes(self.xyxy[i], self.conf[i], self.cls[i], None if self.id is None else self.id[i])
 
     def __iter__(self):
@@ -60,8 +71,7 @@ class Keypoints:
         return self.data.shape[0]
 
     def __getitem__(self, i):
-        i = slice(i, i + 1) if isinstance(i, int) else i
-        return Keypoints(self.data[i])
+        return Keypoints(self.data[_row(i, len(self))])
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -182,7 +192,7 @@ class Masks:
         return self._coef.shape[0]
 
     def __getitem__(self, i):
-        i = slice(i, i + 1) if isinstance(i, int) else i
+        i = _row(i, len(self))
         return Masks(self._proto, self._coef[i], self._boxes[i], self._in_hw, self.orig_shape, self._gain, self._pad,
                      None if self._data is None else self._data[i])
 
@@ -193,6 +203,7 @@ class Masks:
 class Results:
     def __init__(self, orig_img, names, boxes: Optional[Boxes], keypoints: Optional[Keypoints] = None, masks: Optional[Masks] = None):
         self.orig_img, self.names, self.boxes, self.keypoints, self.masks = orig_img, names, boxes, keypoints, masks
+        self.orig_img_device = None      # track_stream(keep_device_frames=True): the frame as a device tensor uint8 [H,W,3] (for Overlay.draw_resident)
 
     def __len__(self):
         return 0 if self.boxes is None else len(self.boxes)
@@ -209,7 +220,7 @@ class YOLO:
     `model.track(..., persist=False)` would."""
 
     def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128,
-                 camera_motion: bool = False, reid_weights: Optional[str] = None):
+                 camera_motion: bool = False, reid_weights: Optional[str] = None, reid_fp32: bool = False):
         self.weights = weights
         self.reid_weights = reid_weights          # OSNet-x0.25 state_dict; same policy as the detector's (raise unless random init is asked for)
         self.random_init_ok = random_init_ok
@@ -228,6 +239,8 @@ class YOLO:
         # test / bench hooks (synthetic head tensors, no weights exist offline): extra pipeline keywords and a callable
         # fill(buffers, virtual_stream, frame_index) that writes pred_in / anchor_gt / gt_feats before a frame runs
         self._pipe_kw = {"cmc": True} if camera_motion else {}    # N4: ECC camera-motion compensation (off by default)
+        if reid_fp32:                                              # accuracy mode: OSNet in fp32 (pipeline.FramePipeline reid_half)
+            self._pipe_kw["reid_half"] = False
         self._fill = None
         self._frame_index = 0
 
@@ -241,28 +254,32 @@ class YOLO:
         cl = None if cl is None else tuple(int(c) for c in (cl if isinstance(cl, (list, tuple)) else [cl]))
         return (tuple(shape), int(device or 0), self._dcfg(), cl)
 
-    def _build(self, cls, shape, device, **kw):
+    def _build(self, cls, shape, device, need_reid=True, **kw):
         from . import nets
         args = dict(reid_batch=self.reid_batch, cfg=StrongSortConfig(), dcfg=self._dcfg(), det_source="detector",
                     feat_source="reid", seed=self.seed)
         args.update(self._pipe_kw)
         args.update(kw)
         pipe = cls(self.arch, 1, shape, device=int(device or 0), **args)
-        # both networks, before the first forward (the fused weight-prep caches are built from the loaded tensors)
+        # the networks' weights, before the first forward (the fused weight-prep caches are built from the loaded tensors).
+        # The ReID weights are needed only once the TRACKER consumes OSNet embeddings: model.predict (yolo_multi_model.py:173)
+        # works with detector weights alone; the first model.track on such a pipeline rebuilds it with the ReID weights.
         nets.load_weights(pipe.detector, self.weights, f"detector {self.arch}", self.random_init_ok)
-        if pipe.feat_source == "reid" and pipe.det_rows == 128:      # the tracker consumes OSNet embeddings
+        pipe.reid_loaded = False
+        if need_reid and pipe.feat_source == "reid" and pipe.det_rows == 128:
             nets.load_weights(pipe.reid, self.reid_weights, "OSNet-x0.25 ReID", self.random_init_ok)
+            pipe.reid_loaded = True
         pipe.eng.nms_set_classes(self.overrides.get("classes"))
         return pipe
 
     # ---- per-frame path -------------------------------------------------------------------------------------
-    def _pipeline(self, image, device):
+    def _pipeline(self, image, device, need_reid=True):
         from .pipeline import FramePipeline
         key = self._state_key(image.shape[:2], device)
-        if self._pipe is None or key != self._key:
+        if self._pipe is None or key != self._key or (need_reid and not self._pipe.reid_loaded and self._pipe.feat_source == "reid"):
             if self._pipe is not None:
                 self._pipe.close()
-            p = self._pipe = self._build(FramePipeline, image.shape[:2], device, graph="split")
+            p = self._pipe = self._build(FramePipeline, image.shape[:2], device, need_reid=need_reid, graph="split")
             self._key = key
             self._frame_index = 0
             H, W = image.shape[:2]
@@ -276,7 +293,7 @@ class YOLO:
     def _run(self, image, device, track):
         if not track and int(self.overrides["max_det"]) > 128:
             return self._run_predict_wide(image, device)
-        pipe = self._pipeline(image, device)
+        pipe = self._pipeline(image, device, need_reid=track)
         pipe.eng.upload(pipe.frames[0], image)
         if self._fill is not None:
             self._fill(pipe, 0, self._frame_index)
@@ -293,8 +310,20 @@ class YOLO:
         pipe.eng.check_errors()
         self._frame_index += 1
         n, m = int(self._h_cnt[0]), int(self._h_cnt[1])
+        self._warn_if_capped(pipe, n, track)
         return self._results(image, pipe, self._h_dets[:n].clone(), self._h_rows[:m].clone() if track else None,
                              self._h_proto.clone() if pipe.nm else None)
+
+    def _warn_if_capped(self, pipe, n_kept, track):
+        """The tracking pipeline carries at most pipe.max_det (<= 128, <= reid_batch) detections per frame, highest scores first;
+        the reference's max_det = 1000 (yolo_multi_model.py:21) applies to its tracker too.  A frame that fills the cap may have
+        lost lower-scored detections: say so once (capacity errors elsewhere are loud; this truncation used to be silent)."""
+        if track and n_kept >= pipe.max_det and pipe.max_det < int(self.overrides["max_det"]) and not getattr(self, "_cap_warned", False):
+            import warnings
+            self._cap_warned = True
+            warnings.warn(f"a frame filled the tracker's per-frame limit of {pipe.max_det} detections (overrides['max_det'] = "
+                          f"{self.overrides['max_det']}): lower-scored detections beyond it are not tracked "
+                          f"(limit = min(max_det, 128, reid_batch = {self.reid_batch}))", RuntimeWarning, stacklevel=3)
 
     def _run_predict_wide(self, image, device):
         """model.predict with max_det > 128 (the reference sets 1000, yolo_multi_model.py:21): a detection-only pipeline
@@ -362,10 +391,13 @@ class YOLO:
 
     # ---- throughput path ------------------------------------------------------------------------------------
     @torch.no_grad()
-    def track_stream(self, frames, batch: int = 16, device=0):
+    def track_stream(self, frames, batch: int = 16, device=0, keep_device_frames: bool = False):
         """Generator over `frames` (BGR uint8 arrays of one size): yields the same [Results] `track(frame)` would, in
         order, `batch` frames at a time through the overlapped two-stream pipeline (stateless stages of group k+1 run
-        while the tracker consumes group k; the tracker reads its galleries once per group)."""
+        while the tracker consumes group k; the tracker reads its galleries once per group).
+        keep_device_frames: every Results also carries `orig_img_device`, the frame as a device tensor (a device-to-device copy
+        of the group's input buffer taken on the tracker's stream), so that an annotated output needs no second upload
+        (`Overlay.draw_resident`); valid until the generator has yielded `ring` more groups."""
         from .pipeline import OverlappedPipeline
         it = iter(frames)
         first = next(it, None)
@@ -387,6 +419,7 @@ class YOLO:
         h_dets = torch.empty(ring, F, pipe.bufs[0].dets.shape[1], pipe.bufs[0].dets.shape[2]).pin_memory()
         h_cnt = torch.zeros(ring, 2, F, dtype=torch.int32).pin_memory()
         h_proto = torch.empty((ring, F) + tuple(pipe.bufs[0].proto.shape[1:]), dtype=pipe.bufs[0].proto.dtype).pin_memory() if pipe.nm else None
+        d_frames = torch.empty((ring, F, H, W, 3), dtype=torch.uint8, device=pipe.dev) if keep_device_frames else None
         done = [torch.cuda.Event() for _ in range(ring)]
         pending = []                                                      # (group index, frames of the group)
         state = {"group": 0, "first": {}, "enqueued": -1}                 # first frame index of a group -> group index
@@ -405,6 +438,8 @@ class YOLO:
             h_dets[slot, :nv].copy_(b.dets[:nv], non_blocking=True)
             if h_proto is not None:
                 h_proto[slot, :nv].copy_(b.proto[:nv], non_blocking=True)
+            if d_frames is not None:
+                d_frames[slot, :nv].copy_(b.frames[:nv], non_blocking=True)       # the set's frames, before the set is refilled
             done[slot].record(torch.cuda.current_stream(pipe.dev))
             state["enqueued"] = g
             del state["first"][frame_idx - f]
@@ -416,8 +451,12 @@ class YOLO:
             done[slot].synchronize()
             for f, img in enumerate(imgs):
                 n, m = int(h_cnt[slot, 0, f]), int(h_cnt[slot, 1, f])
-                yield self._results(img, pipe, h_dets[slot, f, :n].clone(), h_rows[slot, f, :m].clone(),
+                self._warn_if_capped(pipe, n, True)
+                res = self._results(img, pipe, h_dets[slot, f, :n].clone(), h_rows[slot, f, :m].clone(),
                                     None if h_proto is None else h_proto[slot, f].clone())
+                if d_frames is not None:
+                    res[0].orig_img_device = d_frames[slot, f]
+                yield res
 
         try:
             chunk = [first]

@@ -48,3 +48,88 @@ def test_frame_sources(tmp_path):
     got = list(frame_source(str(tmp_path / "s.npy")))
     assert len(got) == 3 and np.array_equal(got[1], stack[1])
     assert len(list(frame_source("synthetic:4"))) == 4
+
+
+class _StubCv2:
+    """Just enough of OpenCV for the optional video branches (N3): VideoCapture over an in-memory clip, VideoWriter into a list."""
+    written, opened = [], []
+
+    class VideoCapture:
+        def __init__(self, src):
+            _StubCv2.opened.append(src)
+            self.k, self.ok = 0, src != "missing.mp4"
+            self.clip = np.random.default_rng(5).integers(0, 255, (4, 6, 8, 3), dtype=np.uint8)
+
+        def isOpened(self):
+            return self.ok
+
+        def read(self):
+            if self.k >= len(self.clip):
+                return False, None
+            self.k += 1
+            return True, self.clip[self.k - 1]
+
+        def release(self):
+            _StubCv2.opened.append("released")
+
+    class VideoWriter:
+        def __init__(self, path, fourcc, fps, size):
+            _StubCv2.written.append(("open", path, fourcc, fps, size))
+
+        def write(self, frame):
+            _StubCv2.written.append(frame.copy())
+
+        def release(self):
+            _StubCv2.written.append("released")
+
+    @staticmethod
+    def VideoWriter_fourcc(*c):
+        return "".join(c)
+
+
+def test_video_sources_and_sinks_go_through_opencv_when_it_is_there(tmp_path, monkeypatch):
+    """yolo_multi_model.py:252 (VideoCapture of a file, or of camera '0'), :256-260 / :331 (VideoWriter mp4v 15 fps) with a stub cv2;
+    without OpenCV the same specs raise an error that says what is missing (this image has no cv2)."""
+    import sys
+    import pytest
+    from strongsort_yolo_amd.cli import FrameSink
+    monkeypatch.setitem(sys.modules, "cv2", None)                       # `import cv2` fails
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        list(frame_source("clip.mp4"))
+    with pytest.raises(RuntimeError, match="OpenCV"):
+        FrameSink(str(tmp_path / "out.mp4"))
+    with pytest.raises(ValueError):
+        list(frame_source("no_such_thing.xyz"))
+    monkeypatch.setitem(sys.modules, "cv2", _StubCv2)
+    _StubCv2.written.clear(); _StubCv2.opened.clear()
+    got = list(frame_source("clip.mp4"))
+    assert len(got) == 4 and got[0].shape == (6, 8, 3) and _StubCv2.opened == ["clip.mp4", "released"]
+    assert len(list(frame_source("0", limit=2))) == 2 and _StubCv2.opened[2] == 0          # a camera index, two frames, released
+    with pytest.raises(RuntimeError, match="could not open"):
+        list(frame_source("missing.mp4"))
+    sink = FrameSink(str(tmp_path / "o" / "out.mp4"))
+    for f in got[:3]:
+        sink.write(f)
+    sink.close()
+    assert _StubCv2.written[0] == ("open", str(tmp_path / "o" / "out.mp4"), "mp4v", 15, (8, 6))
+    assert all(np.array_equal(a, b) for a, b in zip(_StubCv2.written[1:4], got[:3])) and _StubCv2.written[-1] == "released" and sink.n == 3
+
+
+def test_video_source_drives_the_stream_loop(tmp_path, monkeypatch):
+    import sys
+    monkeypatch.setitem(sys.modules, "cv2", _StubCv2)
+    out = process_video({"source": "clip.mp4", "track": True, "count": True, "outdir": str(tmp_path)}, StubModel())
+    assert out["frames"] == 4 and (tmp_path / "clip_labels.txt").exists()
+
+
+def test_result_rows_index_like_tensors():
+    from strongsort_yolo_amd.yolo import Keypoints
+    b = Boxes(torch.arange(12.).view(3, 4), torch.tensor([.9, .8, .7]), torch.zeros(3), torch.tensor([4., 5., 6.]))
+    assert float(b[-1].conf) == float(b[2].conf) and int(b[-3].id) == 4 and len(b[-1]) == 1 and len(b[1:]) == 2
+    k = Keypoints(torch.arange(3 * 17 * 3.).view(3, 17, 3))
+    assert torch.equal(k[-1].data, k[2].data) and len(k[-2]) == 1
+    import pytest
+    with pytest.raises(IndexError):
+        b[3]
+    with pytest.raises(IndexError):
+        b[-4]

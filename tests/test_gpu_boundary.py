@@ -240,6 +240,76 @@ def test_cli_save_annotated_frames(tmp_path):
     model.close()
 
 
+def test_cli_save_draws_on_the_resident_frame_one_upload_per_frame(tmp_path):
+    """N2's reason to exist ("keeps frames on device until encode", VERDICT r3 'next' 7): with --save on the throughput
+    path every frame is uploaded ONCE (by track_stream) and downloaded once — the overlay runs on the device copy the pipeline kept —
+    and the annotated frames equal the ones the upload-draw-download form (Overlay.draw) produces."""
+    from strongsort_yolo_amd.cli import process_video
+    from strongsort_yolo_amd.engine import TrackerEngine
+    calls = {"up": 0, "down": 0}
+    up0, down0 = TrackerEngine.upload, TrackerEngine.download
+
+    def up(self, *a, **k):
+        calls["up"] += 1
+        return up0(self, *a, **k)
+
+    def down(self, *a, **k):
+        calls["down"] += 1
+        return down0(self, *a, **k)
+
+    TrackerEngine.upload, TrackerEngine.download = up, down
+    try:
+        model, frames, ref = _synthetic_model()
+        np.save(tmp_path / "clip.npy", np.stack(frames[:24]))
+        out = process_video({"source": str(tmp_path / "clip.npy"), "track": True, "count": True, "outdir": str(tmp_path), "batch": 8,
+                             "save": str(tmp_path / "resident.npy")}, model)
+        assert out["frames"] == 24 and calls == {"up": 24, "down": 24}, calls
+        res_frames = np.load(tmp_path / "resident.npy")
+        # the same run through the host-frame form (one more upload per frame)
+        model2, _, _ = _synthetic_model()
+        ov, host = None, []
+        from strongsort_yolo_amd.cli import ClassCounter
+        cnt = ClassCounter(model2.names)
+        for k, res in enumerate(model2.track_stream(iter(frames[:24]), batch=8, device=0)):
+            assert res[0].orig_img_device is None
+            cnt.update(res)
+            ov = ov or model2.overlay()
+            fps = ""                                             # the FPS text depends on wall time: compare frames drawn without it
+            host.append(ov.draw(frames[k], res, cnt.counts(), fps))
+        model2.close()
+    finally:
+        TrackerEngine.upload, TrackerEngine.download = up0, down0
+    # frames 0..8 carry no FPS text in either run (it appears from the 10th processed frame on): identical pixels there
+    for k in range(9):
+        assert np.array_equal(res_frames[k], host[k]), f"frame {k}"
+    assert (res_frames[8] != frames[8]).any()
+    model.close()
+
+
+def test_predict_needs_no_reid_weights_and_track_asks_for_them(tmp_path, monkeypatch):
+    """model.predict (yolo_multi_model.py:173) runs on detector weights alone; the first model.track on that object
+    needs the OSNet weights and says so (no silent random-init ReID network)."""
+    from strongsort_yolo_amd import nets
+    from strongsort_yolo_amd.yolo import YOLO
+    monkeypatch.delenv("SS_RANDOM_INIT", raising=False)
+    wd, wr = str(tmp_path / "yolov8n.pt"), str(tmp_path / "osnet_x0_25.pt")
+    torch.save(nets.build_detector("yolov8n", 3).state_dict(), wd)
+    torch.save(nets.build_reid(4).state_dict(), wr)
+    img = np.random.default_rng(0).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    model = YOLO(wd)
+    model.overrides.update(conf=0.9, max_det=50)
+    assert len(model.predict(img, verbose=False, device=0)) == 1 and len(model(img)) == 1
+    with pytest.raises(FileNotFoundError, match="OSNet"):
+        model.track(img, verbose=False, device=0, persist=True)
+    model.close()
+    model = YOLO(wd, reid_weights=wr)
+    model.overrides.update(conf=0.9, max_det=50)
+    assert len(model.predict(img)) == 1
+    for _ in range(2):
+        assert len(model.track(img, verbose=False, device=0, persist=True)) == 1
+    model.close()
+
+
 def test_true_wiring_detector_nms_reid_tracker_edges():
     """det_source='detector', feat_source='reid' (what a deployment runs): the head tensor the detector produced and the
     embeddings OSNet produced are read back and pushed through the oracle chain (C NMS + scale_boxes + tracker); the

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 def _random_list(rng, W, H, n):
     cl = CommandList()
     for _ in range(n):
-        k = int(rng.integers(0, 5))
+        k = int(rng.integers(0, 6))
         x0, y0 = int(rng.integers(-20, W + 20)), int(rng.integers(-20, H + 20))
         x1, y1 = x0 + int(rng.integers(-60, 120)), y0 + int(rng.integers(-40, 90))
         col, grp = int(rng.integers(0, 1 << 24)), bool(rng.random() < 0.25)
@@ -23,6 +23,9 @@ def _random_list(rng, W, H, n):
         elif k == 1: cl.fill(x0, y0, x1, y1, col, grp)
         elif k == 2: cl.circle(x0, y0, int(rng.integers(0, 14)), col, grp)
         elif k == 3: cl.line(x0, y0, x1, y1, col, int(rng.integers(1, 6)), grp)
+        elif k == 5:                                             # mask fill: random (self-intersecting) polygon, even-odd interior, half-half blend
+            nv = int(rng.integers(1, 14))
+            cl.blend(np.stack([x0 + rng.integers(-70, 90, nv), y0 + rng.integers(-60, 70, nv)], 1), (col & 255, (col >> 8) & 255, (col >> 16) & 255))
         else: cl.text("".join(chr(int(c)) for c in rng.integers(32, 127, int(rng.integers(0, 24)))), x0, y0, col, int(rng.integers(1, 4)), grp)
     return cl
 

@@ -116,11 +116,18 @@ def test_mask_commands_interleave_boxes_and_fills():
     prims = cl.arrays()[0]
     assert len(cl.blends) == 2
     (p0, q0, c0), (p1, q1, c1) = cl.blends
-    # pair 0: box (outline, plate, text), its polygon's edges, THEN its fill; pair 1's box comes after that fill (drawn over it)
+    # pair 0: box (outline, plate, text), its polygon's edges, THEN its fill (a POLY primitive at position p0: one ordered list, one
+    # launch); pair 1's box comes after that fill (drawn over it)
+    from strongsort_yolo_amd.overlay import POLY
     assert prims[:3, 0].tolist() == [RECT, FILL, TEXT] and (prims[3:p0, 0] == LINE).all() and p0 - 3 == len(q0)
-    assert prims[p0:p0 + 3, 0].tolist() == [RECT, FILL, TEXT] and prims[p0, 1:5].tolist() == [150, 30, 210, 180]
+    assert prims[p0, 0] == POLY and prims[p0 + 1:p0 + 4, 0].tolist() == [RECT, FILL, TEXT] and prims[p0 + 1, 1:5].tolist() == [150, 30, 210, 180]
     assert (prims[3:p0, 5] == bgr(255, 0, 0)).all() and c0 == tuple(int(v) for v in CLASS_COLORS[0]) and c1 == tuple(int(v) for v in CLASS_COLORS[2])
-    assert q0[:, 0].min() >= 40 and q0[:, 0].max() <= 120 and p1 == len(prims)
+    assert q0[:, 0].min() >= 40 and q0[:, 0].max() <= 120 and p1 == len(prims) - 1 and prims[p1, 0] == POLY
+    # the POLY row: bounding box, colour, vertex count and a 4-byte aligned offset to the vertices in the character buffer
+    chars = cl.arrays()[1]
+    assert prims[p0, 1:5].tolist() == [q0[:, 0].min(), q0[:, 1].min(), q0[:, 0].max(), q0[:, 1].max()] and prims[p0, 5] == bgr(*c0)
+    assert prims[p0, 6] % 4 == 0 and prims[p0, 7] == len(q0) << 1 and len(chars) % 4 == 0
+    assert np.array_equal(np.frombuffer(chars[prims[p0, 6]:prims[p0, 6] + 8 * len(q0)].tobytes(), np.int32).reshape(-1, 2), q0)
     n_lines_first = int((prims[:, 0] == LINE).sum())
     cl2 = ov.commands(_seg_results())                                    # second frame: one trail segment per id, drawn per pair (:101-110)
     assert int((cl2.arrays()[0][:, 0] == LINE).sum()) == n_lines_first + 1 + 2
@@ -140,4 +147,9 @@ def test_rasterise_with_blends_is_painters_order():
     cx, cy = int(q0[:, 0].mean()), int(q0[:, 1].mean())
     assert tuple(out[cy, cx]) == tuple(int(np.rint((90 + c) / 2)) for c in c0)                   # inside mask 0: blended once
     assert tuple(out[130, 40]) == (0, 0, 225) and tuple(out[100, 150]) == (0, 0, 225)            # both box outlines (left edges) survive
-    assert np.array_equal(rasterise_with_blends(frame, prims, chars, font, []), rasterise(frame, prims, chars, font))
+    assert np.array_equal(rasterise_with_blends(frame, prims, chars, font, []), rasterise(frame, prims, chars, font, skip_poly=True))
+    # the one-pass form (POLY primitives in the list: what the kernel executes) == the two-pass form (stretches + fills)
+    assert np.array_equal(rasterise(frame, prims, chars, font), out)
+    noisy = np.random.default_rng(3).integers(0, 256, frame.shape, dtype=np.uint8)
+    cl2 = Overlay({0: "person", 2: "car"}).commands(_seg_results(), {"person": 1}, "FPS: 1.00")      # + blended count plate and FPS text
+    assert np.array_equal(rasterise(noisy, *cl2.arrays(), font), rasterise_with_blends(noisy, *cl2.arrays(), font, cl2.blends))
