@@ -464,6 +464,58 @@ def net_outputs_check(pipe):
             "note": "last timed group: outputs left by the replayed graphs vs an eager re-run of detector and OSNet on the same buffers"}
 
 
+def tracker_only(cfg, n_ids=30, W=1280, H=720, frames=352, timed=192, device=0, frame_batch=32, opts=()):
+    """Rows a6-a10 alone, ONE stream: detections + identity features of a group copied into fixed device buffers (device-to-device),
+    one tracker call per group of `frame_batch` frames — the association launch + the per-frame chain replayed as one captured
+    graph.  Frames/s of the tracker path and the host time to enqueue a frame; every frame checked against the oracle."""
+    import torch
+    from oracle.strongsort_np import OracleStrongSort
+    from strongsort_yolo_amd.engine import TrackerEngine
+    from strongsort_yolo_amd.synth import make_stream
+    FB = frame_batch
+    eng = TrackerEngine(cfg, 1, device)
+    for kv in opts:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    dev = eng.device
+    hd, hf, hn = np.zeros((frames, 1, 128, 6), np.float32), np.zeros((frames, 1, 128, 512), np.float32), np.zeros((frames, 1), np.int32)
+    st = make_stream(6000, W, H, n_ids)
+    for k in range(frames):
+        f = st.next_frame()
+        n = len(f.dets)
+        hd[k, 0, :n], hf[k, 0, :n], hn[k, 0] = f.dets, f.feats, n
+    dets, feats, nd = torch.from_numpy(hd).to(dev), torch.from_numpy(hf).to(dev), torch.from_numpy(hn).to(dev)
+    bd, bf, bn = torch.zeros_like(dets[:FB]), torch.zeros_like(feats[:FB]), torch.zeros_like(nd[:FB])
+    hw = torch.tensor([[H, W]], dtype=torch.int32, device=dev)
+    out, nout = torch.zeros(FB, 1, 256, 8, device=dev), torch.zeros(FB, 1, dtype=torch.int32, device=dev)
+    rows_all, nrows_all = torch.zeros(frames, 1, 256, 8, device=dev), torch.zeros(frames, 1, dtype=torch.int32, device=dev)
+
+    def group(k0):
+        bd.copy_(dets[k0:k0 + FB]); bf.copy_(feats[k0:k0 + FB]); bn.copy_(nd[k0:k0 + FB])
+        eng.update_group(FB, bd, bn, bf, hw, out, nout)
+        rows_all[k0:k0 + FB].copy_(out); nrows_all[k0:k0 + FB].copy_(nout)
+
+    for k0 in range(0, frames - timed, FB):
+        group(k0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k0 in range(frames - timed, frames, FB):
+        group(k0)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_errors()
+    hr, hnr = rows_all.cpu().numpy(), nrows_all.cpu().numpy()
+    eng.close()
+    orc, exact = OracleStrongSort(cfg, "c"), 0
+    for k in range(frames):
+        ref = orc.update(hd[k, 0, :hn[k, 0]], hf[k, 0, :hn[k, 0]], (H, W))
+        got = hr[k, 0, :hnr[k, 0]]
+        exact += int(got.shape == ref.shape and got.tobytes() == ref.tobytes())
+    return {"streams": 1, "frames_per_call": FB, "frames_per_s": round(timed / dt, 1), "us_per_frame": round(dt / timed * 1e6, 2),
+            "host_enqueue_us_per_frame": round(t_enq / timed * 1e6, 2), "frames_bit_exact": f"{exact}/{frames}",
+            "note": "tracker path only (k_group_prep, k_assoc, per-frame chain as one replayed graph), inputs copied device-to-device into fixed buffers"}
+
+
 def front_rooflines(pipe, n_img, mean_dets, reps=20):
     """a1 / a3 / a4 of SURVEY §8(a) on the pipeline's own buffers (one frame group = n_img images): mean duration of the
     library call measured with HIP events on the stream it is launched on, algorithmic bytes of SURVEY §8(d) / that time /
@@ -868,6 +920,7 @@ def main():
             bkw = dict(device=dev_index, n_ids=n_ids, W=W, H=H, preset=args.preset, n_streams=32 if n_ids <= 30 else 8, opts=tuple(args.opt))
             res["roofline_batched"] = batched_association(cfg, frames=160, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16, 32) else (32 if FB > 32 else 8), **bkw)
             res["roofline_batched_frame_at_a_time"] = batched_association(cfg, frames=160, timed=32, frame_batch=1, check=False, **bkw)
+            res["tracker_only"] = tracker_only(cfg, n_ids=n_ids, W=W, H=H, device=dev_index, opts=tuple(args.opt))
         if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
             res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)
         if world == 1 and not args.no_reid_check and not args.no_nets:

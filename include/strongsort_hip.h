@@ -195,7 +195,10 @@ int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, co
  *   "assoc_stage"      how the association kernel brings a work record's detection operand (2 x 32 KiB) into the LDS:
  *                      0 through registers behind one barrier; 1 / 2 / 4 by LDS-DMA in that many pieces, each awaited
  *                      right before the first k-segment that reads it; 5 = 4 with only the first piece requested before
- *                      the first barrier.  Same bits in every form.
+ *                      the first barrier (default).  Same bits in every form.
+ *   "track_graph"      1 (default): the per-frame chain of a group of >= 2 frames (k_frame / k_post / k_newrow, 3 F - 1 dependent
+ *                      launches) is replayed as one captured HIP graph per (frames, caller buffers, options) combination — one
+ *                      hipGraphLaunch of host time instead of up to 95 launches; 0: plain launches
  *   "assoc_xcd_map"    0 (default): a gallery range lives on one XCD (every XCD stages all detection operands);
  *                      1: a detection column-tile pair lives on one XCD (every XCD streams the whole gallery) */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);

@@ -9,7 +9,8 @@
 
 // launchers implemented in ss_track.hip / ss_front.hip
 size_t ss_lsap_lds_bytes();
-void ss_launch_group(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t);
+void ss_launch_group_head(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t);
+void ss_launch_group_chain(const SSDev&, const SSParams&, hipStream_t);
 void ss_launch_normalize(const float*, int, float*, hipStream_t);
 void ss_launch_ema(const float*, const float*, int, float, float, float*, hipStream_t);
 void ss_launch_kf(int, double*, double*, const double*, const double*, int, double, double, hipStream_t);
@@ -77,6 +78,13 @@ struct ss_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t ev_used;
     std::vector<float> ev_ms;   // the durations behind the last ss_assoc_timing mean
+    // the per-frame chain of a group (3 F - 1 launches) as captured HIP graphs, one per distinct kernel-argument set
+    struct Chain { std::vector<char> key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+    std::vector<Chain> chains;
+    hipStream_t cap_stream;     // capture-only stream (nothing ever executes on it)
+    int track_graph;            // option "track_graph": 1 (default) replay the chain as a graph for groups of >= 2 frames, 0 plain launches
+    unsigned long long chain_clock;
+    std::vector<unsigned long long> chain_seen;   // hashes of argument sets launched plainly once
 };
 
 static int fail(ss_ctx* c, int code, const std::string& msg)
@@ -119,8 +127,9 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->ev_used = 0;
     c->cos_grid = 512;           // persistent workgroups of the association kernel: two per CU
     c->comp_rows = 12;
-    c->assoc_stage = 0;
+    c->assoc_stage = 5;          // LDS-DMA in four pieces, first piece + first gallery piece only before the first barrier (r04: 37.8 -> 36.4 us per 1 x 32-frame launch)
     c->xcd_map = 0;
+    c->cap_stream = nullptr; c->track_graph = 1; c->chain_clock = 0;
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
     c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr; c->assoc_event = nullptr;
@@ -189,6 +198,8 @@ extern "C" void ss_destroy(ss_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& g : c->chains) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& st : c->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
     if (c->back.p) (void)hipHostFree(c->back.p);
@@ -333,7 +344,8 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     if (n_frames < 1 || n_frames > SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_track_update_group: 1 <= n_frames <= SS_FMAX");
     // a gallery ring position must be overwritten at most once per group (k_assoc's per-frame row mask, k_newrow)
     if (n_frames > c->cfg.nn_budget) return fail(c, SS_ERR_INVALID, "ss_track_update_group: n_frames <= nn_budget required");
-    SSDev dev = c->dev;
+    SSDev dev;
+    memcpy(&dev, &c->dev, sizeof dev);                          // byte copy: the padding stays zero (the chain graphs are keyed by the struct's bytes)
     dev.F = n_frames;
     dev.dets = d_dets; dev.n_dets = d_ndets; dev.feats_raw = d_feats; dev.img_hw = (int*)d_img_hw;
     dev.out_rows = d_out; dev.n_out = d_nout;
@@ -351,8 +363,59 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
-    ss_launch_group(dev, c->prm, c->stream, e0, e1, c->assoc_event);
+    ss_launch_group_head(dev, c->prm, c->stream, e0, e1, c->assoc_event);
     HIPCHK(c, hipGetLastError());
+    // The chain: k_frame / k_post / k_newrow per frame, strictly dependent.  For a group of several frames that is up to 95
+    // launches (~3.5 us of host time each); replayed as one graph it costs one hipGraphLaunch.  The kernels' arguments are
+    // values (SSDev, SSParams, f): a graph is valid for exactly one (frames, caller buffers, options) combination, which is
+    // what the key compares.  Not inside somebody else's stream capture (torch capturing the frame-at-a-time pipeline).
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (c->stream) HIPCHK(c, hipStreamIsCapturing(c->stream, &cs));
+    if (!c->track_graph || n_frames < 2 || cs != hipStreamCaptureStatusNone) {
+        ss_launch_group_chain(dev, c->prm, c->stream);
+        HIPCHK(c, hipGetLastError());
+        return SS_OK;
+    }
+    std::vector<char> key(sizeof(SSDev) + sizeof(SSParams));
+    memcpy(key.data(), &dev, sizeof(SSDev));
+    memcpy(key.data() + sizeof(SSDev), &c->prm, sizeof(SSParams));
+    ss_ctx::Chain* hit = nullptr;
+    for (auto& g : c->chains) if (g.key == key) { hit = &g; break; }
+    if (!hit) {
+        // a combination is captured the SECOND time it is seen: a caller that walks through fresh buffers (every call another
+        // slice of a long array) would otherwise pay a capture + instantiation per call and never replay anything
+        unsigned long long h = 1469598103934665603ull;
+        for (char ch : key) h = (h ^ (unsigned char)ch) * 1099511628211ull;
+        bool seen = false;
+        for (unsigned long long v : c->chain_seen) seen = seen || v == h;
+        if (!seen) {
+            if (c->chain_seen.size() >= 64) c->chain_seen.erase(c->chain_seen.begin());
+            c->chain_seen.push_back(h);
+            ss_launch_group_chain(dev, c->prm, c->stream);
+            HIPCHK(c, hipGetLastError());
+            return SS_OK;
+        }
+        if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        if (c->chains.size() >= 16) {                            // least recently used entry goes
+            size_t lru = 0;
+            for (size_t i = 1; i < c->chains.size(); ++i) if (c->chains[i].used < c->chains[lru].used) lru = i;
+            (void)hipGraphExecDestroy(c->chains[lru].exec); (void)hipGraphDestroy(c->chains[lru].graph);
+            c->chains.erase(c->chains.begin() + lru);
+        }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        ss_launch_group_chain(dev, c->prm, c->cap_stream);
+        hipError_t le = hipGetLastError();
+        hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
+        if (le != hipSuccess || ee != hipSuccess || !graph)
+            return fail(c, SS_ERR_HIP, std::string("capture of the tracker chain failed: ") + hipGetErrorString(le != hipSuccess ? le : ee));
+        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        c->chains.push_back({ key, graph, exec, 0 });
+        hit = &c->chains.back();
+    }
+    hit->used = ++c->chain_clock;
+    HIPCHK(c, hipGraphLaunch(hit->exec, c->stream));
     return SS_OK;
 }
 
@@ -408,6 +471,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     else if (n == "nms_fused") ss_nms_fused = value != 0;       // process-wide: one workgroup per image after the filter (1, default) or sort / mask / scan launches
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
+    else if (n == "track_graph") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "track_graph: 0 or 1"); c->track_graph = value; }
     else if (n == "assoc_xcd_map") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "assoc_xcd_map: 0 or 1"); c->xcd_map = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
     return SS_OK;

@@ -1572,8 +1572,9 @@ static void launch_assoc(const SSDev& dev, hipStream_t st, hipEvent_t ev0, hipEv
     else hipLaunchKernelGGL((k_assoc<TL, NP>), dim3(dev.cos_grid), dim3(512), ss_assoc_lds_bytes(), st, items, (const int*)dev.n_items, dev.items_cap, dev);
 }
 
-// One group of dev.F frames for every stream.  ev0/ev1 (optional) bracket the association kernel's dispatch.
-void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
+// One group of dev.F frames for every stream, first part: feature prep + work lists, the association kernel.  ev0/ev1
+// (optional) bracket the association kernel's dispatch.
+void ss_launch_group_head(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
     const bool tl = dev.ts_enable > 1;                          // the timeline instantiation (stamps cost registers)
@@ -1585,6 +1586,12 @@ void ss_launch_group(const SSDev& dev, const SSParams& prm, hipStream_t st, hipE
     default: tl ? launch_assoc<true, 0>(dev, st, nullptr, nullptr) : launch_assoc<false, 0>(dev, st, ev0, ev1); break;
     }
     if (ev_assoc) (void)hipEventRecord(ev_assoc, st);          // the caller's "association done" event (ss_track_set_assoc_event)
+}
+
+// ... and the group's per-frame chain (3 F - 1 dependent launches).  ss_api.hip replays it as ONE captured HIP graph per
+// (frames, buffers) when the caller's stream is not itself being captured.
+void ss_launch_group_chain(const SSDev& dev, const SSParams& prm, hipStream_t st)
+{
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);
         hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);

@@ -171,6 +171,40 @@ def test_assoc_operand_staging_variants(stage, S, F, frames, ids):
     _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + s), frames, F=F, wh=wh, opts={"assoc_stage": stage % 100, "assoc_xcd_map": stage // 100})
 
 
+@pytest.mark.parametrize("graph", [1, 0])
+def test_chain_graph_replay_equals_oracle(graph):
+    """The group's per-frame chain replayed as a captured HIP graph (`track_graph`, fixed caller buffers: captured at the second
+    call, replayed from the third) == plain launches == the oracle, every frame; a partial last group (another frame count)
+    takes its own graph / plain launches."""
+    import torch
+    cfg, F, frames = StrongSortConfig(), 8, 93
+    eng, orc = engine(cfg, debug=False), OracleStrongSort(cfg, "c")
+    eng.set_option("track_graph", graph)
+    st = make_stream(91, 1280, 720, 20)
+    dev = eng.device
+    bd, bf, bn = torch.zeros(F, 1, 128, 6, device=dev), torch.zeros(F, 1, 128, 512, device=dev), torch.zeros(F, 1, dtype=torch.int32, device=dev)
+    hw = torch.tensor([[720, 1280]], dtype=torch.int32, device=dev)
+    out, nout = torch.zeros(F, 1, 256, 8, device=dev), torch.zeros(F, 1, dtype=torch.int32, device=dev)
+    for k0 in range(0, frames, F):
+        nf = min(F, frames - k0)
+        hd, hf, hn = np.zeros((F, 1, 128, 6), np.float32), np.zeros((F, 1, 128, 512), np.float32), np.zeros((F, 1), np.int32)
+        ref = []
+        for f in range(nf):
+            fr = st.next_frame()
+            n = len(fr.dets)
+            hd[f, 0, :n], hf[f, 0, :n], hn[f, 0] = fr.dets, fr.feats, n
+            ref.append(orc.update(fr.dets, fr.feats, (720, 1280)))
+        bd.copy_(torch.from_numpy(hd)); bf.copy_(torch.from_numpy(hf)); bn.copy_(torch.from_numpy(hn))
+        eng.update_group(nf, bd, bn, bf, hw, out, nout)
+        eng.check_errors()
+        ho, hno = out.cpu().numpy(), nout.cpu().numpy()
+        for f in range(nf):
+            got = ho[f, 0, :hno[f, 0]]
+            assert got.shape == ref[f].shape and got.tobytes() == ref[f].tobytes(), f"frame {k0 + f}"
+    _compare_table(eng, orc)
+    eng.close()
+
+
 def test_frame_groups_with_births_deaths_and_empty_frames():
     """Tracks die, slots are reused and new tracks get confirmed in the middle of a group; whole frames without
     detections."""
