@@ -54,12 +54,13 @@ PRESETS = {
     "c3": ("yolov8s", 1280, 720, 30, 32),      # configs[2] per GPU
     "c4": ("yolov7", 1920, 1080, 100, 128),    # configs[3] crowded scene
     "c5": ("yolov8n-pose", 1280, 720, 30, 32), # configs[4] per GPU: pose head, keypoints carried by det_idx
+    "c6": ("yolo11n-pose", 1280, 720, 30, 32), # not a BASELINE config: the model file the reference loads by default (yolo_multi_model.py:17)
 }
-CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4}
+CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4, "c6": None}
 # where the two HIP streams' stages are cut inside OSNet.  c2, r03 sweep after the detector got faster (40 steps, two runs each): split 2:
 # 11 232 / 11 244, 4: 11 701 / 11 531, 5: 11 720 / 11 785, 6: 11 509 / 11 014 frames/s.  The larger detectors keep the earlier cut (30 steps, one
 # run each): c3 cut 2: 7 981, cut 5: 7 938; c5 (pose head) cut 2: 9 267, cut 5: 8 446; c4 (yolov7: the detector is the long stage) was only measured at 2
-REID_SPLIT = {"c1": 2, "c2": 5, "c3": 2, "c4": 2, "c5": 2}
+REID_SPLIT = {"c1": 2, "c2": 5, "c3": 2, "c4": 2, "c5": 2, "c6": 2}
 PMC_FILE = "r03_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by preset / streams / frames (tools/pmc_assoc.sh)
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
@@ -776,9 +777,10 @@ def main():
     pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
     pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
     barrier()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
-    t_enq = time.perf_counter() - t0             # host time to enqueue the K steps (the GPU may still be working)
+    t_enq = time.perf_counter() - t0             # host wall time to enqueue the K steps (the GPU may still be working; includes the
+    t_enq_cpu = time.thread_time() - c0          # time the runtime blocks on full hardware queues) and the CPU time this thread used for it
     barrier()
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
@@ -901,14 +903,14 @@ def main():
             "value": round(world * S * KF / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "frames_per_step": FPS, "ms_per_step": round(dt / K * 1e3, 4), "ms_per_step_distribution": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
-            "config": {"workload": f"configs[{CONFIG_INDEX[args.preset]}]: {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
+            "config": {"workload": (f"configs[{CONFIG_INDEX[args.preset]}]" if CONFIG_INDEX[args.preset] is not None else "reference default model (yolo_multi_model.py:17)") + f": {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
                        "parallelism": f"{world} independent stream shard(s), 1 process per GPU"},
             "per_rank_value": [round(S * KF / t, 2) for t in per_rank_dt], "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
             "backend": (backend + ("=RCCL" if backend == "nccl" else "")) if world > 1 else None,
             "devices": "one GPU shared by all ranks (SS_BENCH_SINGLE_DEVICE=1: control-flow run)" if (one_dev and world > 1) else "one GPU per rank",
-            "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "id_match_rate": round(id_rate_min, 6), "frames_bit_exact": f"{exact_min}/{nchk}", "frames_bit_exact_timed": f"{exact_timed_min}/{n_timed}",
+            "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "host_enqueue_cpu_ms_per_frame": round(t_enq_cpu / KF * 1e3, 4), "id_match_rate": round(id_rate_min, 6), "frames_bit_exact": f"{exact_min}/{nchk}", "frames_bit_exact_timed": f"{exact_timed_min}/{n_timed}",
             "id_check": "every rank vs the oracle on its own stream 0 over prefill + warm-up + ALL timed frames, minimum over ranks",
             "roofline": roofline, "roofline_front": roofline_front, "net_outputs_check": nets_check,
         }

@@ -278,6 +278,14 @@ typedef struct ss_conv_desc {
     int B, H, W, Cin, N, ksize, stride, act;
 } ss_conv_desc;
 int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* descs);
+/* One level of the anchor-free (v8) detect head, BOTH branches and all three layers of a branch, in one launch: per branch b
+ * 3x3 (Cin -> cm_b) + SiLU -> 3x3 (cm_b -> cm_b) + SiLU -> 1x1 (cm_b -> nout[b]) + bias, cm_0 = 64 (box), cm_1 = 80 (class); the
+ * intermediates stay in the LDS.  d_x dense NHWC half [B][H][W][Cin], Cin in {64, 128, 256}; weights as ss_op_conv3x3_f16 /
+ * ss_op_pointwise_f16 take them ([cm][3][3][Cin], [cm][3][3][cm], [nout][cm]); d_out[b] dense [B][H][W][nout[b]], nout[b] % 8 == 0,
+ * <= cm_b.  Bit-identical to the three separate launches per branch (non-split-K form).  tile16: 8 x 16 tiles for Cin = 64. */
+int ss_op_head_f16(void* stream, const void* d_x, const void* const* d_w1, const void* const* d_b1, const void* const* d_w2,
+                   const void* const* d_b2, const void* const* d_w3, const void* const* d_b3, void* const* d_out, const int* nout,
+                   int B, int H, int W, int Cin, int tile16);
 /* YOLOv8 anchor-free head decode: per level l<3 the branch outputs d_box[l] [B][H][W][64] and d_cls[l] [B][H][W][nc]
  * (NHWC half, final 1x1 conv without bias; the biases are added here) -> d_pred [B][4+nc][A] float (xywh in input
  * pixels, class sigmoid), A = sum H[l]*W[l] — the tensor ss_nms reads.  H, W, strides are host int[3]. */

@@ -574,29 +574,32 @@ struct BnArgs {
     int B, H, W, add, TW, TH, tiles_x, tiles_y;
 };
 
-template <int C, int PT>
+// 3x3 convolution of PT x 16 pixels per wave out of an LDS tile (pixel pitch CI + 8 halfs): CI input, CO output channels,
+// weights [CO][3][3][CI] streamed in 64-wide K slices through Ws [2][CO][72].
+template <int CI, int CO, int PT>
 __device__ __forceinline__ void bn_conv(const _Float16* __restrict__ In, const int (&pbase)[PT], const int* __restrict__ tapoff,
-                                        const __half* __restrict__ w, _Float16* __restrict__ Ws, f4 (&acc)[C / 16][PT], const int tid)
+                                        const __half* __restrict__ w, _Float16* __restrict__ Ws, f4 (&acc)[CO / 16][PT], const int tid)
 {
-    constexpr int MT = C / 16, WP = 72, K = 9 * C, WV = (C * 8 + 255) / 256;
+    constexpr int C = CI;
+    constexpr int MT = CO / 16, WP = 72, K = 9 * CI, WV = (CO * 8 + 255) / 256;
     const int lane = tid & 63, q = lane >> 4, n = lane & 15;
     const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
     auto load_w = [&](int k0, h8 (&wr)[WV]) {
 #pragma unroll
         for (int j = 0; j < WV; ++j) {
             const int i = tid + j * 256, r = i >> 3, c8 = i & 7, kk = k0 + c8 * 8;
-            wr[j] = (i < C * 8 && kk < K) ? *reinterpret_cast<const h8*>(w + (size_t)r * K + kk) : z8;
+            wr[j] = (i < CO * 8 && kk < K) ? *reinterpret_cast<const h8*>(w + (size_t)r * K + kk) : z8;
         }
     };
     h8 wr[WV], wn[WV];
     load_w(0, wr);
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += 64, buf ^= 1) {
-        _Float16* wb = Ws + buf * (C * WP);
+        _Float16* wb = Ws + buf * (CO * WP);
 #pragma unroll
         for (int j = 0; j < WV; ++j) {
             const int i = tid + j * 256, r = i >> 3, c8 = i & 7;
-            if (i < C * 8) *reinterpret_cast<h8*>(wb + r * WP + c8 * 8) = wr[j];
+            if (i < CO * 8) *reinterpret_cast<h8*>(wb + r * WP + c8 * 8) = wr[j];
         }
         if (k0 + 64 < K) load_w(k0 + 64, wn);
         __syncthreads();                                           // slice k0 (and whatever the caller wrote to LDS before) is visible
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(256) void k_bneck(BnArgs A)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int pt = 0; pt < PT1; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
-        bn_conv<C, PT1>(Xs, pb, tap1, A.w1, Ws, acc, tid);
+        bn_conv<C, C, PT1>(Xs, pb, tap1, A.w1, Ws, acc, tid);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const h4 bb = *reinterpret_cast<const h4*>(A.b1 + mt * 16 + 4 * q);
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(256) void k_bneck(BnArgs A)
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int pt = 0; pt < PT2; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
-        bn_conv<C, PT2>(Ts, pb, tap2, A.w2, Ws, acc, tid);
+        bn_conv<C, C, PT2>(Ts, pb, tap2, A.w2, Ws, acc, tid);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const h4 bb = *reinterpret_cast<const h4*>(A.b2 + mt * 16 + 4 * q);
@@ -752,6 +755,204 @@ __global__ __launch_bounds__(256) void k_bneck(BnArgs A)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_head — one level of the anchor-free detect head, BOTH branches, all three layers of a branch in one launch:
+//   3x3 (CI -> CM) + SiLU -> 3x3 (CM -> CM) + SiLU -> 1x1 (CM -> nout) + bias
+// (nets.Detect.cv2[i] / cv3[i]; CM = 64 for the box branch, 80 for the class branch of yolov8n).  As grouped launches per depth
+// (k_pw_group) these were the largest kernels of the detector: 126 + 108 + 36 us per 32 frames, each layer a round trip of
+// its whole output through HBM / L2.  Here a workgroup owns a TH x TW tile of one image and one branch (blockIdx.y): k_bneck's
+// scheme with CI != CM and no shortcut — input tile + 2-pixel halo staged once, first convolution on the tile + 1-pixel ring
+// into LDS (zero outside the image), second convolution out of it — and the branch's final 1x1 as a third MFMA product: the
+// activated output of the second convolution goes, rounded to half exactly as the separate launch stores it, into a per-wave
+// LDS tile (aliased onto the input tile, which is dead by then) and is multiplied with the 1x1 weights staged in the weight
+// buffers.  Same MFMA instructions, operand layouts, K order and rounding points as the grouped launches: bit-identical.
+struct HeadArgs {
+    const __half* x;
+    const __half* w1[2]; const __half* b1[2]; const __half* w2[2]; const __half* b2[2]; const __half* w3[2]; const __half* b3[2];
+    __half* out[2]; int nout[2];
+    int B, H, W, TW, TH, tiles_x, tiles_y;
+};
+
+template <int CI, int CM, int PT1, int PT2>
+__device__ __forceinline__ void head_body(const HeadArgs& A, const int br, char* smem)
+{
+    constexpr int MT = CM / 16, PX = CI + 8, PM = CM + 8, WP = 72, KB3 = (CM + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int TW = A.TW, TH = A.TH, XW = TW + 4, XH = TH + 4, RW = TW + 2, RH = TH + 2;
+    _Float16* Xs = reinterpret_cast<_Float16*>(smem);                                  // [XH][XW][PX]  input, origin (oy0-2, ox0-2)
+    _Float16* Ts = Xs + ((XH * XW * PX + 7) & ~7);                                     // [RH][RW][PM]  first conv's output, origin (oy0-1, ox0-1)
+    _Float16* Ws = Ts + ((RH * RW * PM + 7) & ~7);                                     // [2][80][WP] weight slices; then the 1x1 weights [CM][PM]
+    int* tap1 = reinterpret_cast<int*>(Ws + 2 * 80 * WP);                              // [16] tap offsets in Xs / Ts
+    int* tap2 = tap1 + 16;
+    _Float16* Us = Xs;                                                                 // [4 waves][PT2 * 16][PM]: second conv's output (Xs is dead by then)
+    const int tpi = A.tiles_x * A.tiles_y;
+    const int img = blockIdx.x / tpi, trm = blockIdx.x - img * tpi, tyi = trm / A.tiles_x, txi = trm - tyi * A.tiles_x;
+    const int oy0 = tyi * TH, ox0 = txi * TW, H = A.H, W = A.W;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (tid < 9) { const int ky = tid / 3, kx = tid - ky * 3; tap1[tid] = (ky * XW + kx) * PX; tap2[tid] = (ky * RW + kx) * PM; }
+    // ---- stage the input tile (halo 2): a wave per row, 8 loads in flight per lane ----
+    const __half* xi = A.x + (size_t)img * H * W * CI;
+    constexpr int VPC = CI / 8;
+    const int rowv = XW * VPC;
+    for (int r = wave; r < XH; r += 4) {
+        const int iy = oy0 - 2 + r;
+        const bool rok = iy >= 0 && iy < H;
+        const __half* src = xi + (size_t)(rok ? iy : 0) * W * CI;
+        _Float16* dst = Xs + r * XW * PX;
+        for (int i0 = lane; i0 < rowv; i0 += 512) {
+            h8 tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u, c = i / VPC, v = i % VPC, ix = ox0 - 2 + c;
+                const bool ok = rok && i < rowv && ix >= 0 && ix < W;
+                tmp[u] = ok ? *reinterpret_cast<const h8*>(src + (size_t)ix * CI + v * 8) : z8;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u, c = i / VPC, v = i % VPC;
+                if (i < rowv) *reinterpret_cast<h8*>(dst + c * PX + v * 8) = tmp[u];
+            }
+        }
+    }
+    // ---- first convolution (CI -> CM) on the tile + 1-pixel ring -> Ts ----
+    {
+        int pb[PT1], tpix[PT1];
+        bool inimg[PT1];
+#pragma unroll
+        for (int pt = 0; pt < PT1; ++pt) {
+            const int p = (wave * PT1 + pt) * 16 + n;
+            int ry = p / RW, rx = p - ry * RW;
+            const bool ok = p < RH * RW;
+            if (!ok) { ry = 0; rx = 0; }
+            const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+            inimg[pt] = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            tpix[pt] = ok ? p : -1;
+            pb[pt] = (ry * XW + rx) * PX;
+        }
+        f4 acc[MT][PT1];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT1; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+        bn_conv<CI, CM, PT1>(Xs, pb, tap1, A.w1[br], Ws, acc, tid);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 bb = *reinterpret_cast<const h4*>(A.b1[br] + mt * 16 + 4 * q);
+#pragma unroll
+            for (int pt = 0; pt < PT1; ++pt) {
+                if (tpix[pt] < 0) continue;
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = act_apply((float)(_Float16)acc[mt][pt][j] + (float)bb[j], 2);
+                    asm volatile("" : "+v"(f));                    // rounded to f32 THEN to half, as the grouped launch (no v_fma_mixlo_f16)
+                    o[j] = inimg[pt] ? (_Float16)f : (_Float16)0.f;
+                }
+                *reinterpret_cast<h4*>(Ts + tpix[pt] * PM + mt * 16 + 4 * q) = o;
+            }
+        }
+    }
+    __syncthreads();                                               // Ts complete; the first K walk's weight buffers and Xs are free
+    // ---- second convolution (CM -> CM) on the tile -> per-wave tile Us ----
+    int opix[PT2];
+    {
+        int pb[PT2];
+#pragma unroll
+        for (int pt = 0; pt < PT2; ++pt) {
+            const int p = (wave * PT2 + pt) * 16 + n;
+            int ty = p / TW, tx = p - ty * TW;
+            const bool ok = p < TH * TW && oy0 + ty < H && ox0 + tx < W;
+            if (!ok) { ty = 0; tx = 0; }
+            pb[pt] = (ty * RW + tx) * PM;
+            opix[pt] = ok ? (img * H + oy0 + ty) * W + ox0 + tx : -1;
+        }
+        f4 acc[MT][PT2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+        bn_conv<CM, CM, PT2>(Ts, pb, tap2, A.w2[br], Ws, acc, tid);
+        _Float16* ut = Us + wave * (PT2 * 16 * PM);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const h4 bb = *reinterpret_cast<const h4*>(A.b2[br] + mt * 16 + 4 * q);
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) {
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float f = act_apply((float)(_Float16)acc[mt][pt][j] + (float)bb[j], 2);
+                    asm volatile("" : "+v"(f));
+                    o[j] = (_Float16)f;
+                }
+                *reinterpret_cast<h4*>(ut + (pt * 16 + n) * PM + mt * 16 + 4 * q) = o;
+            }
+        }
+    }
+    __syncthreads();                                               // every wave has left the second K walk: the weight buffers are free
+    // ---- the branch's 1x1 (CM -> nout): weights [nout][CM] -> LDS [CM rows max][PM], rows >= nout zero ----
+    const int nout = A.nout[br];
+    {
+        const __half* w3 = A.w3[br];
+        for (int i = tid; i < CM * (CM / 8); i += 256) {
+            const int r = i / (CM / 8), c8 = i - r * (CM / 8);
+            *reinterpret_cast<h8*>(Ws + r * PM + c8 * 8) = r < nout ? *reinterpret_cast<const h8*>(w3 + (size_t)r * CM + c8 * 8) : z8;
+        }
+    }
+    __syncthreads();
+    {
+        const _Float16* ut = Us + wave * (PT2 * 16 * PM);
+        f4 acc[MT][PT2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) acc[mt][pt] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int kb = 0; kb < KB3; ++kb) {
+            const int k = kb * 32 + 8 * q;
+            const bool kv = k < CM;                                // (CM = 80: the last 32-wide block is half empty, as in k_pw's walk)
+            h8 b[PT2];
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) b[pt] = kv ? *reinterpret_cast<const h8*>(ut + (pt * 16 + n) * PM + k) : z8;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 a = kv ? *reinterpret_cast<const h8*>(Ws + (mt * 16 + n) * PM + k) : z8;
+                const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
+#pragma unroll
+                for (int pt = 0; pt < PT2; ++pt) {                 // the 1x1 form of k_pw: two 16x16x16 steps per 32-wide block
+                    const h4 b0 = { b[pt][0], b[pt][1], b[pt][2], b[pt][3] }, b1 = { b[pt][4], b[pt][5], b[pt][6], b[pt][7] };
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a0, b0, acc[mt][pt], 0, 0, 0);
+                    acc[mt][pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, acc[mt][pt], 0, 0, 0);
+                }
+            }
+        }
+        __half* out = A.out[br];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oc0 = mt * 16 + 4 * q;
+            if (oc0 >= nout) continue;
+            const h4 bb = *reinterpret_cast<const h4*>(A.b3[br] + oc0);
+#pragma unroll
+            for (int pt = 0; pt < PT2; ++pt) {
+                if (opix[pt] < 0) continue;
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (_Float16)((float)(_Float16)acc[mt][pt][j] + (float)bb[j]);
+                *reinterpret_cast<h4*>(out + (size_t)opix[pt] * nout + oc0) = o;
+            }
+        }
+    }
+}
+
+// blockIdx.y = branch: 0 = box (CM 64), 1 = class (CM 80)
+template <int CI, int PT1, int PT2>
+__global__ __launch_bounds__(256) void k_head(HeadArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) char hd_smem[];
+    if (blockIdx.y == 0) head_body<CI, 64, PT1, PT2>(A, 0, hd_smem);
+    else head_body<CI, 80, PT1, PT2>(A, 1, hd_smem);
 }
 
 // OSNet stem in one pass: conv 7x7 / stride 2 / pad 3 (3 -> 16 channels) + bias + ReLU + max pool 3x3 / stride 2 /
@@ -2290,6 +2491,44 @@ extern "C" int ss_op_bottleneck_f16(void* stream, const void* x, const void* w1,
     if (big) { if (C == 16) SS_BN(16, 3, 2); else if (C == 32) SS_BN(32, 3, 2); else SS_BN(64, 3, 2); }
     else { if (C == 16) SS_BN(16, 2, 1); else if (C == 32) SS_BN(32, 2, 1); else if (C == 64) SS_BN(64, 2, 1); else SS_BN(128, 2, 1); }
 #undef SS_BN
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+// One level of the v8 detect head, both branches, three layers each, in one launch (k_head).  x dense [B][H][W][Cin] half,
+// Cin in {64, 128, 256}; branch 0: w1 [64][3][3][Cin], w2 [64][3][3][64], w3 [nout0][64] (nout0 <= 64); branch 1: the same with 80
+// mid channels (nout1 <= 80); out[b] dense [B][H][W][nout_b].  tile16 != 0: 8 x 16 pixel tiles (Cin = 64 only) instead of 8 x 8.
+extern "C" int ss_op_head_f16(void* stream, const void* x, const void* const* w1, const void* const* b1, const void* const* w2,
+                              const void* const* b2, const void* const* w3, const void* const* b3, void* const* out, const int* nout,
+                              int B, int H, int W, int Cin, int tile16)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out || !nout || B < 1 || H < 1 || W < 1 || (Cin != 64 && Cin != 128 && Cin != 256) ||
+        ((uintptr_t)x % 16))
+        return SS_ERR_INVALID;
+    HeadArgs A;
+    A.x = (const __half*)x;
+    for (int b = 0; b < 2; ++b) {
+        const int cm = b ? 80 : 64;
+        if (!w1[b] || !b1[b] || !w2[b] || !b2[b] || !w3[b] || !b3[b] || !out[b] || nout[b] < 8 || nout[b] % 8 || nout[b] > cm ||
+            ((uintptr_t)w1[b] % 16) || ((uintptr_t)w2[b] % 16) || ((uintptr_t)w3[b] % 16) || ((uintptr_t)out[b] % 8))
+            return SS_ERR_INVALID;
+        A.w1[b] = (const __half*)w1[b]; A.b1[b] = (const __half*)b1[b]; A.w2[b] = (const __half*)w2[b]; A.b2[b] = (const __half*)b2[b];
+        A.w3[b] = (const __half*)w3[b]; A.b3[b] = (const __half*)b3[b]; A.out[b] = (__half*)out[b]; A.nout[b] = nout[b];
+    }
+    const bool big = tile16 != 0 && Cin == 64;
+    A.B = B; A.H = H; A.W = W; A.TW = big ? 16 : 8; A.TH = 8;
+    A.tiles_x = (W + A.TW - 1) / A.TW; A.tiles_y = (H + A.TH - 1) / A.TH;
+    const size_t xs = ((size_t)(A.TH + 4) * (A.TW + 4) * (Cin + 8) + 7) & ~(size_t)7, ts = ((size_t)(A.TH + 2) * (A.TW + 2) * 88 + 7) & ~(size_t)7;
+    const size_t lds = (xs + ts + 2 * 80 * 72) * 2 + 128;
+    if (lds > 160 * 1024 - 512) return SS_ERR_INVALID;
+    const dim3 grid((unsigned)(B * A.tiles_x * A.tiles_y), 2);
+    hipStream_t st = (hipStream_t)stream;
+#define SS_HD(CC, P1, P2) do { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k_head<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
+                               hipLaunchKernelGGL((k_head<CC, P1, P2>), grid, dim3(256), lds, st, A); } while (0)
+    if (big) SS_HD(64, 3, 2);
+    else if (Cin == 64) SS_HD(64, 2, 1);
+    else if (Cin == 128) SS_HD(128, 2, 1);
+    else SS_HD(256, 2, 1);
+#undef SS_HD
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

@@ -205,6 +205,42 @@ def conv_group(items):
     return outs
 
 
+HEAD = _flag("HEAD")                    # a level of the v8 detect head (both branches, 3 layers each) in one launch, intermediates in LDS
+HEAD_TILE16 = _os.environ.get("SS_HEAD_TILE16", "0") == "1"           # A/B: 8 x 16 tiles at the stride-8 level
+
+
+def head_level_ok(x, box_seq, cls_seq) -> bool:
+    """nets.Detect branch pairs that k_head covers: Conv3x3+SiLU, Conv3x3+SiLU, Conv2d 1x1 with 64 (box) / 80 (class) mid channels."""
+    if not (HEAD and usable(x) and x.shape[1] in (64, 128, 256)):
+        return False
+    for seq, cm in ((box_seq, 64), (cls_seq, 80)):
+        a, b, c = seq[0], seq[1], seq[2]
+        if not (hasattr(a, "conv") and hasattr(b, "conv") and conv3x3_ok(a.conv) and conv3x3_ok(b.conv) and a.conv.stride == (1, 1)
+                and b.conv.stride == (1, 1) and type(a.act).__name__ == "SiLU" and type(b.act).__name__ == "SiLU"
+                and a.conv.in_channels == x.shape[1] and a.conv.out_channels == cm and b.conv.in_channels == cm and b.conv.out_channels == cm
+                and pointwise_ok(c) and c.in_channels == cm and c.out_channels <= cm):
+            return False
+    return True
+
+
+def head_level(x, box_seq, cls_seq, tile16=None):
+    """-> (box branch output [B, 64, H, W], class branch output [B, nc, H, W]) of one level, one launch (csrc k_head)."""
+    x = _cl(x)
+    b, cin, h, w = x.shape
+    outs, keep = [], []
+    arr = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    w1, b1, w2, b2, w3, b3 = [], [], [], [], [], []
+    for seq in (box_seq, cls_seq):
+        w1.append(weight_n9k(seq[0], seq[0].conv)); b1.append(seq[0].conv.bias)
+        w2.append(weight_n9k(seq[1], seq[1].conv)); b2.append(seq[1].conv.bias)
+        w3.append(weight_nk(seq[2], seq[2])); b3.append(seq[2].bias)
+        outs.append(torch.empty((b, seq[2].out_channels, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last))
+    nout = (C.c_int * 2)(*[o.shape[1] for o in outs])
+    t16 = HEAD_TILE16 if tile16 is None else bool(tile16)
+    _ck(_lib.load().ss_op_head_f16(_st(x), _p(x), arr(w1), arr(b1), arr(w2), arr(b2), arr(w3), arr(b3), arr(outs), nout, b, h, w, cin, int(t16)))
+    return outs[0], outs[1]
+
+
 def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 

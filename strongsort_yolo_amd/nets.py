@@ -180,6 +180,14 @@ class Detect(nn.Module):
         B = feats[0].shape[0]
         if fused.usable(feats[0]) and self.nk == 0 and self.nm == 0:     # six branch tensors -> [B,4+nc,A] float in one launch
             seqs = list(self.cv2) + list(self.cv3)
+            if len(feats) == 3 and all(fused.head_level_ok(f, self.cv2[i], self.cv3[i]) for i, f in enumerate(feats)):
+                # a level's two branches, three layers each, in ONE launch with the intermediates in LDS (csrc k_head): 3 launches
+                # instead of the 3 grouped ones per depth, without the round trips of the 64- / 80-channel intermediates
+                t = [fused.head_level(f, self.cv2[i], self.cv3[i]) for i, f in enumerate(feats)]
+                z = getattr(self, "_zeros", None)
+                if z is None or z.device != feats[0].device:
+                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
+                return fused.v8_decode([a for a, _ in t], [b for _, b in t], [z] * 3, [z] * 3, self.strides, self.nc)
             if (fused.GROUP and len(feats) == 3 and all(fused.pointwise_ok(s[2]) and fused.conv3x3_ok(s[0].conv) and
                                                          fused.conv3x3_ok(s[1].conv) and isinstance(s[0].act, nn.SiLU) and
                                                          s[2].out_channels <= 80 and s[0].conv.out_channels <= 80 for s in seqs)):

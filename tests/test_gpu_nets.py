@@ -358,6 +358,62 @@ def test_bottleneck_launch_is_bit_identical_to_its_two_convolutions(B, C, H, W, 
     assert torch.equal(cat[:, C:2 * C], ref) and (cat[:, :C] == 3.0).all()
 
 
+@pytest.mark.parametrize("B,cin,H,W,nc,tile16", [(32, 64, 48, 80, 80, False), (32, 128, 24, 40, 80, False), (32, 256, 12, 20, 80, False),
+                                                  (3, 64, 48, 80, 80, True), (2, 64, 13, 21, 16, False), (2, 64, 13, 21, 16, True),
+                                                  (1, 128, 7, 5, 80, False), (5, 256, 9, 11, 8, False)])
+def test_head_level_launch_is_bit_identical_to_its_six_layers(B, cin, H, W, nc, tile16):
+    """k_head (per branch 3x3 + SiLU -> LDS -> 3x3 + SiLU -> per-wave LDS tile -> 1x1 + bias; both branches of a level in one launch)
+    == ss_op_conv3x3_f16 x 2 + ss_op_pointwise_f16 per branch, every bit (the non-split-K form of the small layers: the split-K form
+    adds the K chunks in another order); tiles hanging over the edges, maps smaller than a tile, both tile sizes, class counts < 80;
+    and close to the fp32 convolutions."""
+    import torch.nn.functional as F
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(cin * 100 + H)
+    det = nets.Detect(80, (64, 128, 256))
+    lvl = {64: 0, 128: 1, 256: 2}[cin]
+    if nc != 80:                                                     # fewer output channels than mid channels in both branches
+        det.cv3[lvl][2] = torch.nn.Conv2d(80, nc, 1)
+        det.cv2[lvl][2] = torch.nn.Conv2d(64, 8 + nc, 1)
+    det = det.to(dev, torch.float16)
+    box, cls = det.cv2[lvl], det.cv3[lvl]
+    x = torch.randn(B, cin, H, W).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    assert fused.head_level_ok(x, box, cls)
+    fused.set_option("pw_splitk", 0)
+    try:
+        refs = []
+        for seq in (box, cls):
+            t = fused.conv3x3(x, fused.weight_n9k(seq[0], seq[0].conv), seq[0].conv.bias, 1, "silu")
+            t = fused.conv3x3(t, fused.weight_n9k(seq[1], seq[1].conv), seq[1].conv.bias, 1, "silu")
+            refs.append(fused.pointwise(t, fused.weight_nk(seq[2], seq[2]), seq[2].bias))
+    finally:
+        fused.set_option("pw_splitk", 1)
+    got = fused.head_level(x, box, cls, tile16=tile16)
+    for g, r, seq in zip(got, refs, (box, cls)):
+        assert g.shape == r.shape and torch.equal(g, r), f"{int((g != r).sum())} of {g.numel()} values differ"
+        f32 = seq.float()(x.float())
+        assert (g.float() - f32).abs().max().item() <= 2e-2 * (f32.abs().max().item() + 1.0)
+        seq.half()
+
+
+def test_detector_with_head_level_launches_equals_grouped_launches():
+    """yolov8n at the benchmark batch: the whole detector with k_head == with the grouped head launches (at 32 frames no level takes the
+    split-K form), bit for bit."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    m = nets.build_detector("yolov8n").to(dev).half().to(memory_format=torch.channels_last)
+    x = torch.randn(32, 3, 384, 640, generator=torch.Generator().manual_seed(7)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        flag, fused.HEAD = fused.HEAD, False
+        try:
+            ref = m(x)
+        finally:
+            fused.HEAD = flag
+        assert fused.HEAD
+        got = m(x)
+    assert got.shape == ref.shape and torch.equal(got, ref) and ref[:, 4:].float().max().item() > 0.0
+
+
 @pytest.mark.parametrize("N,H", [(3, 256), (2, 64), (1, 16)])
 def test_osnet_stem_matches_conv_relu_pool(N, H):
     import torch.nn.functional as F

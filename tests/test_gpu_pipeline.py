@@ -216,6 +216,7 @@ def _run_groups(pipe, items, fb):
     ("yolov8s", 1280, 720, 30, 32, 144, 2),    # --preset c3 = configs[2] per GPU: the stage cut the larger detectors keep (OSNet part 2)
     ("yolov8n-pose", 1280, 720, 30, 32, 144, 2),   # --preset c5 = configs[4] per GPU: 51 keypoint columns ride through NMS with the kept rows
     ("yolov5n", 640, 480, 8, 32, 80, 2),       # --preset c1 = configs[0]'s shape (the reference's CPU-runnable case) on the GPU path
+    ("yolo11n-pose", 1280, 720, 30, 32, 112, 2),   # --preset c6: the reference's default weights file (yolo_multi_model.py:17), C3k2 / C2PSA graph, pose head
 ])
 def test_benchmarked_configuration_equals_oracle(detector, w, h, n_ids, reid_batch, n_frames, split):
     """Exactly what bench.py times: frame batch 32, stage cut inside OSNet where bench.REID_SPLIT puts it, deferred tracker call + association gate,

@@ -216,3 +216,27 @@ def test_bottleneck_launch_eligibility():
 def test_bench_stage_cut_defaults_cover_every_preset():
     import bench
     assert set(bench.REID_SPLIT) == set(bench.PRESETS) and all(0 <= v <= nets.OSNet.N_PARTS for v in bench.REID_SPLIT.values())
+
+
+@pytest.mark.parametrize("name,published", [
+    ("yolov8n", 3157200), ("yolov8s", 11166560), ("yolov8m", 25902640), ("yolov8n-pose", 3295470), ("yolov8n-seg", 3409968),
+    ("yolo11n", 2624080), ("yolo11s", 9458752), ("yolov5n", 2654816), ("yolov5s", 9153152)])
+def test_parameter_counts_equal_the_published_model_summaries(name, published):
+    """Third-party pin on the network GRAPHS ('not even the published parameter counts as a test'): the Ultralytics model
+    summaries print these totals for the unfused models (yolov8n: '225 layers, 3157200 parameters'; yolo11n: '319 layers, 2,624,080
+    parameters'; the 'u' heads for yolov5).  The modules here are built in fused-inference form — a biased convolution per Conv +
+    BatchNorm pair — so the published count is ours + one more vector per such pair (BatchNorm has weight AND bias where the folded
+    convolution keeps one bias) + the 16 fixed weights of the DFL projection."""
+    m = nets.build_detector(name)
+    ours = sum(p.numel() for p in m.parameters())
+    bn_pairs = sum(mod.conv.out_channels for mod in m.modules() if isinstance(mod, nets.Conv))
+    assert ours + bn_pairs + 16 == published
+
+
+def test_fused_parameter_count_of_the_reference_default_model():
+    """`yolo11n-pose.pt` (/root/reference/yolo_multi_model.py:17): Ultralytics prints 2,866,468 parameters for the FUSED model (BatchNorm
+    folded, which is the form built here) — ours + the 16 DFL weights.  OSNet-x0.25 is published as a 0.2 M-parameter network."""
+    m = nets.build_detector("yolo11n-pose")
+    assert sum(p.numel() for p in m.parameters()) + 16 == 2866468
+    r = sum(p.numel() for p in nets.build_reid().parameters())
+    assert 190_000 < r < 215_000
