@@ -639,6 +639,8 @@ def main():
     ap.add_argument("--reid-split", type=int, default=-2, help="cut the 2-stage pipeline after this many parts of the ReID backbone (0..10; -1: cut before NMS; -2: the preset's measured best, REID_SPLIT)")
     ap.add_argument("--frame-batch", type=int, default=32, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (ss_set_option), e.g. --opt assoc_comp_rows=0")
+    ap.add_argument("--fused", action="append", default=[], help="A/B switch of a fused kernel family NAME=0|1 (fused.set_flags), e.g. --fused HEAD=0")
+    ap.add_argument("--pipe", action="append", default=[], help="A/B switch of the frame pipeline name=0|1: pack_crops, assoc_gate, track_priority")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -679,6 +681,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.fused:
+        from strongsort_yolo_amd import fused
+        fused.set_flags(**{kv.split("=")[0]: kv.split("=")[1] != "0" for kv in args.fused})
+    pipe_sw = {kv.split("=")[0]: kv.split("=")[1] != "0" for kv in args.pipe}
     detector, W, H, n_ids, rb = PRESETS[args.preset]
     if args.reid_split == -2:
         args.reid_split = REID_SPLIT[args.preset]
@@ -692,7 +698,7 @@ def main():
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                    det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True} if overlap else {}))
+                   run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
     for kv in args.opt:
         pipe.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     gs = scale_geometry(pipe.geom, H, W)

@@ -17,8 +17,34 @@ ENABLED = True
 
 
 def _flag(name: str) -> bool:
-    """A/B switches for measurements: SS_FUSED_<NAME>=0 falls back to the library convolution + separate epilogue."""
-    return _os.environ.get("SS_FUSED_" + name, "1") != "0"
+    """The fused kernel families are module attributes (POINTWISE, CONV3X3, BNECK, GROUP, HEAD, ...), all on.  They are plain
+    process state: flip them with set_flags(NAME=False) (tests, A/B measurements) — nothing here reads the environment at
+    import; measurement tools that take their switches from the command line / environment call flags_from_env() themselves."""
+    return True
+
+
+FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE")
+
+
+def set_flags(**kw):
+    """A/B switches: set_flags(HEAD=False) takes the grouped head launches instead of k_head, ...; BNECK_C=(16, 32) restricts the
+    widths that take k_bneck.  Returns the previous values (to restore)."""
+    g, old = globals(), {}
+    for k, v in kw.items():
+        if k not in FLAG_NAMES and k != "BNECK_C":
+            raise ValueError(f"unknown fused switch {k!r}")
+        old[k] = g[k]
+        g[k] = tuple(int(c) for c in v) if k == "BNECK_C" else bool(v)
+    return old
+
+
+def flags_from_env(env=None):
+    """For measurement tools: SS_FUSED_<NAME>=0|1 and SS_BNECK_C=16,32,.. from the (given) environment -> set_flags."""
+    env = _os.environ if env is None else env
+    kw = {n: env["SS_FUSED_" + n] != "0" for n in FLAG_NAMES if "SS_FUSED_" + n in env}
+    if "SS_BNECK_C" in env:
+        kw["BNECK_C"] = tuple(int(c) for c in env["SS_BNECK_C"].split(","))
+    return set_flags(**kw)
 
 ACT = {"none": 0, "relu": 1, "silu": 2, "sigmoid": 3}
 
@@ -162,7 +188,7 @@ def conv3x3(x, w_n9k, bias, stride=1, act="none", res=None, res_after=False, out
     return ret
 
 
-BNECK_C = tuple(int(c) for c in _os.environ.get("SS_BNECK_C", "16,32,64,128").split(","))     # A/B: channel counts that take the fused kernel
+BNECK_C = (16, 32, 64, 128)             # channel counts that take the fused bottleneck kernel (A/B: set_flags(BNECK_C=...))
 BNECK = _flag("BNECK")                  # a C2f bottleneck (3x3 + 3x3 + shortcut) in one launch, the intermediate in LDS
 
 
@@ -206,7 +232,7 @@ def conv_group(items):
 
 
 HEAD = _flag("HEAD")                    # a level of the v8 detect head (both branches, 3 layers each) in one launch, intermediates in LDS
-HEAD_TILE16 = _os.environ.get("SS_HEAD_TILE16", "0") == "1"           # A/B: 8 x 16 tiles at the stride-8 level
+HEAD_TILE16 = False                     # A/B: 8 x 16 tiles at the stride-8 level (measured neutral, r04)
 
 
 def head_level_ok(x, box_seq, cls_seq) -> bool:

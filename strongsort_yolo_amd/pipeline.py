@@ -289,7 +289,8 @@ class OverlappedPipeline(FramePipeline):
     """
 
     def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
-                 tracker_stream: bool = False, defer_track: bool = False, keep_net_outputs: bool = False, **kw):
+                 tracker_stream: bool = False, defer_track: bool = False, keep_net_outputs: bool = False, pack_crops: bool = True,
+                 assoc_gate: bool = True, track_priority: bool = True, **kw):
         kw = dict(kw)
         # keep_net_outputs: every buffer set keeps a reference to the head tensor and the embeddings its graphs produce
         # (b.head_out / b.emb_out: tensors of the graph's private pool, same address at every replay) even when the synthetic
@@ -308,9 +309,8 @@ class OverlappedPipeline(FramePipeline):
             self.graph_mode = "front"       # the per-frame tracker calls stay eager (partial last groups)
         self.Sv = self.S * self.F
         # packed ReID batches: the group's valid crops contiguous, the OSNet kernels skip the unused slots of the fixed batch
-        # (~28 of 32 slots per frame are used at configs[1]); SS_PACK_CROPS=0: A/B switch
-        import os as _os0
-        self.pack = bool(self.reid_half and self.run_nets and _os0.environ.get("SS_PACK_CROPS", "1") == "1")
+        # (~28 of 32 slots per frame are used at configs[1]); pack_crops=False: A/B switch
+        self.pack = bool(self.reid_half and self.run_nets and pack_crops)
         self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
@@ -340,9 +340,8 @@ class OverlappedPipeline(FramePipeline):
         self.n = len(st)
         # the last stage carries the tracker's short dependent launches and the association kernel: its stream gets high
         # priority, so their workgroups are dispatched ahead of the other stream's network kernels (measured at frame batch
-        # 32: association launch 61 -> 50 us beside the network kernels, 8640 -> 8790 frames/s; SS_TRACK_PRIORITY=0: A/B)
-        import os as _os
-        hi = _os.environ.get("SS_TRACK_PRIORITY", "1") == "1"
+        # 32: association launch 61 -> 50 us beside the network kernels, 8640 -> 8790 frames/s; track_priority=False: A/B)
+        hi = bool(track_priority)
         self.streams = [torch.cuda.Stream(self.dev, priority=(-1 if (hi and j == self.n - 1) else 0)) for j in range(self.n)]
         # tracker_stream=True gives the tracker (one-workgroup kernels, ~70 us a frame) a stream of its own next to the
         # last stage of the following group, with one more buffer set so that stage 0 does not wait for it.  Measured
@@ -361,7 +360,7 @@ class OverlappedPipeline(FramePipeline):
         # for ~40 us the association kernel has the chip to itself (alone: 39.8 us for 32 frames, beside the detector's first
         # layers: 61-65 us)
         self.assoc_ev = None
-        if self.defer and _os.environ.get("SS_ASSOC_GATE", "1") == "1":
+        if self.defer and assoc_gate:
             self.assoc_ev = torch.cuda.Event()
             self.assoc_ev.record(torch.cuda.current_stream(self.dev))
             self.eng.set_assoc_event(self.assoc_ev)

@@ -257,14 +257,15 @@ def test_detect_head_grouped_launches_equal_separate_launches(name, B):
     dev = torch.device("cuda", 0)
     m = nets.build_detector(name).to(dev).half().to(memory_format=torch.channels_last)
     x = torch.randn(B, 3, 384, 640, generator=torch.Generator().manual_seed(5)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        flag, fused.GROUP = fused.GROUP, False
-        try:
+    old = fused.set_flags(HEAD=False)                               # (k_head would take the head before the grouped form is asked)
+    try:
+        with torch.no_grad():
+            fused.set_flags(GROUP=False)
             ref = m(x)
-        finally:
-            fused.GROUP = flag
-        assert fused.GROUP
-        got = m(x)
+            fused.set_flags(GROUP=True)
+            got = m(x)
+    finally:
+        fused.set_flags(GROUP=True, **old)
     assert got.shape == ref.shape and torch.equal(got, ref)
     assert ref[:, 4:].float().max().item() > 0.0
 
@@ -404,11 +405,11 @@ def test_detector_with_head_level_launches_equals_grouped_launches():
     m = nets.build_detector("yolov8n").to(dev).half().to(memory_format=torch.channels_last)
     x = torch.randn(32, 3, 384, 640, generator=torch.Generator().manual_seed(7)).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        flag, fused.HEAD = fused.HEAD, False
+        old = fused.set_flags(HEAD=False)
         try:
             ref = m(x)
         finally:
-            fused.HEAD = flag
+            fused.set_flags(**old)
         assert fused.HEAD
         got = m(x)
     assert got.shape == ref.shape and torch.equal(got, ref) and ref[:, 4:].float().max().item() > 0.0

@@ -133,16 +133,15 @@ def test_two_streams_in_one_pipeline_equal_their_oracles():
     pipe.close()
 
 
-def test_packed_reid_batches_give_the_same_embeddings_and_tracks(monkeypatch):
+def test_packed_reid_batches_give_the_same_embeddings_and_tracks():
     """feat_source="reid": the group's valid crops packed to the front of the fixed ReID batch (OSNet kernels skip the rest,
     embeddings scattered back by offset) vs one slot range per frame: identical feature rows for the detections and identical
     tracker output."""
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
     res = {}
     for pack in ("1", "0"):
-        monkeypatch.setenv("SS_PACK_CROPS", pack)
         pipe = OverlappedPipeline("yolov8n", 1, (H, W), graph="front", det_source="synthetic", feat_source="reid",
-                                  n_stages=2, frame_batch=4, reid_split=2, reid_batch=32, defer_track=True)
+                                  n_stages=2, frame_batch=4, reid_split=2, reid_batch=32, defer_track=True, pack_crops=pack == "1")
         assert pipe.pack == (pack == "1")
         gs, items = _workload(pipe)
         rows, feats = [], []

@@ -3,6 +3,7 @@ milliseconds per replay.  A/B switches: SS_FUSED_<NAME>=0 (fused.py), SS_OP_OPTS
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd import nets, fused
+fused.flags_from_env()                                        # SS_FUSED_<NAME>=0|1, SS_BNECK_C=...
 for kv in os.environ.get("SS_OP_OPTS", "").split(","):          # e.g. SS_OP_OPTS=pw_splitk=0,osnet_chains=0
     if kv:
         fused.set_option(kv.split("=")[0], int(kv.split("=")[1]))
