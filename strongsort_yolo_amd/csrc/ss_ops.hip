@@ -309,6 +309,8 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
                 }
             }
     };
+    // (weights two chunks ahead of their LDS store, pixels one chunk ahead of their MFMAs: a chunk's matrix work is shorter than
+    //  the L2 latency of the next chunk's weights, r04)
     h8 wr[WV], wn[WV], b[KC / 32][PT], bn[KC / 32][PT];
     load_w(0, wr);
     load_b(0, b);
@@ -591,6 +593,12 @@ __device__ __forceinline__ void bn_conv(const _Float16* __restrict__ In, const i
             wr[j] = (i < CO * 8 && kk < K) ? *reinterpret_cast<const h8*>(w + (size_t)r * K + kk) : z8;
         }
     };
+    // weight slices are requested TWO slices ahead of their LDS store: a slice's matrix work (~0.2-0.3 us) is shorter than the L2
+    // latency of its successor's weights, with one slice of distance every iteration waited for them (r04: k_head / k_bneck
+    // spent ~0.8 us per 64-wide slice for 0.15 us of MFMAs)
+    // (measured and rejected, r04: requesting the weight slices TWO slices ahead of their LDS store — same box, same run: yolov8n on 32
+    //  frames 0.968-0.980 -> 0.971-0.988 ms with it here, 1.04-1.06 ms with it in k_pw's walk as well: the extra staging registers and
+    //  loads in flight cost more than the hidden L2 latency returns)
     h8 wr[WV], wn[WV];
     load_w(0, wr);
     int buf = 0;

@@ -231,7 +231,11 @@ def conv_group(items):
     return outs
 
 
-HEAD = _flag("HEAD")                    # a level of the v8 detect head (both branches, 3 layers each) in one launch, intermediates in LDS
+# a level of the v8 detect head (both branches, 3 layers each) in one launch, intermediates in LDS (csrc k_head): bit-identical to the
+# grouped launches and measured NEUTRAL (r04, same box: yolov8n on 32 frames 0.964-0.989 ms with it, 0.968-0.980 without; inside the two-stream
+# pipeline 10.5-10.9 k vs 10.95 k frames/s) — its 60-117 KB of LDS per workgroup leave one or two workgroups per CU.  Off by default;
+# set_flags(HEAD=True) / bench.py --fused HEAD=1 turns it on.
+HEAD = False
 HEAD_TILE16 = False                     # A/B: 8 x 16 tiles at the stride-8 level (measured neutral, r04)
 
 

@@ -379,7 +379,9 @@ def test_head_level_launch_is_bit_identical_to_its_six_layers(B, cin, H, W, nc, 
     det = det.to(dev, torch.float16)
     box, cls = det.cv2[lvl], det.cv3[lvl]
     x = torch.randn(B, cin, H, W).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    old_flags = fused.set_flags(HEAD=True)
     assert fused.head_level_ok(x, box, cls)
+    fused.set_flags(**old_flags)
     fused.set_option("pw_splitk", 0)
     try:
         refs = []
@@ -408,10 +410,10 @@ def test_detector_with_head_level_launches_equals_grouped_launches():
         old = fused.set_flags(HEAD=False)
         try:
             ref = m(x)
+            fused.set_flags(HEAD=True)
+            got = m(x)
         finally:
             fused.set_flags(**old)
-        assert fused.HEAD
-        got = m(x)
     assert got.shape == ref.shape and torch.equal(got, ref) and ref[:, 4:].float().max().item() > 0.0
 
 

@@ -38,9 +38,6 @@ for k, c in agg.items():
     gui = m.get("GRBM_GUI_ACTIVE", 0) / 8.0                         # summed over the 8 XCDs
     if gui > 0:
         e["mfma_busy_frac"] = round(m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (gui * 1024), 4)      # per-SIMD busy cycles / 1024 SIMDs
-        # NOT a clock reading: GUI-active cycles of the counter pass (kernels serialised, dispatch overhead included) over the
-        # kernel's duration in the separate trace pass; values above the 2.4 GHz peak clock come from that mismatch
-        e["gui_active_cycles_per_trace_us_div1000"] = round(gui / (e["avg_us"] * 1e3), 2) if e["avg_us"] else None
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         e["hbm_MB"] = round((m["FETCH_SIZE"] * 2 + m["WRITE_SIZE"]) * 1024 / 1e6, 2)            # FETCH_SIZE x2: gfx950 counts 64 of 128 B
         if e["avg_us"]: e["hbm_TBps"] = round(e["hbm_MB"] / e["avg_us"], 3)

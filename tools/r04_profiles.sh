@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-4 evidence run (GPU box): bench lines of every preset, rocprofv3 kernel stats + the k_assoc launches of the DEFAULT pipeline
+# command, in-kernel timeline, PMC of the association kernel (c2 / c3 / c5 tracker workloads, 1 and 32 streams; c4) and of the network kernels.
+out=$GRAFT_REPO_ROOT/gpurun_out/r04_prof; mkdir -p $out; cd $GRAFT_REPO_ROOT
+nproc > $out/nproc.txt
+( time timeout 900 python bench.py --steps 20 --warmup 5 > $out/r04_bench_c2_s1_driverargs.json 2>$out/bench_c2.err ) 2> $out/bench_c2_time.txt
+for p in c3 c5 c6 c1; do timeout 600 python bench.py --steps 20 --warmup 5 --preset $p --no-cpu-baseline --no-reid-check > $out/r04_bench_${p}_s1.json 2>$out/bench_$p.err; done
+timeout 900 python bench.py --steps 10 --warmup 3 --preset c4 --no-cpu-baseline --no-reid-check > $out/r04_bench_c4_s1.json 2>$out/bench_c4.err
+# kernel stats + per-launch k_assoc durations of the default command (no extra legs: the trace stays the pipeline's own)
+cd /tmp && export TMPDIR=/tmp
+rm -rf $out/prof_bench; mkdir -p $out/prof_bench
+(cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bench -o run -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batched --no-api-path --no-reid-check > $out/prof_bench/cmd.log 2>&1)
+cd $GRAFT_REPO_ROOT
+grep '"metric"' $out/prof_bench/cmd.log | tail -1 > $out/r04_rocprofv3_bench_line_c2_s1_driverargs.json
+f=$(find $out/prof_bench -name "*kernel_stats.csv" | head -1); cp "$f" $out/r04_rocprofv3_kernel_stats_c2_s1_driverargs.csv
+t=$(find $out/prof_bench -name "*kernel_trace.csv" | head -1)
+python tools/assoc_trace_filter.py "$t" 20 > $out/r04_rocprofv3_kernel_trace_k_assoc_pipeline_c2_s1.csv
+python tools/detector_sequence.py "$t" > $out/r04_detector_sequence_32frames.txt 2>&1
+python tools/osnet_sequence.py "$t" > $out/r04_osnet_sequence.txt 2>&1
+find $out/prof_bench -name "*.csv" -size +2M -delete
+SS_TL_DUMP=12 timeout 120 python tools/assoc_timeline.py 1 32 > $out/r04_assoc_timeline.txt 2>&1
+# PMC of the association kernel
+bash tools/pmc_assoc.sh r04_c2_s1_f32 1 32 > $out/pmc_assoc_c2_s1.txt 2>&1
+bash tools/pmc_assoc.sh r04_c2_b32_f32 32 32 > $out/pmc_assoc_c2_b32.txt 2>&1
+bash tools/pmc_assoc.sh r04_c4_s1_f32 1 32 k_assoc 100 1920 1080 > $out/pmc_assoc_c4_s1.txt 2>&1
+bash tools/pmc_assoc.sh r04_c4_b8_f32 8 32 k_assoc 100 1920 1080 > $out/pmc_assoc_c4_b8.txt 2>&1
+# PMC of the network kernels (eager launches, 32 frames / 1024 crops)
+PMC_GROUPS=0,3,4 bash tools/pmc_run.sh r04_nets python tools/nets_eager.py 4 32 > $out/pmc_nets.txt 2>&1
+for d in pmc_r04_c2_s1_f32 pmc_r04_c2_b32_f32 pmc_r04_c4_s1_f32 pmc_r04_c4_b8_f32 pmc_r04_nets; do cp $GRAFT_REPO_ROOT/gpurun_out/$d/summary.json $out/$d.json 2>/dev/null; done
+tail -3 $out/r04_rocprofv3_kernel_trace_k_assoc_pipeline_c2_s1.csv; cat $out/bench_c2_time.txt
+for f in $out/r04_bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d["roofline"]
+    print(sys.argv[1].split("/")[-1], d["value"], "ms/step", d["ms_per_step"], "assoc us", r["mean_launch_us"], r["frac"], r["bound"], "exact", d["frames_bit_exact"])
+except Exception as e: print(sys.argv[1], "ERR", e)
+PY
+done
