@@ -9,6 +9,7 @@
 
 // launchers implemented in ss_track.hip / ss_front.hip
 size_t ss_lsap_lds_bytes();
+size_t ss_frame_lds_bytes(int, int, int);
 void ss_launch_group_head(const SSDev&, const SSParams&, hipStream_t, hipEvent_t, hipEvent_t, hipEvent_t);
 void ss_launch_group_chain(const SSDev&, const SSParams&, hipStream_t);
 void ss_launch_normalize(const float*, int, float*, hipStream_t);
@@ -146,6 +147,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     memset(&d, 0, sizeof d);
     d.S = (int)S;
     d.budget = cfg->nn_budget;
+    d.cap_cost = SS_COST_CAP; d.cap_t = SS_MAXT; d.cap_d = SS_MAXD;
     int rc = SS_OK;
 #define A(field, n) if (rc == SS_OK) rc = dalloc(c, &d.field, (n))
     A(n_tracks, S); A(next_id, S); A(frame, S); A(err, S); A(order, S * T);
@@ -159,7 +161,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     A(M, S * T * FM * D); A(pl, S * SS_PLMAX); A(n_pl, S); A(pf, S * (FM + 1));
     d.items_cap = (int)(S * 4096);        // records per XCD list (<= F * max(cos_grid / (S F), pairs * ceil(tiles / SS_RECT)) per stream, spread over 8 lists)
     A(items, 8 * (size_t)d.items_cap * SS_RECI4); A(n_items, 8);
-    A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(tstamp, 4); A(timeline, 4096 * 16);
+    A(post, S * T); A(n_post, S); A(rowlist, S * T); A(n_rows, S); A(cost_spill, S * T * D); A(frame_scratch, S * (T * 18 + D * 8)); A(tstamp, 4); A(timeline, 4096 * 16);
     if (cfg->debug) {
         A(dbg_cos, FM * S * T * D); A(dbg_maha, FM * S * T * D); A(dbg_cost_a, FM * S * T * D); A(dbg_cost_b, FM * S * T * D);
         A(dbg_gated, FM * S * T * D); A(dbg_lists, FM * S * 4 * T); A(dbg_counts, FM * S * 8);
@@ -471,6 +473,11 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     else if (n == "nms_fused") ss_nms_fused = value != 0;       // process-wide: one workgroup per image after the filter (1, default) or sort / mask / scan launches
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
+    else if (n == "frame_caps") {
+        // value = tracks and detections k_frame keeps in LDS (cost entries = value^2): 0 restores the maxima (256 tracks, 128 detections, 12288 entries)
+        if (value != 0 && (value < 16 || value > 128 || value % 16)) return fail(c, SS_ERR_INVALID, "frame_caps: 0 or a multiple of 16 in 16..128");
+        c->dev.cap_t = value ? value : SS_MAXT; c->dev.cap_d = value ? value : SS_MAXD; c->dev.cap_cost = value ? value * value : SS_COST_CAP;
+    }
     else if (n == "track_graph") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "track_graph: 0 or 1"); c->track_graph = value; }
     else if (n == "assoc_xcd_map") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "assoc_xcd_map: 0 or 1"); c->xcd_map = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");

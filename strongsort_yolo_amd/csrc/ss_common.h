@@ -99,6 +99,8 @@ struct SSDev {
     int* n_rows;                // [S]
     const double* cmc;          // [F][S][8] camera-motion warps of the group (ss_track_set_cmc) or NULL
     double* cost_spill;         // [S][MAXT*MAXD] cost matrices that do not fit the LDS
+    double* frame_scratch;      // [S][MAXT*18 + MAXD*8] k_frame's per-track / per-detection f64 work arrays when they exceed cap_t / cap_d
+    int cap_cost, cap_t, cap_d; // what k_frame keeps in LDS: cost entries, tracks, detections (ss_set_option "frame_caps")
     unsigned long long* tstamp; // [4] in-kernel timing of the association kernel: min start, max end (100 MHz), sum, count
     int ts_enable;              // 1: first-start / last-end stamps; 2: + per-workgroup timeline
     long long* timeline;        // [4096 workgroups][16] stamps of each workgroup's first item (profiling aid)

@@ -1046,14 +1046,22 @@ struct FrameLds {
     LsapLds L;
     int *matchdet, *dettrk, *asg, *cand, *cols, *neworder, *freelist, *conf_l, *slot_l, *tsu_l, *used, *rcnt, *ccnt, *rsel, *wtot;
 };
-__device__ inline FrameLds carve_frame(char* p)
+// The f64 work areas are sized by the context (frame_caps: cost entries / tracks / detections kept in LDS); a frame with more
+// tracks or detections than that takes the same arrays from the stream's global scratch (same arithmetic, L1 / L2 latency).
+// Why it matters: with everything at its maximum the kernel asked for 156 KB — a whole CU's LDS — so its single workgroup could
+// only start on a completely empty CU and, on the high-priority stream, held the other stream's workgroups back while it
+// waited: the tracker chain ran almost serially with the networks' kernels instead of beside them (r04 trace: two kernels
+// in flight 11 % of the time).
+__device__ inline FrameLds carve_frame(char* p, const SSDev& dev, int s, int nT, int D)
 {
     FrameLds m;
-    m.cost = (double*)p; p += (size_t)SS_COST_CAP * 8;
-    m.chol = (double*)p; p += SS_MAXT * 14 * 8;
-    m.ttl = (double*)p; p += SS_MAXT * 4 * 8;
-    m.zs = (double*)p; p += SS_MAXD * 4 * 8;
-    m.dtl = (double*)p; p += SS_MAXD * 4 * 8;
+    m.cost = (double*)p; p += (size_t)dev.cap_cost * 8;
+    const bool tl = nT <= dev.cap_t, dl = D <= dev.cap_d;
+    double* g = dev.frame_scratch + (size_t)s * (SS_MAXT * 18 + SS_MAXD * 8);
+    m.chol = tl ? (double*)p : g; p += (size_t)dev.cap_t * 14 * 8;
+    m.ttl = tl ? (double*)p : g + SS_MAXT * 14; p += (size_t)dev.cap_t * 4 * 8;
+    m.zs = dl ? (double*)p : g + SS_MAXT * 18; p += (size_t)dev.cap_d * 4 * 8;
+    m.dtl = dl ? (double*)p : g + SS_MAXT * 18 + SS_MAXD * 4; p += (size_t)dev.cap_d * 4 * 8;
     m.L = carve_lsap(p);
     int** a[] = { &m.matchdet, &m.dettrk, &m.asg, &m.cand, &m.cols, &m.neworder, &m.freelist, &m.conf_l, &m.slot_l, &m.tsu_l, &m.used,
                   &m.rcnt, &m.ccnt, &m.rsel };
@@ -1061,7 +1069,7 @@ __device__ inline FrameLds carve_frame(char* p)
     m.wtot = (int*)p; p += 64;
     return m;
 }
-size_t ss_frame_lds_bytes() { return (size_t)SS_COST_CAP * 8 + SS_MAXT * 14 * 8 + SS_MAXT * 4 * 8 + 2 * SS_MAXD * 4 * 8 + 15 * 256 * 4 + 64; }
+size_t ss_frame_lds_bytes(int cap_cost, int cap_t, int cap_d) { return (size_t)cap_cost * 8 + (size_t)cap_t * 18 * 8 + 2 * (size_t)cap_d * 4 * 8 + 15 * 256 * 4 + 64; }
 
 // Assignment of one stage.  n_rows x n_cols is the matrix in its natural orientation (rows = tracks); cost is stored
 // [nr][nc] after the transposition rule (rows = the smaller side).  Result: m.asg[row] = column or -1.
@@ -1095,11 +1103,11 @@ __device__ inline int frame_assign(int n_rows, int n_cols, bool big, const doubl
 __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FrameLds m = carve_frame(smem);
     const int s = blockIdx.x, tid = threadIdx.x, S = dev.S;
     const size_t sb = (size_t)s * SS_MAXT;
     const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;        // (frame, stream) and its detection base
     const int nT = dev.n_tracks[s], D = min(dev.n_dets[fs], SS_MAXD);
+    const FrameLds m = carve_frame(smem, dev, s, nT, D);
     if (s == 0 && tid == 0) {
 #pragma unroll
         for (int x = 0; x < 8; ++x) dev.n_items[x] = 0;              // re-arm the work lists for the next group
@@ -1167,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     if (nC > 0 && D > 0) {
         const bool tr = D < nC;
         const int nr = tr ? D : nC, nc = tr ? nC : D;
-        const bool big = nr * nc > SS_COST_CAP;
+        const bool big = nr * nc > dev.cap_cost;
         double* cost = big ? spill : m.cost;
         for (int idx = tid; idx < nC * D; idx += 256) {
             const int r = idx / D, d = idx % D;
@@ -1225,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     if (nCand > 0 && nCols > 0) {
         const bool tr = nCols < nCand;
         const int nr = tr ? nCols : nCand, nc = tr ? nCand : nCols;
-        const bool big = nr * nc > SS_COST_CAP;
+        const bool big = nr * nc > dev.cap_cost;
         double* cost = big ? spill : m.cost;
         for (int idx = tid; idx < nCand * nCols; idx += 256) {
             const int r = idx / nCols, c = idx % nCols;
@@ -1557,7 +1565,7 @@ size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 7 * 2048 + 64; }
 extern "C" void ss_step_kernel_attr()
 {
     // a failure here surfaces as a launch error on first use (checked with hipGetLastError after every launch)
-    (void)hipFuncSetAttribute((const void*)k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_frame_lds_bytes());
+    (void)hipFuncSetAttribute((const void*)k_frame, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ss_frame_lds_bytes(SS_COST_CAP, SS_MAXT, SS_MAXD));
     for (const void* k : { (const void*)k_assoc<false, 0>, (const void*)k_assoc<true, 0>, (const void*)k_assoc<false, 1>, (const void*)k_assoc<true, 1>,
                            (const void*)k_assoc<false, 2>, (const void*)k_assoc<true, 2>, (const void*)k_assoc<false, 4>, (const void*)k_assoc<true, 4>,
                            (const void*)k_assoc<false, 5>, (const void*)k_assoc<true, 5> })
@@ -1593,7 +1601,7 @@ void ss_launch_group_head(const SSDev& dev, const SSParams& prm, hipStream_t st,
 void ss_launch_group_chain(const SSDev& dev, const SSParams& prm, hipStream_t st)
 {
     for (int f = 0; f < dev.F; ++f) {
-        hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(), st, dev, prm, f);
+        hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(dev.cap_cost, dev.cap_t, dev.cap_d), st, dev, prm, f);
         hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);
         if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(64, dev.S), dim3(512), 0, st, dev, f);
     }

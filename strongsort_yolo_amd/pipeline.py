@@ -290,12 +290,13 @@ class OverlappedPipeline(FramePipeline):
 
     def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
                  tracker_stream: bool = False, defer_track: bool = False, keep_net_outputs: bool = False, pack_crops: bool = True,
-                 assoc_gate: bool = True, track_priority: bool = True, **kw):
+                 assoc_gate: bool = True, track_priority: bool = True, skip_tracker: bool = False, **kw):
         kw = dict(kw)
         # keep_net_outputs: every buffer set keeps a reference to the head tensor and the embeddings its graphs produce
         # (b.head_out / b.emb_out: tensors of the graph's private pool, same address at every replay) even when the synthetic
         # workload does not consume them — bench.py compares them with an eager re-run after the timed region
         self.keep_net_outputs = bool(keep_net_outputs)
+        self.skip_tracker = bool(skip_tracker)      # MEASUREMENT ONLY: no tracker calls (rows stay empty) — what the stateless stages alone cost
         kw["graph"] = kw.get("graph", "front")
         if kw["graph"] == "none":
             raise ValueError("OverlappedPipeline needs graph='front' or 'all'")
@@ -348,7 +349,7 @@ class OverlappedPipeline(FramePipeline):
         # at configs[1], same box, frame batch 8: 3110 frames/s with it vs 3280 without — a third concurrent launch
         # chain costs more in the dispatcher than the queue stall it removes (same finding as the 4-stage split) — so
         # it is off by default.
-        self.sT = torch.cuda.Stream(self.dev) if (tracker_stream and self.graph_mode == "front") else None
+        self.sT = torch.cuda.Stream(self.dev, priority=-1 if hi else 0) if (tracker_stream and self.graph_mode == "front") else None
         # defer_track: the tracker call of group k is enqueued on the last stage's stream AFTER that stream has waited for
         # stage 0 of group k+1 — it then runs beside the START of the other stream's next group (letterbox, the detector's
         # short-lived workgroups) instead of beside whatever that stream happens to be in.  The association kernel needs
@@ -495,7 +496,7 @@ class OverlappedPipeline(FramePipeline):
         e = self.eng
         nv = self.F if n_valid is None else n_valid
         G, S = self.eng.max_group_frames, self.S             # frames per library call (SS_FMAX)
-        for f0 in range(0, nv, G):
+        for f0 in range(0, nv if not self.skip_tracker else 0, G):
             n, v0, v1 = min(G, nv - f0), f0 * S, min(nv, f0 + G) * S
             if self.cmc:
                 e.set_cmc(b.warps[f0:f0 + n])

@@ -171,6 +171,14 @@ def test_assoc_operand_staging_variants(stage, S, F, frames, ids):
     _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + s), frames, F=F, wh=wh, opts={"assoc_stage": stage % 100, "assoc_xcd_map": stage // 100})
 
 
+@pytest.mark.parametrize("caps,ids,wh", [(32, 30, (1280, 720)), (16, 30, (1280, 720)), (64, 100, (1920, 1080)), (0, 100, (1920, 1080)), (32, 12, (640, 480))])
+def test_frame_kernel_work_areas_in_lds_or_global_scratch(caps, ids, wh):
+    """`frame_caps`: k_frame keeps its f64 work arrays (Cholesky factors, predicted boxes, detection vectors, cost matrix) in LDS up to
+    that many tracks / detections and takes them from the stream's global scratch beyond — 30 and 100 identities against caps of 16,
+    32, 64 and the maxima: tracks over, detections over, cost matrix spilled, everything inside; every frame and intermediate equal."""
+    _run_streams(2, lambda s: ids + 2 * s, 45, F=5, wh=wh, opts={"frame_caps": caps})
+
+
 @pytest.mark.parametrize("graph", [1, 0])
 def test_chain_graph_replay_equals_oracle(graph):
     """The group's per-frame chain replayed as a captured HIP graph (`track_graph`, fixed caller buffers: captured at the second
