@@ -61,7 +61,8 @@ CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4, "c6": None}
 # 11 232 / 11 244, 4: 11 701 / 11 531, 5: 11 720 / 11 785, 6: 11 509 / 11 014 frames/s.  The larger detectors keep the earlier cut (30 steps, one
 # run each): c3 cut 2: 7 981, cut 5: 7 938; c5 (pose head) cut 2: 9 267, cut 5: 8 446; c4 (yolov7: the detector is the long stage) was only measured at 2
 REID_SPLIT = {"c1": 2, "c2": 5, "c3": 2, "c4": 2, "c5": 2, "c6": 2}
-PMC_FILE = "r03_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by preset / streams / frames (tools/pmc_assoc.sh)
+PMC_FILE = "r04_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by tracker workload / streams / frames (tools/pmc_assoc.sh)
+PMC_WORKLOAD = {"c1": None, "c2": "c2", "c3": "c2", "c5": "c2", "c6": "c2", "c4": "c4"}   # presets that differ only in the detector share a tracker workload
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
 
@@ -292,7 +293,7 @@ def batched_association(cfg, n_streams=32, n_ids=30, W=1280, H=720, frames=152, 
     pmc = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(f"{preset}_b{n_streams}_f{FB}", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(f"{PMC_WORKLOAD.get(preset)}_b{n_streams}_f{FB}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     return {"kernel": "k_assoc", "streams_per_launch": n_streams, "frames_per_launch": FB, "identities_per_stream": n_ids, "frame": f"{W}x{H}",
@@ -790,7 +791,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
-    assoc_each_us = np.sort(pipe.eng.assoc_timing_values().astype(np.float64) * 1e3)
+    assoc_order_us = pipe.eng.assoc_timing_values().astype(np.float64) * 1e3         # in launch order
+    assoc_each_us = np.sort(assoc_order_us)
     assoc_ik_us, assoc_ik_n = pipe.eng.assoc_inkernel_timing(False)
     # per-step durations inside the timed region: time between the completion marks of consecutive frame groups
     step_ms = None
@@ -831,7 +833,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", PMC_FILE)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(f"{args.preset}_s{S}_f{int(round(frames_launch))}", {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(pmc)).get(f"{PMC_WORKLOAD.get(args.preset)}_s{S}_f{int(round(frames_launch))}", {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         # The bound is read off the data: the kernel reads a gallery once per frame GROUP, so its HBM traffic is a fraction of the
@@ -857,13 +859,15 @@ def main():
                     "achieved": round(ach_f if fp32_bound else ach_b, 2), "peak": 157.3 if fp32_bound else 8000.0,
                     "unit": "TFLOP/s" if fp32_bound else "GB/s",
                     "frac": round(ach_f / 157.3 if fp32_bound else ach_b / 8000.0, 4), "traffic": traffic,
-                    "traffic_source": f"profiles/{PMC_FILE} (separate rocprofv3 --pmc passes of the same workload; not measured in this run)" if traffic else None,
+                    "traffic_source": f"profiles/{PMC_FILE} entry {PMC_WORKLOAD.get(args.preset)}_s{S}_f{int(round(frames_launch))} (separate rocprofv3 --pmc passes over the tracker-only launch loop of this tracker workload; not measured in this run)" if traffic else None,
                     "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
                     "hbm_GBps_measured_traffic": round(traffic / t_ev / 1e9, 1) if traffic else None,
                     "frames_per_launch": round(frames_launch, 2), "algorithmic_bytes_per_frame": int(bytes_frame),
                     "algorithmic_bytes_per_launch": int(alg_bytes), "flops_per_launch": int(flops),
                     "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n,
                     "launch_us_distribution": {"p50": pct(assoc_each_us, 50), "p95": pct(assoc_each_us, 95), "min": pct(assoc_each_us, 0), "max": pct(assoc_each_us, 100)},
+                    "launch_us_in_order": [round(float(v), 1) for v in assoc_order_us[:64]],
+                    "frac_at_median_launch": (round((flops / (np.median(assoc_order_us) * 1e-6) / 1e12 / 157.3) if fp32_bound else (alg_bytes / (np.median(assoc_order_us) * 1e-6) / 1e9 / 8000.0), 4) if len(assoc_order_us) else None),
                     "timing": "HIP start/stop events on the kernel's own dispatches inside the timed region",
                     "hbm_equivalent": {"GBps": round(ach_b, 1), "frac_of_8TBps": round(ach_b / 8000.0, 4),
                                        "note": "SURVEY §8(d) algorithmic bytes x frames per launch / launch time: what a frame-by-frame implementation would have to move"},

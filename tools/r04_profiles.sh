@@ -3,6 +3,7 @@
 # command, in-kernel timeline, PMC of the association kernel (c2 / c3 / c5 tracker workloads, 1 and 32 streams; c4) and of the network kernels.
 out=$GRAFT_REPO_ROOT/gpurun_out/r04_prof; mkdir -p $out; cd $GRAFT_REPO_ROOT
 nproc > $out/nproc.txt
+( time timeout 1500 python -m pytest tests/ -q -m gpu > $out/pytest_gpu_full.txt 2>&1 ) 2> $out/pytest_time.txt; tail -2 $out/pytest_gpu_full.txt
 ( time timeout 900 python bench.py --steps 20 --warmup 5 > $out/r04_bench_c2_s1_driverargs.json 2>$out/bench_c2.err ) 2> $out/bench_c2_time.txt
 for p in c3 c5 c6 c1; do timeout 600 python bench.py --steps 20 --warmup 5 --preset $p --no-cpu-baseline --no-reid-check > $out/r04_bench_${p}_s1.json 2>$out/bench_$p.err; done
 timeout 900 python bench.py --steps 10 --warmup 3 --preset c4 --no-cpu-baseline --no-reid-check > $out/r04_bench_c4_s1.json 2>$out/bench_c4.err
@@ -17,6 +18,7 @@ t=$(find $out/prof_bench -name "*kernel_trace.csv" | head -1)
 python tools/assoc_trace_filter.py "$t" 20 > $out/r04_rocprofv3_kernel_trace_k_assoc_pipeline_c2_s1.csv
 python tools/detector_sequence.py "$t" > $out/r04_detector_sequence_32frames.txt 2>&1
 python tools/osnet_sequence.py "$t" > $out/r04_osnet_sequence.txt 2>&1
+python tools/trace_busy.py "$t" 16 > $out/r04_gpu_busy_c2_s1.txt 2>&1
 find $out/prof_bench -name "*.csv" -size +2M -delete
 SS_TL_DUMP=12 timeout 120 python tools/assoc_timeline.py 1 32 > $out/r04_assoc_timeline.txt 2>&1
 # PMC of the association kernel
