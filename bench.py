@@ -824,6 +824,18 @@ def main():
     bytes_frame = sum(Tc * B * 512 * 4 + Dm * 512 * 4 + Tc * 576 + Dm * 32 + Tc * Dm * 5 for Tc, B in T_conf)
     flops_frame = sum(2 * Tc * B * Dm * 512 + 60 * Tc * Dm for Tc, B in T_conf)
     roofline = None
+    # Dispatch stalls: about one launch in 150 shows ~850 us between its HIP start / stop events while the kernel's own stamps and the
+    # rocprofv3 dispatch record of such launches read the usual ~35 us (profiles/r04_*; the gap is about one tracker chain long: the
+    # runtime waiting, between the start marker and the kernel packet, for earlier work to retire).  They say nothing about the
+    # kernel, so `achieved` uses the launches within 2x the median; every excluded duration is listed, the all-launch mean stays
+    # in the line (`mean_launch_us_all`).
+    assoc_ms_all, outliers = assoc_ms, []
+    if len(assoc_order_us):
+        med = float(np.median(assoc_order_us))
+        keep = assoc_order_us <= 2.0 * med
+        outliers = [round(float(v), 1) for v in assoc_order_us[~keep]]
+        if keep.any():
+            assoc_ms = float(assoc_order_us[keep].mean()) * 1e-3
     if assoc_n > 0 and assoc_ms > 0:
         frames_launch = KF / assoc_n                      # frames of a stream per association launch
         alg_bytes, flops = bytes_frame * frames_launch, flops_frame * frames_launch
@@ -864,7 +876,8 @@ def main():
                     "hbm_GBps_measured_traffic": round(traffic / t_ev / 1e9, 1) if traffic else None,
                     "frames_per_launch": round(frames_launch, 2), "algorithmic_bytes_per_frame": int(bytes_frame),
                     "algorithmic_bytes_per_launch": int(alg_bytes), "flops_per_launch": int(flops),
-                    "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n,
+                    "mean_launch_us": round(assoc_ms * 1e3, 2), "launches_timed": assoc_n, "mean_launch_us_all": round(assoc_ms_all * 1e3, 2),
+                    "launches_excluded_as_dispatch_stalls": outliers, "exclusion_rule": "HIP-event duration > 2 x the median of the run's launches",
                     "launch_us_distribution": {"p50": pct(assoc_each_us, 50), "p95": pct(assoc_each_us, 95), "min": pct(assoc_each_us, 0), "max": pct(assoc_each_us, 100)},
                     "launch_us_in_order": [round(float(v), 1) for v in assoc_order_us[:64]],
                     "frac_at_median_launch": (round((flops / (np.median(assoc_order_us) * 1e-6) / 1e12 / 157.3) if fp32_bound else (alg_bytes / (np.median(assoc_order_us) * 1e-6) / 1e9 / 8000.0), 4) if len(assoc_order_us) else None),
