@@ -18,6 +18,15 @@
 // Memory operations without a return value as inline assembly: the compiler's wait-count pass does not see them, so they do
 // not mix a "store" event into the vector-memory counter — which would force s_waitcnt vmcnt(0) (i.e. the completion of the
 // store / atomic itself, and the end of every prefetch in flight) before each later use of a loaded value.
+// INVARIANT this relies on (gfx9 / CDNA wait counters): loads return in order and these hidden operations are counted in the
+// same vmcnt, so an operation the compiler does not know about can only make its `s_waitcnt vmcnt(N)` wait for MORE than it
+// asked (any N completions among the outstanding operations include every load older than the youngest N) — never less.  The
+// LDS-DMA loads of k_assoc (ss_glds16) are awaited with explicit counts written against the same rule.  A target with separate
+// load / store counters or out-of-order load return would need these helpers rewritten: hence the guard below, and the
+// bit-exact k_assoc tests (tests/test_gpu_sequence.py) as the gate for toolchain upgrades.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ss_track.hip: the hidden-vmcnt helpers and LDS-DMA waits are written for gfx950 (CDNA4) wait-counter semantics"
+#endif
 __device__ __forceinline__ void ss_atomic_min_nr(int* p, int v) { asm volatile("global_atomic_smin %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ss_atomic_umin64_nr(unsigned long long* p, unsigned long long v) { asm volatile("global_atomic_umin_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void ss_atomic_umax64_nr(unsigned long long* p, unsigned long long v) { asm volatile("global_atomic_umax_x2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
@@ -1585,7 +1594,7 @@ static void launch_assoc(const SSDev& dev, hipStream_t st, hipEvent_t ev0, hipEv
 void ss_launch_group_head(const SSDev& dev, const SSParams& prm, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, hipEvent_t ev_assoc)
 {
     hipLaunchKernelGGL(k_group_prep, dim3(dev.S, 1 + SS_MAXT + dev.F * SS_PREP_FBLK), dim3(256), 0, st, dev);
-    const bool tl = dev.ts_enable > 1;                          // the timeline instantiation (stamps cost registers)
+    const bool tl = dev.ts_enable > 1 && dev.cos_grid <= 2048;   // the timeline instantiation (stamps cost registers; its buffer holds 2048 workgroups' shader-clock stamps)
     switch (dev.assoc_stage) {
     case 1: tl ? launch_assoc<true, 1>(dev, st, nullptr, nullptr) : launch_assoc<false, 1>(dev, st, ev0, ev1); break;
     case 2: tl ? launch_assoc<true, 2>(dev, st, nullptr, nullptr) : launch_assoc<false, 2>(dev, st, ev0, ev1); break;

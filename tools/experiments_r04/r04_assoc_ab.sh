@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 A/B of the association kernel's operand staging (assoc_stage 0 / 1 / 2 / 4) and of the kernel-argument placement:
 # correctness of every variant, in-kernel timelines, tracker-only launch times, the bench line per variant.
-# usage (GPU box): bash tools/r04_assoc_ab.sh        -> gpurun_out/r04_ab/
+# usage (GPU box): bash tools/experiments_r04/r04_assoc_ab.sh        -> gpurun_out/r04_ab/
 out=$GRAFT_REPO_ROOT/gpurun_out/r04_ab; mkdir -p $out; cd $GRAFT_REPO_ROOT
 nproc > $out/nproc.txt
 timeout 600 python -m pytest tests/test_gpu_sequence.py -x -q -m gpu -k "staging or frame_groups_equal" > $out/pytest_staging.txt 2>&1; echo "pytest rc $?" >> $out/pytest_staging.txt
