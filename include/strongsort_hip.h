@@ -295,7 +295,7 @@ int ss_op_v8_decode_f16(void* stream, const void* const* d_box, const void* cons
 int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
                         int N, int H, int W, int C, int act);
 /* OSNet LightConv3x3 in one pass: y = relu(dw3x3(pw1x1(x)) + bias); w1 [C][C] (out, in), w9 [9][C], C in
- * {16,24,32}, W % 8 == 0, 18*(W+2)*C*2 <= 65536 (the band lives in LDS; SS_ERR_INVALID otherwise). */
+ * {16,24,32}, W % 8 == 0, 18*(W+2)*PS*2 <= 65536 with PS = C rounded up to 16 (the band lives in LDS; SS_ERR_INVALID otherwise). */
 int ss_op_lightconv_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
                         void* d_y, int N, int H, int W, int C);
 /* The detector's first convolution: 3x3 / stride 2 / pad 1, 3 -> Cout in {16, 32, 48} channels, + bias + activation on
@@ -321,13 +321,19 @@ int ss_op_osnet_stem_f16(void* stream, const void* d_x, const void* d_w_prep, co
                          int W, const void* d_w1 /*[16][16] or NULL*/, const void* d_b1, void* d_y1);
 /* The four LightConv3x3 chains of an OSNet block (1..4 layers deep, same input) in one launch; the intermediates stay in
  * registers (16- / 32-wide images: a wave streams the rows of a band through the layers) or in LDS:
- * d_w1 [10][C][C], d_w9 [10][9][C], d_bias [10][C] = the layers of the 1-, 2-, 3-, 4-deep chain in that order;
- * d_ys[4] the chain outputs [N][H][W][C]; d_psum [4][N][bands][C] float = per-band channel sums of each output
+ * d_w1 [10][C][C] = the pointwise weights of the layers of the 1-, 2-, 3-, 4-deep chain in that order; d_dwtab = their depthwise
+ * taps and biases as the kernels' matrix-core operand table (ss_op_dwtab_f16 over the same ten layers, built once per set of
+ * weights); d_ys[4] the chain outputs [N][H][W][C]; d_psum [4][N][bands][C] float = per-band channel sums of each output
  * (for ss_op_gate_apply_f16 / ss_op_osnet_tail_f16), bands = ss_op_osnet_streams_bands(N, H, W, C).  C in {16,24,32},
- * W % 8 == 0, 24*(2W+2)*C*2 <= 65536. */
+ * W % 8 == 0, 24*(2W+2)*PS*2 <= 65536 with PS = C rounded up to 16. */
 int ss_op_osnet_streams_bands(int N, int H, int W, int C);
-int ss_op_osnet_streams_f16(void* stream, const void* d_x, const void* d_w1, const void* d_w9, const void* d_bias,
+int ss_op_osnet_streams_f16(void* stream, const void* d_x, const void* d_w1, const void* d_dwtab,
                             void* const* d_ys, float* d_psum, int N, int H, int W, int C);
+/* The depthwise 3x3 taps d_w9 [layers][9][C] (tap-major) and biases d_bias [layers][C] of LightConv layers as the operand table of
+ * the matrix-core depthwise (csrc/ss_ops.hip DwDiag / DwTab: per layer and 16 channels six diagonal operands of 17 x 16 bytes
+ * + the bias in fp32) -> d_out, ss_op_dwtab_bytes(layers, C) bytes.  C in {16, 24, 32}. */
+long long ss_op_dwtab_bytes(int layers, int C);
+int ss_op_dwtab_f16(void* stream, const void* d_w9, const void* d_bias, int layers, int C, void* d_out);
 /* Aggregation gate with the channel means given as `parts` partial sums per (stream, image) times `scale`. */
 int ss_op_gate_apply_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
                          const void* d_w2, const void* d_b2, const float* d_sums, int parts, float scale, void* d_out,

@@ -1150,6 +1150,158 @@ __global__ __launch_bounds__(256) void k_conv0(const __half* __restrict__ x, con
 // registers, same fmaf order as k_dw3x3).  HBM traffic = read x once (+2/TH halo) + write y once.
 #define LC_TH 16
 
+// The depthwise 3x3 of a LightConv on the matrix cores.  v_fma_mix_f32 / DPP / conversions issue at one wave-instruction per
+// ~4.4 cycles per SIMD on gfx950 (tools/probe_valu.hip), and the 36 multiply-adds per (pixel, 4 channels) of the vector form
+// were 55 % of the instructions of k_osnet_chains (190 us per stage-1 launch, VALU-issue bound, matrix cores 5 % busy).  A
+// depthwise tap is a diagonal [16 x 16] matrix over the channels, so two taps are one v_mfma_f32_16x16x32_f16: lane (q, n)
+// of the B operand holds k-slots 8q..8q+7 = (tap a, channels 4q..4q+3 of pixel n), (tap b, the same channels) — exactly the
+// two packed registers the pointwise MFMA's output layout leaves in that lane — and lane (q, m) of the A operand holds row
+// m = output channel: w_a[m] at slot (m & 3), w_b[m] at slot 4 + (m & 3) when q == m >> 2, zeros elsewhere.  D comes out as
+// channels 4q..4q+3 of pixel n again: the next layer's B operand after the rounding.
+// ONE accumulation order for every kernel form (k_lightconv, k_osnet_streams, k_osnet_chains — their outputs are compared
+// bit for bit): accumulator = bias (fp32), then for ky = 0, 1, 2 (input rows y-1, y, y+1):
+//     acc = MFMA(A1[ky], (left, centre), acc)        taps (ky, 0), (ky, 1)
+//     acc = MFMA(A2[ky], (centre, right), acc)       taps  -  (zero weight on the centre), (ky, 2)
+// (left, centre, right) are three consecutive register pairs, so both B operands are windows of them.  (The 16-deep
+// v_mfma_f32_16x16x16_f16 for the single tap would halve A2's registers, but accumulating it onto the 32-deep form's result
+// gave wrong sums with this toolchain — a dependent-MFMA hazard between the two opcodes — so one opcode it is.)  Products of halves are
+// exact in fp32 and the zero slots add exact zeros; the hardware's summation inside one MFMA is not fmaf-by-fmaf, so results
+// are not those of k_dw3x3's chain bit for bit (tests: nearly every output equals the two-step torch form's, the rest by
+// one half ulp).  A non-finite activation poisons the 16 channels of its pixel (0 x inf), not one.
+template <int C>
+struct DwDiag {
+    static constexpr int MT = (C + 15) / 16;
+    h8 A1[MT][3], A2[MT][3];
+    f4 bf[MT];
+    // w9l: [9][C] taps of this layer, biasl: [C]
+    __device__ __forceinline__ void init(const __half* __restrict__ w9l, const __half* __restrict__ biasl, int q, int n)
+    {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c = mt * 16 + n, c4 = mt * 16 + 4 * q;
+            const bool on = c < C && (n >> 2) == q;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const _Float16 w0 = on ? (_Float16)__half2float(w9l[(ky * 3 + 0) * C + c]) : (_Float16)0.f;
+                const _Float16 w1 = on ? (_Float16)__half2float(w9l[(ky * 3 + 1) * C + c]) : (_Float16)0.f;
+                const _Float16 w2 = on ? (_Float16)__half2float(w9l[(ky * 3 + 2) * C + c]) : (_Float16)0.f;
+                h8 a1 = { 0, 0, 0, 0, 0, 0, 0, 0 }, a2 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool at = (n & 3) == j;
+                    a1[j] = at ? w0 : (_Float16)0.f; a1[4 + j] = at ? w1 : (_Float16)0.f;
+                    a2[4 + j] = at ? w2 : (_Float16)0.f;
+                }
+                A1[mt][ky] = a1; A2[mt][ky] = a2;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[mt][e] = c4 + e < C ? __half2float(biasl[c4 + e]) : 0.f;
+        }
+    }
+    // the same operands out of a DwTab layer (LDS): aoff = ((n >> 2) == q ? n : 16) * 16
+    __device__ __forceinline__ void load(const char* tl, int aoff, int q)
+    {
+        constexpr int OPB = 17 * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                A1[mt][ky] = *reinterpret_cast<const h8*>(tl + (mt * 6 + 2 * ky) * OPB + aoff);
+                A2[mt][ky] = *reinterpret_cast<const h8*>(tl + (mt * 6 + 2 * ky + 1) * OPB + aoff);
+            }
+            bf[mt] = *reinterpret_cast<const f4*>(tl + MT * 6 * OPB + mt * 64 + q * 16);
+        }
+    }
+    // one input row's taps onto an accumulator
+    static __device__ __forceinline__ f4 row(const h8& a1, const h8& a2, uint2 L, uint2 Cn, uint2 R, f4 acc)
+    {
+        const uint4 lc = { L.x, L.y, Cn.x, Cn.y }, cr = { Cn.x, Cn.y, R.x, R.y };
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(h8, lc), acc, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(h8, cr), acc, 0, 0, 0);
+    }
+    // the whole 3x3 of one (16 pixels, 16 channels) tile: v[ky][kx] = this lane's 4 channels of pixel (x - 1 + kx, y - 1 + ky)
+    __device__ __forceinline__ f4 run(int mt, const uint2 (&v)[3][3]) const
+    {
+        f4 acc = bf[mt];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc = row(A1[mt][ky], A2[mt][ky], v[ky][0], v[ky][1], v[ky][2], acc);
+        return acc;
+    }
+};
+// rounding to half, then ReLU (round(max(x, 0)) == max(round(x), 0)): one v_pk_max_f16 per two channels
+__device__ __forceinline__ uint2 ss_relu_h4(const f4& f)
+{
+    const h4 o = { (_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3] };
+    uint2 v = __builtin_bit_cast(uint2, o);
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(v.x) : "v"(v.x));
+    asm("v_pk_max_f16 %0, %1, 0" : "=v"(v.y) : "v"(v.y));
+    return v;
+}
+
+// LDS layout of the pointwise outputs the LDS-form kernels (k_lightconv, k_osnet_streams) run the depthwise on: PS = MT * 16
+// halfs per pixel; with two M-tiles a lane's four channels of tile 0 and of tile 1 sit side by side (half q * 8 + mt * 4), so
+// ONE 16-byte read per tap feeds both tiles' B operands and the 64 lanes of a read cover 16 pixels x 64 contiguous bytes.  (In
+// channel order the 8-byte reads of a tile hit 32 bytes of every 64: four pixels per bank group, a 4-way conflict on each of
+// the 18 reads per 16 pixels — the LDS pipe, not the matrix cores, set the pace: 108 us for the 16x8 maps of 1024 crops.)
+// Channels past C of the second tile are written as the zeros the MFMA produces for them (never left uninitialised: they meet
+// zero weights, and 0 x NaN would not be 0).
+template <int MT>
+__device__ __forceinline__ int lc_slot(int mt, int q) { return MT == 2 ? q * 8 + mt * 4 : 4 * q; }
+template <int C>
+__device__ __forceinline__ void lc_taps(const _Float16* Pp /* pixel (x-1, y-1), this lane's slot of tile 0 */, int WPS /* (W+2) * PS */,
+                                        uint2 (&v)[(C + 15) / 16][3][3])
+{
+    constexpr int MT = (C + 15) / 16, PS = MT * 16;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            if constexpr (MT == 2) {
+                const uint4 t = *reinterpret_cast<const uint4*>(Pp + (size_t)ky * WPS + kx * PS);
+                v[0][ky][kx] = uint2{ t.x, t.y }; v[1][ky][kx] = uint2{ t.z, t.w };
+            } else
+                v[0][ky][kx] = *reinterpret_cast<const uint2*>(Pp + (size_t)ky * WPS + kx * PS);
+        }
+}
+
+// DwDiag's operands of several layers as an LDS table, for the kernels whose registers cannot hold them (32 channels x 4 layers
+// = 192 registers): an operand is nonzero in 16 of its 64 lanes (q == n >> 2), so the table keeps 16 entries of 16 bytes plus
+// one zero entry per operand and a lane reads its own or the zero entry (one ds_read_b128); the bias as 4 floats per q.
+template <int C>
+struct DwTab {
+    static constexpr int MT = (C + 15) / 16, OPB = 17 * 16, LAYER = MT * 6 * OPB + MT * 64;
+    // table bytes global -> LDS, 16 bytes per thread and step, all loads in flight at once
+    static __device__ __forceinline__ void copy(char* tab, const char* __restrict__ g, int layers, int tid)
+    {
+        for (int i = tid; i < layers * LAYER / 16; i += 256) reinterpret_cast<uint4*>(tab)[i] = reinterpret_cast<const uint4*>(g)[i];
+    }
+    static __device__ __forceinline__ void fill(char* tab, const __half* __restrict__ w9, const __half* __restrict__ bias, int layers, int tid)
+    {
+        for (int i = tid; i < layers * MT * 6 * 17; i += 256) {
+            const int e = i % 17, op = (i / 17) % 6, mt = (i / (17 * 6)) % MT, l = i / (17 * 6 * MT);
+            const int ky = op >> 1, c = mt * 16 + e;
+            h8 a = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            if (e < 16 && c < C) {
+                const __half* wl = w9 + (size_t)l * 9 * C;
+                if (!(op & 1)) { a[e & 3] = (_Float16)__half2float(wl[(ky * 3 + 0) * C + c]); a[4 + (e & 3)] = (_Float16)__half2float(wl[(ky * 3 + 1) * C + c]); }
+                else a[4 + (e & 3)] = (_Float16)__half2float(wl[(ky * 3 + 2) * C + c]);
+            }
+            *reinterpret_cast<h8*>(tab + (size_t)l * LAYER + (mt * 6 + op) * OPB + e * 16) = a;
+        }
+        for (int i = tid; i < layers * MT * 16; i += 256) {
+            const int c = i % (MT * 16), l = i / (MT * 16);
+            reinterpret_cast<float*>(tab + (size_t)l * LAYER + MT * 6 * OPB)[c] = c < C ? __half2float(bias[(size_t)l * C + c]) : 0.f;
+        }
+    }
+};
+
+// the table in global memory, built once per set of weights (ss_op_dwtab_f16): the chain kernels copy it to LDS
+template <int C>
+__global__ __launch_bounds__(256) void k_dwtab(const __half* __restrict__ w9, const __half* __restrict__ bias, int layers, char* __restrict__ out)
+{
+    DwTab<C>::fill(out, w9, bias, layers, threadIdx.x);
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                   const __half* __restrict__ w9, const __half* __restrict__ bias,
@@ -1157,16 +1309,17 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
 {
     constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
-    _Float16* T = (_Float16*)lc_smem;                       // [(TH+2)][W+2][C]
+    constexpr int PS = MT * 16;
+    _Float16* T = (_Float16*)lc_smem;                       // [(TH+2)][W+2][PS] (lc_slot order)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int img = blockIdx.x / bands, y0 = (blockIdx.x - img * bands) * TH;
     const int WP = W + 2;
     const h4 z4 = { 0, 0, 0, 0 };
 
-    for (int i = tid; i < (TH + 2) * 2 * C8; i += 256) {    // zero pad columns 0 and W+1
-        const int c8 = i % C8, rc = i / C8, r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
+    for (int i = tid; i < (TH + 2) * 2 * (PS / 8); i += 256) {    // zero pad columns 0 and W+1
+        const int c8 = i % (PS / 8), rc = i / (PS / 8), r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
         h8 z = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        *reinterpret_cast<h8*>(T + ((size_t)(r * WP + col) * C + c8 * 8)) = z;
+        *reinterpret_cast<h8*>(T + ((size_t)(r * WP + col) * PS + c8 * 8)) = z;
     }
 
     // ---- phase 1: pointwise product on the matrix cores ----
@@ -1200,46 +1353,28 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
             f4 d = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt][ks], bcur[ks], d, 0, 0, 0);
-            const int oc0 = mt * 16 + 4 * q;
-            if (oc0 < C) {
-                h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
-                *reinterpret_cast<h4*>(T + ((size_t)(r * WP + c + 1) * C + oc0)) = o;
-            }
+            h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
+            *reinterpret_cast<h4*>(T + ((size_t)(r * WP + c + 1) * PS + lc_slot<MT>(mt, q))) = o;
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
     }
     __syncthreads();
 
-    // ---- phase 2: depthwise 3x3 + bias + ReLU out of LDS ----
-    constexpr int PXPAR = 256 / C8;
-    const int c8 = tid % C8, ps = tid / C8;
-    if (ps >= PXPAR) return;
-    h8 wk[9];
+    // ---- phase 2: depthwise 3x3 + bias + ReLU out of LDS, on the matrix cores (DwDiag) ----
+    DwDiag<C> dw;
+    dw.init(w9, bias, q, n);
+    const int ntile = TH * W / 16;
+    for (int ti = wave; ti < ntile; ti += 4) {
+        const int p = ti * 16 + n, py = p / W, px = p - py * W, gy = y0 + py;
+        uint2 v[MT][3][3];
+        lc_taps<C>(T + ((size_t)(py * WP + px) * PS + lc_slot<MT>(0, q)), WP * PS, v);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9)[k * C8 + c8];
-    const h8 bb = reinterpret_cast<const h8*>(bias)[c8];
-    const int npx = TH * W;
-    const int dpy = PXPAR / W, dpx = PXPAR - dpy * W;       // pixel step of the loop as (rows, columns): no division per pixel
-    int py = ps / W, px = ps - py * W;
-    for (int p = ps; p < npx; p += PXPAR, py += dpy, px += dpx) {
-        if (px >= W) { px -= W; ++py; }
-        const int gy = y0 + py;
-        if (gy >= H) break;
-        float acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = (float)bb[k];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const h8 v = *reinterpret_cast<const h8*>(T + ((size_t)((py + ky) * WP + px + kx) * C + c8 * 8));
-                ss_dw_tap8(v, wk[ky * 3 + kx], acc);
-            }
-        h8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] > 0.f ? acc[k] : 0.f);
-        reinterpret_cast<h8*>(y)[(((size_t)img * H + gy) * W + px) * C8 + c8] = o;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int c4 = mt * 16 + 4 * q;
+            const uint2 o = ss_relu_h4(dw.run(mt, v[mt]));
+            if (gy < H && c4 < C) *reinterpret_cast<uint2*>(y + ((((size_t)img * H + gy) * W + px) * C + c4)) = o;
+        }
     }
 }
 
@@ -1256,42 +1391,62 @@ struct StreamOut { __half* y[4]; };
 
 template <int C>
 __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict__ x, const __half* __restrict__ w1,
-                                                      const __half* __restrict__ w9, const __half* __restrict__ bias,
+                                                      const char* __restrict__ gtab,
                                                       StreamOut out, float* __restrict__ psum, int N, int H, int W,
                                                       int bands, const int* __restrict__ nvalid)
 {
     if (nvalid && (int)(blockIdx.x / bands) >= *nvalid) return;
-    constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH, PXPAR = 256 / C8;
+    constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
     const int WP = W + 2;
-    _Float16* P = (_Float16*)lc_smem;                                        // [TH+2*TMAX][W+2][C]
-    _Float16* X = P + (size_t)(TH + 2 * OS_TMAX) * WP * C;                   // [TH+2*TMAX][W][C]
+    constexpr int PS = MT * 16;
+    _Float16* P = (_Float16*)lc_smem;                                        // [TH+2*TMAX][W+2][PS] (lc_slot order)
+    _Float16* X = P + (size_t)(TH + 2 * OS_TMAX) * WP * PS;                  // [TH+2*TMAX][W][PS] (lc_slot order: one 16-byte read per pixel feeds both K halves of the pointwise MFMA)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n16 = lane & 15;
     const int t = blockIdx.y + 1, lbase = (t * (t - 1)) / 2;
+    const int aoff = ((n16 >> 2) == q ? n16 : 16) * 16;
     const int img = blockIdx.x / bands, band = blockIdx.x - img * bands, y0 = band * TH;
     const int R = TH + 2 * t;                                                // local row i <-> image row y0 - t + i
     const h4 z4 = { 0, 0, 0, 0 };
     const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    for (int i = tid; i < R * 2 * C8; i += 256) {                            // zero pad columns of P
-        const int c8 = i % C8, rc = i / C8, r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
-        *reinterpret_cast<h8*>(P + ((size_t)(r * WP + col) * C + c8 * 8)) = z8;
+    for (int i = tid; i < R * 2 * (PS / 8); i += 256) {                      // zero pad columns of P
+        const int c8 = i % (PS / 8), rc = i / (PS / 8), r = rc >> 1, col = (rc & 1) ? W + 1 : 0;
+        *reinterpret_cast<h8*>(P + ((size_t)(r * WP + col) * PS + c8 * 8)) = z8;
     }
     const __half* xi = x + (size_t)img * H * W * C;
-    const int c8 = tid % C8, ps = tid / C8;
-    float s8[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    float s4[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[mt][k] = 0.f;
     // The band's input rows (R consecutive image rows = one contiguous span of x) go to X with coalesced 16-byte loads,
     // all in flight at once; rows outside the image are zeros.  (Reading the first layer's MFMA operand straight from
     // global memory was a chain of dependent 8-byte loads, one memory latency per 16 pixels: 357 us per launch at 512
     // crops before, see profiles/.)
     for (int i = tid; i < R * W * C8; i += 256) {
-        const int r = i / (W * C8), gr = y0 - t + r;
-        *reinterpret_cast<h8*>(X + (size_t)i * 8) =
-            (gr >= 0 && gr < H) ? *reinterpret_cast<const h8*>(xi + (size_t)gr * W * C + (size_t)(i - r * W * C8) * 8) : z8;
+        const int r = i / (W * C8), gr = y0 - t + r, pc8 = i - r * W * C8, pix = pc8 / C8, c8 = pc8 - pix * C8;
+        const h8 v = (gr >= 0 && gr < H) ? *reinterpret_cast<const h8*>(xi + (size_t)gr * W * C + (size_t)pc8 * 8) : z8;
+        if constexpr (MT == 2) {                              // channels 8 c8 .. 8 c8 + 7 = K half c8 >> 1, lanes q = 2 (c8 & 1) and + 1
+            _Float16* d = X + ((size_t)r * W + pix) * PS;
+            const uint4 u = __builtin_bit_cast(uint4, v);
+            *reinterpret_cast<uint2*>(d + lc_slot<MT>(c8 >> 1, 2 * (c8 & 1))) = uint2{ u.x, u.y };
+            *reinterpret_cast<uint2*>(d + lc_slot<MT>(c8 >> 1, 2 * (c8 & 1) + 1)) = uint2{ u.z, u.w };
+        } else
+            *reinterpret_cast<h8*>(X + (size_t)i * 8) = v;
     }
+    if constexpr (MT == 2 && C < 32)                          // the slots of channels C .. 31 are never written again: zeros (they meet zero weights)
+        for (int i = tid; i < R * W * ((32 - C) / 4); i += 256) {
+            const int pix = i / ((32 - C) / 4), j = i - pix * ((32 - C) / 4);
+            *reinterpret_cast<uint2*>(X + (size_t)pix * PS + lc_slot<MT>(1, (C - 16) / 4 + j)) = uint2{ 0u, 0u };
+        }
     __syncthreads();
 
     for (int l = 1; l <= t; ++l) {
         const int Lw = lbase + l - 1;
+        // this layer's depthwise operands straight from the global table (lane's own entry or the zero entry), in flight during
+        // the pointwise phase (an LDS copy of the table cost two of five resident workgroups per CU)
+        DwDiag<C> dw;
+        dw.load(gtab + (size_t)Lw * DwTab<C>::LAYER, aoff, q);
         // ---- pointwise product of local rows [l-1, R-l] ----
         h4 a[MT][KS];
 #pragma unroll
@@ -1304,11 +1459,11 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
         const int rlo = l - 1, NT = (R - 2 * l + 2) * W / 16;
         auto load_b = [&](int ti, h4 (&b)[KS]) {
             const int p = ti * 16 + n16, rr = p / W, c = p - rr * W, r = rlo + rr;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int ic0 = ks * 16 + 4 * q;
-                b[ks] = (ti < NT && ic0 < C) ? *reinterpret_cast<const h4*>(X + ((size_t)r * W + c) * C + ic0) : z4;
-            }
+            if constexpr (MT == 2) {
+                const uint4 u = ti < NT ? *reinterpret_cast<const uint4*>(X + ((size_t)r * W + c) * PS + lc_slot<MT>(0, q)) : uint4{ 0u, 0u, 0u, 0u };
+                b[0] = __builtin_bit_cast(h4, uint2{ u.x, u.y }); b[1] = __builtin_bit_cast(h4, uint2{ u.z, u.w });
+            } else
+                b[0] = ti < NT ? *reinterpret_cast<const h4*>(X + ((size_t)r * W + c) * PS + 4 * q) : z4;
         };
         h4 bcur[KS], bnext[KS];
         load_b(wave, bcur);
@@ -1320,66 +1475,61 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
                 f4 d = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt][ks], bcur[ks], d, 0, 0, 0);
-                const int oc0 = mt * 16 + 4 * q;
-                if (oc0 < C) {
-                    h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
-                    *reinterpret_cast<h4*>(P + ((size_t)(r * WP + c + 1) * C + oc0)) = o;
-                }
+                h4 o = { (_Float16)d[0], (_Float16)d[1], (_Float16)d[2], (_Float16)d[3] };
+                *reinterpret_cast<h4*>(P + ((size_t)(r * WP + c + 1) * PS + lc_slot<MT>(mt, q))) = o;
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
         }
         __syncthreads();
 
-        // ---- depthwise 3x3 + bias + ReLU of local rows [l, R-l-1] ----
-        if (ps < PXPAR) {
-            h8 wk[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wk[k] = reinterpret_cast<const h8*>(w9 + (size_t)Lw * 9 * C)[k * C8 + c8];
-            const h8 bb = reinterpret_cast<const h8*>(bias + (size_t)Lw * C)[c8];
-            const int npx = (R - 2 * l) * W;
-            const int dpr = PXPAR / W, dpx = PXPAR - dpr * W;               // pixel step as (rows, columns)
-            int pr = ps / W, px = ps - pr * W;
-            for (int p = ps; p < npx; p += PXPAR, pr += dpr, px += dpx) {
-                if (px >= W) { px -= W; ++pr; }
-                const int py = pr + l, gr = y0 - t + py;
+        // ---- depthwise 3x3 + bias + ReLU of local rows [l, R-l-1], on the matrix cores (DwDiag: k_lightconv's arithmetic) ----
+        // The valid rows are contiguous in X and in the output, so pixel p of the region sits at (l * W + p) there; only P (padded
+        // rows) needs the (row, column) split — a shift for the power-of-two widths of OSNet's maps.
+        {
+            const int npx = (R - 2 * l) * W, ntile = (npx + 15) / 16;
+            const bool pow2 = (W & (W - 1)) == 0;
+            const int wsh = 31 - __builtin_clz(W);
+            const size_t obase = ((size_t)img * H + (y0 - t + l)) * W;              // output pixel index of p = 0 (may be "negative" rows: masked)
+            for (int ti = wave; ti < ntile; ti += 4) {
+                const int p0 = ti * 16 + n16, p = p0 < npx ? p0 : npx - 1;  // a ragged last tile (8-wide maps) repeats its last pixel
+                const int pr = pow2 ? p >> wsh : p / W, px = p - pr * W, py = pr + l, gr = y0 - t + py;
                 const bool inside = gr >= 0 && gr < H;
-                float acc[8];
+                uint2 v[MT][3][3];
+                lc_taps<C>(P + ((size_t)((py - 1) * WP + px) * PS + lc_slot<MT>(0, q)), WP * PS, v);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = (float)bb[k];
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int c4 = mt * 16 + 4 * q;
+                    const bool cok = (C % 16 == 0) || c4 < C;
+                    const uint2 o = ss_relu_h4(dw.run(mt, v[mt]));
+                    if (!cok || p0 >= npx) continue;
+                    if (l < t) {
+                        *reinterpret_cast<uint2*>(X + ((size_t)(l * W + p) * PS + lc_slot<MT>(mt, q))) = inside ? o : uint2{ 0u, 0u };
+                    } else if (inside) {
+                        *reinterpret_cast<uint2*>(out.y[t - 1] + ((obase + p) * C + c4)) = o;
+                        const h4 ov = __builtin_bit_cast(h4, o);
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const h8 v = *reinterpret_cast<const h8*>(P + ((size_t)((py - 1 + ky) * WP + px + kx) * C + c8 * 8));
-                        ss_dw_tap8(v, wk[ky * 3 + kx], acc);
+                        for (int k = 0; k < 4; ++k) s4[mt][k] += (float)ov[k];
                     }
-                h8 o;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = (_Float16)(acc[k] > 0.f ? acc[k] : 0.f);
-                if (l < t) {
-                    *reinterpret_cast<h8*>(X + ((size_t)(py * W + px) * C + c8 * 8)) = inside ? o : z8;
-                } else if (inside) {
-                    reinterpret_cast<h8*>(out.y[t - 1])[(((size_t)img * H + gr) * W + px) * C8 + c8] = o;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) s8[k] += (float)o[k];
                 }
             }
         }
         __syncthreads();
     }
 
-    // band's channel sums of the chain output, fixed order (deterministic)
-    float* red = reinterpret_cast<float*>(lc_smem);                          // [256][8]
+    // band's channel sums of the chain output, fixed order (deterministic): the 16 pixel lanes of a wave, then the four waves
+    float* red = reinterpret_cast<float*>(lc_smem);                          // [4][MT * 16]
 #pragma unroll
-    for (int k = 0; k < 8; ++k) red[tid * 8 + k] = ps < PXPAR ? s8[k] : 0.f;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = s4[mt][k];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+            if (n16 == 0) red[wave * (MT * 16) + mt * 16 + 4 * q + k] = v;
+        }
     __syncthreads();
-    if (tid < C) {
-        const int cg = tid >> 3, k = tid & 7;
-        float a = 0.f;
-        for (int j = 0; j < PXPAR; ++j) a += red[(j * C8 + cg) * 8 + k];
-        psum[(((size_t)(t - 1) * N + img) * bands + band) * C + tid] = a;
-    }
+    if (tid < C) psum[(((size_t)(t - 1) * N + img) * bands + band) * C + tid] =
+        ((red[tid] + red[MT * 16 + tid]) + red[2 * MT * 16 + tid]) + red[3 * MT * 16 + tid];
 }
 
 // ---- the LightConv chains as a register-resident row stream (W = 16 or 32) ----
@@ -1404,44 +1554,57 @@ __device__ __forceinline__ unsigned ss_dpp_shl1_o(unsigned old, unsigned v) { re
 __device__ __forceinline__ unsigned ss_dpp_ror1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned ss_dpp_ror15(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x12F, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned ss_pk_relu(unsigned v) { unsigned d; asm("v_pk_max_f16 %0, %1, 0" : "=v"(d) : "v"(v)); return d; }
-// first tap: the accumulator starts at the (half) bias, widened inside the instruction
-__device__ __forceinline__ float ss_mix_lo_b(unsigned a, unsigned b, unsigned c)
-{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ float ss_mix_hi_b(unsigned a, unsigned b, unsigned c)
-{ float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,1,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-
-// A depthwise output row is finished over three steps without changing the order of its additions: when pointwise row r
-// arrives, the accumulator of output row r+1 starts (bias + its ky = 0 taps), that of row r continues (ky = 1) and that of
-// row r-1 finishes (ky = 2) — two partial accumulators per layer instead of two rows x (left, centre, right) of history.
-// Tap weights (per lane: 4 channels) come from LDS per layer and step.
-template <int C, int NT, int T>
+// A depthwise output row is finished over three steps without changing the order of its accumulation (DwDiag: bias, then the
+// input rows y-1, y, y+1): when pointwise row r arrives, the accumulator of output row r+1 starts (bias + its ky = 0 MFMAs),
+// that of row r continues (ky = 1) and that of row r-1 finishes (ky = 2) — two partial accumulators per layer instead of two
+// rows x (left, centre, right) of history.  The (left, centre) operands (12 registers per layer) stay in registers for the life
+// of the wave at 16 channels; the (centre, right) operands and the bias — and at 24 / 32 channels all of them — are read from
+// the workgroup's LDS copy of DwTab in every step.
+// A step runs its T layers first to last, each consuming the row the one before just finished (xs).
+// OS_SKEW 1 (A/B build, -DOS_SKEW=1): layer l consumes the row layer l-1 finished in the PREVIOUS step, so the T layers of a step
+// are independent of one another — measured slower (150 vs 149 us at 16 channels, 101 vs 94 at 24: T-1 more steps, no better
+// overlap), as was asking the scheduler for "one MFMA, three vector instructions" groups (+10 us); profiles/r04_osnet_dw_mfma_ab.txt.
+#ifndef OS_SKEW
+#define OS_SKEW 0
+#endif
+template <int C, int NT, int T, bool ALDS>
 struct OsChain {
     static constexpr int MT = (C + 15) / 16, KS = MT, CP = MT * 16;
     uint2 A[T][MT][KS];                  // pointwise weights (MFMA A operand)
-    uint2 Bs[T][MT];                     // depthwise bias
-    float acc0[T][NT][MT][4], acc1[T][NT][MT][4];
+    h8 A1[ALDS ? 1 : T][MT][3];          // DwDiag's (left, centre) operands; (centre, right) and the bias come from DwTab per step (ALDS: all three)
+    f4 acc0[T][NT][MT], acc1[T][NT][MT];
+    uint2 xs[T > 1 ? T - 1 : 1][NT][MT]; // layer l's output row = layer l+1's input
     float s[MT][4];                      // channel sums of the stored outputs
 
-    __device__ __forceinline__ void init(const __half* w1, const __half* bias, int q, int n)
+    __device__ __forceinline__ void init(const __half* w1, const char* tab, int aoff, int q, int n)
     {
         constexpr int lbase = (T * (T - 1)) / 2;
         const uint2 z = { 0u, 0u };
+        const f4 z4 = { 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
-        for (int l = 0; l < T; ++l)
+        for (int l = 0; l < T; ++l) {
+            if constexpr (!ALDS) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+                        A1[l][mt][ky] = *reinterpret_cast<const h8*>(tab + (size_t)(lbase + l) * DwTab<C>::LAYER + (mt * 6 + 2 * ky) * DwTab<C>::OPB + aoff);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int oc = mt * 16 + n, c4 = mt * 16 + 4 * q;
+                const int oc = mt * 16 + n;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int ic0 = ks * 16 + 4 * q;
                     A[l][mt][ks] = (oc < C && ic0 < C) ? *reinterpret_cast<const uint2*>(w1 + ((size_t)(lbase + l) * C + oc) * C + ic0) : z;
                 }
-                Bs[l][mt] = c4 < C ? *reinterpret_cast<const uint2*>(bias + (size_t)(lbase + l) * C + c4) : z;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc0[l][j][mt][e] = acc1[l][j][mt][e] = 0.f;
+                for (int j = 0; j < NT; ++j) {
+                    acc0[l][j][mt] = acc1[l][j][mt] = z4;
+                    if (l + 1 < T) xs[l][j][mt] = z;
+                }
             }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1449,25 +1612,19 @@ struct OsChain {
     }
 
     // One step: `in` = layer 0's input row `row` (zeros outside the image); layer l finishes its output row (row - l - 1);
-    // `out` = the last layer's (row - T).  taps: LDS [10][9][CP] halfs, this lane's 4 channels at + 4q.
-    __device__ __forceinline__ void step(const uint2 (&in)[NT][KS], int row, int H, const _Float16* taps, int q, uint2 (&out)[NT][MT])
+    // `out` = the last layer's (row - T).
+    __device__ __forceinline__ void step(const uint2 (&in)[NT][KS], int row, int H, const char* tab, int aoff, int q, uint2 (&out)[NT][MT])
     {
         constexpr int lbase = (T * (T - 1)) / 2;
-        uint2 x[NT][KS];
+        asm volatile("" : "+v"(aoff));                      // keeps the table reads inside the row loop (hoisted, they cost 24 VGPRs per layer)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int li = 0; li < T; ++li) {
+            const int l = OS_SKEW ? T - 1 - li : li;         // (OS_SKEW: last to first, a layer reads xs[l-1] before layer l-1 replaces it)
+            uint2 x[NT][KS];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) x[j][ks] = in[j][ks];
-        int toff = 4 * q;
-        asm volatile("" : "+v"(toff));                      // keeps the tap reads inside the row loop (hoisted, they cost 18 VGPRs per layer)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int l = 0; l < T; ++l) {
-            uint2 w[MT][9];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    w[mt][k] = *reinterpret_cast<const uint2*>(taps + ((lbase + l) * 9 + k) * CP + mt * 16 + toff);
+                for (int ks = 0; ks < KS; ++ks) x[j][ks] = l == 0 ? in[j][ks] : xs[l > 0 ? l - 1 : 0][j][ks];
             uint2 pc[NT][MT], pl[NT][MT], pr[NT][MT];
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -1496,58 +1653,44 @@ struct OsChain {
                         pr[j][mt].x = ss_dpp_shl1_o(ss_dpp_ror15(nx.x), c.x); pr[j][mt].y = ss_dpp_shl1_o(ss_dpp_ror15(nx.y), c.y);
                     }
                 }
-            const int orow = row - l - 1;
+            const int orow = row - (OS_SKEW ? 2 * l : l) - 1;
             const bool inside = orow >= 0 && orow < H;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const uint2 L = pl[j][mt], Cn = pc[j][mt], R = pr[j][mt];
-                    float (&a0)[4] = acc0[l][j][mt];
-                    float (&a1)[4] = acc1[l][j][mt];
-                    float f[4];
-                    // finish row (orow): ky = 2
-                    f[0] = ss_mix_lo(L.x, w[mt][6].x, a1[0]); f[1] = ss_mix_hi(L.x, w[mt][6].x, a1[1]);
-                    f[2] = ss_mix_lo(L.y, w[mt][6].y, a1[2]); f[3] = ss_mix_hi(L.y, w[mt][6].y, a1[3]);
-                    f[0] = ss_mix_lo(Cn.x, w[mt][7].x, f[0]); f[1] = ss_mix_hi(Cn.x, w[mt][7].x, f[1]);
-                    f[2] = ss_mix_lo(Cn.y, w[mt][7].y, f[2]); f[3] = ss_mix_hi(Cn.y, w[mt][7].y, f[3]);
-                    f[0] = ss_mix_lo(R.x, w[mt][8].x, f[0]); f[1] = ss_mix_hi(R.x, w[mt][8].x, f[1]);
-                    f[2] = ss_mix_lo(R.y, w[mt][8].y, f[2]); f[3] = ss_mix_hi(R.y, w[mt][8].y, f[3]);
-                    // continue row (orow + 1): ky = 1
-                    a1[0] = ss_mix_lo(L.x, w[mt][3].x, a0[0]); a1[1] = ss_mix_hi(L.x, w[mt][3].x, a0[1]);
-                    a1[2] = ss_mix_lo(L.y, w[mt][3].y, a0[2]); a1[3] = ss_mix_hi(L.y, w[mt][3].y, a0[3]);
-                    a1[0] = ss_mix_lo(Cn.x, w[mt][4].x, a1[0]); a1[1] = ss_mix_hi(Cn.x, w[mt][4].x, a1[1]);
-                    a1[2] = ss_mix_lo(Cn.y, w[mt][4].y, a1[2]); a1[3] = ss_mix_hi(Cn.y, w[mt][4].y, a1[3]);
-                    a1[0] = ss_mix_lo(R.x, w[mt][5].x, a1[0]); a1[1] = ss_mix_hi(R.x, w[mt][5].x, a1[1]);
-                    a1[2] = ss_mix_lo(R.y, w[mt][5].y, a1[2]); a1[3] = ss_mix_hi(R.y, w[mt][5].y, a1[3]);
-                    // start row (orow + 2): bias, ky = 0
-                    const uint2 b = Bs[l][mt];
-                    a0[0] = ss_mix_lo_b(L.x, w[mt][0].x, b.x); a0[1] = ss_mix_hi_b(L.x, w[mt][0].x, b.x);
-                    a0[2] = ss_mix_lo_b(L.y, w[mt][0].y, b.y); a0[3] = ss_mix_hi_b(L.y, w[mt][0].y, b.y);
-                    a0[0] = ss_mix_lo(Cn.x, w[mt][1].x, a0[0]); a0[1] = ss_mix_hi(Cn.x, w[mt][1].x, a0[1]);
-                    a0[2] = ss_mix_lo(Cn.y, w[mt][1].y, a0[2]); a0[3] = ss_mix_hi(Cn.y, w[mt][1].y, a0[3]);
-                    a0[0] = ss_mix_lo(R.x, w[mt][2].x, a0[0]); a0[1] = ss_mix_hi(R.x, w[mt][2].x, a0[1]);
-                    a0[2] = ss_mix_lo(R.y, w[mt][2].y, a0[2]); a0[3] = ss_mix_hi(R.y, w[mt][2].y, a0[3]);
-                    // ReLU after the rounding (round(max(x,0)) == max(round(x),0)): one v_pk_max_f16 per two channels
-                    const h4 o = { (_Float16)f[0], (_Float16)f[1], (_Float16)f[2], (_Float16)f[3] };
-                    uint2 ov = __builtin_bit_cast(uint2, o);
-                    ov.x = ss_pk_relu(ov.x); ov.y = ss_pk_relu(ov.y);
+                    h8 a1[3], a2[3];
+                    const char* tl = tab + (size_t)(lbase + l) * DwTab<C>::LAYER;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        if constexpr (ALDS) a1[ky] = *reinterpret_cast<const h8*>(tl + (mt * 6 + 2 * ky) * DwTab<C>::OPB + aoff);
+                        else a1[ky] = A1[l][mt][ky];
+                        a2[ky] = *reinterpret_cast<const h8*>(tl + (mt * 6 + 2 * ky + 1) * DwTab<C>::OPB + aoff);
+                    }
+                    const f4 bfv = *reinterpret_cast<const f4*>(tl + MT * 6 * DwTab<C>::OPB + mt * 64 + q * 16);
+                    // finish row (orow): ky = 2; continue row (orow + 1): ky = 1; start row (orow + 2): bias, ky = 0
+                    const f4 f = DwDiag<C>::row(a1[2], a2[2], L, Cn, R, acc1[l][j][mt]);
+                    acc1[l][j][mt] = DwDiag<C>::row(a1[1], a2[1], L, Cn, R, acc0[l][j][mt]);
+                    acc0[l][j][mt] = DwDiag<C>::row(a1[0], a2[0], L, Cn, R, bfv);
+                    uint2 ov = ss_relu_h4(f);
                     if (!inside) ov = uint2{ 0u, 0u };
-                    if (l + 1 < T) x[j][mt] = ov; else out[j][mt] = ov;
+                    if (l + 1 < T) xs[l][j][mt] = ov; else out[j][mt] = ov;
                 }
         }
     }
 };
 
-template <int C, int NT, int T>
-__device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, const __half* __restrict__ w1, const _Float16* taps,
-                                             const __half* __restrict__ bias, __half* __restrict__ yo, float* __restrict__ ps, int H,
+template <int C, int NT, int T, bool ALDS>
+__device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, const __half* __restrict__ w1, const char* tab,
+                                             __half* __restrict__ yo, float* __restrict__ ps, int H,
                                              int y0, int TH, int lane)
 {
     constexpr int MT = (C + 15) / 16, KS = MT, W = 16 * NT;
     const int q = lane >> 4, n = lane & 15;
-    OsChain<C, NT, T> ch;
-    ch.init(w1, bias, q, n);
+    OsChain<C, NT, T, ALDS> ch;
+    const int aoff = ((n >> 2) == q ? n : 16) * 16;
+    ch.init(w1, tab, aoff, q, n);
     const uint2 z = { 0u, 0u };
     auto load_row = [&](int row, uint2 (&r)[NT][KS]) {
         const bool ok = row >= 0 && row < H;
@@ -1575,14 +1718,16 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
                 }
             }
     };
-    // rows y0 - T .. yend - 1 + T enter layer 0; three rows are in flight ahead of the one being processed
-    const int r_first = y0 - T, r_last = yend - 1 + T;
+    // rows y0 - T .. enter layer 0 (the band's last output row yend - 1 leaves the last layer at step yend + 2T - 2; rows past
+    // yend - 1 + T only feed discarded rows); three rows are in flight ahead of the one being processed
+    constexpr int DELAY = OS_SKEW ? 2 * T - 1 : T;          // steps between a row entering layer 0 and leaving the last layer
+    const int r_first = y0 - T, r_last = yend - 1 + DELAY;
     uint2 r0[NT][KS], r1[NT][KS], r2[NT][KS], o[NT][MT];
     load_row(r_first, r0); load_row(r_first + 1, r1); load_row(r_first + 2, r2);
     for (int row = r_first; row <= r_last; row += 3) {
-        ch.step(r0, row, H, taps, q, o); load_row(row + 3, r0); emit(row - T, o);
-        if (row + 1 <= r_last) { ch.step(r1, row + 1, H, taps, q, o); load_row(row + 4, r1); emit(row + 1 - T, o); }
-        if (row + 2 <= r_last) { ch.step(r2, row + 2, H, taps, q, o); load_row(row + 5, r2); emit(row + 2 - T, o); }
+        ch.step(r0, row, H, tab, aoff, q, o); load_row(row + 3, r0); emit(row - DELAY, o);
+        if (row + 1 <= r_last) { ch.step(r1, row + 1, H, tab, aoff, q, o); load_row(row + 4, r1); emit(row + 1 - DELAY, o); }
+        if (row + 2 <= r_last) { ch.step(r2, row + 2, H, tab, aoff, q, o); load_row(row + 5, r2); emit(row + 2 - DELAY, o); }
     }
     // band sums of this lane's channels: over the 16 pixel lanes of the DPP row, fixed order
 #pragma unroll
@@ -1597,17 +1742,15 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
 
 // wave = (image, band of TH rows); blockIdx.y selects the chains the wave runs (bit t-1 of nibble blockIdx.y of `masks`)
 template <int C, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 16 ? 3 : 2, C == 16 ? 3 : 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
-                                                     const __half* __restrict__ w9, const __half* __restrict__ bias,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
+                                                     const char* __restrict__ gtab,
                                                      StreamOut out, float* __restrict__ psum, int N, int H, int TH, int bands,
                                                      unsigned masks, const int* __restrict__ nvalid)
 {
-    constexpr int W = 16 * NT, MT = (C + 15) / 16, CP = MT * 16;
-    __shared__ __attribute__((aligned(16))) _Float16 taps[10 * 9 * CP];
-    for (int i = threadIdx.x; i < 10 * 9 * CP; i += 256) {
-        const int c = i % CP, lk = i / CP;
-        taps[i] = c < C ? (_Float16)__half2float(w9[(size_t)lk * C + c]) : (_Float16)0.f;
-    }
+    constexpr int W = 16 * NT;
+    constexpr bool ALDS = C > 16;                            // 16 channels: the (left, centre) operands of four layers stay in registers
+    __shared__ __attribute__((aligned(16))) char tab[10 * DwTab<C>::LAYER];
+    DwTab<C>::copy(tab, gtab, 10, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
@@ -1619,7 +1762,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 16 ? 3
     const size_t io = (size_t)img * H * W * C;
 #define SS_CH(TT)                                                                                                              \
     if (m & (1u << (TT - 1)))                                                                                                  \
-        os_chain_run<C, NT, TT>(xi, w1, taps, bias, out.y[TT - 1] + io, psum + (((size_t)(TT - 1) * N + img) * bands + band) * C, H, y0, \
+        os_chain_run<C, NT, TT, ALDS>(xi, w1, tab, out.y[TT - 1] + io, psum + (((size_t)(TT - 1) * N + img) * bands + band) * C, H, y0, \
                                 TH, lane)
     SS_CH(4); SS_CH(3); SS_CH(2); SS_CH(1);
 #undef SS_CH
@@ -2238,7 +2381,7 @@ extern "C" int ss_op_lightconv_f16(void* stream, const void* x, const void* w1, 
                                    int N, int H, int W, int C)
 {
     if (!x || !w1 || !w9 || !bias || !y || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
-    const size_t lds = (size_t)(LC_TH + 2) * (W + 2) * C * 2;
+    const size_t lds = (size_t)(LC_TH + 2) * (W + 2) * (((C + 15) / 16) * 16) * 2;   // pixel stride of the pointwise buffer: lc_slot
     if (lds > 65536) return SS_ERR_INVALID;
     const int bands = (H + LC_TH - 1) / LC_TH;
     hipStream_t st = (hipStream_t)stream;
@@ -2304,10 +2447,26 @@ extern "C" int ss_op_osnet_streams_bands(int N, int H, int W, int C)
     return (H + th - 1) / th;
 }
 
-extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* w1, const void* w9, const void* bias,
+extern "C" long long ss_op_dwtab_bytes(int layers, int C)
+{
+    if (layers < 1 || (C != 16 && C != 24 && C != 32)) return SS_ERR_INVALID;
+    return (long long)layers * (C == 16 ? DwTab<16>::LAYER : C == 24 ? DwTab<24>::LAYER : DwTab<32>::LAYER);
+}
+
+extern "C" int ss_op_dwtab_f16(void* stream, const void* w9, const void* bias, int layers, int C, void* out)
+{
+    if (!w9 || !bias || !out || ss_op_dwtab_bytes(layers, C) < 0) return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) hipLaunchKernelGGL(k_dwtab<16>, dim3(1), dim3(256), 0, st, (const __half*)w9, (const __half*)bias, layers, (char*)out);
+    else if (C == 24) hipLaunchKernelGGL(k_dwtab<24>, dim3(1), dim3(256), 0, st, (const __half*)w9, (const __half*)bias, layers, (char*)out);
+    else hipLaunchKernelGGL(k_dwtab<32>, dim3(1), dim3(256), 0, st, (const __half*)w9, (const __half*)bias, layers, (char*)out);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* w1, const void* dwtab,
                                        void* const* ys, float* psum, int N, int H, int W, int C)
 {
-    if (!x || !w1 || !w9 || !bias || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
+    if (!x || !w1 || !dwtab || !ys || !psum || N < 1 || H < 1 || W < 8 || W % 8) return SS_ERR_INVALID;
     const int TH = os_band_rows(N, H, W, C), bands = (H + TH - 1) / TH;
     StreamOut o;
     for (int t = 0; t < 4; ++t) { if (!ys[t]) return SS_ERR_INVALID; o.y[t] = (__half*)ys[t]; }
@@ -2318,21 +2477,22 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
         const unsigned masks = 0x69u;
         dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), 2), block(256);
 #define SS_CHN(CC, NT) hipLaunchKernelGGL((k_osnet_chains<CC, NT>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
-                                          (const __half*)w9, (const __half*)bias, o, psum, N, H, TH, bands, masks, nv)
+                                          (const char*)dwtab, o, psum, N, H, TH, bands, masks, nv)
         if (W == 32) SS_CHN(16, 2);                          // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
         else { if (C == 16) SS_CHN(16, 1); else if (C == 24) SS_CHN(24, 1); else SS_CHN(32, 1); }
 #undef SS_CHN
         return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
     }
-    const size_t lds = (size_t)(LC_TH + 2 * OS_TMAX) * (2 * W + 2) * C * 2;
+    if (C != 16 && C != 24 && C != 32) return SS_ERR_INVALID;
+    const int PS = ((C + 15) / 16) * 16;                     // pixel stride of the pointwise buffer (lc_slot)
+    const size_t lds = (size_t)(LC_TH + 2 * OS_TMAX) * (size_t)(2 * W + 2) * PS * 2;
     if (lds > 65536) return SS_ERR_INVALID;
     dim3 grid((unsigned)((size_t)N * bands), 4), block(256);
 #define SS_OS(CC) hipLaunchKernelGGL(k_osnet_streams<CC>, grid, block, lds, st, (const __half*)x, (const __half*)w1, \
-                                     (const __half*)w9, (const __half*)bias, o, psum, N, H, W, bands, nv)
+                                     (const char*)dwtab, o, psum, N, H, W, bands, nv)
     if (C == 16) SS_OS(16);
     else if (C == 24) SS_OS(24);
-    else if (C == 32) SS_OS(32);
-    else return SS_ERR_INVALID;
+    else SS_OS(32);
 #undef SS_OS
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }

@@ -301,7 +301,7 @@ LIGHTCONV = _flag("LIGHTCONV")            # fused pointwise + depthwise path of 
 
 def lightconv_ok(x) -> bool:
     n, c, h, w = x.shape
-    return LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 18 * (w + 2) * c * 2 <= 65536
+    return LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 18 * (w + 2) * ((c + 15) // 16 * 16) * 2 <= 65536
 
 
 def lightconv(x, w1, w9, bias):
@@ -388,23 +388,36 @@ STREAMS = _flag("STREAMS")              # all four LightConv chains of an OSNet 
 
 
 def streams_ok_dims(c, w) -> bool:
-    return STREAMS and LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 24 * (2 * w + 2) * c * 2 <= 65536
+    return STREAMS and LIGHTCONV and c in (16, 24, 32) and w % 8 == 0 and 24 * (2 * w + 2) * ((c + 15) // 16 * 16) * 2 <= 65536
 
 
 def streams_ok(x) -> bool:
     return streams_ok_dims(x.shape[1], x.shape[3])
 
 
-def osnet_streams(x, w1, w9, bias):
+def dwtab(w9, bias):
+    """Depthwise taps w9 [L,9,C] (tap-major) + biases [L,C] of LightConv layers -> the operand table of the matrix-core depthwise
+    (uint8 tensor; build once per set of weights)."""
+    layers, _, c = w9.shape
+    L = _lib.load()
+    out = torch.empty(int(L.ss_op_dwtab_bytes(layers, c)), dtype=torch.uint8, device=w9.device)
+    _ck(L.ss_op_dwtab_f16(_st(w9), _p(w9.contiguous()), _p(bias.contiguous()), layers, c, _p(out)))
+    return out
+
+
+def osnet_streams(x, w1, w9, bias, tab=None):
     """x [N,C,H,W] channels-last half; w1 [10,C,C], w9 [10,9,C], bias [10,C]: the layers of the 1-, 2-, 3- and 4-deep
-    chains in that order.  Returns the four chain outputs and the per-band channel sums psum [4,N,bands,C] (float; the library picks the band height)."""
+    chains in that order; tab = dwtab(w9, bias) (built here when not given).  Returns the four chain outputs and the per-band
+    channel sums psum [4,N,bands,C] (float; the library picks the band height)."""
     x = _cl(x)
     n, c, h, w = x.shape
+    if tab is None:
+        tab = dwtab(w9, bias)
     bands = _lib.load().ss_op_osnet_streams_bands(n, h, w, c)
     ys = [torch.empty_like(x, memory_format=torch.channels_last) for _ in range(4)]
     psum = torch.empty(4, n, bands, c, dtype=torch.float32, device=x.device)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
-    _ck(_lib.load().ss_op_osnet_streams_f16(_st(x), _p(x), _p(w1), _p(w9), _p(bias), arr, _p(psum), n, h, w, c))
+    _ck(_lib.load().ss_op_osnet_streams_f16(_st(x), _p(x), _p(w1), _p(tab), arr, _p(psum), n, h, w, c))
     return ys, psum
 
 

@@ -597,9 +597,9 @@ class OSBlock(nn.Module):
         if sw is None or sw[0].device != x1.device:
             c = x1.shape[1]
             layers = [m for st in self.streams for m in st]
-            sw = self._sw = (torch.stack([m.pw.weight.detach().reshape(c, c) for m in layers]).contiguous(),
-                             torch.stack([m.dw.weight.detach().reshape(c, 9).t() for m in layers]).contiguous(),
-                             torch.stack([m.dw.bias.detach() for m in layers]).contiguous())
+            w9 = torch.stack([m.dw.weight.detach().reshape(c, 9).t() for m in layers]).contiguous()
+            b = torch.stack([m.dw.bias.detach() for m in layers]).contiguous()
+            sw = self._sw = (torch.stack([m.pw.weight.detach().reshape(c, c) for m in layers]).contiguous(), w9, b, fused.dwtab(w9, b))
         return sw
 
     def tail_ok(self, x, nxt, pool) -> bool:
