@@ -650,7 +650,7 @@ def main():
     ap.add_argument("--frame-batch", type=int, default=32, help="frames of a stream that travel through the stateless stages (detector, NMS, crops, OSNet) together; the tracker still consumes them one by one in order")
     ap.add_argument("--opt", action="append", default=[], help="library tuning switch name=value (ss_set_option), e.g. --opt assoc_comp_rows=0")
     ap.add_argument("--fused", action="append", default=[], help="A/B switch of a fused kernel family NAME=0|1 (fused.set_flags), e.g. --fused HEAD=0")
-    ap.add_argument("--pipe", action="append", default=[], help="A/B switch of the frame pipeline name=0|1: pack_crops, assoc_gate, track_priority")
+    ap.add_argument("--pipe", action="append", default=[], help="A/B switch of the frame pipeline name=0|1: pack_crops, assoc_gate, track_priority; chain_cus=N (compute units reserved for the detached tracker chain)")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -694,7 +694,7 @@ def main():
     if args.fused:
         from strongsort_yolo_amd import fused
         fused.set_flags(**{kv.split("=")[0]: kv.split("=")[1] != "0" for kv in args.fused})
-    pipe_sw = {kv.split("=")[0]: kv.split("=")[1] != "0" for kv in args.pipe}
+    pipe_sw = {kv.split("=")[0]: (int(kv.split("=")[1]) if kv.split("=")[0] == "chain_cus" else kv.split("=")[1] != "0") for kv in args.pipe}
     detector, W, H, n_ids, rb = PRESETS[args.preset]
     if args.reid_split == -2:
         args.reid_split = REID_SPLIT[args.preset]

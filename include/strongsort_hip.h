@@ -200,8 +200,24 @@ int ss_track_update_host(ss_ctx* ctx, int stream, const float* h_dets, int n, co
  *                      launches) is replayed as one captured HIP graph per (frames, caller buffers, options) combination — one
  *                      hipGraphLaunch of host time instead of up to 95 launches; 0: plain launches
  *   "assoc_xcd_map"    0 (default): a gallery range lives on one XCD (every XCD stages all detection operands);
- *                      1: a detection column-tile pair lives on one XCD (every XCD streams the whole gallery) */
+ *                      1: a detection column-tile pair lives on one XCD (every XCD streams the whole gallery)
+ *   "frame_caps"       0 (default) or a multiple of 16 in 16..128: the per-frame kernel's LDS work areas are sized for that many
+ *                      tracks / detections (larger frames use a global scratch area)
+ *   "chain_cus"        0 (default): the per-frame chain runs on the context's stream after the association launch; n (a multiple
+ *                      of 8, <= 128): DETACHED — the chain goes to a stream of the library whose queue owns the first n compute
+ *                      units of the device's CU mask (n / 8 of every XCD), ordered after the association launch; the call returns
+ *                      with the caller's stream free to run its next launches.  Whoever reads d_out / d_nout (or any tracker state)
+ *                      afterwards first calls ss_track_join on the stream it reads on; the library's own readers and the next
+ *                      ss_track_update_group do so themselves.  The reservation is only real when every other stream of the
+ *                      application is created with ss_stream_create(ctx, n, ..), i.e. without those compute units.  -1: detached onto
+ *                      a plain high-priority stream (every compute unit, nothing reserved). */
 int ss_set_option(ss_ctx* ctx, const char* name, int value);
+/* `hip_stream` waits for the detached chain of the last ss_track_update_group (no-op without one). */
+int ss_track_join(ss_ctx* ctx, void* hip_stream);
+/* A non-blocking HIP stream whose queue may use every compute unit except the first `skip_cus` of the CU mask (bit i = compute
+ * unit i / 8 of XCD i % 8; skip_cus == 0: a plain stream) -> *out (hipStream_t); ss_stream_destroy releases it. */
+int ss_stream_create(ss_ctx* ctx, int skip_cus, void** out);
+int ss_stream_destroy(ss_ctx* ctx, void* hip_stream);
 
 /* Per-stream error flags raised on the device (capacity, infeasible); synchronous. */
 int ss_check_errors(ss_ctx* ctx);

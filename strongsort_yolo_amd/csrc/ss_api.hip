@@ -86,6 +86,12 @@ struct ss_ctx {
     int track_graph;            // option "track_graph": 1 (default) replay the chain as a graph for groups of >= 2 frames, 0 plain launches
     unsigned long long chain_clock;
     std::vector<unsigned long long> chain_seen;   // hashes of argument sets launched plainly once
+    // option "chain_cus": the per-frame chain runs on a stream of its own that owns the first `chain_cus` compute units of the
+    // CU mask (see ss_stream_create) instead of on the caller's stream
+    int chain_cus;
+    hipStream_t chain_stream;
+    hipEvent_t ev_head, ev_chain;
+    bool chain_pending;
 };
 
 static int fail(ss_ctx* c, int code, const std::string& msg)
@@ -113,6 +119,27 @@ static int dalloc(ss_ctx* c, T** p, size_t n, bool zero = true)
     return SS_OK;
 }
 
+// CU masks: bit i of the mask = compute unit i / n_xcd of XCD i % n_xcd (the driver deals the bits of a queue's mask out to the
+// XCDs in turn), so the first 8 k bits are k compute units of every XCD.
+static int cu_mask_stream(ss_ctx* c, int first, int count, hipStream_t* out)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c ? c->device : 0));
+    const int total = prop.multiProcessorCount;
+    if (first < 0 || count < 1 || first + count > total) return fail(c, SS_ERR_INVALID, "CU mask: range outside the device's compute units");
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int i = first; i < first + count; ++i) mask[i >> 5] |= 1u << (i & 31);
+    HIPCHK(c, hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
+    return SS_OK;
+}
+
+// a later launch on `s` sees what the detached chain wrote (no-op when nothing is detached)
+static int chain_join(ss_ctx* c, hipStream_t s)
+{
+    if (c->chain_pending) HIPCHK(c, hipStreamWaitEvent(s, c->ev_chain, 0));
+    return SS_OK;
+}
+
 extern "C" const char* ss_last_error(const ss_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
 extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
@@ -131,6 +158,7 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     c->assoc_stage = 5;          // LDS-DMA in four pieces, first piece + first gallery piece only before the first barrier (r04: 37.8 -> 36.4 us per 1 x 32-frame launch)
     c->xcd_map = 0;
     c->cap_stream = nullptr; c->track_graph = 1; c->chain_clock = 0;
+    c->chain_cus = 0; c->chain_stream = nullptr; c->ev_head = c->ev_chain = nullptr; c->chain_pending = false;
     c->inkernel = 0;
     c->cls_mask[0] = c->cls_mask[1] = ~0ull;
     c->cmc_small = nullptr; c->cmc_stride = 0; c->cmc_hw[0] = c->cmc_hw[1] = 0; c->cmc_warps = nullptr; c->assoc_event = nullptr;
@@ -202,6 +230,9 @@ extern "C" void ss_destroy(ss_ctx* c)
     for (auto& e : c->ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (auto& g : c->chains) { (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); }
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    if (c->chain_stream) { (void)hipStreamSynchronize(c->chain_stream); (void)hipStreamDestroy(c->chain_stream); }
+    if (c->ev_head) (void)hipEventDestroy(c->ev_head);
+    if (c->ev_chain) (void)hipEventDestroy(c->ev_chain);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& st : c->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
     if (c->back.p) (void)hipHostFree(c->back.p);
@@ -308,6 +339,7 @@ extern "C" int ss_overlay(ss_ctx* c, void* hip_stream, uint8_t* d_frames, int ba
 extern "C" int ss_synchronize(ss_ctx* c)
 {
     if (!c) return SS_ERR_INVALID;
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SS_OK;
 }
@@ -315,6 +347,7 @@ extern "C" int ss_synchronize(ss_ctx* c)
 extern "C" int ss_reset(ss_ctx* c, int stream)
 {
     if (!c || stream >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_reset: bad stream");
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     SSDev& d = c->dev;
     const int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? d.S : stream + 1;
     const size_t T = SS_MAXT;
@@ -365,6 +398,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         }
         e0 = c->ev[c->ev_used].first; e1 = c->ev[c->ev_used].second; ++c->ev_used;
     }
+    if (int rc = chain_join(c, c->stream)) return rc;          // the previous group's detached chain wrote the track tables this call reads
     ss_launch_group_head(dev, c->prm, c->stream, e0, e1, c->assoc_event);
     HIPCHK(c, hipGetLastError());
     // The chain: k_frame / k_post / k_newrow per frame, strictly dependent.  For a group of several frames that is up to 95
@@ -373,8 +407,20 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
     // what the key compares.  Not inside somebody else's stream capture (torch capturing the frame-at-a-time pipeline).
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (c->stream) HIPCHK(c, hipStreamIsCapturing(c->stream, &cs));
+    // Detached chain (option "chain_cus"): the chain's one- to 64-workgroup kernels go to a stream whose queue owns a few compute
+    // units, ordered after the association launch by an event; the caller's stream goes on with its next launches (the networks
+    // of the following group) and ss_track_join makes whoever consumes the rows wait for the chain.
+    hipStream_t chain_st = c->stream;
+    struct Done { ss_ctx* c; hipStream_t st; bool on; ~Done() { if (on && hipEventRecord(c->ev_chain, st) == hipSuccess) c->chain_pending = true; } };
+    const bool detach = c->chain_stream && cs == hipStreamCaptureStatusNone;
+    if (detach) {
+        HIPCHK(c, hipEventRecord(c->ev_head, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->chain_stream, c->ev_head, 0));
+        chain_st = c->chain_stream;
+    }
+    Done done{ c, chain_st, detach };                          // recorded after whichever form of the chain is enqueued below
     if (!c->track_graph || n_frames < 2 || cs != hipStreamCaptureStatusNone) {
-        ss_launch_group_chain(dev, c->prm, c->stream);
+        ss_launch_group_chain(dev, c->prm, chain_st);
         HIPCHK(c, hipGetLastError());
         return SS_OK;
     }
@@ -393,7 +439,7 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         if (!seen) {
             if (c->chain_seen.size() >= 64) c->chain_seen.erase(c->chain_seen.begin());
             c->chain_seen.push_back(h);
-            ss_launch_group_chain(dev, c->prm, c->stream);
+            ss_launch_group_chain(dev, c->prm, chain_st);
             HIPCHK(c, hipGetLastError());
             return SS_OK;
         }
@@ -417,7 +463,32 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         hit = &c->chains.back();
     }
     hit->used = ++c->chain_clock;
-    HIPCHK(c, hipGraphLaunch(hit->exec, c->stream));
+    HIPCHK(c, hipGraphLaunch(hit->exec, chain_st));
+    return SS_OK;
+}
+
+extern "C" int ss_track_join(ss_ctx* c, void* hip_stream)
+{
+    if (!c) return SS_ERR_INVALID;
+    return chain_join(c, (hipStream_t)hip_stream);
+}
+
+extern "C" int ss_stream_create(ss_ctx* c, int skip_cus, void** out)
+{
+    if (!c || !out || skip_cus < 0) return fail(c, SS_ERR_INVALID, "ss_stream_create: bad argument");
+    hipDeviceProp_t prop;
+    HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+    hipStream_t st = nullptr;
+    if (skip_cus == 0) HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    else if (int rc = cu_mask_stream(c, skip_cus, prop.multiProcessorCount - skip_cus, &st)) return rc;
+    *out = (void*)st;
+    return SS_OK;
+}
+
+extern "C" int ss_stream_destroy(ss_ctx* c, void* hip_stream)
+{
+    if (!c || !hip_stream) return SS_ERR_INVALID;
+    HIPCHK(c, hipStreamDestroy((hipStream_t)hip_stream));
     return SS_OK;
 }
 
@@ -454,6 +525,7 @@ extern "C" int ss_track_update_host(ss_ctx* c, int stream, const float* h_dets, 
     HIPCHK(c, hipMemcpyAsync(c->d_imghw, hw, 8, hipMemcpyHostToDevice, c->stream));
     int rc = ss_track_update(c, c->d_dets, c->d_ndets, c->d_feats, c->d_imghw, c->d_out, c->d_nout);
     if (rc) return rc;
+    if (int rcj = chain_join(c, c->stream)) return rcj;
     int cnt[2] = { 0, 0 }, err = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt[0], c->d_nout, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(&err, c->dev.err, 4, hipMemcpyDeviceToHost, c->stream));
@@ -478,6 +550,20 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
         if (value != 0 && (value < 16 || value > 128 || value % 16)) return fail(c, SS_ERR_INVALID, "frame_caps: 0 or a multiple of 16 in 16..128");
         c->dev.cap_t = value ? value : SS_MAXT; c->dev.cap_d = value ? value : SS_MAXD; c->dev.cap_cost = value ? value * value : SS_COST_CAP;
     }
+    else if (n == "chain_cus") {
+        if (value < -1 || value > 128 || (value > 0 && value % 8)) return fail(c, SS_ERR_INVALID, "chain_cus: 0 (off), -1 (detached, no reservation) or a multiple of 8 up to 128");
+        if (c->chain_stream) { HIPCHK(c, hipStreamSynchronize(c->chain_stream)); HIPCHK(c, hipStreamDestroy(c->chain_stream)); c->chain_stream = nullptr; }
+        c->chain_pending = false;
+        if (value) {
+            if (value < 0) {                                     // detached onto a plain high-priority stream: every compute unit, no reservation
+                int lo = 0, hi = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->chain_stream, hipStreamNonBlocking, hi));
+            } else if (int rc = cu_mask_stream(c, 0, value, &c->chain_stream)) return rc;
+            if (!c->ev_head) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_chain, hipEventDisableTiming)); }
+        }
+        c->chain_cus = value;
+    }
     else if (n == "track_graph") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "track_graph: 0 or 1"); c->track_graph = value; }
     else if (n == "assoc_xcd_map") { if (value != 0 && value != 1) return fail(c, SS_ERR_INVALID, "assoc_xcd_map: 0 or 1"); c->xcd_map = value; }
     else return fail(c, SS_ERR_INVALID, "ss_set_option: unknown option '" + n + "'");
@@ -487,6 +573,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
 extern "C" int ss_check_errors(ss_ctx* c)
 {
     if (!c) return SS_ERR_INVALID;
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     std::vector<int> e(c->dev.S);
     HIPCHK(c, hipMemcpyAsync(e.data(), c->dev.err, e.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -689,6 +776,7 @@ extern "C" int ss_get_tracks(ss_ctx* c, int s, int cap, int* n_tracks, int* next
                              double* cov, float* smooth, int* gal_count)
 {
     if (!c || s < 0 || s >= c->dev.S) return fail(c, SS_ERR_INVALID, "ss_get_tracks: bad stream");
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     HIPCHK(c, hipStreamSynchronize(c->stream));
     SSDev& d = c->dev;
     int nt = 0, nid = 0;
@@ -727,6 +815,7 @@ extern "C" int ss_get_debug(ss_ctx* c, int s, int frame, int* counts, float* cos
                             double* cost_a, double* cost_b, int* lists)
 {
     if (!c || s < 0 || s >= c->dev.S || frame < 0 || frame >= SS_FMAX) return fail(c, SS_ERR_INVALID, "ss_get_debug: bad stream / frame");
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     if (!c->cfg.debug) return fail(c, SS_ERR_INVALID, "ss_get_debug: context created without debug");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     SSDev& d = c->dev;
@@ -745,6 +834,7 @@ extern "C" int ss_get_debug(ss_ctx* c, int s, int frame, int* counts, float* cos
 extern "C" int ss_get_gallery(ss_ctx* c, int s, int track_index, float* rows, int cap_rows, int* count)
 {
     if (!c || s < 0 || s >= c->dev.S || track_index < 0 || track_index >= SS_MAXT) return fail(c, SS_ERR_INVALID, "ss_get_gallery: bad argument");
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     HIPCHK(c, hipStreamSynchronize(c->stream));
     SSDev& d = c->dev;
     int slot = 0, cnt = 0;
@@ -765,6 +855,7 @@ extern "C" int ss_get_gallery(ss_ctx* c, int s, int track_index, float* rows, in
 extern "C" int ss_assoc_inkernel_timing(ss_ctx* c, int enable, double* mean_us, int* launches)
 {
     if (!c) return SS_ERR_INVALID;
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     HIPCHK(c, hipStreamSynchronize(c->stream));
     unsigned long long t[4] = { 0, 0, 0, 0 };
     HIPCHK(c, hipMemcpy(t, c->dev.tstamp, sizeof t, hipMemcpyDeviceToHost));
@@ -780,6 +871,7 @@ extern "C" int ss_assoc_inkernel_timing(ss_ctx* c, int enable, double* mean_us, 
 extern "C" int ss_assoc_timeline(ss_ctx* c, long long* out, int n_workgroups)
 {
     if (!c || !out || n_workgroups < 1 || n_workgroups > 4096) return SS_ERR_INVALID;
+    if (int rcj = chain_join(c, c->stream)) return rcj;               // a detached chain wrote what this call reads
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->dev.timeline, (size_t)n_workgroups * 16 * 8, hipMemcpyDeviceToHost));
     return SS_OK;

@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_lightconv(const __half* __restrict__ x,
                                                   const __half* __restrict__ w9, const __half* __restrict__ bias,
                                                   __half* __restrict__ y, int H, int W, int bands)
 {
-    constexpr int KS = (C + 15) / 16, MT = KS, C8 = C / 8, TH = LC_TH;
+    constexpr int KS = (C + 15) / 16, MT = KS, TH = LC_TH;
     extern __shared__ __attribute__((aligned(16))) char lc_smem[];
     constexpr int PS = MT * 16;
     _Float16* T = (_Float16*)lc_smem;                       // [(TH+2)][W+2][PS] (lc_slot order)

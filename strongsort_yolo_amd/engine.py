@@ -74,6 +74,9 @@ class TrackerEngine:
     def close(self):
         if getattr(self, "ctx", None) and self.ctx.value:
             torch.cuda.synchronize(self.device)          # nothing of ours may still be in flight on any stream
+            for h in getattr(self, "_streams_keep", []):
+                self.L.ss_stream_destroy(self.ctx, C.c_void_p(h))
+            self._streams_keep = []
             self.L.ss_destroy(self.ctx)
             self.ctx = C.c_void_p()
 
@@ -158,6 +161,21 @@ class TrackerEngine:
         association launch of every following update_group call."""
         self._assoc_ev_keep = event
         self._ck(self.L.ss_track_set_assoc_event(self.ctx, C.c_void_p(event.cuda_event if event is not None else 0)))
+
+    def track_join(self, stream):
+        """`stream` (torch.cuda.Stream) waits for the detached per-frame chain of the last update_group (option "chain_cus")."""
+        self._ck(self.L.ss_track_join(self.ctx, C.c_void_p(stream.cuda_stream)))
+
+    def create_stream(self, skip_cus: int = 0):
+        """A stream whose queue leaves the first `skip_cus` compute units of the CU mask alone (ss_stream_create) as a
+        torch.cuda.ExternalStream; the handle lives as long as the engine."""
+        import torch
+        h = C.c_void_p()
+        self._ck(self.L.ss_stream_create(self.ctx, int(skip_cus), C.byref(h)))
+        if not hasattr(self, "_streams_keep"):
+            self._streams_keep = []
+        self._streams_keep.append(h.value)
+        return torch.cuda.ExternalStream(h.value, device=self.device)
 
     def update_host(self, dets: np.ndarray, feats: np.ndarray, img_hw) -> np.ndarray:
         """Single-stream synchronous update with host arrays -> rows [M,8] float32."""

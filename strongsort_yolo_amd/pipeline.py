@@ -290,7 +290,7 @@ class OverlappedPipeline(FramePipeline):
 
     def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
                  tracker_stream: bool = False, defer_track: bool = False, keep_net_outputs: bool = False, pack_crops: bool = True,
-                 assoc_gate: bool = True, track_priority: bool = True, skip_tracker: bool = False, **kw):
+                 assoc_gate: bool = True, track_priority: bool = True, skip_tracker: bool = False, chain_cus: int = 0, **kw):
         kw = dict(kw)
         # keep_net_outputs: every buffer set keeps a reference to the head tensor and the embeddings its graphs produce
         # (b.head_out / b.emb_out: tensors of the graph's private pool, same address at every replay) even when the synthetic
@@ -343,7 +343,20 @@ class OverlappedPipeline(FramePipeline):
         # priority, so their workgroups are dispatched ahead of the other stream's network kernels (measured at frame batch
         # 32: association launch 61 -> 50 us beside the network kernels, 8640 -> 8790 frames/s; track_priority=False: A/B)
         hi = bool(track_priority)
-        self.streams = [torch.cuda.Stream(self.dev, priority=(-1 if (hi and j == self.n - 1) else 0)) for j in range(self.n)]
+        # chain_cus = n > 0: the tracker's per-frame chain (one- to 64-workgroup kernels, ~27 us a frame, strictly dependent) is
+        # detached onto a library stream that owns n compute units (n / 8 per XCD), every stream of this pipeline is created without
+        # them, and the rows are fetched on a results stream that waits for the chain: the chain then runs beside the networks
+        # instead of between their kernels in the dispatcher.  (CU-masked streams have no priority: track_priority does not apply.)
+        # chain_cus = -1: detached onto a plain high-priority stream, nothing reserved.
+        self.chain_cus = int(chain_cus)
+        if self.chain_cus:
+            self.eng.set_option("chain_cus", self.chain_cus)
+        if self.chain_cus > 0:
+            self.streams = [self.eng.create_stream(self.chain_cus) for _ in range(self.n)]
+        else:
+            self.streams = [torch.cuda.Stream(self.dev, priority=(-1 if (hi and j == self.n - 1) else 0)) for j in range(self.n)]
+        self.sR = torch.cuda.Stream(self.dev) if self.chain_cus else None      # result copies / buffer-set release of a detached chain
+        self._res_ev = None
         # tracker_stream=True gives the tracker (one-workgroup kernels, ~70 us a frame) a stream of its own next to the
         # last stage of the following group, with one more buffer set so that stage 0 does not wait for it.  Measured
         # at configs[1], same box, frame batch 8: 3110 frames/s with it vs 3280 without — a third concurrent launch
@@ -377,7 +390,7 @@ class OverlappedPipeline(FramePipeline):
         # flight — instead of at the head of stage 0's stream, which is exactly when the deferred tracker call of an older group
         # launches its association kernel (the copies' blit kernels and k_assoc then share the chip: on some boxes / runs the
         # association launch took 86 us instead of 38).  Filling on `sA` stays correct (it is ordered before stage 0).
-        self.s_in = torch.cuda.Stream(self.dev)
+        self.s_in = self.eng.create_stream(self.chain_cus) if self.chain_cus > 0 else torch.cuda.Stream(self.dev)
         self.ev_in = [torch.cuda.Event() for _ in range(self.nb)]
         self.sB = self.sT if self.sT is not None else self.streams[-1]                    # tracker + result stream
         self.k = 0                          # groups (of frame_batch frames) submitted
@@ -496,15 +509,20 @@ class OverlappedPipeline(FramePipeline):
         e = self.eng
         nv = self.F if n_valid is None else n_valid
         G, S = self.eng.max_group_frames, self.S             # frames per library call (SS_FMAX)
+        if self.sR is not None and self._res_ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._res_ev)     # the previous group's rows have left self.outs
         for f0 in range(0, nv if not self.skip_tracker else 0, G):
             n, v0, v1 = min(G, nv - f0), f0 * S, min(nv, f0 + G) * S
             if self.cmc:
                 e.set_cmc(b.warps[f0:f0 + n])
             e.update_group(n, b.dets6[v0:v1], b.ndets[v0:v1], b.feats_v[v0:v1], self.img_hw, self.outs[f0:f0 + n], self.nouts[f0:f0 + n])
+        if self.sR is not None:                                 # detached chain: the rows exist once the chain's stream is done
+            e.track_join(self.sR)
         if group is not None and self.on_result is not None:
             self.cur_bufs, self.cur_valid = b, nv               # the buffer set / real-frame count the callbacks below refer to
-            for f in range(nv):
-                self.on_result(group + f, f)           # e.g. enqueue the D2H copy of self.outs[f] on this stream
+            with torch.cuda.stream(self.sR if self.sR is not None else torch.cuda.current_stream(self.dev)):
+                for f in range(nv):
+                    self.on_result(group + f, f)       # e.g. enqueue the D2H copy of self.outs[f] on this stream
 
     def _ss_stream(self, st):
         import ctypes as C
@@ -577,15 +595,23 @@ class OverlappedPipeline(FramePipeline):
                         self._track_b(self.bufs[i], self.valid[i], self.base[i])
                     elif self.on_result is not None:
                         self.on_result(self.base[i], 0)          # graph == "all" implies frame_batch == 1
-                self.ev[j][i].record(st)
+                    self._mark_tracked(i, st)
+                else:
+                    self.ev[j][i].record(st)
         self.stage_done[j] = frame_idx + 1
+
+    def _mark_tracked(self, i, st):
+        """Buffer set i has left the tracker (its rows are fetched): on the results stream when the chain is detached."""
+        ev = self.ev[self.n - 1][i]
+        ev.record(self.sR if self.sR is not None else st)
+        self._res_ev = ev
 
     def _flush_track(self, st):
         i = self._pending_track
         if i is not None:
             self._pending_track = None
             self._track_b(self.bufs[i], self.valid[i], self.base[i])
-            self.ev[self.n - 1][i].record(st)
+            self._mark_tracked(i, st)
             self._gate = self.assoc_ev is not None
 
     def submit(self, n_valid: int = None):

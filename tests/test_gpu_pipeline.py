@@ -218,6 +218,17 @@ def _run_groups(pipe, items, fb):
     ("yolo11n-pose", 1280, 720, 30, 32, 112, 2),   # --preset c6: the reference's default weights file (yolo_multi_model.py:17), C3k2 / C2PSA graph, pose head
 ])
 def test_benchmarked_configuration_equals_oracle(detector, w, h, n_ids, reid_batch, n_frames, split):
+    _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, split)
+
+
+def test_detached_tracker_chain_on_reserved_compute_units_equals_oracle():
+    """Pipeline option chain_cus=16 (library option "chain_cus", ss_stream_create, ss_track_join): the per-frame chain on a stream that
+    owns two compute units of every XCD, the pipeline's streams without them, rows fetched on a results stream that joined the chain —
+    the same bytes as the oracle (the form is off by default: profiles/r04_chain_cus_ab.txt)."""
+    _benchmarked("yolov5n", 640, 480, 8, 32, 80, 2, chain_cus=16)
+
+
+def _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, split, **pipe_kw):
     """Exactly what bench.py times: frame batch 32, stage cut inside OSNet where bench.REID_SPLIT puts it, deferred tracker call + association gate,
     packed ReID crops, galleries filling up to nn_budget rows — every frame tobytes()-equal to the oracle chain
     (VERDICT r2 'next' item 1, r3 'next' item 1a; arithmetic behind /root/reference/yolo_multi_model.py:41).  Pose head: the keypoint
@@ -227,8 +238,9 @@ def test_benchmarked_configuration_equals_oracle(detector, w, h, n_ids, reid_bat
     preset = {v[0]: k for k, v in bench.PRESETS.items()}[detector]
     assert bench.REID_SPLIT[preset] == split and bench.PRESETS[preset][1:] == (w, h, n_ids, reid_batch)
     pipe = OverlappedPipeline(detector, 1, (h, w), half=True, reid_batch=reid_batch, det_source="synthetic",
-                              feat_source="by_anchor", graph="front", n_stages=2, frame_batch=32, reid_split=split, defer_track=True)
+                              feat_source="by_anchor", graph="front", n_stages=2, frame_batch=32, reid_split=split, defer_track=True, **pipe_kw)
     assert pipe.pack and pipe.defer and pipe.assoc_ev is not None and pipe.nb == 3 and pipe.eng.max_group_frames == 32
+    assert (pipe.sR is not None) == bool(pipe_kw.get("chain_cus"))
     gs = scale_geometry(pipe.geom, h, w)
     st, rng = make_stream(77, w, h, n_ids), np.random.default_rng(77)
     items, dcfg, orc = [], DetectConfig(), OracleStrongSort(StrongSortConfig(), "c")
