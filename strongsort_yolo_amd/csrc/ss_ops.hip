@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_osnet_streams(const __half* __restrict_
         ((red[tid] + red[MT * 16 + tid]) + red[2 * MT * 16 + tid]) + red[3 * MT * 16 + tid];
 }
 
-// ---- the LightConv chains as a register-resident row stream (W = 16 or 32) ----
+// ---- the LightConv chains as a register-resident row stream (W = 8, 16 or 32; 8: two images per 16-lane tile) ----
 // k_osnet_streams keeps every layer's pointwise output in LDS and reads it back nine times per output (9 x 16 bytes per
 // (pixel, 8 channels)): at 512 crops the stage-1 launch is bound by VALU issue + LDS traffic (186 us, rocprofv3).  The MFMA
 // output layout makes LDS unnecessary: after v_mfma_f32_16x16x16_f16 (A = weights, B = 16 pixels of one image row) lane
@@ -1567,7 +1567,7 @@ __device__ __forceinline__ unsigned ss_pk_relu(unsigned v) { unsigned d; asm("v_
 #ifndef OS_SKEW
 #define OS_SKEW 0
 #endif
-template <int C, int NT, int T, bool ALDS>
+template <int C, int NT, int T, bool ALDS, bool PAIR>
 struct OsChain {
     static constexpr int MT = (C + 15) / 16, KS = MT, CP = MT * 16;
     uint2 A[T][MT][KS];                  // pointwise weights (MFMA A operand)
@@ -1575,9 +1575,11 @@ struct OsChain {
     f4 acc0[T][NT][MT], acc1[T][NT][MT];
     uint2 xs[T > 1 ? T - 1 : 1][NT][MT]; // layer l's output row = layer l+1's input
     float s[MT][4];                      // channel sums of the stored outputs
+    unsigned mL, mR;                     // PAIR (two 8-wide images in one 16-lane tile): lane 8 has no left, lane 7 no right neighbour
 
     __device__ __forceinline__ void init(const __half* w1, const char* tab, int aoff, int q, int n)
     {
+        mL = (PAIR && n == 8) ? 0u : ~0u; mR = (PAIR && n == 7) ? 0u : ~0u;
         constexpr int lbase = (T * (T - 1)) / 2;
         const uint2 z = { 0u, 0u };
         const f4 z4 = { 0.f, 0.f, 0.f, 0.f };
@@ -1652,6 +1654,7 @@ struct OsChain {
                         const uint2 nx = pc[j + 1][mt];
                         pr[j][mt].x = ss_dpp_shl1_o(ss_dpp_ror15(nx.x), c.x); pr[j][mt].y = ss_dpp_shl1_o(ss_dpp_ror15(nx.y), c.y);
                     }
+                    if constexpr (PAIR) { pl[j][mt].x &= mL; pl[j][mt].y &= mL; pr[j][mt].x &= mR; pr[j][mt].y &= mR; }
                 }
             const int orow = row - (OS_SKEW ? 2 * l : l) - 1;
             const bool inside = orow >= 0 && orow < H;
@@ -1681,25 +1684,31 @@ struct OsChain {
     }
 };
 
-template <int C, int NT, int T, bool ALDS>
+template <int C, int NT, int T, bool ALDS, bool PAIR>
 __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, const __half* __restrict__ w1, const char* tab,
                                              __half* __restrict__ yo, float* __restrict__ ps, int H,
-                                             int y0, int TH, int lane)
+                                             int y0, int TH, int lane, bool img1ok, int ps_img_stride)
 {
-    constexpr int MT = (C + 15) / 16, KS = MT, W = 16 * NT;
+    // PAIR: 8-wide maps, the 16-lane tile holds row `row` of TWO images (lanes n < 8: image 0 at xi / yo / ps, n >= 8: the next
+    // image, one image further in all three; img1ok: it exists)
+    constexpr int MT = (C + 15) / 16, KS = MT, W = PAIR ? 8 : 16 * NT;
+    static_assert(!PAIR || NT == 1, "PAIR: one tile of two 8-wide images");
     const int q = lane >> 4, n = lane & 15;
-    OsChain<C, NT, T, ALDS> ch;
+    const int col = PAIR ? (n & 7) : n;
+    const size_t lane_img = PAIR ? (size_t)(n >> 3) * H * W * C : 0;
+    const bool lane_ok = !PAIR || n < 8 || img1ok;
+    OsChain<C, NT, T, ALDS, PAIR> ch;
     const int aoff = ((n >> 2) == q ? n : 16) * 16;
     ch.init(w1, tab, aoff, q, n);
     const uint2 z = { 0u, 0u };
     auto load_row = [&](int row, uint2 (&r)[NT][KS]) {
-        const bool ok = row >= 0 && row < H;
+        const bool ok = row >= 0 && row < H && lane_ok;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int ic0 = ks * 16 + 4 * q;
-                r[j][ks] = (ok && ic0 < C) ? *reinterpret_cast<const uint2*>(xi + ((size_t)row * W + j * 16 + n) * C + ic0) : z;
+                r[j][ks] = (ok && ic0 < C) ? *reinterpret_cast<const uint2*>(xi + lane_img + ((size_t)row * W + j * 16 + col) * C + ic0) : z;
             }
     };
     const int yend = (y0 + TH < H ? y0 + TH : H);
@@ -1710,16 +1719,16 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int c4 = mt * 16 + 4 * q;
-                if (c4 < C) {
-                    *reinterpret_cast<uint2*>(yo + ((size_t)orow * W + j * 16 + n) * C + c4) = o[j][mt];
+                if (c4 < C && lane_ok) {
+                    *reinterpret_cast<uint2*>(yo + lane_img + ((size_t)orow * W + j * 16 + col) * C + c4) = o[j][mt];
                     const h4 v = __builtin_bit_cast(h4, o[j][mt]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ch.s[mt][e] += (float)v[e];
                 }
             }
     };
-    // rows y0 - T .. enter layer 0 (the band's last output row yend - 1 leaves the last layer at step yend + 2T - 2; rows past
-    // yend - 1 + T only feed discarded rows); three rows are in flight ahead of the one being processed
+    // rows y0 - T .. enter layer 0 (the band's last output row yend - 1 leaves the last layer DELAY steps after it entered; rows
+    // past yend - 1 + T only feed discarded rows); three rows are in flight ahead of the one being processed
     constexpr int DELAY = OS_SKEW ? 2 * T - 1 : T;          // steps between a row entering layer 0 and leaving the last layer
     const int r_first = y0 - T, r_last = yend - 1 + DELAY;
     uint2 r0[NT][KS], r1[NT][KS], r2[NT][KS], o[NT][MT];
@@ -1729,41 +1738,45 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
         if (row + 1 <= r_last) { ch.step(r1, row + 1, H, tab, aoff, q, o); load_row(row + 4, r1); emit(row + 1 - DELAY, o); }
         if (row + 2 <= r_last) { ch.step(r2, row + 2, H, tab, aoff, q, o); load_row(row + 5, r2); emit(row + 2 - DELAY, o); }
     }
-    // band sums of this lane's channels: over the 16 pixel lanes of the DPP row, fixed order
+    // band sums of this lane's channels: over the pixel lanes of the image (16, or 8 per image of a pair), fixed order
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = ch.s[mt][e];
-            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-            if (n == 0 && mt * 16 + 4 * q + e < C) ps[mt * 16 + 4 * q + e] = v;
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            if constexpr (!PAIR) v += __shfl_xor(v, 8);
+            if (col == 0 && lane_ok && mt * 16 + 4 * q + e < C) ps[(PAIR ? (n >> 3) * ps_img_stride : 0) + mt * 16 + 4 * q + e] = v;
         }
 }
 
-// wave = (image, band of TH rows); blockIdx.y selects the chains the wave runs (bit t-1 of nibble blockIdx.y of `masks`)
-template <int C, int NT>
+// wave = (image — PAIR: two consecutive 8-wide images —, band of TH rows); blockIdx.y selects the chains the wave runs (bit t-1 of
+// nibble blockIdx.y of `masks`)
+template <int C, int NT, bool PAIR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_osnet_chains(const __half* __restrict__ x, const __half* __restrict__ w1,
                                                      const char* __restrict__ gtab,
                                                      StreamOut out, float* __restrict__ psum, int N, int H, int TH, int bands,
                                                      unsigned masks, const int* __restrict__ nvalid)
 {
-    constexpr int W = 16 * NT;
+    constexpr int W = PAIR ? 8 : 16 * NT;
     constexpr bool ALDS = C > 16;                            // 16 channels: the (left, centre) operands of four layers stay in registers
     __shared__ __attribute__((aligned(16))) char tab[10 * DwTab<C>::LAYER];
     DwTab<C>::copy(tab, gtab, 10, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * 4 + wave;
-    if (item >= N * bands) return;
-    const int img = item / bands, band = item - img * bands, y0 = band * TH;
-    if (nvalid && img >= *nvalid) return;
+    const int item = blockIdx.x * 4 + wave, units = PAIR ? (N + 1) / 2 : N;
+    if (item >= units * bands) return;
+    const int unit = item / bands, band = item - unit * bands, y0 = band * TH, img = PAIR ? 2 * unit : unit;
+    const int nv = nvalid ? min(*nvalid, N) : N;
+    if (img >= nv) return;
+    const bool img1ok = img + 1 < nv;
     const unsigned m = (masks >> (4 * blockIdx.y)) & 15u;
     const __half* xi = x + (size_t)img * H * W * C;
     const size_t io = (size_t)img * H * W * C;
 #define SS_CH(TT)                                                                                                              \
     if (m & (1u << (TT - 1)))                                                                                                  \
-        os_chain_run<C, NT, TT, ALDS>(xi, w1, tab, out.y[TT - 1] + io, psum + (((size_t)(TT - 1) * N + img) * bands + band) * C, H, y0, \
-                                TH, lane)
+        os_chain_run<C, NT, TT, ALDS, PAIR>(xi, w1, tab, out.y[TT - 1] + io, psum + (((size_t)(TT - 1) * N + img) * bands + band) * C, H, y0, \
+                                            TH, lane, img1ok, bands * C)
     SS_CH(4); SS_CH(3); SS_CH(2); SS_CH(1);
 #undef SS_CH
 }
@@ -2426,7 +2439,7 @@ extern "C" int ss_op_gate_sum_f16(void* stream, const void* const* xs, int T, co
 static bool os_chain_form(int N, int W, int C)
 {
     const bool chains = g_opt_osnet_chains != 0;
-    return chains && N >= 96 && ((W == 32 && C == 16) || (W == 16 && (C == 16 || C == 24 || C == 32)));
+    return chains && N >= 96 && ((W == 32 && C == 16) || ((W == 16 || W == 8) && (C == 16 || C == 24 || C == 32)));
 }
 // band height of the stream form: as many bands as give one round of waves (32-wide: 3 waves per SIMD = 3072, 16-wide:
 // 2048; two chain groups per band), at least 8 rows per band
@@ -2434,7 +2447,8 @@ static int os_band_rows(int N, int H, int W, int C)
 {
     if (!os_chain_form(N, W, C)) return LC_TH;
     const int target = W == 32 ? 3072 : 2048;
-    int bands = target / (2 * N);
+    const int units = W == 8 ? (N + 1) / 2 : N;             // 8-wide maps: a wave takes two images
+    int bands = target / (2 * units);
     if (bands < 1) bands = 1;
     if (bands > (H + 7) / 8) bands = (H + 7) / 8;
     return (H + bands - 1) / bands;
@@ -2475,11 +2489,13 @@ extern "C" int ss_op_osnet_streams_f16(void* stream, const void* x, const void* 
     if (os_chain_form(N, W, C)) {
         // one wave per (image, band, chain group); groups {4,1} and {3,2}: five layers each
         const unsigned masks = 0x69u;
-        dim3 grid((unsigned)(((size_t)N * bands + 3) / 4), 2), block(256);
-#define SS_CHN(CC, NT) hipLaunchKernelGGL((k_osnet_chains<CC, NT>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
-                                          (const char*)dwtab, o, psum, N, H, TH, bands, masks, nv)
-        if (W == 32) SS_CHN(16, 2);                          // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
-        else { if (C == 16) SS_CHN(16, 1); else if (C == 24) SS_CHN(24, 1); else SS_CHN(32, 1); }
+        const size_t units = W == 8 ? ((size_t)N + 1) / 2 : (size_t)N;
+        dim3 grid((unsigned)((units * bands + 3) / 4), 2), block(256);
+#define SS_CHN(CC, NT, PR) hipLaunchKernelGGL((k_osnet_chains<CC, NT, PR>), grid, block, 0, st, (const __half*)x, (const __half*)w1, \
+                                              (const char*)dwtab, o, psum, N, H, TH, bands, masks, nv)
+        if (W == 32) SS_CHN(16, 2, false);                   // (wider channel counts at 32 columns exceed 256 VGPRs: LDS form)
+        else if (W == 16) { if (C == 16) SS_CHN(16, 1, false); else if (C == 24) SS_CHN(24, 1, false); else SS_CHN(32, 1, false); }
+        else { if (C == 16) SS_CHN(16, 1, true); else if (C == 24) SS_CHN(24, 1, true); else SS_CHN(32, 1, true); }
 #undef SS_CHN
         return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
     }

@@ -54,7 +54,8 @@ def test_host_side_entry_points_without_a_gpu():
     assert L.ss_op_osnet_streams_bands(1024, 64, 32, 16) == 1
     assert L.ss_op_osnet_streams_bands(128, 64, 32, 16) == 8
     assert L.ss_op_osnet_streams_bands(512, 32, 16, 24) == 2
-    assert L.ss_op_osnet_streams_bands(512, 16, 8, 32) == 1            # 8-wide maps stay on the LDS form
+    assert L.ss_op_osnet_streams_bands(512, 16, 8, 32) == 2            # 8-wide maps: two images per wave, 256 units
+    assert L.ss_op_osnet_streams_bands(32, 16, 8, 32) == 1             # below 96 images: the LDS form, whole 16-row bands
     assert L.ss_op_osnet_streams_bands(0, 64, 32, 16) < 0
     assert L.ss_op_set_valid_images(None, None, 0) == 0 and L.ss_op_set_valid_images(None, None, 5) == 0       # NULL count: off
     assert L.ss_op_set_option(b"pw_splitk", 1) == 0 and L.ss_op_set_option(b"no_such_switch", 1) == lib.SS_ERR_INVALID

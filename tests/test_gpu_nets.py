@@ -159,7 +159,9 @@ def test_pointwise_matches_conv_bias_act(M_hw, K, N, act):
 @pytest.mark.parametrize("shape", [(3, 16, 64, 32), (2, 24, 32, 16), (4, 32, 16, 8), (2, 16, 40, 24), (1, 32, 5, 8), (5, 16, 37, 32), (3, 32, 19, 16),
                                    (2, 16, 7, 16), (1, 24, 64, 16),
                                    # >= 96 images: the register-stream form (bands chosen from the image count)
-                                   (96, 16, 64, 32), (130, 16, 37, 32), (200, 24, 32, 16), (97, 32, 19, 16), (100, 16, 7, 16), (512, 16, 64, 32)])
+                                   (96, 16, 64, 32), (130, 16, 37, 32), (200, 24, 32, 16), (97, 32, 19, 16), (100, 16, 7, 16), (512, 16, 64, 32),
+                                   # 8-wide maps in the register-stream form: two images per 16-lane tile (odd counts: the last wave has one)
+                                   (97, 32, 16, 8), (200, 32, 16, 8), (131, 16, 11, 8), (96, 24, 5, 8), (1024, 32, 16, 8)])
 def test_osnet_streams_equal_layerwise_chains(shape):
     """Chain-fused kernel (intermediates in LDS, shrinking halo) vs the same ten layers run one launch each: outputs
     bit-identical (same arithmetic per layer), band sums equal the float sum of the outputs; then the gate built on
