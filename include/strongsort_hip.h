@@ -308,6 +308,14 @@ int ss_op_head_f16(void* stream, const void* d_x, const void* const* d_w1, const
 int ss_op_v8_decode_f16(void* stream, const void* const* d_box, const void* const* d_cls, const void* const* d_box_bias,
                         const void* const* d_cls_bias, const int* H, const int* W, const int* strides, int B, int nc,
                         float* d_pred);
+/* The same with the head's third branch as extra rows 4 + nc .. 4 + nc + n_ext of the prediction [B][4 + nc + n_ext][A]: d_ext[3]
+ * [B][H][W][ext_ld] half with the bias already added (the branch's last 1x1 through ss_op_pointwise_f16); ext_mode 1: keypoint
+ * triplets decoded as Ultralytics Pose.kpts_decode ((2 v + cell) * stride for x and y, sigmoid for the visibility), n_ext % 3 == 0;
+ * ext_mode 0: raw values (Segment's mask coefficients).  cls_ld >= nc: channels per pixel of the class tensors (a one-class head
+ * zero-padded to 8 so that its last 1x1 runs on ss_op_pointwise_f16).  n_ext == 0 and cls_ld == nc: ss_op_v8_decode_f16. */
+int ss_op_v8_decode_ext_f16(void* stream, const void* const* d_box, const void* const* d_cls, const void* const* d_box_bias,
+                            const void* const* d_cls_bias, const void* const* d_ext, int n_ext, int ext_ld, int ext_mode,
+                            const int* H, const int* W, const int* strides, int B, int nc, int cls_ld, float* d_pred);
 int ss_op_dwconv3x3_f16(void* stream, const void* d_x, const void* d_w9 /*[9][C]*/, const void* d_bias, void* d_y,
                         int N, int H, int W, int C, int act);
 /* OSNet LightConv3x3 in one pass: y = relu(dw3x3(pw1x1(x)) + bias); w1 [C][C] (out, in), w9 [9][C], C in

@@ -167,6 +167,12 @@ struct V8Levels {
     const __half* box[3]; const __half* cls[3];             // [B][H][W][64], [B][H][W][nc]
     const __half* box_bias[3]; const __half* cls_bias[3];
     int H[3], W[3], stride[3];
+    // the head's third branch (keypoints / mask coefficients), bias already added: [B][H][W][ext_ld], n_ext of them used ->
+    // rows 4 + nc .. of the prediction; ext_mode 1: Ultralytics Pose.kpts_decode ((2 v + cell) * stride for x and y, sigmoid for
+    // the visibility of every (x, y, v) triplet), 0: raw (Segment's mask coefficients)
+    const __half* ext[3];
+    int n_ext, ext_ld, ext_mode;
+    int cls_ld;                                             // channels per pixel of the class tensors (>= nc: a 1-class head padded to 8)
 };
 
 __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, int A, float* __restrict__ pred)
@@ -196,10 +202,18 @@ __global__ __launch_bounds__(128) void k_v8_decode(V8Levels L, int B, int nc, in
     }
     const float ax = (float)px + 0.5f, ay = (float)py + 0.5f, st = (float)L.stride[l];
     const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-    float* o = pred + (size_t)b * (4 + nc) * A + a;
+    float* o = pred + (size_t)b * (4 + nc + L.n_ext) * A + a;
     o[0] = (x1 + x2) * 0.5f * st; o[(size_t)A] = (y1 + y2) * 0.5f * st;
     o[(size_t)2 * A] = (x2 - x1) * st; o[(size_t)3 * A] = (y2 - y1) * st;
-    const __half* cl = L.cls[l] + ((size_t)b * hw + p) * nc;
+    if (L.n_ext) {
+        const __half* e = L.ext[l] + ((size_t)b * hw + p) * L.ext_ld;
+        float* oe = o + (size_t)(4 + nc) * A;
+        for (int k = 0, j = 0; k < L.n_ext; ++k, j = j == 2 ? 0 : j + 1) {
+            const float v = __half2float(e[k]);
+            oe[(size_t)k * A] = L.ext_mode == 0 ? v : j == 0 ? (v * 2.0f + (float)px) * st : j == 1 ? (v * 2.0f + (float)py) * st : 1.0f / (1.0f + __expf(-v));
+        }
+    }
+    const __half* cl = L.cls[l] + ((size_t)b * hw + p) * L.cls_ld;
     const __half* cb = L.cls_bias[l];
     if (nc % 8 == 0) {
         for (int k8 = 0; k8 < nc / 8; ++k8) {
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(256) void k_pw_splitk(PwArgs A) { pw_splitk_body<BN
 // branches are 18 launches of 60-1920 workgroups each, run one after the other; grouped by depth they are 3 launches whose
 // small levels fill the CUs the stride-8 level leaves idle.  blockIdx.x walks the problems' workgroup ranges; a problem is
 // either in k_pw's form (64 pixels per workgroup) or in the split-K form (16 pixels, long K walk, few pixels).
-#define PW_GROUP_MAX 8
+#define PW_GROUP_MAX 12
 // form[p]: 0 = 64 pixels per workgroup, 1 = split-K.  A problem with N <= 64 in a BN = 80 group (the box branches next to the class
 // branches) runs 4, not 5, channel tiles.  (128-pixel workgroups for the stride-8 level were measured too: the 148 VGPRs of that form
 // set the occupancy of EVERY problem in the launch to 2 waves per SIMD - detector 1.03 -> 1.05 ms.)
@@ -2298,21 +2312,31 @@ extern "C" int ss_op_bias_act_place_f16(void* stream, const void* x, const void*
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 
-extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const void* const* cls, const void* const* box_bias,
-                                   const void* const* cls_bias, const int* H, const int* W, const int* strides, int B, int nc,
-                                   float* pred)
+extern "C" int ss_op_v8_decode_ext_f16(void* stream, const void* const* box, const void* const* cls, const void* const* box_bias,
+                                       const void* const* cls_bias, const void* const* ext, int n_ext, int ext_ld, int ext_mode,
+                                       const int* H, const int* W, const int* strides, int B, int nc, int cls_ld, float* pred)
 {
-    if (!box || !cls || !box_bias || !cls_bias || !H || !W || !strides || !pred || B < 1 || B > 65535 || nc < 1) return SS_ERR_INVALID;
+    if (!box || !cls || !box_bias || !cls_bias || !H || !W || !strides || !pred || B < 1 || B > 65535 || nc < 1 || cls_ld < nc) return SS_ERR_INVALID;
+    if (n_ext < 0 || (n_ext && (!ext || ext_ld < n_ext || (ext_mode != 0 && ext_mode != 1) || (ext_mode == 1 && n_ext % 3)))) return SS_ERR_INVALID;
     V8Levels L;
     int A = 0;
+    L.n_ext = n_ext; L.ext_ld = ext_ld; L.ext_mode = ext_mode; L.cls_ld = cls_ld;
     for (int l = 0; l < 3; ++l) {
         L.box[l] = (const __half*)box[l]; L.cls[l] = (const __half*)cls[l];
         L.box_bias[l] = (const __half*)box_bias[l]; L.cls_bias[l] = (const __half*)cls_bias[l];
+        L.ext[l] = n_ext ? (const __half*)ext[l] : nullptr;
         L.H[l] = H[l]; L.W[l] = W[l]; L.stride[l] = strides[l];
         A += H[l] * W[l];
     }
     hipLaunchKernelGGL(k_v8_decode, dim3((A + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, L, B, nc, A, pred);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_v8_decode_f16(void* stream, const void* const* box, const void* const* cls, const void* const* box_bias,
+                                   const void* const* cls_bias, const int* H, const int* W, const int* strides, int B, int nc,
+                                   float* pred)
+{
+    return ss_op_v8_decode_ext_f16(stream, box, cls, box_bias, cls_bias, nullptr, 0, 0, 0, H, W, strides, B, nc, nc, pred);
 }
 
 static int launch_pw(hipStream_t st, bool conv3, const void* x, const void* w, const void* bias, const void* res, long long M, int K,

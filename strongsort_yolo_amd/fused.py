@@ -23,7 +23,7 @@ def _flag(name: str) -> bool:
     return True
 
 
-FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE")
+FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE", "DW3X3", "HEAD_EXT", "C3K2")
 
 
 def set_flags(**kw):
@@ -214,7 +214,7 @@ GROUP = _flag("GROUP")                  # independent convolutions of the detect
 
 def conv_group(items):
     """items: [(x, w_prepared, bias, ksize, stride, act)], all 3x3 (pad 1; weight_n9k) or all 1x1 (weight_nk), N <= 80, at most
-    8 entries.  Returns the dense channels-last outputs; ONE launch (csrc k_pw_group)."""
+    12 entries.  Returns the dense channels-last outputs; ONE launch (csrc k_pw_group)."""
     n = len(items)
     descs = (_lib.ss_conv_desc * n)()
     outs, keep = [], []
@@ -275,17 +275,83 @@ def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 
 
-def v8_decode(boxes, clss, box_bias, cls_bias, strides, nc):
-    """DFL + dist2bbox + sigmoid + level concat of the anchor-free head in one launch -> [B, 4+nc, A] float32."""
+def v8_decode(boxes, clss, box_bias, cls_bias, strides, nc, ext=None, n_ext=0, ext_mode=0):
+    """DFL + dist2bbox + sigmoid + level concat of the anchor-free head in one launch -> [B, 4+nc(+n_ext), A] float32.
+    ext: the third branch's three outputs [B, >= n_ext, H, W] (bias added), decoded as keypoint triplets (ext_mode 1) or copied raw
+    (ext_mode 0: mask coefficients) into rows 4+nc.. of the same tensor."""
     boxes, clss = [_cl(t) for t in boxes], [_cl(t) for t in clss]
     B = boxes[0].shape[0]
     H = (C.c_int * 3)(*[t.shape[2] for t in boxes]); W = (C.c_int * 3)(*[t.shape[3] for t in boxes])
     A = sum(t.shape[2] * t.shape[3] for t in boxes)
-    pred = torch.empty(B, 4 + nc, A, dtype=torch.float32, device=boxes[0].device)
+    pred = torch.empty(B, 4 + nc + n_ext, A, dtype=torch.float32, device=boxes[0].device)
     arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
-    _ck(_lib.load().ss_op_v8_decode_f16(_st(pred), arr(boxes), arr(clss), arr(box_bias), arr(cls_bias), H, W,
-                                        (C.c_int * 3)(*strides), B, nc, _p(pred)))
+    if n_ext or clss[0].shape[1] != nc:                  # a third branch, or class tensors padded past nc channels
+        ext = [_cl(t) for t in ext] if n_ext else clss
+        _ck(_lib.load().ss_op_v8_decode_ext_f16(_st(pred), arr(boxes), arr(clss), arr(box_bias), arr(cls_bias), arr(ext), n_ext, ext[0].shape[1],
+                                                ext_mode, H, W, (C.c_int * 3)(*strides), B, nc, clss[0].shape[1], _p(pred)))
+    else:
+        _ck(_lib.load().ss_op_v8_decode_f16(_st(pred), arr(boxes), arr(clss), arr(box_bias), arr(cls_bias), H, W,
+                                            (C.c_int * 3)(*strides), B, nc, _p(pred)))
     return pred
+
+
+HEAD_EXT = _flag("HEAD_EXT")            # pose / segmentation heads: the third branch on the convolution kernels (zero-padded widths) and its rows written by the decode launch
+C3K2 = _flag("C3K2")                    # v11's C3k2 / C3k blocks with every producer writing its slice of the concat buffer (no chunk / cat / add launches)
+DW3X3 = _flag("DW3X3")                  # depthwise 3x3 / stride 1 convolutions (the v11 head's DWConv) on k_dw3x3 instead of MIOpen
+
+
+def dw3x3_ok(conv) -> bool:
+    return (DW3X3 and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.stride == (1, 1)
+            and conv.groups == conv.in_channels == conv.out_channels and conv.in_channels % 8 == 0 and conv.bias is not None)
+
+
+def weight_dw9(mod, conv):
+    """[9, C] (tap-major) copy of a depthwise 3x3 weight, cached on the module."""
+    w = getattr(mod, "_w_dw9", None)
+    if w is None or w.device != conv.weight.device or w.dtype != conv.weight.dtype:
+        w = conv.weight.detach().reshape(conv.weight.shape[0], 9).t().contiguous()
+        mod._w_dw9 = w
+    return w
+
+
+def padded_last(mod, conv):
+    """A 1x1 Conv2d whose output count is not a multiple of 8 (the class branch of a one-class head) as (w_nk, bias) zero-padded to 8
+    rows, cached on `mod`; conv.in_channels % 8 == 0."""
+    p = getattr(mod, "_padded_last", None)
+    if p is None or p[0].device != conv.weight.device or p[0].dtype != conv.weight.dtype:
+        n, np_ = conv.out_channels, (conv.out_channels + 7) // 8 * 8
+        w = torch.zeros(np_, conv.in_channels, device=conv.weight.device, dtype=conv.weight.dtype)
+        w[:n] = conv.weight.detach().reshape(n, -1)
+        b = torch.zeros(np_, device=conv.weight.device, dtype=conv.weight.dtype)
+        b[:n] = conv.bias.detach()
+        p = mod._padded_last = (w, b)
+    return p
+
+
+def padded_branch(mod, seq, mult=16):
+    """A head branch Conv 3x3 -> Conv 3x3 -> Conv2d 1x1 whose hidden width is not a multiple of 8 (the pose branch: 51 channels) as
+    zero-padded weights the convolution kernels take: [(w_n9k, bias)] x 2 + (w_nk, bias) with the hidden width rounded up to `mult`
+    and the output rows to 8; the padded channels carry exact zeros (SiLU(0) = 0).  Cached on `mod`."""
+    p = getattr(mod, "_padded", None)
+    c0 = seq[0].conv
+    if p is None or p[0][0].device != c0.weight.device or p[0][0].dtype != c0.weight.dtype:
+        up = lambda v, m: (v + m - 1) // m * m
+        h, hp = c0.out_channels, up(c0.out_channels, mult)
+        n, np_ = seq[2].out_channels, up(seq[2].out_channels, 8)
+        dev, dt = c0.weight.device, c0.weight.dtype
+        def pad(w, rows, cols_in):                       # [N, Cin, kh, kw] -> [rows, kh*kw*cols_in], tap-major
+            N, Cin, kh, kw = w.shape
+            o = torch.zeros(rows, kh, kw, cols_in, device=dev, dtype=dt)
+            o[:N, :, :, :Cin] = w.detach().permute(0, 2, 3, 1)
+            return o.reshape(rows, -1).contiguous()
+        def padb(b, rows):
+            o = torch.zeros(rows, device=dev, dtype=dt)
+            o[:b.shape[0]] = b.detach()
+            return o
+        p = mod._padded = ((pad(c0.weight, hp, c0.in_channels), padb(c0.bias, hp)),
+                           (pad(seq[1].conv.weight, hp, hp), padb(seq[1].conv.bias, hp)),
+                           (pad(seq[2].weight, np_, hp), padb(seq[2].bias, np_)))
+    return p
 
 
 def dwconv3x3(x, w9, bias, act="relu"):

@@ -41,6 +41,8 @@ class Conv(nn.Module):
                 return fused.conv3x3(x, fused.weight_n9k(self, c), c.bias, c.stride[0], act)
             if fused.conv0_ok(x, c):         # the first convolution (3 input channels, stride 2)
                 return fused.conv0(x, fused.conv0_weight(self, c), c.bias, act)
+            if fused.dw3x3_ok(c):            # depthwise 3x3 (v11 head): MIOpen has only its naive kernel for these (55 us a launch)
+                return fused.dwconv3x3(x, fused.weight_dw9(self, c), c.bias, act)
             # k x k: conv without bias (MIOpen) + one fused bias+SiLU pass
             y = F.conv2d(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
             return fused.bias_act_(y, c.bias, act)
@@ -176,42 +178,72 @@ class Detect(nn.Module):
             strd.append(torch.full((1, h * w), float(s), device=f.device, dtype=f.dtype))
         return torch.cat(pts, 1).unsqueeze(0), torch.cat(strd, 1).unsqueeze(0)
 
+    def _zero_bias(self, like):
+        z = getattr(self, "_zeros", None)
+        if z is None or z.device != like.device:
+            z = self._zeros = torch.zeros(max(64, self.nc), dtype=like.dtype, device=like.device)
+        return [z] * 3
+
+    @staticmethod
+    def _last_ok(conv):
+        return fused.POINTWISE and fused.is_pointwise(conv) and conv.in_channels % 8 == 0 and conv.bias is not None
+
+    @staticmethod
+    def _last_wb(conv):
+        """(w_nk, bias) of a branch's last 1x1, its rows zero-padded to a multiple of 8 when needed (a one-class head)."""
+        return (fused.weight_nk(conv, conv), conv.bias) if conv.out_channels % 8 == 0 else fused.padded_last(conv, conv)
+
+    def _ext_ok(self):
+        """The third branch (keypoints / mask coefficients) can run on the convolution kernels with zero-padded widths."""
+        return fused.HEAD_EXT and all(s[0].conv.in_channels % 8 == 0 and isinstance(s[0].act, nn.SiLU) and s[0].conv.kernel_size == (3, 3)
+                                      and s[0].conv.out_channels <= 80 for s in self.cv4)
+
+    def _decode(self, feats, box, cls, bb, cb, ext=None):
+        """box / cls / ext: the branches' last-layer outputs per level -> the prediction tensor (+ prototypes for a mask head)."""
+        n_ext = (self.nk or self.nm) if ext is not None else 0
+        pred = fused.v8_decode(box, cls, bb, cb, self.strides, self.nc, ext, n_ext, 1 if self.nk else 0)
+        return (pred, self.proto(feats[0])) if self.nm else pred
+
     def forward(self, feats):
         B = feats[0].shape[0]
-        if fused.usable(feats[0]) and self.nk == 0 and self.nm == 0:     # six branch tensors -> [B,4+nc,A] float in one launch
+        ext_head = bool(self.nk or self.nm)
+        if fused.usable(feats[0]) and (not ext_head or self._ext_ok()):    # branch tensors -> [B, 4+nc(+nk|nm), A] float in one launch
             seqs = list(self.cv2) + list(self.cv3)
-            if len(feats) == 3 and all(fused.head_level_ok(f, self.cv2[i], self.cv3[i]) for i, f in enumerate(feats)):
+            pads = [fused.padded_branch(self.cv4[i], self.cv4[i]) for i in range(len(feats))] if ext_head else []
+            if not ext_head and len(feats) == 3 and all(fused.head_level_ok(f, self.cv2[i], self.cv3[i]) for i, f in enumerate(feats)):
                 # a level's two branches, three layers each, in ONE launch with the intermediates in LDS (csrc k_head): 3 launches
                 # instead of the 3 grouped ones per depth, without the round trips of the 64- / 80-channel intermediates
                 t = [fused.head_level(f, self.cv2[i], self.cv3[i]) for i, f in enumerate(feats)]
-                z = getattr(self, "_zeros", None)
-                if z is None or z.device != feats[0].device:
-                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
-                return fused.v8_decode([a for a, _ in t], [b for _, b in t], [z] * 3, [z] * 3, self.strides, self.nc)
-            if (fused.GROUP and len(feats) == 3 and all(fused.pointwise_ok(s[2]) and fused.conv3x3_ok(s[0].conv) and
+                z = self._zero_bias(feats[0])
+                return self._decode(feats, [a for a, _ in t], [b for _, b in t], z, z)
+            if (fused.GROUP and len(feats) == 3 and all(self._last_ok(s[2]) and fused.conv3x3_ok(s[0].conv) and
                                                          fused.conv3x3_ok(s[1].conv) and isinstance(s[0].act, nn.SiLU) and
                                                          s[2].out_channels <= 80 and s[0].conv.out_channels <= 80 for s in seqs)):
-                # the six branches are independent: one grouped launch per depth instead of 18 small ones
-                xs = list(feats) * 2
-                t = fused.conv_group([(x, fused.weight_n9k(s[0], s[0].conv), s[0].conv.bias, 3, 1, "silu") for s, x in zip(seqs, xs)])
-                t = fused.conv_group([(x, fused.weight_n9k(s[1], s[1].conv), s[1].conv.bias, 3, 1, "silu") for s, x in zip(seqs, t)])
-                t = fused.conv_group([(x, fused.weight_nk(s[2], s[2]), s[2].bias, 1, 1, "none") for s, x in zip(seqs, t)])
-                z = getattr(self, "_zeros", None)
-                if z is None or z.device != feats[0].device:
-                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
-                return fused.v8_decode(t[:3], t[3:], [z] * 3, [z] * 3, self.strides, self.nc)
-            if all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
+                # the branches are independent: one grouped launch per depth instead of 18 (27 with a third branch) small ones
+                xs = list(feats) * (3 if ext_head else 2)
+                w = [[(fused.weight_n9k(s[d], s[d].conv), s[d].conv.bias) for s in seqs] + [p[d] for p in pads] for d in (0, 1)]
+                w.append([self._last_wb(s[2]) for s in seqs] + [p[2] for p in pads])
+                t = fused.conv_group([(x, wd, b, 3, 1, "silu") for (wd, b), x in zip(w[0], xs)])
+                t = fused.conv_group([(x, wd, b, 3, 1, "silu") for (wd, b), x in zip(w[1], t)])
+                t = fused.conv_group([(x, wd, b, 1, 1, "none") for (wd, b), x in zip(w[2], t)])
+                z = self._zero_bias(feats[0])
+                return self._decode(feats, t[:3], t[3:6], z, z, t[6:] if ext_head else None)
+            ext = None
+            if ext_head:                     # the third branch layer by layer on the convolution kernels (padded widths)
+                ext = []
+                for p, f in zip(pads, feats):
+                    u = fused.conv3x3(f, p[0][0], p[0][1], 1, "silu")
+                    u = fused.conv3x3(u, p[1][0], p[1][1], 1, "silu")
+                    ext.append(fused.pointwise(u, p[2][0], p[2][1]))
+            if all(self._last_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
                 # final 1x1 of every branch on the pointwise kernel (bias in its epilogue; the decode adds zeros)
-                last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)
-                z = getattr(self, "_zeros", None)
-                if z is None or z.device != feats[0].device:
-                    z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
-                bb, cb = [z] * 3, [z] * 3
+                last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), *self._last_wb(seq[2]))
+                bb = cb = self._zero_bias(feats[0])
             else:
                 last = lambda seq, f: F.conv2d(seq[1](seq[0](f)), seq[2].weight)
                 bb, cb = [s[2].bias for s in self.cv2], [s[2].bias for s in self.cv3]
-            return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)],
-                                   [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, self.strides, self.nc)
+            return self._decode(feats, [last(self.cv2[i], f) for i, f in enumerate(feats)],
+                                [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, ext)
         return self._forward_torch(feats)
 
     def _forward_torch(self, feats):
@@ -297,6 +329,47 @@ class C3k(nn.Module):
     def forward(self, x):
         return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
 
+    def placed_ok(self) -> bool:
+        a, b, c3 = self.cv1.conv, self.cv2.conv, self.cv3.conv
+        silu = all(isinstance(cv.act, nn.SiLU) for cv in (self.cv1, self.cv2, self.cv3))
+        inner = all(type(m) is Bottleneck and isinstance(m.cv1.act, nn.SiLU) and isinstance(m.cv2.act, nn.SiLU) and
+                    (fused.bottleneck_ok(m) or (fused.conv3x3_ok(m.cv1.conv) and fused.conv3x3_ok(m.cv2.conv) and m.cv2.conv.stride == (1, 1)))
+                    for m in self.m)
+        return (silu and inner and len(self.m) >= 1 and fused.pointwise_ok(a) and fused.pointwise_ok(b) and fused.pointwise_ok(c3)
+                and a.in_channels == b.in_channels and fused.place_ok(a.out_channels, 2 * a.out_channels))
+
+    def _w12(self):
+        """cv1 and cv2 read the same input: one 1x1 with both sets of output rows ([cv1 | cv2], the concat order of forward)."""
+        w = getattr(self, "_w12_", None)
+        a, b = self.cv1.conv, self.cv2.conv
+        if w is None or w[0].device != a.weight.device or w[0].dtype != a.weight.dtype:
+            w = self._w12_ = (torch.cat((a.weight.detach().reshape(a.out_channels, -1), b.weight.detach().reshape(b.out_channels, -1)), 0).contiguous(),
+                              torch.cat((a.bias.detach(), b.bias.detach())).contiguous())
+        return w
+
+    def forward_placed(self, x, out, c_off, out2=None):
+        """The same arithmetic with every producer writing where its consumer reads: [cv1 | cv2] in one pointwise launch into the
+        inner concat buffer (cv1's half mirrored densely for the first bottleneck), the bottlenecks' results into cv1's slot, cv3's
+        output into channels [c_off, c_off + c2) of `out` (+ the dense copy `out2`)."""
+        c_ = self.cv1.conv.out_channels
+        B, _, H, W = x.shape
+        inner = torch.empty((B, 2 * c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dense = lambda: torch.empty((B, c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        cur = dense()
+        w12, b12 = self._w12()
+        fused.pointwise(x, w12, b12, "silu", out=inner, c_off=0, out2=cur, c0=0)
+        for j, m in enumerate(self.m):
+            nxt = dense() if j + 1 < len(self.m) else None
+            if fused.bottleneck_ok(m):
+                fused.bottleneck(cur, m, inner, 0, out2=nxt)
+            else:
+                cv = m.cv2.conv
+                fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, 1, "silu", res=cur if m.add else None, res_after=True,
+                              out=inner, c_off=0, out2=nxt, c0=0)
+            cur = nxt
+        c3 = self.cv3.conv
+        fused.pointwise(inner, fused.weight_nk(self.cv3, c3), c3.bias, "silu", out=out, c_off=c_off, out2=out2, c0=0)
+
 
 class C3k2(nn.Module):
     """C2f whose inner blocks are C3k (c3k=True) or plain Bottlenecks with e = 0.5; hidden width c = int(c2 * e)."""
@@ -308,11 +381,43 @@ class C3k2(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(C3k(self.c, self.c, 2, shortcut) if c3k else Bottleneck(self.c, self.c, shortcut) for _ in range(n))
 
+    def _placed_ok(self, x) -> bool:
+        def inner_ok(m):
+            if type(m) is C3k:
+                return m.placed_ok()
+            return (type(m) is Bottleneck and isinstance(m.cv1.act, nn.SiLU) and isinstance(m.cv2.act, nn.SiLU) and
+                    fused.conv3x3_ok(m.cv1.conv) and fused.conv3x3_ok(m.cv2.conv) and m.cv2.conv.stride == (1, 1))
+        return (fused.C3K2 and fused.usable(x) and fused.place_ok(self.c, (2 + len(self.m)) * self.c) and fused.pointwise_ok(self.cv1.conv)
+                and isinstance(self.cv1.act, nn.SiLU) and all(inner_ok(m) for m in self.m))
+
     def forward(self, x):
+        if self._placed_ok(x):
+            return self._forward_placed(x)
         y = list(self.cv1(x).chunk(2, 1))
         for m in self.m:
             y.append(m(y[-1]))
         return self.cv2(torch.cat(y, 1))
+
+    def _forward_placed(self, x):
+        """C2f._forward_placed for v11's inner blocks: no chunk / cat / add launches; a Bottleneck's second convolution adds the
+        shortcut and writes its slice of the concat buffer, a C3k block places its output itself."""
+        c, n = self.c, len(self.m)
+        B, _, H, W = x.shape
+        cat = torch.empty((B, (2 + n) * c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dense = lambda: torch.empty((B, c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        cv = self.cv1.conv
+        cur = dense()
+        fused.pointwise(x, fused.weight_nk(self.cv1, cv), cv.bias, "silu", out=cat, c_off=0, out2=cur, c0=c)
+        for i, m in enumerate(self.m):
+            nxt = dense() if i + 1 < n else None
+            if type(m) is C3k:
+                m.forward_placed(cur, cat, (2 + i) * c, nxt)
+            else:
+                cv = m.cv2.conv
+                fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, 1, "silu", res=cur if m.add else None, res_after=True,
+                              out=cat, c_off=(2 + i) * c, out2=nxt, c0=0)
+            cur = nxt
+        return self.cv2(cat)
 
 
 class Attention(nn.Module):
@@ -377,13 +482,34 @@ class Detect11(Detect):
                                                nn.Sequential(Conv(c3, c3, 3, g=c3), Conv(c3, c3, 1)), nn.Conv2d(c3, nc, 1)) for x in ch)
 
     def forward(self, feats):
-        if fused.usable(feats[0]) and self.nk == 0 and self.nm == 0 and all(fused.pointwise_ok(s[2]) for s in list(self.cv2) + list(self.cv3)):
-            last = lambda seq, f: fused.pointwise(seq[1](seq[0](f)), fused.weight_nk(seq[2], seq[2]), seq[2].bias)
-            z = getattr(self, "_zeros", None)
-            if z is None or z.device != feats[0].device:
-                z = self._zeros = torch.zeros(max(64, self.nc), dtype=feats[0].dtype, device=feats[0].device)
-            return fused.v8_decode([last(self.cv2[i], f) for i, f in enumerate(feats)], [last(self.cv3[i], f) for i, f in enumerate(feats)],
-                                   [z] * 3, [z] * 3, self.strides, self.nc)
+        ext_head = bool(self.nk or self.nm)
+        if (fused.usable(feats[0]) and (not ext_head or self._ext_ok()) and len(feats) == 3
+                and all(self._last_ok(s[2]) for s in list(self.cv2) + list(self.cv3))):
+            z = self._zero_bias(feats[0])
+            # class branch: DWConv 3x3 -> 1x1, twice, -> 1x1 (each layer one launch of its own kernel)
+            cls = [fused.pointwise(s[1](s[0](f)), *self._last_wb(s[2])) for s, f in zip(self.cv3, feats)]
+            grp = list(self.cv2)
+            pads = [fused.padded_branch(self.cv4[i], self.cv4[i]) for i in range(3)] if ext_head else []
+            if fused.GROUP and all(fused.conv3x3_ok(s[0].conv) and fused.conv3x3_ok(s[1].conv) and isinstance(s[0].act, nn.SiLU)
+                                   and s[0].conv.out_channels <= 80 for s in grp):
+                # the box branches (and the keypoint / coefficient branches) are independent 3x3 -> 3x3 -> 1x1 chains: one grouped
+                # launch per depth
+                xs = list(feats) * (2 if ext_head else 1)
+                w = [[(fused.weight_n9k(s[d], s[d].conv), s[d].conv.bias) for s in grp] + [p[d] for p in pads] for d in (0, 1)]
+                w.append([self._last_wb(s[2]) for s in grp] + [p[2] for p in pads])
+                t = fused.conv_group([(x, wd, b, 3, 1, "silu") for (wd, b), x in zip(w[0], xs)])
+                t = fused.conv_group([(x, wd, b, 3, 1, "silu") for (wd, b), x in zip(w[1], t)])
+                t = fused.conv_group([(x, wd, b, 1, 1, "none") for (wd, b), x in zip(w[2], t)])
+                return self._decode(feats, t[:3], cls, z, z, t[3:] if ext_head else None)
+            box = [fused.pointwise(s[1](s[0](f)), *self._last_wb(s[2])) for s, f in zip(self.cv2, feats)]
+            ext = None
+            if ext_head:
+                ext = []
+                for p, f in zip(pads, feats):
+                    u = fused.conv3x3(f, p[0][0], p[0][1], 1, "silu")
+                    u = fused.conv3x3(u, p[1][0], p[1][1], 1, "silu")
+                    ext.append(fused.pointwise(u, p[2][0], p[2][1]))
+            return self._decode(feats, box, cls, z, z, ext)
         return self._forward_torch(feats)
 
 
