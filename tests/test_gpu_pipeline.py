@@ -213,8 +213,8 @@ def _run_groups(pipe, items, fb):
     ("yolov8n", 1280, 720, 30, 32, 176, 5),    # bench.py default = BASELINE configs[1]: 5 groups of 32 + a partial group of 16
     ("yolov7", 1920, 1080, 100, 128, 80, 2),   # bench.py --preset c4 = configs[3]: 2 groups of 32 + 16
     ("yolov8s", 1280, 720, 30, 32, 144, 2),    # --preset c3 = configs[2] per GPU: the stage cut the larger detectors keep (OSNet part 2)
-    ("yolov8n-pose", 1280, 720, 30, 32, 144, 2),   # --preset c5 = configs[4] per GPU: 51 keypoint columns ride through NMS with the kept rows
-    ("yolov5n", 640, 480, 8, 32, 80, 2),       # --preset c1 = configs[0]'s shape (the reference's CPU-runnable case) on the GPU path
+    ("yolov8n-pose", 1280, 720, 30, 32, 144, 5),   # --preset c5 = configs[4] per GPU: 51 keypoint columns ride through NMS with the kept rows
+    ("yolov5n", 640, 480, 8, 32, 80, 4),       # --preset c1 = configs[0]'s shape (the reference's CPU-runnable case) on the GPU path
     ("yolo11n-pose", 1280, 720, 30, 32, 112, 2),   # --preset c6: the reference's default weights file (yolo_multi_model.py:17), C3k2 / C2PSA graph, pose head
 ])
 def test_benchmarked_configuration_equals_oracle(detector, w, h, n_ids, reid_batch, n_frames, split):
@@ -225,7 +225,7 @@ def test_detached_tracker_chain_on_reserved_compute_units_equals_oracle():
     """Pipeline option chain_cus=16 (library option "chain_cus", ss_stream_create, ss_track_join): the per-frame chain on a stream that
     owns two compute units of every XCD, the pipeline's streams without them, rows fetched on a results stream that joined the chain —
     the same bytes as the oracle (the form is off by default: profiles/r04_chain_cus_ab.txt)."""
-    _benchmarked("yolov5n", 640, 480, 8, 32, 80, 2, chain_cus=16)
+    _benchmarked("yolov5n", 640, 480, 8, 32, 80, 4, chain_cus=16)
 
 
 def _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, split, **pipe_kw):
