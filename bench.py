@@ -589,6 +589,8 @@ def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device
     def fill(b, v, k):
         b.pred_in[v].copy_(dp[k]); b.anchor_gt[v].copy_(da[k]); b.gt_feats[v].copy_(df[k])
 
+    out = {}
+
     def model():
         m = YOLO(detector + ".pt", random_init_ok=True, reid_batch=32)
         m.overrides.update(conf=dcfg.conf, iou=dcfg.iou, agnostic_nms=dcfg.agnostic_nms, max_det=dcfg.max_det)
@@ -602,7 +604,6 @@ def api_path(detector, W, H, n_ids, geom_scale, nc, n_anchors, cfg, dcfg, device
         return (len(r) == 0 and len(b) == 0) or (b.id is not None and np.array_equal(b.id.numpy(), r[:, 4]) and np.array_equal(b.xyxy.numpy(), r[:, :4]))
 
     import warnings
-    out = {}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
         m = model()
@@ -950,13 +951,13 @@ def main():
         res["cpu_baseline"] = None
     pipe.close()
     if rank == 0:
+        if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
+            res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)
         if world == 1 and not args.no_batched:
             bkw = dict(device=dev_index, n_ids=n_ids, W=W, H=H, preset=args.preset, n_streams=32 if n_ids <= 30 else 8, opts=tuple(args.opt))
             res["roofline_batched"] = batched_association(cfg, frames=160, timed=32, frame_batch=FB if FB in (1, 2, 4, 8, 16, 32) else (32 if FB > 32 else 8), **bkw)
             res["roofline_batched_frame_at_a_time"] = batched_association(cfg, frames=160, timed=32, frame_batch=1, check=False, **bkw)
             res["tracker_only"] = tracker_only(cfg, n_ids=n_ids, W=W, H=H, device=dev_index, opts=tuple(args.opt))
-        if world == 1 and not args.no_api_path and not args.no_nets and args.preset in ("c2", "c3"):
-            res["api_path"] = api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, device=dev_index)
         if world == 1 and not args.no_reid_check and not args.no_nets:
             res["reid_f16_vs_f32"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index)
             res["reid_f16_vs_f32"]["fp32_reid_mode"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index, reid_half=False)
