@@ -1734,7 +1734,7 @@ __device__ __forceinline__ void os_chain_run(const __half* __restrict__ xi, cons
             for (int mt = 0; mt < MT; ++mt) {
                 const int c4 = mt * 16 + 4 * q;
                 if (c4 < C && lane_ok) {
-                    *reinterpret_cast<uint2*>(yo + lane_img + ((size_t)orow * W + j * 16 + col) * C + c4) = o[j][mt];
+                    *reinterpret_cast<uint2*>(yo + lane_img + ((size_t)orow * W + j * 16 + col) * C + c4) = o[j][mt];   // (a non-temporal store here costs the tail more than it saves: the rows are still in the last-level cache when it reads them)
                     const h4 v = __builtin_bit_cast(h4, o[j][mt]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ch.s[mt][e] += (float)v[e];
@@ -2070,7 +2070,9 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
     const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
     const bool kval = 8 * q < MID;
 
-    // everything this workgroup reads from global memory is requested up front: one memory round trip
+    // everything this workgroup reads from global memory is requested up front: one memory round trip.  The chain outputs and the
+    // shortcut input are read exactly once: non-temporal loads (no L2 allocation) took 189 / 173 / 82 us -> 173 / 162 / 78 us at
+    // 1 024 crops
     float4 gq[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -2082,20 +2084,20 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
     for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            yv[pt][t] = kval ? *reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q) : z8;
+            yv[pt][t] = kval ? __builtin_nontemporal_load(reinterpret_cast<const h8*>(ys.x[t] + (px0 + pt * 16 + n) * MID + 8 * q)) : z8;
     if constexpr (C1 > 0) {
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int k = ks * 32 + 8 * q;
-                xb[pt][ks] = k < C1 ? *reinterpret_cast<const h8*>(idn + (px0 + pt * 16 + n) * C1 + k) : z8;
+                xb[pt][ks] = k < C1 ? __builtin_nontemporal_load(reinterpret_cast<const h8*>(idn + (px0 + pt * 16 + n) * C1 + k)) : z8;
             }
     } else {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-            rs[it] = *reinterpret_cast<const h8*>(idn + (px0 + row) * C2 + cg * 8);
+            rs[it] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(idn + (px0 + row) * C2 + cg * 8));
         }
     }
 #pragma unroll
