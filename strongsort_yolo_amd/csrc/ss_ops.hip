@@ -2177,7 +2177,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
 #pragma unroll
             for (int it = 0; it < 32 * CG / 64; ++it) {                      // the block output, 16-byte vectors
                 const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
-                *reinterpret_cast<h8*>(out + (px0 + row) * C2 + cg * 8) = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
+                __builtin_nontemporal_store(*reinterpret_cast<const h8*>(tile + row * EP + cg * 8), reinterpret_cast<h8*>(out + (px0 + row) * C2 + cg * 8));
             }
         }
     } else {
@@ -2203,7 +2203,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
                 f += (float)r[j];
                 o[j] = (_Float16)(f > 0.f ? f : 0.f);
             }
-            if (out) *reinterpret_cast<h8*>(out + px * C2 + cg * 8) = o;
+            if (out) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(out + px * C2 + cg * 8));
             *reinterpret_cast<h8*>(tile + row * EP + cg * 8) = o;
         }
         __builtin_amdgcn_wave_barrier();
