@@ -581,6 +581,15 @@ class YOLOv5u(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # YOLOv7-style detector (ELAN backbone + SPPCSPC neck), anchor-free head for a uniform NMS layout
 # --------------------------------------------------------------------------------------------------
+def _w_pair(mod, a, b):
+    """Two 1x1 convolutions on the same input as one: (weights [Ca + Cb, Cin], bias), cached on `mod`."""
+    w = getattr(mod, "_w_pair_", None)
+    if w is None or w[0].device != a.weight.device or w[0].dtype != a.weight.dtype:
+        w = mod._w_pair_ = (torch.cat((a.weight.detach().reshape(a.out_channels, -1), b.weight.detach().reshape(b.out_channels, -1)), 0).contiguous(),
+                            torch.cat((a.bias.detach(), b.bias.detach())).contiguous())
+    return w
+
+
 class ELAN(nn.Module):
     def __init__(self, c1, c_, c2, depth=4):
         super().__init__()
@@ -588,7 +597,15 @@ class ELAN(nn.Module):
         self.m = nn.ModuleList(Conv(c_, c_, 3) for _ in range(depth))
         self.out = Conv(c_ * (2 + depth // 2), c2, 1)
 
+    def _placed_ok(self, x) -> bool:
+        a, b = self.cv1.conv, self.cv2.conv
+        return (fused.C3K2 and fused.usable(x) and fused.pointwise_ok(a) and fused.pointwise_ok(b) and fused.place_ok(a.out_channels, self.out.conv.in_channels)
+                and all(isinstance(c.act, nn.SiLU) for c in [self.cv1, self.cv2] + list(self.m))
+                and all(fused.conv3x3_ok(m.conv) and m.conv.stride == (1, 1) for m in self.m))
+
     def forward(self, x):
+        if self._placed_ok(x):
+            return self._forward_placed(x)
         y = [self.cv1(x), self.cv2(x)]
         t = y[-1]
         for i, m in enumerate(self.m):
@@ -597,6 +614,27 @@ class ELAN(nn.Module):
                 y.append(t)
         return self.out(torch.cat(y, 1))
 
+    def _forward_placed(self, x):
+        """The same arithmetic without the concat copy: [cv1 | cv2] as one 1x1 launch into the concat buffer (cv2's half mirrored
+        densely for the 3x3 chain), every second 3x3 writes its slice (and a dense copy for the next one)."""
+        c_ = self.cv1.conv.out_channels
+        B, _, H, W = x.shape
+        cat = torch.empty((B, self.out.conv.in_channels, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dense = lambda: torch.empty((B, c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        cur = dense()
+        w12, b12 = _w_pair(self, self.cv1.conv, self.cv2.conv)
+        fused.pointwise(x, w12, b12, "silu", out=cat, c_off=0, out2=cur, c0=c_)
+        n = len(self.m)
+        for i, m in enumerate(self.m):
+            cv = m.conv
+            if i % 2 == 1:
+                nxt = dense() if i + 1 < n else None
+                fused.conv3x3(cur, fused.weight_n9k(m, cv), cv.bias, 1, "silu", out=cat, c_off=(2 + i // 2) * c_, out2=nxt, c0=0)
+                cur = nxt
+            else:
+                cur = fused.conv3x3(cur, fused.weight_n9k(m, cv), cv.bias, 1, "silu")
+        return self.out(cat)
+
 
 class MP(nn.Module):
     def __init__(self, c1, c2):
@@ -604,6 +642,15 @@ class MP(nn.Module):
         self.cv1, self.cv2, self.cv3 = Conv(c1, c2 // 2, 1), Conv(c1, c2 // 2, 1), Conv(c2 // 2, c2 // 2, 3, 2)
 
     def forward(self, x):
+        a, c3 = self.cv1.conv, self.cv3.conv
+        if (fused.C3K2 and fused.usable(x) and fused.pointwise_ok(a) and fused.conv3x3_ok(c3) and isinstance(self.cv1.act, nn.SiLU)
+                and isinstance(self.cv3.act, nn.SiLU) and fused.place_ok(a.out_channels, 2 * a.out_channels) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+            h = a.out_channels                           # both branches write their half of the output
+            B, _, H, W = x.shape
+            out = torch.empty((B, 2 * h, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            fused.conv3x3(self.cv2(x), fused.weight_n9k(self.cv3, c3), c3.bias, 2, "silu", out=out, c_off=0)
+            fused.pointwise(F.max_pool2d(x, 2, 2), fused.weight_nk(self.cv1, a), a.bias, "silu", out=out, c_off=h)
+            return out
         return torch.cat((self.cv3(self.cv2(x)), self.cv1(F.max_pool2d(x, 2, 2))), 1)
 
 
@@ -617,6 +664,18 @@ class SPPCSPC(nn.Module):
 
     def forward(self, x):
         x1 = self.cv4(self.cv3(self.cv1(x)))
+        c2, c6 = self.cv2.conv, self.cv6.conv
+        if (fused.C3K2 and fused.sppf_pools_ok(x1) and fused.pointwise_ok(c2) and fused.conv3x3_ok(c6) and isinstance(self.cv2.act, nn.SiLU)
+                and isinstance(self.cv6.act, nn.SiLU) and fused.place_ok(c6.out_channels, 2 * c6.out_channels)):
+            # max pools of 5, 9, 13 = the cascade of three 5-pools (max over nested windows): the SPPF launch gives cat(x1, p5, p9, p13);
+            # cv6 and cv2 write their halves of cv7's input
+            t = self.cv5(fused.sppf_pools(x1))
+            c_ = c6.out_channels
+            B, _, H, W = x.shape
+            cat = torch.empty((B, 2 * c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            fused.conv3x3(t, fused.weight_n9k(self.cv6, c6), c6.bias, 1, "silu", out=cat, c_off=0)
+            fused.pointwise(x, fused.weight_nk(self.cv2, c2), c2.bias, "silu", out=cat, c_off=c_)
+            return self.cv7(cat)
         y1 = self.cv6(self.cv5(torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1)))
         return self.cv7(torch.cat((y1, self.cv2(x)), 1))
 

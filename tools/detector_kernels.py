@@ -3,8 +3,15 @@ after it), grouped by name: launches, total us.  usage: python tools/detector_ke
 import collections, csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-s = max(i for i, r in enumerate(rows) if 'k_conv0' in r['Kernel_Name'])
-e = next((i for i in range(s, len(rows)) if 'k_osnet_stem' in rows[i]['Kernel_Name']), len(rows))
+stems = [i for i, r in enumerate(rows) if 'k_osnet_stem' in r['Kernel_Name']]
+c0 = [i for i, r in enumerate(rows) if 'k_conv0' in r['Kernel_Name']]
+if c0:
+    s = max(c0)
+    e = next((i for i in stems if i > s), len(rows))
+else:                                    # a detector whose first convolution is not k_conv0 (yolov7): everything between the last two OSNet passes
+    e = stems[-1]                        # except OSNet's own kernels (a few library kernels of its head stay in the listing)
+    s = next(i for i in range(stems[-2], e) if 'k_osnet_tail<32, 128, 128' in rows[i]['Kernel_Name']) + 5
+rows = [r for i, r in enumerate(rows) if not (s <= i < e) or ('osnet' not in r['Kernel_Name'] and 'k_gate_vec' not in r['Kernel_Name'])]
 agg, tot = collections.OrderedDict(), 0.0
 for r in rows[s:e]:
     n = r['Kernel_Name'].replace('void ', '')

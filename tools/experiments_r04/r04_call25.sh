@@ -1,0 +1,14 @@
+#!/bin/bash
+# yolov7 with placed ELAN / MP / SPPCSPC outputs: parity vs the torch modules, kernel listing, short c4 bench line
+out=$GRAFT_REPO_ROOT/gpurun_out/r04_c25; mkdir -p $out; cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests/test_gpu_nets.py -q -m gpu -x -k "fused_ops" > $out/pytest.txt 2>&1; echo "pytest rc $?" >> $out/pytest.txt; tail -4 $out/pytest.txt
+cd /tmp && export TMPDIR=/tmp
+rm -rf $out/prof; mkdir -p $out/prof
+(cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace --output-format csv -d $out/prof -o run -- python tools/nets_eager.py 3 32 yolov7 > $out/prof/log.txt 2>&1)
+f=$(find $out/prof -name "*kernel_trace.csv" | head -1)
+(cd $GRAFT_REPO_ROOT && python tools/detector_kernels.py $f 14) > $out/kernels_yolov7.txt 2>&1; tail -16 $out/kernels_yolov7.txt
+rm -rf $out/prof
+cd $GRAFT_REPO_ROOT
+timeout 600 python bench.py --preset c4 --steps 10 --warmup 3 --no-cpu-baseline --no-batched --no-api-path --no-reid-check 2>$out/bench_c4.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c4 value',d['value'],'ms/step',d['ms_per_step'],'exact',d.get('frames_bit_exact'))"
