@@ -21,14 +21,10 @@ python tools/osnet_sequence.py "$t" > $out/r04_osnet_sequence.txt 2>&1
 python tools/trace_busy.py "$t" 16 > $out/r04_gpu_busy_c2_s1.txt 2>&1
 find $out/prof_bench -name "*.csv" -size +2M -delete
 SS_TL_DUMP=12 timeout 120 python tools/assoc_timeline.py 1 32 > $out/r04_assoc_timeline.txt 2>&1
-# PMC of the association kernel
-bash tools/pmc_assoc.sh r04_c2_s1_f32 1 32 > $out/pmc_assoc_c2_s1.txt 2>&1
-bash tools/pmc_assoc.sh r04_c2_b32_f32 32 32 > $out/pmc_assoc_c2_b32.txt 2>&1
-bash tools/pmc_assoc.sh r04_c4_s1_f32 1 32 k_assoc 100 1920 1080 > $out/pmc_assoc_c4_s1.txt 2>&1
-bash tools/pmc_assoc.sh r04_c4_b8_f32 8 32 k_assoc 100 1920 1080 > $out/pmc_assoc_c4_b8.txt 2>&1
+# (PMC of the association kernel: profiles/r04_pmc_assoc.json from the first evidence run of the round — ss_track.hip unchanged since)
 # PMC of the network kernels (eager launches, 32 frames / 1024 crops)
 PMC_GROUPS=0,3,4 bash tools/pmc_run.sh r04_nets python tools/nets_eager.py 4 32 > $out/pmc_nets.txt 2>&1
-for d in pmc_r04_c2_s1_f32 pmc_r04_c2_b32_f32 pmc_r04_c4_s1_f32 pmc_r04_c4_b8_f32 pmc_r04_nets; do cp $GRAFT_REPO_ROOT/gpurun_out/$d/summary.json $out/$d.json 2>/dev/null; done
+for d in pmc_r04_nets; do cp $GRAFT_REPO_ROOT/gpurun_out/$d/summary.json $out/$d.json 2>/dev/null; done
 tail -3 $out/r04_rocprofv3_kernel_trace_k_assoc_pipeline_c2_s1.csv; cat $out/bench_c2_time.txt
 for f in $out/r04_bench_*.json; do python - "$f" <<'PY'
 import json,sys
