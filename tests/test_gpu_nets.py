@@ -122,6 +122,42 @@ def test_v8_decode_matches_float_reference():
     assert (got[:, 4:] - ref[:, 4:]).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("nc,cls_ld,n_ext,ext_ld,mode", [(1, 8, 51, 56, 1), (80, 80, 32, 32, 0), (1, 8, 0, 0, 0), (3, 8, 6, 8, 1)])
+def test_v8_decode_extra_rows_match_float_reference(nc, cls_ld, n_ext, ext_ld, mode):
+    """The decode launch with a third branch (ss_op_v8_decode_ext_f16): keypoint triplets as Ultralytics Pose.kpts_decode — x, y =
+    (2 v + cell index) * stride, visibility = sigmoid(v) — or raw mask coefficients in rows 4 + nc .. of the prediction, class
+    tensors padded past nc channels (a one-class head padded to 8 rows); rows 0 .. 4 + nc equal the plain decode."""
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(nc + n_ext)
+    B, sizes, strides = 2, [(12, 20), (6, 10), (3, 5)], (8, 16, 32)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev, torch.float16)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    boxes = [cl(2 * mk(B, 64, h, w)) for h, w in sizes]
+    clss = [cl(2 * mk(B, cls_ld, h, w)) for h, w in sizes]
+    ext = [cl(mk(B, ext_ld, h, w)) for h, w in sizes] if n_ext else None
+    z = torch.zeros(max(64, cls_ld), dtype=torch.float16, device=dev)
+    got = fused.v8_decode(boxes, clss, [z] * 3, [z] * 3, strides, nc, ext, n_ext, mode)
+    A = sum(h * w for h, w in sizes)
+    assert got.shape == (B, 4 + nc + n_ext, A) and got.dtype == torch.float32
+    base = fused.v8_decode(boxes, [cl(t[:, :nc].contiguous()) for t in clss] if nc % 8 == 0 else clss, [z] * 3, [z] * 3, strides, nc)
+    assert torch.equal(got[:, :4 + nc], base[:, :4 + nc])
+    cls = torch.cat([t[:, :nc].float().reshape(B, nc, -1) for t in clss], 2)
+    assert (got[:, 4:4 + nc] - cls.sigmoid()).abs().max().item() <= 1e-5
+    if n_ext:
+        e = torch.cat([t[:, :n_ext].float().reshape(B, n_ext, -1) for t in ext], 2)              # [B, n_ext, A]
+        if mode == 0:
+            assert torch.equal(got[:, 4 + nc:], e)
+        else:
+            col = torch.cat([torch.arange(w, device=dev, dtype=torch.float32).repeat(h) for h, w in sizes])
+            row = torch.cat([torch.arange(h, device=dev, dtype=torch.float32).repeat_interleave(w) for h, w in sizes])
+            st = torch.cat([torch.full((h * w,), float(s), device=dev) for (h, w), s in zip(sizes, strides)])
+            k = e.view(B, n_ext // 3, 3, A)
+            ref = torch.stack(((k[:, :, 0] * 2.0 + col) * st, (k[:, :, 1] * 2.0 + row) * st, k[:, :, 2].sigmoid()), 2).view(B, n_ext, A)
+            assert (got[:, 4 + nc:] - ref).abs().max().item() <= 1e-4 * (ref.abs().max().item() + 1.0)
+            assert torch.equal(got[:, 4 + nc::3][:, :n_ext // 3], ref[:, 0::3]) and torch.equal(got[:, 5 + nc::3][:, :n_ext // 3], ref[:, 1::3])   # the affine rows: exact
+
+
 @pytest.mark.parametrize("M_hw,K,N,act", [((8, 48, 80), 64, 32, "silu"), ((2, 12, 20), 384, 128, "silu"), ((64, 64, 32), 16, 64, "relu"),
                                           ((3, 7, 9), 24, 96, "none"), ((5, 16, 8), 128, 128, "relu"), ((1, 5, 5), 512, 256, "silu"),
                                           ((40, 64, 32), 16, 16, "relu"), ((2, 3, 5), 8, 8, "sigmoid"),

@@ -240,3 +240,42 @@ def test_fused_parameter_count_of_the_reference_default_model():
     assert sum(p.numel() for p in m.parameters()) + 16 == 2866468
     r = sum(p.numel() for p in nets.build_reid().parameters())
     assert 190_000 < r < 215_000
+
+
+def test_padded_head_branch_computes_the_same_channels():
+    """fused.padded_branch / padded_last: the pose head's 51-channel branch with its widths zero-padded to 64 / 56 and a one-class
+    head's last 1x1 padded to 8 rows (what the convolution kernels take) compute the original channels exactly — SiLU(0) = 0 keeps
+    the padding at zero through both 3x3 layers — and zeros in the padded ones (fp32 torch convolutions on the prepared weights)."""
+    torch.manual_seed(5)
+    det = nets.Detect(1, (64, 128, 256), nk=51).float()
+    seq = det.cv4[0]
+    (w0, b0), (w1, b1), (w2, b2) = fused.padded_branch(torch.nn.Module(), seq)
+    assert w0.shape == (64, 9 * 64) and w1.shape == (64, 9 * 64) and w2.shape == (56, 64) and b2.shape == (56,)
+    x = torch.randn(2, 64, 9, 11)
+    as_conv = lambda w, k: w.view(w.shape[0], k, k, -1).permute(0, 3, 1, 2).contiguous()         # [N, kh*kw*Cin] tap-major -> [N, Cin, kh, kw]
+    t = F.silu(F.conv2d(x, as_conv(w0, 3), b0, padding=1))
+    assert (t[:, 51:] == 0).all()
+    t = F.silu(F.conv2d(t, as_conv(w1, 3), b1, padding=1))
+    assert (t[:, 51:] == 0).all()
+    got = F.conv2d(t, w2.view(56, 64, 1, 1), b2)
+    ref = seq(x)
+    assert (got[:, 51:] == 0).all() and torch.allclose(got[:, :51], ref, rtol=0, atol=1e-5)
+    last = det.cv3[0][2]                                           # Conv2d(c3, 1, 1): one class
+    w, b = fused.padded_last(torch.nn.Module(), last)
+    assert w.shape == (8, last.in_channels) and (w[1:] == 0).all() and (b[1:] == 0).all()
+    assert torch.equal(w[:1], last.weight.detach().reshape(1, -1)) and torch.equal(b[:1], last.bias.detach())
+
+
+def test_merged_pointwise_pairs_keep_the_concat_order():
+    """C3k._w12 / nets._w_pair: cv1 and cv2 of a C3k / ELAN block read the same input and their outputs are concatenated [cv1 | cv2] —
+    one 1x1 with both sets of output rows in that order."""
+    torch.manual_seed(6)
+    blk = nets.C3k(32, 32, 2).float()
+    w, b = blk._w12()
+    x = torch.randn(1, 32, 5, 7)
+    got = F.silu(F.conv2d(x, w.view(w.shape[0], -1, 1, 1), b))
+    assert torch.allclose(got, torch.cat((blk.cv1(x), blk.cv2(x)), 1), rtol=0, atol=1e-6)
+    el = nets.ELAN(32, 16, 64).float()
+    w, b = nets._w_pair(el, el.cv1.conv, el.cv2.conv)
+    got = F.silu(F.conv2d(x, w.view(w.shape[0], -1, 1, 1), b))
+    assert torch.allclose(got, torch.cat((el.cv1(x), el.cv2(x)), 1), rtol=0, atol=1e-6)
