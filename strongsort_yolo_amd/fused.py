@@ -314,6 +314,19 @@ def weight_dw9(mod, conv):
     return w
 
 
+PREPARED = ("_w_nk", "_w_n9k", "_w_dw9", "_w_t", "_w_c0", "_w_stem", "_w1", "_w9", "_padded", "_padded_last", "_w12_", "_w_pair_", "_sw", "_gw")
+
+
+def clear_prepared(module):
+    """Drop every kernel-side copy of the weights cached on the sub-modules of `module` (weight_nk / weight_n9k / padded_branch / the
+    OSBlock stacks and operand tables ...): the next forward rebuilds them from the tensors the modules hold NOW.  nets.load_weights
+    calls it, so a checkpoint loaded after a forward pass cannot run on stale copies."""
+    for m in module.modules():
+        for a in PREPARED:
+            if a in m.__dict__:
+                del m.__dict__[a]
+
+
 def padded_last(mod, conv):
     """A 1x1 Conv2d whose output count is not a multiple of 8 (the class branch of a one-class head) as (w_nk, bias) zero-padded to 8
     rows, cached on `mod`; conv.in_channels % 8 == 0."""

@@ -958,6 +958,7 @@ def load_weights(module: nn.Module, path, what: str, random_init_ok: bool = Fals
     if any(k.startswith("model.") for k in ck):                 # an Ultralytics DetectionModel state_dict: layer indices + Conv/BN pairs
         ck = convert_ultralytics_state_dict(module, ck)
     module.load_state_dict(ck, strict=True)
+    fused.clear_prepared(module)                                   # kernel-side copies built from the previous tensors, if any
     return True
 
 

@@ -279,3 +279,21 @@ def test_merged_pointwise_pairs_keep_the_concat_order():
     w, b = nets._w_pair(el, el.cv1.conv, el.cv2.conv)
     got = F.silu(F.conv2d(x, w.view(w.shape[0], -1, 1, 1), b))
     assert torch.allclose(got, torch.cat((el.cv1(x), el.cv2(x)), 1), rtol=0, atol=1e-6)
+
+
+def test_loading_weights_drops_the_prepared_copies(tmp_path):
+    """nets.load_weights after a forward pass: the kernel-side weight copies cached on the modules (fused.weight_nk, padded_branch, ...)
+    are dropped, so the next forward prepares them from the loaded tensors."""
+    torch.manual_seed(7)
+    det = nets.Detect(1, (64, 128, 256), nk=51)
+    c = det.cv2[0][2]
+    before = fused.weight_nk(c, c).clone()
+    fused.padded_branch(det.cv4[0], det.cv4[0])
+    assert "_w_nk" in c.__dict__ and "_padded" in det.cv4[0].__dict__
+    other = nets.Detect(1, (64, 128, 256), nk=51)
+    f = tmp_path / "w.pt"
+    torch.save(other.state_dict(), f)
+    assert nets.load_weights(det, str(f), "test head")
+    assert "_w_nk" not in c.__dict__ and "_padded" not in det.cv4[0].__dict__
+    after = fused.weight_nk(c, c)
+    assert not torch.equal(before, after) and torch.equal(after, other.cv2[0][2].weight.detach().reshape(after.shape))
