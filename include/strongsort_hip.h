@@ -381,6 +381,10 @@ int ss_op_upcat_f16(void* stream, const void* d_lo, const void* d_hi, void* d_ou
 /* SPPF's pooling pyramid: d_out [B][H][W][4C] = concat(x, m(x), m(m(x)), m(m(m(x)))), m = max pool 5x5 / 1 / pad 2.
  * H*W <= 1024, C % 8 == 0. */
 int ss_op_sppf_pools_f16(void* stream, const void* d_x, void* d_out, int B, int H, int W, int C);
+/* C2PSA attention of the v11 detectors in one launch: d_qkv [B][N][heads * 128] half, per head [q 32 | k 32 | v 64] (the fused 1x1's
+ * output, N = H * W positions <= 256), d_out[b][i][h * 64 + c] = sum_j v[c][j] softmax_j(scale q_i . k_j) (+ d_pe[b][i][h * 64 + c], the
+ * depthwise positional term of v, when given); fp32 scores / softmax / accumulation, probabilities rounded to half. */
+int ss_op_psa_attention_f16(void* stream, const void* d_qkv, const void* d_pe, void* d_out, int B, int N, int heads, float scale);
 /* 2x2 / stride 2 average pooling, NHWC half (H, W even; C % 8 == 0). */
 int ss_op_avgpool2_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */

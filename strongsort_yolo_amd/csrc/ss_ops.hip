@@ -2277,6 +2277,103 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
     }
 }
 
+// ---- C2PSA attention (v11: 2-8 heads over the H*W positions of the stride-32 map, key_dim 32, head_dim 64) in one launch ----
+// qkv: the fused 1x1's output [B][N][heads * 128] half, per head [q 32 | k 32 | v 64] (nets.Attention); out[b][i][h*64 + c] =
+// sum_j v[c][j] * softmax_j(scale * q_i . k_j) (+ pe[b][i][h*64 + c], the depthwise positional term, when given).
+// Workgroup = (64 queries, head, image), wave = 16 queries.  Everything stays in the MFMA layouts:
+//   * S^T = K Q^T per 16-key tile: A = 16 keys x 32 dims, B = 16 queries x 32 dims, both 16-byte loads straight from qkv;
+//     D: lane (q, n) holds keys 16t + 4q .. + 3 of query n — the whole score row of a query lives in the 4 lanes n, n + 16, ..
+//     (softmax: two shuffles for the max, two for the sum);
+//   * O^T = V^T P^T: two key tiles' probabilities (rounded to half, 2 + 2 registers) ARE the B operand of v_mfma_f32_16x16x32_f16
+//     when its k-slots 8q .. 8q + 7 are read as (tile a: keys 4q .. 4q + 3, tile b: the same) — the depthwise-MFMA trick of
+//     DwDiag — and the A operand is two 8-byte LDS reads of V^T (staged once per workgroup as [64][N + pad], conflict-free pitch);
+//   * O^T's D layout is 4 channels of a query per lane: 8-byte stores into the NHWC output.
+// fp32 scores, softmax and accumulation; N <= 256 positions (640 x 384 input: 240).
+#define PSA_MAXT 16
+__global__ __launch_bounds__(256) void k_psa_attn(const __half* __restrict__ qkv, const __half* __restrict__ pe, __half* __restrict__ out,
+                                                 int N, int heads, float scale)
+{
+    extern __shared__ __attribute__((aligned(16))) char psa_smem[];
+    _Float16* VT = reinterpret_cast<_Float16*>(psa_smem);               // [64][VP]
+    const int NP = (N + 31) & ~31, VP = NP + 16, NT = NP / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
+    const int h = blockIdx.y, b = blockIdx.z, CT = heads * 128, C = heads * 64;
+    const __half* base = qkv + (size_t)b * N * CT + h * 128;
+    // V^T -> LDS (zeros for the padded positions)
+    for (int i = tid; i < NP * 8; i += 256) {
+        const int j = i >> 3, c8 = i & 7;
+        h8 v = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (j < N) v = *reinterpret_cast<const h8*>(base + (size_t)j * CT + 64 + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) VT[(c8 * 8 + e) * VP + j] = v[e];
+    }
+    __syncthreads();
+    const int i0 = (blockIdx.x * 4 + wave) * 16;
+    if (i0 >= N) return;
+    const int iq = i0 + n < N ? i0 + n : N - 1;
+    const h8 z8 = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const h8 bq = *reinterpret_cast<const h8*>(base + (size_t)iq * CT + 8 * q);
+    f4 S[PSA_MAXT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < PSA_MAXT; ++t) {
+        S[t] = f4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+        if (t < NT) {
+            const int j = 16 * t + n;
+            const h8 ak = j < N ? *reinterpret_cast<const h8*>(base + (size_t)j * CT + 32 + 8 * q) : z8;
+            const f4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak, bq, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                S[t][e] = 16 * t + 4 * q + e < N ? d[e] * scale : -INFINITY;
+                m = fmaxf(m, S[t][e]);
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < PSA_MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { S[t][e] = __expf(S[t][e] - m); sum += S[t][e]; }     // exp(-inf) = 0 for the masked keys
+    sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    uint2 P[PSA_MAXT];
+#pragma unroll
+    for (int t = 0; t < PSA_MAXT; ++t) {
+        const h4 p = { (_Float16)(S[t][0] * inv), (_Float16)(S[t][1] * inv), (_Float16)(S[t][2] * inv), (_Float16)(S[t][3] * inv) };
+        P[t] = __builtin_bit_cast(uint2, p);
+    }
+    f4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f4{ 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int tp = 0; tp < PSA_MAXT / 2; ++tp) {
+        if (2 * tp >= NT) break;
+        const uint4 bp = { P[2 * tp].x, P[2 * tp].y, P[2 * tp + 1].x, P[2 * tp + 1].y };
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const _Float16* vr = VT + (ct * 16 + n) * VP + 32 * tp + 4 * q;
+            const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 16);
+            const uint4 av = { a0.x, a0.y, a1.x, a1.y };
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, av), __builtin_bit_cast(h8, bp), acc[ct], 0, 0, 0);
+        }
+    }
+    if (i0 + n < N) {
+        const size_t o = ((size_t)b * N + i0 + n) * C + h * 64 + 4 * q;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            f4 v = acc[ct];
+            if (pe) {
+                const h4 pv = *reinterpret_cast<const h4*>(pe + o + ct * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)(_Float16)v[e] + (float)pv[e];     // the product rounded to half, then the sum (as the two torch ops)
+            }
+            const h4 r = { (_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3] };
+            *reinterpret_cast<h4*>(out + o + ct * 16) = r;
+        }
+    }
+}
+
 static inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 extern "C" int ss_op_bias_act_f16(void* stream, void* x, const void* bias, const void* res, long long n_pix, int C, int act)
@@ -2653,6 +2750,15 @@ extern "C" int ss_op_upcat_f16(void* stream, const void* lo, const void* hi, voi
     const size_t total = (size_t)B * 4 * h * w * ((C1 + C2) / 8);
     hipLaunchKernelGGL(k_upcat, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)lo, (const __half*)hi,
                        (__half*)out, B, h, w, C1 / 8, C2 / 8, lo_first);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_psa_attention_f16(void* stream, const void* qkv, const void* pe, void* out, int B, int N, int heads, float scale)
+{
+    if (!qkv || !out || B < 1 || B > 65535 || N < 1 || N > 16 * PSA_MAXT || heads < 1 || heads > 64) return SS_ERR_INVALID;
+    const int NP = (N + 31) & ~31;
+    hipLaunchKernelGGL(k_psa_attn, dim3((N + 63) / 64, heads, B), dim3(256), (size_t)64 * (NP + 16) * 2, (hipStream_t)stream,
+                       (const __half*)qkv, (const __half*)pe, (__half*)out, N, heads, scale);
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

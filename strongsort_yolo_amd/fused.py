@@ -23,7 +23,7 @@ def _flag(name: str) -> bool:
     return True
 
 
-FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE", "DW3X3", "HEAD_EXT", "C3K2")
+FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE", "DW3X3", "HEAD_EXT", "C3K2", "PSA")
 
 
 def set_flags(**kw):
@@ -592,6 +592,23 @@ def sppf_pools(x):
     b, c, h, w = x.shape
     out = torch.empty((b, 4 * c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     _ck(_lib.load().ss_op_sppf_pools_f16(_st(x), _p(x), _p(out), b, h, w, c))
+    return out
+
+
+PSA = _flag("PSA")                      # v11's C2PSA attention (QK^T, softmax, PV, + positional term) in one launch
+
+
+def psa_ok(x, heads, key_dim, head_dim) -> bool:
+    return PSA and usable(x) and key_dim == 32 and head_dim == 64 and x.shape[2] * x.shape[3] <= 256 and heads <= 64
+
+
+def psa_attention(qkv, pe, heads, scale):
+    """qkv [B, heads*128, H, W] channels-last half (per head q 32 | k 32 | v 64), pe [B, heads*64, H, W] or None ->
+    softmax(scale q^T k) applied to v, + pe: [B, heads*64, H, W] channels-last."""
+    qkv = _cl(qkv)
+    b, _, h, w = qkv.shape
+    out = torch.empty((b, heads * 64, h, w), dtype=qkv.dtype, device=qkv.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op_psa_attention_f16(_st(qkv), _p(qkv), _p(_cl(pe) if pe is not None else None), _p(out), b, h * w, heads, float(scale)))
     return out
 
 

@@ -436,6 +436,12 @@ class Attention(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         N = H * W
+        if fused.psa_ok(x, self.num_heads, self.key_dim, self.head_dim) and x.is_contiguous(memory_format=torch.channels_last):
+            # one launch for QK^T, softmax, PV and the sum with the positional term; v's dense copy feeds the depthwise convolution
+            qkv = self.qkv(x)                                                           # [B, heads*128, H, W], NHWC in memory
+            per = 2 * self.key_dim + self.head_dim
+            v = qkv.permute(0, 2, 3, 1).reshape(B, H, W, self.num_heads, per)[..., 2 * self.key_dim:].reshape(B, H, W, C).permute(0, 3, 1, 2)
+            return self.proj(fused.psa_attention(qkv, self.pe(v), self.num_heads, self.scale))
         qkv = self.qkv(x).contiguous().view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N)
         q, k, v = qkv.split([self.key_dim, self.key_dim, self.head_dim], dim=2)
         attn = ((q.transpose(-2, -1) @ k) * self.scale).softmax(dim=-1)

@@ -122,6 +122,30 @@ def test_v8_decode_matches_float_reference():
     assert (got[:, 4:] - ref[:, 4:]).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("B,dim,H,W", [(3, 128, 12, 20), (2, 256, 6, 10), (1, 128, 16, 16), (2, 128, 3, 5), (32, 128, 12, 20)])
+def test_psa_attention_launch_matches_the_module(B, dim, H, W):
+    """nets.Attention (v11 C2PSA: heads of key_dim 32 / head_dim 64 over the H*W positions, depthwise positional term on v) through
+    the one-launch kernel against the module's torch path in fp32 on the same half weights and input."""
+    from strongsort_yolo_amd import fused, nets
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(dim + H)
+    att = nets.Attention(dim, num_heads=dim // 64, attn_ratio=0.5).to(dev, torch.float16)
+    x = (torch.randn(B, dim, H, W) * 0.7).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    assert fused.psa_ok(x, att.num_heads, att.key_dim, att.head_dim)
+    with torch.no_grad():
+        got = att(x).float()
+        old = fused.ENABLED
+        fused.ENABLED = False
+        try:
+            ref = att.float()(x.float())
+        finally:
+            fused.ENABLED = old
+            att.half()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err, scale = (got - ref).abs().max().item(), ref.abs().max().item()
+    assert err <= 1e-2 * (scale + 1.0), (err, scale)
+
+
 @pytest.mark.parametrize("nc,cls_ld,n_ext,ext_ld,mode", [(1, 8, 51, 56, 1), (80, 80, 32, 32, 0), (1, 8, 0, 0, 0), (3, 8, 6, 8, 1)])
 def test_v8_decode_extra_rows_match_float_reference(nc, cls_ld, n_ext, ext_ld, mode):
     """The decode launch with a third branch (ss_op_v8_decode_ext_f16): keypoint triplets as Ultralytics Pose.kpts_decode — x, y =
