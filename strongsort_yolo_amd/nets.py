@@ -433,7 +433,8 @@ class Attention(nn.Module):
         self.qkv, self.proj = Conv(dim, h, 1, act=False), Conv(dim, dim, 1, act=False)
         self.pe = Conv(dim, dim, 3, 1, g=dim, act=False)
 
-    def forward(self, x):
+    def forward(self, x, res=None):
+        """res: added to the output (PSABlock's shortcut)."""
         B, C, H, W = x.shape
         N = H * W
         if fused.psa_ok(x, self.num_heads, self.key_dim, self.head_dim) and x.is_contiguous(memory_format=torch.channels_last):
@@ -441,7 +442,11 @@ class Attention(nn.Module):
             qkv = self.qkv(x)                                                           # [B, heads*128, H, W], NHWC in memory
             per = 2 * self.key_dim + self.head_dim
             v = qkv.permute(0, 2, 3, 1).reshape(B, H, W, self.num_heads, per)[..., 2 * self.key_dim:].reshape(B, H, W, C).permute(0, 3, 1, 2)
-            return self.proj(fused.psa_attention(qkv, self.pe(v), self.num_heads, self.scale))
+            y = fused.psa_attention(qkv, self.pe(v), self.num_heads, self.scale)
+            pc = self.proj.conv
+            if res is not None and fused.pointwise_ok(pc):                               # PSABlock's x + attn(x) in the projection's epilogue
+                return fused.pointwise(y, fused.weight_nk(self.proj, pc), pc.bias, "none", res=res)
+            return self.proj(y) if res is None else res + self.proj(y)
         qkv = self.qkv(x).contiguous().view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N)
         q, k, v = qkv.split([self.key_dim, self.key_dim, self.head_dim], dim=2)
         attn = ((q.transpose(-2, -1) @ k) * self.scale).softmax(dim=-1)
@@ -450,7 +455,7 @@ class Attention(nn.Module):
         y = (v @ attn.transpose(-2, -1)).reshape(B, C, H, W) + self.pe(vv.contiguous(memory_format=torch.channels_last) if cl else vv)
         if cl:
             y = y.contiguous(memory_format=torch.channels_last)
-        return self.proj(y)
+        return self.proj(y) if res is None else res + self.proj(y)
 
 
 class PSABlock(nn.Module):
@@ -459,9 +464,20 @@ class PSABlock(nn.Module):
         self.attn = Attention(c, num_heads, attn_ratio)
         self.ffn = nn.Sequential(Conv(c, c * 2, 1), Conv(c * 2, c, 1, act=False))
 
-    def forward(self, x):
-        x = x + self.attn(x)
-        return x + self.ffn(x)
+    def forward(self, x, out=None, c_off=0):
+        """out / c_off: the result also goes to channels [c_off, c_off + c) of `out` (C2PSA's concat buffer) when the fused path runs."""
+        x = self.attn(x, res=x)
+        f1 = self.ffn[1].conv
+        if fused.usable(x) and fused.pointwise_ok(f1):                                   # x + ffn(x) in the second 1x1's epilogue
+            if out is not None:
+                fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x, out=out, c_off=c_off)
+                return None
+            return fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x)
+        y = x + self.ffn(x)
+        if out is not None:
+            out[:, c_off:c_off + y.shape[1]] = y
+            return None
+        return y
 
 
 class C2PSA(nn.Module):
@@ -472,6 +488,18 @@ class C2PSA(nn.Module):
         self.m = nn.Sequential(*(PSABlock(self.c, 0.5, max(self.c // 64, 1)) for _ in range(n)))
 
     def forward(self, x):
+        cv = self.cv1.conv
+        if (fused.C3K2 and fused.usable(x) and fused.pointwise_ok(cv) and isinstance(self.cv1.act, nn.SiLU) and fused.place_ok(self.c, 2 * self.c)
+                and len(self.m) >= 1 and all(fused.pointwise_ok(blk.ffn[1].conv) for blk in self.m)):
+            # cv1 writes [a | b] into cv2's input and mirrors b densely for the attention blocks; the last block's shortcut epilogue
+            # writes its result over b's slot: no split / contiguous / cat launches
+            B, _, H, W = x.shape
+            cat = torch.empty((B, 2 * self.c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            b = torch.empty((B, self.c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            fused.pointwise(x, fused.weight_nk(self.cv1, cv), cv.bias, "silu", out=cat, c_off=0, out2=b, c0=self.c)
+            for i, blk in enumerate(self.m):
+                b = blk(b) if i + 1 < len(self.m) else blk(b, out=cat, c_off=self.c)
+            return self.cv2(cat)
         a, b = self.cv1(x).split((self.c, self.c), 1)
         if x.is_contiguous(memory_format=torch.channels_last):
             b = b.contiguous(memory_format=torch.channels_last)
