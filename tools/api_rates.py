@@ -1,6 +1,5 @@
-"""The drop-in calls on their own (bench.api_path in a fresh process: per-frame YOLO.track and YOLO.track_stream with host frames in,
-Results out, checked against the oracle).  Inside bench.py the same leg runs after the main measurement's pipeline has used its
-streams and graph pools and reports ~20 % less for track_stream.  usage: python tools/api_rates.py [preset=c2] [repeats=2]"""
+"""The drop-in calls on their own (bench.api_path without the rest of the bench: per-frame YOLO.track and YOLO.track_stream with host
+frames in, Results out, checked against the oracle).  usage: python tools/api_rates.py [preset=c2] [repeats=2]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
