@@ -209,6 +209,36 @@ def bottleneck(x, m, out, c_off, out2=None):
     return out
 
 
+def bottleneck_padded_ok(m) -> bool:
+    """A Bottleneck c -> c/2 -> c (v11's e = 0.5) can run on k_bneck with its hidden width zero-padded to c."""
+    a, b = m.cv1.conv, m.cv2.conv
+    silu = all(type(cv.act).__name__ == "SiLU" for cv in (m.cv1, m.cv2))
+    return (BNECK and silu and conv3x3_ok(a) and conv3x3_ok(b) and a.stride == (1, 1) and b.stride == (1, 1) and a.in_channels == b.out_channels
+            and a.out_channels == b.in_channels and a.out_channels < a.in_channels and a.in_channels in BNECK_C)
+
+
+def bottleneck_padded(x, m, out, c_off, out2=None):
+    """fused.bottleneck for a Bottleneck whose hidden width is smaller than its in / out width c: the first convolution's missing
+    output channels get zero weights and biases (SiLU(0) = 0), the second one's matching input columns zero weights — the equal-width
+    kernel computes the same sums plus exact zeros.  Prepared weights cached on `m`."""
+    x = _cl(x)
+    b, c, h, w = x.shape
+    a, bb = m.cv1.conv, m.cv2.conv
+    p = getattr(m, "_padded", None)
+    if p is None or p[0].device != a.weight.device or p[0].dtype != a.weight.dtype:
+        hid = a.out_channels
+        w1 = torch.zeros(c, 3, 3, c, device=a.weight.device, dtype=a.weight.dtype)
+        w1[:hid] = a.weight.detach().permute(0, 2, 3, 1)
+        b1 = torch.zeros(c, device=a.weight.device, dtype=a.weight.dtype)
+        b1[:hid] = a.bias.detach()
+        w2 = torch.zeros(c, 3, 3, c, device=a.weight.device, dtype=a.weight.dtype)
+        w2[:, :, :, :hid] = bb.weight.detach().permute(0, 2, 3, 1)
+        p = m._padded = (w1.reshape(c, -1).contiguous(), b1, w2.reshape(c, -1).contiguous())
+    _ck(_lib.load().ss_op_bottleneck_f16(_st(x), _p(x), _p(p[0]), _p(p[1]), _p(p[2]), _p(bb.bias), b, h, w, c, int(m.add),
+                                         C.c_void_p(out.data_ptr() + 2 * c_off), out.shape[1], _p(out2)))
+    return out
+
+
 GROUP = _flag("GROUP")                  # independent convolutions of the detect head in one launch per depth
 
 

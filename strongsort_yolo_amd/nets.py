@@ -412,6 +412,8 @@ class C3k2(nn.Module):
             nxt = dense() if i + 1 < n else None
             if type(m) is C3k:
                 m.forward_placed(cur, cat, (2 + i) * c, nxt)
+            elif fused.bottleneck_padded_ok(m):      # c -> c/2 -> c: one launch of the equal-width kernel on zero-padded weights
+                fused.bottleneck_padded(cur, m, cat, (2 + i) * c, out2=nxt)
             else:
                 cv = m.cv2.conv
                 fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, 1, "silu", res=cur if m.add else None, res_after=True,

@@ -297,3 +297,21 @@ def test_loading_weights_drops_the_prepared_copies(tmp_path):
     assert "_w_nk" not in c.__dict__ and "_padded" not in det.cv4[0].__dict__
     after = fused.weight_nk(c, c)
     assert not torch.equal(before, after) and torch.equal(after, other.cv2[0][2].weight.detach().reshape(after.shape))
+
+
+def test_padded_bottleneck_weights_compute_the_same_block():
+    """fused.bottleneck_padded's prepared weights (a c -> c/2 -> c Bottleneck as c -> c -> c with zero rows / columns) through plain torch
+    convolutions: the block's output, exactly the same sums plus zeros."""
+    torch.manual_seed(8)
+    m = nets.Bottleneck(32, 32, True, e=0.5).float()
+    assert fused.bottleneck_padded_ok(m) and not fused.bottleneck_ok(m)
+    c, hid = 32, 16
+    a, b = m.cv1.conv, m.cv2.conv
+    w1 = torch.zeros(c, 3, 3, c); w1[:hid] = a.weight.detach().permute(0, 2, 3, 1)
+    b1 = torch.zeros(c); b1[:hid] = a.bias.detach()
+    w2 = torch.zeros(c, 3, 3, c); w2[:, :, :, :hid] = b.weight.detach().permute(0, 2, 3, 1)
+    x = torch.randn(2, 32, 7, 9)
+    t = F.silu(F.conv2d(x, w1.permute(0, 3, 1, 2), b1, padding=1))
+    assert (t[:, hid:] == 0).all()
+    got = x + F.silu(F.conv2d(t, w2.permute(0, 3, 1, 2), b.bias, padding=1))
+    assert torch.allclose(got, m(x), rtol=0, atol=1e-5)
