@@ -105,15 +105,66 @@ class C2f(nn.Module):
         return self.cv2(cat)
 
 
+def _w_pair(mod, a, b):
+    """Two 1x1 convolutions on the same input as one: (weights [Ca + Cb, Cin], bias), cached on `mod`."""
+    w = getattr(mod, "_w_pair_", None)
+    if w is None or w[0].device != a.weight.device or w[0].dtype != a.weight.dtype:
+        w = mod._w_pair_ = (torch.cat((a.weight.detach().reshape(a.out_channels, -1), b.weight.detach().reshape(b.out_channels, -1)), 0).contiguous(),
+                            torch.cat((a.bias.detach(), b.bias.detach())).contiguous())
+    return w
+
+
 class C3(nn.Module):
-    def __init__(self, c1, c2, n=1, shortcut=True):
+    def __init__(self, c1, c2, n=1, shortcut=True, k=(1, 3)):
         super().__init__()
         c_ = c2 // 2
         self.cv1, self.cv2, self.cv3 = Conv(c1, c_, 1), Conv(c1, c_, 1), Conv(2 * c_, c2, 1)
-        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, k=(1, 3), e=1.0) for _ in range(n)))
+        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, k=k, e=1.0) for _ in range(n)))
 
     def forward(self, x):
+        if fused.C3K2 and fused.usable(x) and self.placed_ok():
+            B, _, H, W = x.shape
+            out = torch.empty((B, self.cv3.conv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            self.forward_placed(x, out, 0)
+            return out
         return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
+
+    def placed_ok(self) -> bool:
+        a, b, c3 = self.cv1.conv, self.cv2.conv, self.cv3.conv
+        silu = all(isinstance(cv.act, nn.SiLU) for cv in (self.cv1, self.cv2, self.cv3))
+        inner = all(type(m) is Bottleneck and isinstance(m.cv1.act, nn.SiLU) and isinstance(m.cv2.act, nn.SiLU) and
+                    (fused.bottleneck_ok(m) or ((fused.conv3x3_ok(m.cv1.conv) or fused.pointwise_ok(m.cv1.conv)) and fused.conv3x3_ok(m.cv2.conv)
+                                                and m.cv2.conv.stride == (1, 1)))
+                    for m in self.m)
+        return (silu and inner and len(self.m) >= 1 and fused.pointwise_ok(a) and fused.pointwise_ok(b) and fused.pointwise_ok(c3)
+                and a.in_channels == b.in_channels and fused.place_ok(a.out_channels, 2 * a.out_channels))
+
+    def _w12(self):
+        """cv1 and cv2 read the same input: one 1x1 with both sets of output rows ([cv1 | cv2], the concat order of forward)."""
+        return _w_pair(self, self.cv1.conv, self.cv2.conv)
+
+    def forward_placed(self, x, out, c_off, out2=None):
+        """The same arithmetic with every producer writing where its consumer reads: [cv1 | cv2] in one pointwise launch into the
+        inner concat buffer (cv1's half mirrored densely for the first bottleneck), the bottlenecks' results (shortcut in the second
+        convolution's epilogue) into cv1's slot, cv3's output into channels [c_off, c_off + c2) of `out` (+ the dense copy `out2`)."""
+        c_ = self.cv1.conv.out_channels
+        B, _, H, W = x.shape
+        inner = torch.empty((B, 2 * c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dense = lambda: torch.empty((B, c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        cur = dense()
+        w12, b12 = self._w12()
+        fused.pointwise(x, w12, b12, "silu", out=inner, c_off=0, out2=cur, c0=0)
+        for j, m in enumerate(self.m):
+            nxt = dense() if j + 1 < len(self.m) else None
+            if fused.bottleneck_ok(m):
+                fused.bottleneck(cur, m, inner, 0, out2=nxt)
+            else:
+                cv = m.cv2.conv
+                fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, 1, "silu", res=cur if m.add else None, res_after=True,
+                              out=inner, c_off=0, out2=nxt, c0=0)
+            cur = nxt
+        c3 = self.cv3.conv
+        fused.pointwise(inner, fused.weight_nk(self.cv3, c3), c3.bias, "silu", out=out, c_off=c_off, out2=out2, c0=0)
 
 
 class SPPF(nn.Module):
@@ -317,58 +368,11 @@ class YOLOv8(nn.Module):
 # depthwise-separable class branch of the v11 Detect head); nothing of it is in the reference snapshot, and no weights exist
 # offline, so the only check available here is structural (strict state_dict key / shape match through
 # `convert_ultralytics_state_dict`).  Module attribute names follow the Ultralytics layer indices (b0..b10, h13.., detect = 23).
-class C3k(nn.Module):
+class C3k(C3):
     """C3 with n Bottlenecks of two k x k convolutions (e = 1.0 inside)."""
 
     def __init__(self, c1, c2, n=2, shortcut=True, k=3):
-        super().__init__()
-        c_ = c2 // 2
-        self.cv1, self.cv2, self.cv3 = Conv(c1, c_, 1), Conv(c1, c_, 1), Conv(2 * c_, c2, 1)
-        self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, k=(k, k), e=1.0) for _ in range(n)))
-
-    def forward(self, x):
-        return self.cv3(torch.cat((self.m(self.cv1(x)), self.cv2(x)), 1))
-
-    def placed_ok(self) -> bool:
-        a, b, c3 = self.cv1.conv, self.cv2.conv, self.cv3.conv
-        silu = all(isinstance(cv.act, nn.SiLU) for cv in (self.cv1, self.cv2, self.cv3))
-        inner = all(type(m) is Bottleneck and isinstance(m.cv1.act, nn.SiLU) and isinstance(m.cv2.act, nn.SiLU) and
-                    (fused.bottleneck_ok(m) or (fused.conv3x3_ok(m.cv1.conv) and fused.conv3x3_ok(m.cv2.conv) and m.cv2.conv.stride == (1, 1)))
-                    for m in self.m)
-        return (silu and inner and len(self.m) >= 1 and fused.pointwise_ok(a) and fused.pointwise_ok(b) and fused.pointwise_ok(c3)
-                and a.in_channels == b.in_channels and fused.place_ok(a.out_channels, 2 * a.out_channels))
-
-    def _w12(self):
-        """cv1 and cv2 read the same input: one 1x1 with both sets of output rows ([cv1 | cv2], the concat order of forward)."""
-        w = getattr(self, "_w12_", None)
-        a, b = self.cv1.conv, self.cv2.conv
-        if w is None or w[0].device != a.weight.device or w[0].dtype != a.weight.dtype:
-            w = self._w12_ = (torch.cat((a.weight.detach().reshape(a.out_channels, -1), b.weight.detach().reshape(b.out_channels, -1)), 0).contiguous(),
-                              torch.cat((a.bias.detach(), b.bias.detach())).contiguous())
-        return w
-
-    def forward_placed(self, x, out, c_off, out2=None):
-        """The same arithmetic with every producer writing where its consumer reads: [cv1 | cv2] in one pointwise launch into the
-        inner concat buffer (cv1's half mirrored densely for the first bottleneck), the bottlenecks' results into cv1's slot, cv3's
-        output into channels [c_off, c_off + c2) of `out` (+ the dense copy `out2`)."""
-        c_ = self.cv1.conv.out_channels
-        B, _, H, W = x.shape
-        inner = torch.empty((B, 2 * c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        dense = lambda: torch.empty((B, c_, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-        cur = dense()
-        w12, b12 = self._w12()
-        fused.pointwise(x, w12, b12, "silu", out=inner, c_off=0, out2=cur, c0=0)
-        for j, m in enumerate(self.m):
-            nxt = dense() if j + 1 < len(self.m) else None
-            if fused.bottleneck_ok(m):
-                fused.bottleneck(cur, m, inner, 0, out2=nxt)
-            else:
-                cv = m.cv2.conv
-                fused.conv3x3(m.cv1(cur), fused.weight_n9k(m.cv2, cv), cv.bias, 1, "silu", res=cur if m.add else None, res_after=True,
-                              out=inner, c_off=0, out2=nxt, c0=0)
-            cur = nxt
-        c3 = self.cv3.conv
-        fused.pointwise(inner, fused.weight_nk(self.cv3, c3), c3.bias, "silu", out=out, c_off=c_off, out2=out2, c0=0)
+        super().__init__(c1, c2, n, shortcut, k=(k, k))
 
 
 class C3k2(nn.Module):
@@ -617,15 +621,6 @@ class YOLOv5u(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # YOLOv7-style detector (ELAN backbone + SPPCSPC neck), anchor-free head for a uniform NMS layout
 # --------------------------------------------------------------------------------------------------
-def _w_pair(mod, a, b):
-    """Two 1x1 convolutions on the same input as one: (weights [Ca + Cb, Cin], bias), cached on `mod`."""
-    w = getattr(mod, "_w_pair_", None)
-    if w is None or w[0].device != a.weight.device or w[0].dtype != a.weight.dtype:
-        w = mod._w_pair_ = (torch.cat((a.weight.detach().reshape(a.out_channels, -1), b.weight.detach().reshape(b.out_channels, -1)), 0).contiguous(),
-                            torch.cat((a.bias.detach(), b.bias.detach())).contiguous())
-    return w
-
-
 class ELAN(nn.Module):
     def __init__(self, c1, c_, c2, depth=4):
         super().__init__()
