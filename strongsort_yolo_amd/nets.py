@@ -68,15 +68,23 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, e=1.0) for _ in range(n))
 
-    def forward(self, x):
-        if fused.usable(x) and fused.place_ok(self.c, (2 + len(self.m)) * self.c) and all(type(m) is Bottleneck for m in self.m):
-            return self._forward_placed(x)
+    def placed_ok(self, x) -> bool:
+        return fused.usable(x) and fused.place_ok(self.c, (2 + len(self.m)) * self.c) and all(type(m) is Bottleneck for m in self.m)
+
+    def forward(self, x, also=None, c_off=0):
+        """also / c_off: the block's output is ALSO written into channels [c_off, c_off + c2) of the channels-last tensor `also` (a
+        later concat's buffer) by the last 1x1's epilogue — only with the placed path (placed_ok) and a pointwise-capable cv2."""
+        if self.placed_ok(x):
+            return self._forward_placed(x, also, c_off)
         y = list(self.cv1(x).chunk(2, 1))
         for m in self.m:
             y.append(m(y[-1]))
-        return self.cv2(torch.cat(y, 1))
+        y = self.cv2(torch.cat(y, 1))
+        if also is not None:
+            also[:, c_off:c_off + y.shape[1]] = y
+        return y
 
-    def _forward_placed(self, x):
+    def _forward_placed(self, x, also=None, c_off=0):
         """Same arithmetic, no chunk / add / cat launches: every producer's bias+SiLU epilogue writes straight into
         its channel slice of the concat buffer (and a dense copy of the half the next 3x3 conv reads)."""
         c, n = self.c, len(self.m)
@@ -102,7 +110,15 @@ class C2f(nn.Module):
                 fused.bias_act_place(t, cv.bias, "silu", cat, (2 + i) * c, res=cur if m.add else None, res_after=True,
                                      out2=nxt, c0=0)
             cur = nxt
-        return self.cv2(cat)
+        cv = self.cv2.conv
+        if also is not None and fused.pointwise_ok(cv) and isinstance(self.cv2.act, nn.SiLU):
+            y = torch.empty((B, cv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            fused.pointwise(cat, fused.weight_nk(self.cv2, cv), cv.bias, "silu", out=also, c_off=c_off, out2=y, c0=0)
+            return y
+        y = self.cv2(cat)
+        if also is not None:
+            also[:, c_off:c_off + y.shape[1]] = y
+        return y
 
 
 def _w_pair(mod, a, b):
@@ -351,6 +367,23 @@ class YOLOv8(nn.Module):
         return p3, p4, p5
 
     def forward_head(self, p3, p4, p5):
+        c16, c19 = self.h16.conv, self.h19.conv
+        if (fused.C3K2 and fused.usable(p3) and fused.conv3x3_ok(c16) and fused.conv3x3_ok(c19) and isinstance(self.h16.act, nn.SiLU)
+                and isinstance(self.h19.act, nn.SiLU) and c16.out_channels % 8 == 0 and c19.out_channels % 8 == 0):
+            # the two down-path concats as placement: h12 lands in h18's input from its own last 1x1, the stride-2 convolutions write
+            # their slices; only p5 (made in the backbone half, which may be another captured graph) is copied
+            B = p3.shape[0]
+            x18 = torch.empty((B, c16.out_channels + self.h12.cv2.conv.out_channels, p4.shape[2], p4.shape[3]), dtype=p3.dtype, device=p3.device,
+                              memory_format=torch.channels_last)
+            h12 = self.h12(_upcat(p5, p4), also=x18, c_off=c16.out_channels)
+            h15 = self.h15(_upcat(h12, p3))
+            fused.conv3x3(h15, fused.weight_n9k(self.h16, c16), c16.bias, 2, "silu", out=x18, c_off=0)
+            h18 = self.h18(x18)
+            x21 = torch.empty((B, c19.out_channels + p5.shape[1], p5.shape[2], p5.shape[3]), dtype=p3.dtype, device=p3.device,
+                              memory_format=torch.channels_last)
+            fused.conv3x3(h18, fused.weight_n9k(self.h19, c19), c19.bias, 2, "silu", out=x21, c_off=0)
+            x21[:, c19.out_channels:] = p5
+            return self.detect([h15, h18, self.h21(x21)])
         h12 = self.h12(_upcat(p5, p4))
         h15 = self.h15(_upcat(h12, p3))
         h18 = self.h18(torch.cat((self.h16(h15), h12), 1))
