@@ -385,6 +385,10 @@ int ss_op_sppf_pools_f16(void* stream, const void* d_x, void* d_out, int B, int 
  * output, N = H * W positions <= 256), d_out[b][i][h * 64 + c] = sum_j v[c][j] softmax_j(scale q_i . k_j) (+ d_pe[b][i][h * 64 + c], the
  * depthwise positional term of v, when given); fp32 scores / softmax / accumulation, probabilities rounded to half. */
 int ss_op_psa_attention_f16(void* stream, const void* d_qkv, const void* d_pe, void* d_out, int B, int N, int heads, float scale);
+/* OSNet's head in one launch: d_out[n][f] = relu(sum_c d_w[f][c] * mean_hw(d_x[n][.][c]) + d_bias[f]); d_x [N][HW][C] half (the last 1x1's
+ * output), C == 128; the means are rounded to half before the product (as the tensor a GEMM would read), fp32 accumulation.  Honours
+ * ss_op_set_valid_images. */
+int ss_op_osnet_head_f16(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F);
 /* 2x2 / stride 2 average pooling, NHWC half (H, W even; C % 8 == 0). */
 int ss_op_avgpool2_f16(void* stream, const void* d_x, void* d_y, int N, int H, int W, int C);
 /* k x k max pooling (stride, pad with -inf), output floor((H+2p-k)/s)+1. */

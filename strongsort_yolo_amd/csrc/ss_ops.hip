@@ -2374,6 +2374,74 @@ __global__ __launch_bounds__(256) void k_psa_attn(const __half* __restrict__ qkv
     }
 }
 
+// OSNet's head: global average over the HW positions of the last feature map, the 128 -> F fully connected layer, + bias, ReLU, in one
+// launch (torch: a reduction kernel, a library GEMM and two element-wise passes, ~33 us per 1 024 crops).  Workgroup = 4 crops: all their
+// pixels are requested at once (thread = 8 channels x every 16th pixel), the means (rounded to half, as the tensor the GEMM would
+// read) go to LDS, every thread owns F / 256 output features of the 4 crops and walks its weight rows once (16-byte loads; fp32
+// accumulation in k order).  x [N][HW][C] half, w [F][C] half, out [N][F] half.
+template <int C>
+__global__ __launch_bounds__(256) void k_osnet_head(const __half* __restrict__ x, const __half* __restrict__ w, const __half* __restrict__ bias,
+                                                   __half* __restrict__ out, int N, int HW, int F, const int* __restrict__ nvalid)
+{
+    constexpr int CR = 4, C8 = C / 8, PG = 256 / C8;
+    __shared__ float part[CR][PG][C];                                  // 16 pixel groups x C partial sums per crop (32 KiB)
+    __shared__ __attribute__((aligned(16))) _Float16 mean[CR][C];
+    const int tid = threadIdx.x, n0 = blockIdx.x * CR;
+    const int nv = nvalid ? min(*nvalid, N) : N;
+    if (n0 >= nv) return;
+    const int c8 = tid % C8, pg = tid / C8;
+    float a[CR][8];
+#pragma unroll
+    for (int cr = 0; cr < CR; ++cr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[cr][k] = 0.f;
+    for (int p = pg; p < HW; p += PG) {
+        h8 v[CR];
+#pragma unroll
+        for (int cr = 0; cr < CR; ++cr)
+            v[cr] = n0 + cr < nv ? *reinterpret_cast<const h8*>(x + (((size_t)(n0 + cr) * HW + p) * C + c8 * 8)) : h8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int cr = 0; cr < CR; ++cr)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[cr][k] += (float)v[cr][k];
+    }
+#pragma unroll
+    for (int cr = 0; cr < CR; ++cr)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) part[cr][pg][c8 * 8 + k] = a[cr][k];
+    __syncthreads();
+    for (int i = tid; i < CR * C; i += 256) {
+        const int cr = i / C, c = i - cr * C;
+        float t = 0.f;
+        for (int g = 0; g < PG; ++g) t += part[cr][g][c];
+        mean[cr][c] = (_Float16)(t / (float)HW);
+    }
+    __syncthreads();
+    for (int o = tid; o < F; o += 256) {
+        float acc[CR];
+#pragma unroll
+        for (int cr = 0; cr < CR; ++cr) acc[cr] = 0.f;
+        const h8* wr = reinterpret_cast<const h8*>(w + (size_t)o * C);
+#pragma unroll 4
+        for (int k8 = 0; k8 < C8; ++k8) {
+            const h8 wv = wr[k8];
+#pragma unroll
+            for (int cr = 0; cr < CR; ++cr) {
+                const h8 mv = *reinterpret_cast<const h8*>(&mean[cr][k8 * 8]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[cr] = fmaf((float)wv[k], (float)mv[k], acc[cr]);
+            }
+        }
+        const float b = __half2float(bias[o]);
+#pragma unroll
+        for (int cr = 0; cr < CR; ++cr)
+            if (n0 + cr < nv) {
+                const float f = (float)(_Float16)acc[cr] + b;          // the product rounded to half, then the bias (as the GEMM + bias epilogue)
+                out[(size_t)(n0 + cr) * F + o] = __float2half(f > 0.f ? f : 0.f);
+            }
+    }
+}
+
 static inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g ? g : 1)); }
 
 extern "C" int ss_op_bias_act_f16(void* stream, void* x, const void* bias, const void* res, long long n_pix, int C, int act)
@@ -2750,6 +2818,14 @@ extern "C" int ss_op_upcat_f16(void* stream, const void* lo, const void* hi, voi
     const size_t total = (size_t)B * 4 * h * w * ((C1 + C2) / 8);
     hipLaunchKernelGGL(k_upcat, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __half*)lo, (const __half*)hi,
                        (__half*)out, B, h, w, C1 / 8, C2 / 8, lo_first);
+    return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
+}
+
+extern "C" int ss_op_osnet_head_f16(void* stream, const void* x, const void* w, const void* bias, void* out, int N, int HW, int C, int F)
+{
+    if (!x || !w || !bias || !out || N < 1 || HW < 1 || C != 128 || F < 1) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(k_osnet_head<128>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const __half*)x, (const __half*)w,
+                       (const __half*)bias, (__half*)out, N, HW, F, nv_for(stream, N));
     return hipGetLastError() == hipSuccess ? SS_OK : SS_ERR_HIP;
 }
 

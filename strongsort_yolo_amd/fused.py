@@ -23,7 +23,7 @@ def _flag(name: str) -> bool:
     return True
 
 
-FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE", "DW3X3", "HEAD_EXT", "C3K2", "PSA")
+FLAG_NAMES = ("POINTWISE", "CONV3X3", "BNECK", "GROUP", "HEAD", "HEAD_TILE16", "LIGHTCONV", "CONV0", "STEM", "STEM_CONV1", "STREAMS", "TAIL", "GLUE", "DW3X3", "HEAD_EXT", "C3K2", "PSA", "OSHEAD")
 
 
 def set_flags(**kw):
@@ -622,6 +622,21 @@ def sppf_pools(x):
     b, c, h, w = x.shape
     out = torch.empty((b, 4 * c, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     _ck(_lib.load().ss_op_sppf_pools_f16(_st(x), _p(x), _p(out), b, h, w, c))
+    return out
+
+
+OSHEAD = _flag("OSHEAD")                # OSNet's average pool + fully connected layer + ReLU in one launch
+
+
+def osnet_head_ok(x, fc) -> bool:
+    return OSHEAD and usable(x) and x.shape[1] == 128 and fc.in_features == 128 and fc.bias is not None and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def osnet_head(x, fc):
+    """relu(fc(mean_hw(x))): x [N, 128, H, W] channels-last half -> [N, F] half."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, fc.out_features), dtype=x.dtype, device=x.device)
+    _ck(_lib.load().ss_op_osnet_head_f16(_st(x), _p(x), _p(fc.weight), _p(fc.bias), _p(out), n, h * w, c, fc.out_features))
     return out
 
 

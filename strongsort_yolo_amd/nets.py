@@ -957,6 +957,8 @@ class OSNet(nn.Module):
         """`x`: what forward_a(., start) returned (a tensor or a tuple of tensors)."""
         for k in range(start, self.N_PARTS):
             x = self._part(k, x)
+        if fused.osnet_head_ok(x, self.fc):                  # average pool + fc + ReLU in one launch
+            return fused.osnet_head(x, self.fc)
         return F.relu(self.fc(x.mean((2, 3))))
 
     def forward(self, x):

@@ -596,3 +596,20 @@ def test_valid_image_counts_belong_to_their_stream():
         od = mk(); fused.pointwise(x, w, bias, "relu", out=od)
     torch.cuda.synchronize()
     assert torch.equal(od, ref)
+
+
+@pytest.mark.parametrize("N,H,W,F", [(13, 16, 8, 512), (1, 16, 8, 512), (1024, 16, 8, 512), (9, 4, 4, 64)])
+def test_osnet_head_launch_matches_mean_fc_relu(N, H, W, F):
+    """relu(fc(mean_hw(x))) in one launch against torch on the same half tensors (means rounded to half, fp32 accumulation)."""
+    from strongsort_yolo_amd import fused
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(N + F)
+    x = torch.randn(N, 128, H, W, generator=g).to(dev, torch.float16).contiguous(memory_format=torch.channels_last)
+    fc = torch.nn.Linear(128, F).to(dev, torch.float16)
+    assert fused.osnet_head_ok(x, fc)
+    got = fused.osnet_head(x, fc).float()
+    m = x.float().mean((2, 3)).half().float()
+    ref = torch.relu((m @ fc.weight.float().t()).half().float() + fc.bias.float()).half().float()
+    assert got.shape == ref.shape == (N, F)
+    assert (got - ref).abs().max().item() <= 2e-3 * (ref.abs().max().item() + 1.0)
+    assert (got != ref).float().mean().item() < 0.05
