@@ -429,10 +429,12 @@ def reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=0, frames=150, reid
                     first_div = k
             elif first_div is None:
                 first_div = k
+    own32 = bool(getattr(pipe.reid, "_ok32", False))
     pipe.close()
     cat = lambda a: np.concatenate(a) if a else np.zeros(0)
     ds, dd = cat(d_same), cat(d_diff)
-    return {"reid_precision": "f16 (fused HIP kernels)" if reid_half else "fp32 (library convolutions)", "frames": frames, "crops": crops_n, "embedding_unit_max_abs_err": round(emb_err, 7), "cosine_f16_vs_f32_same_crop_max": round(pair_err, 7),
+    return {"reid_precision": "f16 (fused HIP kernels)" if reid_half else ("fp32 (hand-written kernels, csrc/ss_ops32.hip)" if own32 else "fp32 (library convolutions)"),
+            "reid_kernels": "hip-f16" if reid_half else ("hip-fp32" if own32 else "library-fp32"), "frames": frames, "crops": crops_n, "embedding_unit_max_abs_err": round(emb_err, 7), "cosine_f16_vs_f32_same_crop_max": round(pair_err, 7),
             "cost_matrix_cosine_max_abs_err": round(cos_err, 7), "cost_matrix_frames_compared": cos_frames, "north_star_bound": 1e-4,
             "within_bound": bool(cos_err <= 1e-4), "id_match_rate": round(same / max(tot, 1), 6), "rows_compared": tot,
             "id_match_rate_up_to_relabeling": round(same_relabel / max(tot, 1), 6),
@@ -441,7 +443,7 @@ def reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=0, frames=150, reid
             "fp32_cosine_different_identities_mean": round(float(dd.mean()), 6) if dd.size else None,
             "fp32_cosine_different_identities_min": round(float(dd.min()), 6) if dd.size else None,
             "cpu_fp32_reid_ms_per_frame": round(t_cpu / frames * 1e3, 2),
-            "note": "product: HIP crops (f16) -> f16 HIP OSNet -> HIP tracker; checker: C-oracle crops (f32) -> the same seeded OSNet-x0.25 in CPU fp32 -> "
+            "note": "product: HIP crops -> HIP OSNet (precision as `reid_precision`) -> HIP tracker; checker: C-oracle crops (f32) -> the same seeded OSNet-x0.25 in CPU fp32 -> "
                     "C-oracle tracker; rendered synthetic frames (identity textures), seeded weights calibrated to zero-mean / unit-variance layer outputs "
                     "(calibrate_reid_: the statistics of folded Conv+BatchNorm pairs; no trained checkpoint exists offline); the distance matrices are compared while the two "
                     "track tables have the same shape and no id has diverged; id_match_rate counts rows equal in box, id, class and age (one differently timed "
@@ -560,11 +562,11 @@ def front_rooflines(pipe, n_img, mean_dets, reps=20):
                   "mean_call_us": round(t * 1e6, 2), "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4),
                   "note": "the filter pass is the HBM-bound part; sort / IoU bit matrix / greedy scan are latency-bound on ~30 candidates per image"}
     if pipe.pack:
-        t = timed(lambda: e.crop_norm_packed(b.frames, b.dets6, pipe.RB, b.ndets, b.crop_off, b.crops, half=True))
+        t = timed(lambda: e.crop_norm_packed(b.frames, b.dets6, pipe.RB, b.ndets, b.crop_off, b.crops, half=pipe.reid_half))
     else:
-        t = timed(lambda: e.crop_norm_batch(b.frames, b.dets6, pipe.RB, counts=b.ndets, half=pipe.half, out=b.crops, channels_last=True))
+        t = timed(lambda: e.crop_norm_batch(b.frames, b.dets6, pipe.RB, counts=b.ndets, half=pipe.reid_half, out=b.crops, channels_last=True))
     ncrop = int(b.ndets.clamp(max=pipe.RB).sum().item())
-    by = ncrop * 3 * 256 * 128 * esz
+    by = ncrop * 3 * 256 * 128 * (2 if pipe.reid_half else 4)
     out["crop"] = {"kernel": "k_crop_hwc8 (a4)", "crops": ncrop, "algorithmic_bytes": by, "mean_call_us": round(t * 1e6, 2),
                    "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4),
                    "note": "output bytes only (D x 3 x 256 x 128 halfs); the source boxes are read from L2"}
@@ -644,6 +646,9 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--no-api-path", action="store_true", help="skip the YOLO.track / track_stream measurement")
     ap.add_argument("--no-reid-check", action="store_true", help="skip the f16 HIP OSNet vs CPU fp32 OSNet measurement on the true feat_source='reid' path")
+    ap.add_argument("--reid-fp32", action="store_true", help="the ACCURACY MODE as the measured configuration: ReID crops + OSNet-x0.25 with fp32 activations on the hand-written fp32 kernels (csrc/ss_ops32.hip); the default line carries the same measurement on fewer steps as `accuracy_mode`")
+    ap.add_argument("--no-accuracy-mode", action="store_true", help="skip the second, shorter timed run with the fp32 ReID network (`accuracy_mode`)")
+    ap.add_argument("--accuracy-steps", type=int, default=10, help="timed steps of the `accuracy_mode` run")
     ap.add_argument("--check-frames", type=int, default=-1, help="frames (from the start of the run) compared with the oracle; -1: all of them, the timed ones included")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--defer-track", type=int, default=1, help="1: the tracker call of a group is enqueued after the last stage's stream has waited for stage 0 of the next group (it then runs beside the start of that group, away from the OSNet row-stream kernel)")
@@ -703,125 +708,160 @@ def main():
     overlap = args.overlap > 1 and args.graph != "none" and not args.no_nets
     FB = args.frame_batch if overlap else 1
     FPS = FB * args.groups_per_step                     # frames of a stream per step
-    S, K, Wm = args.streams, args.steps, args.warmup
-    KF, WF = K * FPS, Wm * FPS                          # timed / warm-up frames per stream
-    total = PREFILL + WF + KF
+    S = args.streams
     PipeCls = OverlappedPipeline if overlap else FramePipeline
-    pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
-                   det_source="synthetic", feat_source="by_anchor", graph=args.graph,
-                   run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
-    for kv in args.opt:
-        pipe.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-    gs = scale_geometry(pipe.geom, H, W)
-    nc, A = pipe.nc, pipe.n_anchors
-    wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A, pipe.nk) for s in range(S)]
-    dev = pipe.dev
-    pools = [dict(preds=torch.from_numpy(w["preds"]).to(dev), agt=torch.from_numpy(w["agt"]).to(dev),
-                  feats=torch.from_numpy(w["feats"]).to(dev), pixels=torch.from_numpy(w["pixels"]).to(dev)) for w in wls]
-    for p in pools:                                         # the frame pool laid out cyclically, one group longer than itself: any
-        npix = p["pixels"].shape[0]                         # FB consecutive frames of the cycle are one contiguous slice
-        p["npix"] = npix
-        p["cycle"] = p["pixels"].repeat((FB + npix - 1) // npix + 1, 1, 1, 1)
-    out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
-    nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
+    from types import SimpleNamespace
 
-    def feed(k, b, f=0):
-        for s, p in enumerate(pools):
-            v = f * S + s                                   # virtual stream of frame f of the group
-            b.frames[v].copy_(p["pixels"][k % p["pixels"].shape[0]])
-            b.pred_in[v].copy_(p["preds"][k])
-            b.anchor_gt[v].copy_(p["agt"][k])
-            b.gt_feats[v].copy_(p["feats"][k])
+    def timed_pipeline(reid_half, K, Wm):
+        """PREFILL + Wm warm-up + exactly K timed steps of the whole hot path with the ReID network in half (throughput default) or
+        fp32 (accuracy mode); returns everything the line is built from.  The pipeline stays open (caller closes R.pipe)."""
+        KF, WF = K * FPS, Wm * FPS                          # timed / warm-up frames per stream
+        total = PREFILL + WF + KF
+        pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
+                       det_source="synthetic", feat_source="by_anchor", graph=args.graph, reid_half=reid_half,
+                       run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
+        for kv in args.opt:
+            pipe.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        gs = scale_geometry(pipe.geom, H, W)
+        nc, A = pipe.nc, pipe.n_anchors
+        wls = [make_workload(1000 * rank + s, W, H, n_ids, total, gs, nc, A, pipe.nk) for s in range(S)]
+        dev = pipe.dev
+        pools = [dict(preds=torch.from_numpy(w["preds"]).to(dev), agt=torch.from_numpy(w["agt"]).to(dev),
+                      feats=torch.from_numpy(w["feats"]).to(dev), pixels=torch.from_numpy(w["pixels"]).to(dev)) for w in wls]
+        for p in pools:                                         # the frame pool laid out cyclically, one group longer than itself: any
+            npix = p["pixels"].shape[0]                         # FB consecutive frames of the cycle are one contiguous slice
+            p["npix"] = npix
+            p["cycle"] = p["pixels"].repeat((FB + npix - 1) // npix + 1, 1, 1, 1)
+        out_host = torch.empty(total, S, 256, 8, dtype=torch.float32).pin_memory()
+        nout_host = torch.empty(total, S, dtype=torch.int32).pin_memory()
 
-    def feed_group(g0, n, b):
-        """Frames g0..g0+n-1 of every stream into the group's buffers: one device copy per input tensor per stream
-        (stands for the decoder writing its frames into the batch buffer)."""
-        for s, p in enumerate(pools):
-            k0 = g0 % p["npix"]
-            b.frames.view(FB, S, *b.frames.shape[1:])[:n, s].copy_(p["cycle"][k0:k0 + n])
-            b.pred_in.view(FB, S, *b.pred_in.shape[1:])[:n, s].copy_(p["preds"][g0:g0 + n])
-            b.anchor_gt.view(FB, S, *b.anchor_gt.shape[1:])[:n, s].copy_(p["agt"][g0:g0 + n])
-            b.gt_feats.view(FB, S, *b.gt_feats.shape[1:])[:n, s].copy_(p["feats"][g0:g0 + n])
+        def feed(k, b, f=0):
+            for s, p in enumerate(pools):
+                v = f * S + s                                   # virtual stream of frame f of the group
+                b.frames[v].copy_(p["pixels"][k % p["pixels"].shape[0]])
+                b.pred_in[v].copy_(p["preds"][k])
+                b.anchor_gt[v].copy_(p["agt"][k])
+                b.gt_feats[v].copy_(p["feats"][k])
 
-    if overlap:
-        seg_last = set()                                    # frame indices that end a (possibly partial) group
+        def feed_group(g0, n, b):
+            """Frames g0..g0+n-1 of every stream into the group's buffers: one device copy per input tensor per stream
+            (stands for the decoder writing its frames into the batch buffer)."""
+            for s, p in enumerate(pools):
+                k0 = g0 % p["npix"]
+                b.frames.view(FB, S, *b.frames.shape[1:])[:n, s].copy_(p["cycle"][k0:k0 + n])
+                b.pred_in.view(FB, S, *b.pred_in.shape[1:])[:n, s].copy_(p["preds"][g0:g0 + n])
+                b.anchor_gt.view(FB, S, *b.anchor_gt.shape[1:])[:n, s].copy_(p["agt"][g0:g0 + n])
+                b.gt_feats.view(FB, S, *b.gt_feats.shape[1:])[:n, s].copy_(p["feats"][g0:g0 + n])
 
-        step_marks = []                                     # (index of the group's last frame, event after its result copies)
+        if overlap:
+            seg_last = set()                                    # frame indices that end a (possibly partial) group
 
-        def fetch(k, f):
-            # results of a whole group leave in two device-to-host copies once its last frame is tracked
-            if f == FB - 1 or k in seg_last:
-                out_host[k - f:k + 1].copy_(pipe.outs[:f + 1], non_blocking=True)
-                nout_host[k - f:k + 1].copy_(pipe.nouts[:f + 1], non_blocking=True)
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record(torch.cuda.current_stream(dev))
-                step_marks.append((k, ev))
+            step_marks = []                                     # (index of the group's last frame, event after its result copies)
 
-        pipe.on_result = fetch
+            def fetch(k, f):
+                # results of a whole group leave in two device-to-host copies once its last frame is tracked
+                if f == FB - 1 or k in seg_last:
+                    out_host[k - f:k + 1].copy_(pipe.outs[:f + 1], non_blocking=True)
+                    nout_host[k - f:k + 1].copy_(pipe.nouts[:f + 1], non_blocking=True)
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record(torch.cuda.current_stream(dev))
+                    step_marks.append((k, ev))
 
-        def run(k0, k1):
-            for g0 in range(k0, k1, FB):
-                n = min(FB, k1 - g0)
-                seg_last.add(g0 + n - 1)
-                b = pipe.begin_frame()
-                with torch.cuda.stream(pipe.s_in):
-                    feed_group(g0, n, b)
-                pipe.submit(n)
+            pipe.on_result = fetch
 
-        def drain():
-            pipe.flush()
-    else:
-        def run(k0, k1):
-            for k in range(k0, k1):
-                feed(k, pipe)
-                pipe.step()
-                out_host[k].copy_(pipe.out, non_blocking=True)
-                nout_host[k].copy_(pipe.nout, non_blocking=True)
+            def run(k0, k1):
+                for g0 in range(k0, k1, FB):
+                    n = min(FB, k1 - g0)
+                    seg_last.add(g0 + n - 1)
+                    b = pipe.begin_frame()
+                    with torch.cuda.stream(pipe.s_in):
+                        feed_group(g0, n, b)
+                    pipe.submit(n)
 
-        def drain():
-            pass
+            def drain():
+                pipe.flush()
+        else:
+            def run(k0, k1):
+                for k in range(k0, k1):
+                    feed(k, pipe)
+                    pipe.step()
+                    out_host[k].copy_(pipe.out, non_blocking=True)
+                    nout_host[k].copy_(pipe.nout, non_blocking=True)
 
-    def barrier():
+            def drain():
+                pass
+
+        def barrier():
+            drain()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        run(0, PREFILL)                              # untimed: galleries reach nn_budget rows
+        run(PREFILL, PREFILL + WF)                   # W untimed warm-up steps
         drain()
-        if world > 1:
-            dist.barrier()
         torch.cuda.synchronize()
+        pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
+        pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
+        barrier()
+        t0, c0 = time.perf_counter(), time.thread_time()
+        run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
+        t_enq = time.perf_counter() - t0             # host wall time to enqueue the K steps (the GPU may still be working; includes the
+        t_enq_cpu = time.thread_time() - c0          # time the runtime blocks on full hardware queues) and the CPU time this thread used for it
+        barrier()
+        dt = time.perf_counter() - t0
+        assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
+        assoc_order_us = pipe.eng.assoc_timing_values().astype(np.float64) * 1e3         # in launch order
+        assoc_each_us = np.sort(assoc_order_us)
+        assoc_ik_us, assoc_ik_n = pipe.eng.assoc_inkernel_timing(False)
+        # per-step durations inside the timed region: time between the completion marks of consecutive frame groups
+        step_ms = None
+        if overlap:
+            tm = [ev for k, ev in step_marks if k >= PREFILL + WF]
+            d = np.array([tm[i].elapsed_time(tm[i + 1]) for i in range(len(tm) - 1)], np.float64) / args.groups_per_step if len(tm) > 1 else np.zeros(0)
+            if d.size:
+                step_ms = {"p50": round(float(np.percentile(d, 50)), 4), "p95": round(float(np.percentile(d, 95)), 4), "min": round(float(d.min()), 4),
+                           "max": round(float(d.max()), 4), "n": int(d.size), "how": "HIP events after each group's result copies on the tracker stream, consecutive differences"}
+        pct = lambda a, q: round(float(np.percentile(a, q)), 2) if len(a) else None
+        pipe.eng.check_errors()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        per_rank_dt = [dt]
+        if world > 1:
+            gathered = [torch.zeros_like(tmax) for _ in range(world)]
+            dist.all_gather(gathered, tmax)                     # every rank's own time between the barriers (rank 0 reports them)
+            per_rank_dt = [float(t.item()) for t in gathered]
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        return SimpleNamespace(pipe=pipe, K=K, Wm=Wm, KF=KF, WF=WF, total=total, dt=dt, per_rank_dt=per_rank_dt, t_enq=t_enq, t_enq_cpu=t_enq_cpu, wls=wls, gs=gs,
+                               nc=nc, A=A, out_host=out_host, nout_host=nout_host, step_ms=step_ms, assoc_ms=assoc_ms, assoc_n=assoc_n, assoc_order_us=assoc_order_us,
+                               assoc_each_us=assoc_each_us, assoc_ik_us=assoc_ik_us, assoc_ik_n=assoc_ik_n, dev=dev)
 
-    run(0, PREFILL)                              # untimed: galleries reach nn_budget rows
-    run(PREFILL, PREFILL + WF)                   # W untimed warm-up steps
-    drain()
-    torch.cuda.synchronize()
-    pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
-    pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
-    barrier()
-    t0, c0 = time.perf_counter(), time.thread_time()
-    run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
-    t_enq = time.perf_counter() - t0             # host wall time to enqueue the K steps (the GPU may still be working; includes the
-    t_enq_cpu = time.thread_time() - c0          # time the runtime blocks on full hardware queues) and the CPU time this thread used for it
-    barrier()
-    dt = time.perf_counter() - t0
-    assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
-    assoc_order_us = pipe.eng.assoc_timing_values().astype(np.float64) * 1e3         # in launch order
-    assoc_each_us = np.sort(assoc_order_us)
-    assoc_ik_us, assoc_ik_n = pipe.eng.assoc_inkernel_timing(False)
-    # per-step durations inside the timed region: time between the completion marks of consecutive frame groups
-    step_ms = None
-    if overlap:
-        tm = [ev for k, ev in step_marks if k >= PREFILL + WF]
-        d = np.array([tm[i].elapsed_time(tm[i + 1]) for i in range(len(tm) - 1)], np.float64) / args.groups_per_step if len(tm) > 1 else np.zeros(0)
-        if d.size:
-            step_ms = {"p50": round(float(np.percentile(d, 50)), 4), "p95": round(float(np.percentile(d, 95)), 4), "min": round(float(d.min()), 4),
-                       "max": round(float(d.max()), 4), "n": int(d.size), "how": "HIP events after each group's result copies on the tracker stream, consecutive differences"}
+    def id_check(R, nchk):
+        """Rows of stream 0 against the exact-order oracle over the first nchk frames of the run R -> (same rows, rows, exact frames, exact timed frames, timed frames)."""
+        ref = oracle_rows(R.wls[0], nchk, W, H, R.gs, R.nc, cfg, dcfg)
+        tot = same = exact_frames = exact_timed = n_timed = 0
+        t_first = PREFILL + R.WF                              # first timed frame
+        for k in range(nchk):
+            n = int(R.nout_host[k, 0])
+            got = R.out_host[k, 0, :n].numpy()
+            r = ref[k]
+            tot += max(len(r), n)
+            ex = 0
+            if got.shape == r.shape:
+                eq = (got[:, [4, 5, 7]] == r[:, [4, 5, 7]]).all(axis=1) & (np.abs(got[:, :4] - r[:, :4]).max(axis=1) == 0)
+                same += int(eq.sum())
+                ex = int(got.tobytes() == r.tobytes())
+            exact_frames += ex
+            if k >= t_first:
+                exact_timed += ex
+                n_timed += 1
+        return same, tot, exact_frames, exact_timed, n_timed
+
+    R = timed_pipeline(not args.reid_fp32, args.steps, args.warmup)
+    pipe, K, Wm, KF, WF, total, dt, per_rank_dt, t_enq, t_enq_cpu, wls, gs, nc, A, dev = (R.pipe, R.K, R.Wm, R.KF, R.WF, R.total, R.dt, R.per_rank_dt, R.t_enq, R.t_enq_cpu,
+                                                                                   R.wls, R.gs, R.nc, R.A, R.dev)
+    step_ms, assoc_ms, assoc_n, assoc_order_us, assoc_each_us, assoc_ik_us, assoc_ik_n = R.step_ms, R.assoc_ms, R.assoc_n, R.assoc_order_us, R.assoc_each_us, R.assoc_ik_us, R.assoc_ik_n
     pct = lambda a, q: round(float(np.percentile(a, q)), 2) if len(a) else None
-    pipe.eng.check_errors()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    per_rank_dt = [dt]
-    if world > 1:
-        gathered = [torch.zeros_like(tmax) for _ in range(world)]
-        dist.all_gather(gathered, tmax)                     # every rank's own time between the barriers (rank 0 reports them)
-        per_rank_dt = [float(t.item()) for t in gathered]
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
 
     # ---- roofline of the association kernel ----
     # algorithmic bytes: SURVEY §8(d)'s per-frame figure (gallery T*B*512*4 + detections D*512*4 + T*576 + D*32 + cost
@@ -907,24 +947,8 @@ def main():
     # ---- identical-ID rate vs the exact-order oracle: every rank checks ITS stream 0 over the WHOLE run (prefill, warm-up
     # and every timed frame: the oracle is a recurrence, so it has to see all of them anyway), rank 0 reports the minimum ----
     nchk = total if args.check_frames < 0 else min(args.check_frames, total)
-    ref = oracle_rows(wls[0], nchk, W, H, gs, nc, cfg, dcfg)
-    tot = same = 0
-    exact_frames = exact_timed = n_timed = 0
-    t_first = PREFILL + WF                                # first timed frame
-    for k in range(nchk):
-        n = int(nout_host[k, 0])
-        got = out_host[k, 0, :n].numpy()
-        r = ref[k]
-        tot += max(len(r), n)
-        ex = 0
-        if got.shape == r.shape:
-            eq = (got[:, [4, 5, 7]] == r[:, [4, 5, 7]]).all(axis=1) & (np.abs(got[:, :4] - r[:, :4]).max(axis=1) == 0)
-            same += int(eq.sum())
-            ex = int(got.tobytes() == r.tobytes())
-        exact_frames += ex
-        if k >= t_first:
-            exact_timed += ex
-            n_timed += 1
+    same, tot, exact_frames, exact_timed, n_timed = id_check(R, nchk)
+    out_host, nout_host = R.out_host, R.nout_host
     id_rate = same / max(tot, 1)
     id_min = torch.tensor([id_rate, float(exact_frames), float(exact_timed)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -935,7 +959,9 @@ def main():
             "metric": f"tracked frames/sec (whole node), {W}x{H}@{n_ids}det",
             "value": round(world * S * KF / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "frames_per_step": FPS, "ms_per_step": round(dt / K * 1e3, 4), "ms_per_step_distribution": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)", "data": "synthetic",
+            "dtype": ("f32 association / f64 Kalman+LSAP (f16 detector convs, fp32 ReID network on own v_mfma_f32 kernels: accuracy mode)" if args.reid_fp32 else
+                      "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)"), "data": "synthetic",
+            "reid_precision": "fp32 (hand-written kernels, csrc/ss_ops32.hip)" if args.reid_fp32 else "f16 (hand-written kernels, csrc/ss_ops.hip)",
             "config": {"workload": (f"configs[{CONFIG_INDEX[args.preset]}]" if CONFIG_INDEX[args.preset] is not None else "reference default model (yolo_multi_model.py:17)") + f": {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
@@ -961,6 +987,26 @@ def main():
         if world == 1 and not args.no_reid_check and not args.no_nets:
             res["reid_f16_vs_f32"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index)
             res["reid_f16_vs_f32"]["fp32_reid_mode"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index, reid_half=False)
+        if world == 1 and overlap and not args.no_nets and not args.reid_fp32 and not args.no_accuracy_mode:
+            # the configuration that meets north_star's float bound, measured the same way on fewer steps: the whole hot path with the
+            # ReID crops + OSNet in fp32 on the hand-written fp32 kernels; its distance error / id rate on the true ReID data path are
+            # the fp32_reid_mode figures above
+            A2 = timed_pipeline(False, max(2, args.accuracy_steps), 2)
+            a_same, a_tot, a_exact, a_exact_timed, a_ntimed = id_check(A2, A2.total)
+            a_nets = net_outputs_check(A2.pipe)
+            on_own = bool(getattr(A2.pipe.reid, "_ok32", False))
+            A2.pipe.close()
+            tp = (res.get("reid_f16_vs_f32") or {}).get("fp32_reid_mode") or {}
+            res["accuracy_mode"] = {
+                "reid_precision": "fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)",
+                "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
+                "ratio_to_default": round((S * A2.KF / A2.dt) / (S * KF / dt), 4),
+                "id_match_rate": round(a_same / max(a_tot, 1), 6), "frames_bit_exact": f"{a_exact}/{A2.total}", "frames_bit_exact_timed": f"{a_exact_timed}/{a_ntimed}",
+                "distance_err": tp.get("cost_matrix_cosine_max_abs_err"), "embedding_err": tp.get("embedding_unit_max_abs_err"),
+                "true_path_id_match_rate": tp.get("id_match_rate"), "within_north_star_bound_1e-4": tp.get("within_bound"),
+                "net_outputs_check": a_nets,
+                "note": "same workload, same pipeline, same checks as the default line with reid_half=False; distance_err / true_path_id_match_rate: "
+                        "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32.fp32_reid_mode)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, H, n_ids, nc, A, detector)
         print(json.dumps(res), flush=True)

@@ -397,6 +397,35 @@ int ss_op_maxpool_f16(void* stream, const void* d_x, void* d_y, int N, int H, in
 int ss_op_gate_sum_f16(void* stream, const void* const* d_xs, int T, const void* d_w1, const void* d_b1,
                        const void* d_w2, const void* d_b2, float* d_means_ws, void* d_out, int N, int HW, int C, int Cr);
 
+/* ---- ReID network in fp32 (the accuracy mode, csrc/ss_ops32.hip) -------------------------------------
+ * OSNet-x0.25 with fp32 activations and weights on v_mfma_f32_16x16x4_f32: what stands behind the ReID forward pass inside
+ * model.track (/root/reference/yolo_multi_model.py:41, which passes no half=) when the float distances must agree with a CPU
+ * fp32 network to north_star's 1e-4.  All tensors dense NHWC float; weights [out][in] row-major float; d_nvalid (optional,
+ * device int): only the first *d_nvalid images are computed (packed ReID batches), the launch grids stay fixed. */
+/* relu?(W x + bias (+ res)): d_x [M][K], d_w [N][K], d_out / d_res [M][N].  (K, N) one of the OSNet-x0.25 pairs. */
+int ss_op32_pointwise(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, void* d_out,
+                      long long M, int K, int N, int relu, const int* d_nvalid, int img_px);
+/* The four LightConv chains of an OSBlock (layer = 1x1 linear, depthwise 3x3 + bias + ReLU; chains 1, 2, 3, 4 layers deep, ten
+ * layers in that order): d_x1 [N][H][W][C] -> d_ys[0..3] (same shape) and d_psum [4][N][bands][C] = channel sums of each output
+ * per band, bands = ss_op32_chains_bands(H, W, C).  d_w1 [10][C][C], d_w9 [10][9][C] (tap-major), d_bias [10][C].
+ * (C, W) in {(16, 32), (24, 16), (32, 8)}. */
+int ss_op32_chains_bands(int H, int W, int C);
+int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, const void* d_w9, const void* d_bias, void* const* d_ys,
+                   float* d_psum, int N, int H, int W, int C, const int* d_nvalid);
+/* OSBlock tail + the 1x1 ConvBR after it: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) (fc1 [hidden][MID], fc2 [MID][hidden]),
+ * x2 = sum_t gate_t * ys[t], o = relu(w3 x2 + b3 + shortcut) -> d_out (may be NULL), o2 = relu(w4 o + b4) -> d_out2, 2x2-averaged
+ * when pool.  shortcut = d_xin [N][H][W][C2] (C1 == 0) or wd d_xin + bd with d_xin [N][H][W][C1]. */
+int ss_op32_tail(void* stream, const void* const* d_ys, const float* d_psum, int bands, const void* d_gw1, const void* d_gb1,
+                 const void* d_gw2, const void* d_gb2, int hidden, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
+                 const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
+                 int H, int W, int MID, int C2, int N2, const int* d_nvalid);
+/* conv 7x7 / 2 (3 -> 16) + bias + ReLU + max pool 3x3 / 2: d_x [N][256][128][3] -> d_y [N][64][32][16]; d_w [16][148] with
+ * k = (ky * 7 + kx) * 3 + c and a zero in column 147. */
+int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid);
+/* d_out[n][f] = relu(sum_c d_w[f][c] * mean_hw(d_x[n][.][c]) + d_bias[f]), C == 128. */
+int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F,
+                 const int* d_nvalid);
+
 /* ---- profiling support ----------------------------------------------------------------------- */
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last
  * call, measured with HIP events on the context stream; also returns the launch count. */

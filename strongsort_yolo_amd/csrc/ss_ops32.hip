@@ -1,0 +1,606 @@
+// ss_ops32.hip — the ReID network (row a5, OSNet-x0.25) with fp32 activations and fp32 weights on the f32-input matrix
+// instruction v_mfma_f32_16x16x4_f32: the ACCURACY MODE of the path.
+//
+// Why it exists: BASELINE north_star bounds the float distances at 1e-4 against the CPU reference, and the reference passes no
+// half= (/root/reference/yolo_multi_model.py:41): its arithmetic is fp32.  With f16 activations (ss_ops.hip) this network's
+// appearance distances are off by 3e-2 (bench.py reid_f16_vs_f32); fp32 activations give 1e-5.  Until round 5 that mode ran on
+// the library convolutions.  These five kernels replace them:
+//
+//   k32_stem    conv 7x7/2 (3 -> 16) + bias + ReLU + max pool 3x3/2            implicit GEMM, K = 147, input band in LDS
+//   k32_pw      1x1 convolution + bias (+ shortcut) (+ ReLU)                     weights in LDS, pixels straight from HBM
+//   k32_chains  the ten LightConv layers (1x1 linear -> depthwise 3x3 + bias + ReLU) of an OSBlock's four chains for a band of
+//               one image, every intermediate in LDS; writes the four chain outputs + their per-band channel sums
+//   k32_tail    channel gates (from the sums) -> gate-weighted sum of the four chains -> conv3 + bias + shortcut (identity or
+//               1x1 `down`) + ReLU -> [block output] -> the 1x1 ConvBR that follows (next block's conv1 / the stage's ConvBR
+//               [+ 2x2 average] / conv5) -- one launch, the block output never leaves the registers between the two products
+//   k32_head    global average pool + fully connected layer + bias + ReLU
+//
+// One operand convention everywhere.  A tensor is NHWC fp32; a pixel's C channels are C/4 CHUNKS of 4 floats (one 16-byte
+// vector).  For a 16-pixel tile, lane (kq = lane >> 4, n = lane & 15) of a wave holds chunks kq, kq + 4, kq + 8, .. of pixel n.
+// v_mfma_f32_16x16x4_f32 takes A[m][k] from lane (k, m) and B[k][n] from lane (k, n), one float each, so component s of chunk
+// kq + 4 jj is B's k-slot kq of the MFMA (jj, s), whose A operand is W[m][4 (kq + 4 jj) + s]: every operand is a 16-byte load and
+// the K axis is walked in the order (jj, s, kq).  The result D puts output channels 16 mt + 4 q .. + 3 of pixel n into lane
+// (q, n) -- chunk 4 mt + q of the OUTPUT pixel, i.e. the accumulators of M-tile mt ARE the B chunks jj = mt of the next 1x1
+// product (k32_tail feeds conv3's accumulators straight into the following convolution).
+//
+// Sums are fp32 in a fixed order (no atomics), so a launch is reproducible; the order is not PyTorch's, so the results agree
+// with the fp32 CPU network to rounding (1e-6 relative per layer), not bit for bit: tests/test_gpu_nets32.py states the bounds.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/strongsort_hip.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+static __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+static __device__ __forceinline__ void st4(float* p, const f4 v) { *reinterpret_cast<f4*>(p) = v; }
+static __device__ __forceinline__ f4 zero4() { return f4{ 0.f, 0.f, 0.f, 0.f }; }
+static __device__ __forceinline__ f4 fma4(const f4 a, const f4 b, const f4 c)
+{
+    return f4{ __builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]), __builtin_fmaf(a[3], b[3], c[3]) };
+}
+static __device__ __forceinline__ f4 relu4(const f4 v)
+{
+    return f4{ v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f, v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f };
+}
+static __device__ __forceinline__ f4 max4(const f4 a, const f4 b)
+{
+    return f4{ a[0] > b[0] ? a[0] : b[0], a[1] > b[1] ? a[1] : b[1], a[2] > b[2] ? a[2] : b[2], a[3] > b[3] ? a[3] : b[3] };
+}
+
+// Weight matrix [N][K] -> LDS rows of KP = 16 JJ + 4 floats (the + 4 keeps the 16-byte operand reads of 16 consecutive rows on
+// distinct banks), zero in the padding columns and in the rows N .. NP - 1 (24 output channels = two M-tiles, the second half empty)
+template <int K, int N, int NTHR>
+static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const float* __restrict__ w, int tid)
+{
+    constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 4, NP = (N + 15) / 16 * 16;
+    for (int i = tid; i < NP * (KP / 4); i += NTHR) {
+        const int r = i / (KP / 4), c = i - r * (KP / 4);
+        f4 v = zero4();
+        if (r < N && c < CH) v = ld4(w + (size_t)r * K + 4 * c);
+        st4(Ws + r * KP + 4 * c, v);
+    }
+}
+template <int K, int N>
+constexpr int w_lds_floats() { return ((N + 15) / 16 * 16) * (16 * ((K / 4 + 3) / 4) + 4); }
+
+// acc[mt] += W[16 mt .. + 15][:] x B for the 16 pixels of the tile; b[jj] = this lane's chunks kq + 4 jj
+template <int K, int N>
+static __device__ __forceinline__ void mm_tile(const float* __restrict__ Ws, const f4 (&b)[(K / 4 + 3) / 4], f4 (&acc)[(N + 15) / 16], int kq, int n)
+{
+    constexpr int JJ = (K / 4 + 3) / 4, KP = 16 * JJ + 4, MT = (N + 15) / 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const f4 a = ld4(Ws + (mt * 16 + n) * KP + 4 * (kq + 4 * jj));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[mt] = MFMA4(a[s], b[jj][s], acc[mt]);
+        }
+}
+
+// ---- k32_pw ------------------------------------------------------------------------------------------------------------
+// out[p][0..N) = [relu](W x[p] + bias [+ res[p]]), p < M.  A wave owns 16-pixel tiles; workgroup = 4 waves x `tpw` tiles.
+template <int K, int N>
+__global__ __launch_bounds__(256) void k32_pw(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                              const float* __restrict__ res, float* __restrict__ out, long long M, int relu, int tpw,
+                                              const int* __restrict__ n_img, int img_px)
+{
+    constexpr int CH = K / 4, JJ = (CH + 3) / 4, MT = (N + 15) / 16;
+    __shared__ __attribute__((aligned(16))) float Ws[w_lds_floats<K, N>()];
+    if (n_img) { const long long mv = (long long)(*n_img) * img_px; if (mv < M) M = mv; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    if ((long long)blockIdx.x * 64 * tpw >= M) return;
+    stage_w<K, N, 256>(Ws, w, tid);
+    __syncthreads();
+    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * tpw;
+    for (int it = 0; it < tpw; ++it) {
+        const long long p0 = (tile0 + it) * 16;
+        if (p0 >= M) break;
+        const long long px = p0 + n;
+        const bool valid = px < M;
+        f4 b[JJ];
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const int c = kq + 4 * jj;
+            b[jj] = (valid && c < CH) ? ld4(x + px * K + 4 * c) : zero4();
+        }
+        f4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4();
+        mm_tile<K, N>(Ws, b, acc, kq, n);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int oc = 16 * mt + 4 * kq;
+            if (oc >= N || !valid) continue;
+            f4 v = acc[mt] + ld4(bias + oc);
+            if (res) v = v + ld4(res + px * N + oc);
+            if (relu) v = relu4(v);
+            st4(out + px * N + oc, v);
+        }
+    }
+}
+
+// ---- k32_chains ----------------------------------------------------------------------------------------------------------
+// The four LightConv chains (1, 2, 3 and 4 layers deep; layer = 1x1 linear -> depthwise 3x3 + bias + ReLU) of an OSBlock on a band
+// of R rows of one image (+ HALO rows above and below when the image has several bands: four stacked 3x3 layers need 4).
+// LDS: P (the 1x1 output of the current layer) and Q (the layer's output = next layer's input), [RB rows][W][C + 4] floats each;
+// the pixel pitch C + 4 (20 / 28 / 36 dwords) spreads the 16-byte accesses of any 16 distinct columns over all 64 banks.
+// Rows outside the image hold ZERO in P (they are the depthwise layer's padding); rows outside the LDS window count as zero too,
+// which only reaches halo rows whose values are never stored.  Outputs: ys[t] band rows, psum[t][img][band][c] = their channel sums.
+#define C32_THREADS 768
+template <int C, int W>
+__global__ __launch_bounds__(C32_THREADS) void k32_chains(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
+                                                        const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
+                                                        float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
+                                                        float* __restrict__ y3, float* __restrict__ psum, int Nimg, int H, int R, int HALO,
+                                                        const int* __restrict__ n_img)
+{
+    constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = (C + 15) / 16, PITCH = C + 4, SLOTS = C32_THREADS / CH, RGS = SLOTS / W;
+    static_assert(C32_THREADS % CH == 0 && SLOTS % W == 0, "thread map");
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
+    if (n_img && img >= *n_img) return;
+    const int RB = R + 2 * HALO, r0 = band * R - HALO;          // image row of LDS row 0
+    float* __restrict__ P = smem32;
+    float* __restrict__ Q = P + RB * W * PITCH;
+    float* __restrict__ S = Q + RB * W * PITCH;                 // [SLOTS][C] partial channel sums of a chain's last layer
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int chunk = tid % CH, slot = tid / CH, xx = slot % W, rg = slot / W;
+    const int RPG = (RB + RGS - 1) / RGS, ra = rg * RPG, rb = (ra + RPG < RB) ? ra + RPG : RB;
+    const int ntiles = RB * W / 16;
+    const size_t ibase = (size_t)img * H * W * C;
+    int layer = 0;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        float* __restrict__ yt = t == 0 ? y0 : t == 1 ? y1 : t == 2 ? y2 : y3;
+#pragma unroll 1
+        for (int d = 0; d <= t; ++d, ++layer) {
+            // ---- 1x1 (no bias, no activation): source x1 (global) for a chain's first layer, Q afterwards
+            {
+                f4 a[MT][JJ];
+                const float* wl = w1 + (size_t)layer * C * C;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const int row = 16 * mt + n, c = kq + 4 * jj;
+                        a[mt][jj] = (row < C && c < CH) ? ld4(wl + row * C + 4 * c) : zero4();
+                    }
+                for (int tile = wave; tile < ntiles; tile += C32_THREADS / 64) {
+                    const int p = tile * 16 + n, r = p / W, y = r0 + r;
+                    const bool inimg = y >= 0 && y < H;
+                    f4 b[JJ];
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const int c = kq + 4 * jj;
+                        if (c >= CH) b[jj] = zero4();
+                        else if (d == 0) b[jj] = inimg ? ld4(x1 + ibase + ((size_t)y * W + (p - r * W)) * C + 4 * c) : zero4();
+                        else b[jj] = ld4(Q + p * PITCH + 4 * c);
+                    }
+                    f4 acc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4();
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc[mt] = MFMA4(a[mt][jj][s], b[jj][s], acc[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int co = 4 * mt + kq;                 // output chunk
+                        if (co < CH) st4(P + p * PITCH + 4 * co, inimg ? acc[mt] : zero4());
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- depthwise 3x3 + bias + ReLU: thread = (chunk, column, run of RPG rows), a rolling 3x3 window of 16-byte vectors
+            {
+                const bool last = d == t;
+                const float* wt = w9 + (size_t)layer * 9 * C + 4 * chunk;
+                f4 k9[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) k9[i] = ld4(wt + i * C);
+                const f4 bb = ld4(bs + layer * C + 4 * chunk);
+                f4 psa = zero4();
+                auto ld = [&](int r, int x) -> f4 {
+                    return (r >= 0 && r < RB && x >= 0 && x < W) ? ld4(P + (r * W + x) * PITCH + 4 * chunk) : zero4();
+                };
+                if (ra < rb) {
+                    f4 t0 = ld(ra - 1, xx - 1), t1 = ld(ra - 1, xx), t2 = ld(ra - 1, xx + 1);
+                    f4 m0 = ld(ra, xx - 1), m1 = ld(ra, xx), m2 = ld(ra, xx + 1);
+                    for (int r = ra; r < rb; ++r) {
+                        const f4 b0 = ld(r + 1, xx - 1), b1 = ld(r + 1, xx), b2 = ld(r + 1, xx + 1);
+                        f4 o = bb;
+                        o = fma4(k9[0], t0, o); o = fma4(k9[1], t1, o); o = fma4(k9[2], t2, o);
+                        o = fma4(k9[3], m0, o); o = fma4(k9[4], m1, o); o = fma4(k9[5], m2, o);
+                        o = fma4(k9[6], b0, o); o = fma4(k9[7], b1, o); o = fma4(k9[8], b2, o);
+                        o = relu4(o);
+                        st4(Q + (r * W + xx) * PITCH + 4 * chunk, o);
+                        const int y = r0 + r;
+                        if (last && r >= HALO && r < HALO + R && y >= 0 && y < H) {
+                            st4(yt + ibase + ((size_t)y * W + xx) * C + 4 * chunk, o);
+                            psa = psa + o;
+                        }
+                        t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+                    }
+                }
+                if (last) st4(S + slot * C + 4 * chunk, psa);
+            }
+            __syncthreads();
+        }
+        if (tid < C) {                                               // channel sums of chain t over this band, slots in order
+            float s = 0.f;
+            for (int i = 0; i < SLOTS; ++i) s += S[i * C + tid];
+            psum[(((size_t)t * Nimg + img) * bands + band) * C + tid] = s;
+        }
+    }
+}
+
+// ---- k32_tail ------------------------------------------------------------------------------------------------------------
+// Per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chain sums; per pixel: x2 = sum_t gate_t * y_t;
+// o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block input x, C1 channels); o -> d_out when asked;
+// o2 = relu(W4 o + b4) -> d_out2, averaged over 2x2 pixels when POOL.  A wave owns 16-pixel tiles (POOL: 2 rows x 8 columns).
+#define T32_THREADS 512
+template <int MID, int C2, int C1, int N2, bool POOL>
+__global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
+                                                const float* __restrict__ y3, const float* __restrict__ psum, int bands, float scale,
+                                                const float* __restrict__ gw1, const float* __restrict__ gb1, const float* __restrict__ gw2,
+                                                const float* __restrict__ gb2, int hidden, const float* __restrict__ w3,
+                                                const float* __restrict__ b3, const float* __restrict__ xin, const float* __restrict__ wd,
+                                                const float* __restrict__ bd, float* __restrict__ out, const float* __restrict__ w4,
+                                                const float* __restrict__ b4, float* __restrict__ out2, int Nimg, int H, int W, int tpw,
+                                                const int* __restrict__ n_img)
+{
+    constexpr int CHM = MID / 4, JM = (CHM + 3) / 4, MT3 = C2 / 16, CH1 = C1 / 4, J1 = (CH1 + 3) / 4, MT4 = (N2 + 15) / 16, CH4 = N2 / 4;
+    constexpr int L3 = w_lds_floats<MID, C2>(), LD = C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0, L4 = w_lds_floats<C2, N2>();
+    static_assert(C2 % 16 == 0, "C2");
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* __restrict__ W3s = smem32;
+    float* __restrict__ Wds = W3s + L3;
+    float* __restrict__ W4s = Wds + LD;
+    float* __restrict__ G = W4s + L4;                      // [4][MID] gates, then [4][MID] means, [4][4] hidden
+    float* __restrict__ Mn = G + 4 * MID;
+    float* __restrict__ Hd = Mn + 4 * MID;
+    const int img = blockIdx.y;
+    if (n_img && img >= *n_img) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    stage_w<MID, C2, T32_THREADS>(W3s, w3, tid);
+    if (C1) stage_w<(C1 ? C1 : 16), C2, T32_THREADS>(Wds, wd, tid);
+    stage_w<C2, N2, T32_THREADS>(W4s, w4, tid);
+    if (tid < 4 * MID) {                                     // channel means of the four chain outputs (bands in order)
+        const int t = tid / MID, c = tid - t * MID;
+        float s = 0.f;
+        for (int b = 0; b < bands; ++b) s += psum[(((size_t)t * Nimg + img) * bands + b) * MID + c];
+        Mn[tid] = s * scale;
+    }
+    __syncthreads();
+    if (tid < 4 * hidden) {
+        const int t = tid / hidden, j = tid - t * hidden;
+        float s = gb1[j];
+        for (int c = 0; c < MID; ++c) s = __builtin_fmaf(gw1[j * MID + c], Mn[t * MID + c], s);
+        Hd[t * 4 + j] = s > 0.f ? s : 0.f;
+    }
+    __syncthreads();
+    if (tid < 4 * MID) {
+        const int t = tid / MID, c = tid - t * MID;
+        float s = gb2[c];
+        for (int j = 0; j < hidden; ++j) s = __builtin_fmaf(gw2[c * hidden + j], Hd[t * 4 + j], s);
+        G[tid] = 1.0f / (1.0f + expf(-s));
+    }
+    __syncthreads();
+    const int HW = H * W, tiles_img = HW / 16;
+    const size_t pbase = (size_t)img * HW;
+    const float* const ys[4] = { y0, y1, y2, y3 };
+    const int tile0 = (blockIdx.x * (T32_THREADS / 64) + wave) * tpw;
+    for (int it = 0; it < tpw; ++it) {
+        const int tile = tile0 + it;
+        if (tile >= tiles_img) break;
+        int pl;                                              // pixel of this lane inside the image
+        if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; pl = (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
+        else pl = tile * 16 + n;
+        const size_t px = pbase + pl;
+        // x2 chunks
+        f4 bm[JM];
+#pragma unroll
+        for (int jj = 0; jj < JM; ++jj) {
+            const int c = kq + 4 * jj;
+            if (c < CHM) {
+                f4 v = ld4(G + 4 * c) * ld4(ys[0] + px * MID + 4 * c);
+#pragma unroll
+                for (int t = 1; t < 4; ++t) v = v + ld4(G + t * MID + 4 * c) * ld4(ys[t] + px * MID + 4 * c);
+                bm[jj] = v;
+            } else bm[jj] = zero4();
+        }
+        f4 acc[MT3];
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt) acc[mt] = zero4();
+        mm_tile<MID, C2>(W3s, bm, acc, kq, n);
+        if (C1) {                                            // shortcut = Wd x + bd as a second product into the same accumulators
+            f4 bx[J1 ? J1 : 1];
+#pragma unroll
+            for (int jj = 0; jj < J1; ++jj) {
+                const int c = kq + 4 * jj;
+                bx[jj] = c < CH1 ? ld4(xin + px * C1 + 4 * c) : zero4();
+            }
+            mm_tile<(C1 ? C1 : 16), C2>(Wds, bx, acc, kq, n);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT3; ++mt) {
+            const int oc = 16 * mt + 4 * kq;
+            f4 v = acc[mt] + ld4(b3 + oc);
+            if (C1) v = v + ld4(bd + oc);
+            else v = v + ld4(xin + px * C2 + oc);
+            v = relu4(v);
+            acc[mt] = v;
+            if (out) st4(out + px * C2 + oc, v);
+        }
+        // the 1x1 ConvBR that follows: the block output's accumulators are its B chunks
+        f4 acc2[MT4];
+#pragma unroll
+        for (int mt = 0; mt < MT4; ++mt) acc2[mt] = zero4();
+        mm_tile<C2, N2>(W4s, acc, acc2, kq, n);
+#pragma unroll
+        for (int mt = 0; mt < MT4; ++mt) {
+            const int oc = 16 * mt + 4 * kq;
+            f4 v = zero4();
+            if (4 * mt + kq < CH4) v = relu4(acc2[mt] + ld4(b4 + oc));
+            if (POOL) {
+                f4 s;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { float a = v[j]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 8); s[j] = a * 0.25f; }
+                if (4 * mt + kq < CH4 && n < 8 && !(n & 1)) {
+                    const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw;
+                    const size_t po = (size_t)img * (HW / 4) + (size_t)ty * (W / 2) + 4 * tx + (n >> 1);
+                    st4(out2 + po * N2 + oc, s);
+                }
+            } else if (4 * mt + kq < CH4) st4(out2 + px * N2 + oc, v);
+        }
+    }
+}
+
+// ---- k32_stem ------------------------------------------------------------------------------------------------------------
+// conv 7x7 / stride 2 / pad 3 (3 -> 16) + bias + ReLU + max pool 3x3 / stride 2 / pad 1 on NHWC fp32 crops [N][256][128][3].
+// Workgroup = (image, band of 4 pooled rows): the 23 input rows the band's 9 convolution rows need are staged once (zero
+// outside the image; a row = 12 zero floats, 384 values, 8 zero floats), the K axis of the implicit GEMM is k = 21 ky + 3 kx + c --
+// a patch row is 21 CONSECUTIVE floats of an NHWC input row -- so B[k][n] is one ds_read_b32 at base(n) + k + (k / 21)(pitch - 21)
+// (columns of a tile are 6 floats apart: 32 lanes hit 32 banks), A (16 x 148 weights) lives in 37 registers per lane.
+#define ST_ROWP 404
+#define ST_PR 4
+__global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict__ x, const float* __restrict__ w /*[16][148]*/,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img)
+{
+    constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, IN_ROWS = 24, CROWS = 2 * ST_PR + 1, CSP = 20;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* __restrict__ In = smem32;                         // [24][404]
+    float* __restrict__ Cs = In + IN_ROWS * ST_ROWP;         // [9][64][20] convolution rows after bias + ReLU
+    const int img = blockIdx.y, band = blockIdx.x;
+    if (n_img && img >= *n_img) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int pr0 = band * ST_PR, cy0 = 2 * pr0 - 1, iy0 = 2 * cy0 - 3;
+    const float* xi = x + (size_t)img * H * Wd * 3;
+    for (int i = tid; i < IN_ROWS * (ST_ROWP / 4); i += C32_THREADS) {
+        const int lr = i / (ST_ROWP / 4), c4 = i - lr * (ST_ROWP / 4), iy = iy0 + lr;
+        f4 v = zero4();
+        if (iy >= 0 && iy < H && c4 >= 3 && c4 < 99) v = ld4(xi + (size_t)iy * (Wd * 3) + 4 * (c4 - 3));
+        st4(In + lr * ST_ROWP + 4 * c4, v);
+    }
+    float a[37];
+#pragma unroll
+    for (int s = 0; s < 37; ++s) a[s] = w[n * 148 + 4 * s + kq];
+    const f4 bb = ld4(bias + 4 * kq);
+    __syncthreads();
+    for (int tile = wave; tile < CROWS * 4; tile += C32_THREADS / 64) {
+        const int cyl = tile >> 2, cx0 = (tile & 3) * 16, cy = cy0 + cyl;
+        if (cy < 0 || cy >= H / 2) continue;
+        const float* bp = In + 2 * cyl * ST_ROWP + 3 + 6 * (cx0 + n) + kq;
+        f4 acc = zero4();
+#pragma unroll
+        for (int s = 0; s < 37; ++s) {
+            const int k = 4 * s + kq, ky = k / 21;
+            acc = MFMA4(a[s], bp[4 * s + ky * (ST_ROWP - 21)], acc);
+        }
+        st4(Cs + (cyl * OW + cx0 + n) * CSP + 4 * kq, relu4(acc + bb));
+    }
+    __syncthreads();
+    if (tid < ST_PR * PW * 4) {
+        const int q = tid & 3, pxl = (tid >> 2) & 31, prl = tid >> 7;
+        f4 m = f4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int cyl = 2 * prl + dy, cy = cy0 + cyl;
+            if (cy < 0 || cy >= H / 2) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int cx = 2 * pxl - 1 + dx;
+                if (cx < 0 || cx >= OW) continue;
+                m = max4(m, ld4(Cs + (cyl * OW + cx) * CSP + 4 * q));
+            }
+        }
+        st4(y + (((size_t)img * PH + pr0 + prl) * PW + pxl) * 16 + 4 * q, m);
+    }
+}
+
+// ---- k32_head ------------------------------------------------------------------------------------------------------------
+// out[i][f] = relu(b[f] + sum_c w[f][c] * mean_p x[i][p][c]); 4 images per workgroup, C = 128.
+__global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                float* __restrict__ out, int Nimg, int HW, int F, const int* __restrict__ n_img)
+{
+    constexpr int C = 128;
+    __shared__ __attribute__((aligned(16))) float mean[4][C];
+    const int tid = threadIdx.x, i0 = blockIdx.x * 4;
+    int nv = Nimg;
+    if (n_img && *n_img < nv) nv = *n_img;
+    if (i0 >= nv) return;
+    const float inv = 1.0f / (float)HW;
+#pragma unroll 1
+    for (int k = tid; k < 4 * C; k += 256) {
+        const int i = k / C, c = k - i * C, img = i0 + i;
+        float s = 0.f;
+        if (img < nv) {
+            const float* p = x + (size_t)img * HW * C + c;
+#pragma unroll 8
+            for (int q = 0; q < HW; ++q) s += p[(size_t)q * C];
+        }
+        mean[i][c] = s * inv;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int f = tid; f < F; f += 256) {
+        float s[4] = { bias[f], bias[f], bias[f], bias[f] };
+        const float* wr = w + (size_t)f * C;
+#pragma unroll 4
+        for (int c4 = 0; c4 < C / 4; ++c4) {
+            const f4 wv = ld4(wr + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f4 mv = ld4(&mean[i][4 * c4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[i] = __builtin_fmaf(wv[j], mv[j], s[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i0 + i < nv) out[(size_t)(i0 + i) * F + f] = s[i] > 0.f ? s[i] : 0.f;
+    }
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------------------
+#define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
+
+template <int K, int N>
+static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
+                       const int* nv, int img_px)
+{
+    const long long tiles = (M + 15) / 16;
+    int tpw = 1;
+    while (tpw < 8 && tiles / (4 * tpw) > 8192) tpw *= 2;      // a workgroup re-stages the weights: amortise over more tiles on large maps
+    const long long grid = (tiles + 4 * tpw - 1) / (4 * tpw);
+    hipLaunchKernelGGL((k32_pw<K, N>), dim3((unsigned)grid), dim3(256), 0, st, x, w, b, res, out, M, relu, tpw, nv, img_px);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+extern "C" int ss_op32_pointwise(void* stream, const void* d_x, const void* d_w, const void* d_bias, const void* d_res, void* d_out,
+                                 long long M, int K, int N, int relu, const int* d_nvalid, int img_px)
+{
+    if (!d_x || !d_w || !d_bias || !d_out || M < 1 || (d_nvalid && img_px < 1)) return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const float *x = (const float*)d_x, *w = (const float*)d_w, *b = (const float*)d_bias, *r = (const float*)d_res;
+    float* o = (float*)d_out;
+#define PW32(KK, NN) if (K == KK && N == NN) return launch_pw32<KK, NN>(st, x, w, b, r, o, M, relu, d_nvalid, img_px)
+    PW32(16, 16); PW32(16, 64); PW32(64, 16); PW32(64, 24); PW32(64, 64); PW32(64, 96); PW32(96, 24); PW32(96, 32); PW32(96, 96);
+    PW32(96, 128); PW32(128, 32); PW32(128, 128);
+#undef PW32
+    return SS_ERR_INVALID;
+}
+
+// bands of the chain launch for an H x W map with C mid channels: stage 1 (64 x 32, 16) 4 bands of 16 rows + 4 halo rows each side,
+// the smaller maps one band = the whole image (no halo)
+static int chains_rows(int H, int W, int C, int* halo)
+{
+    const size_t whole = 2ull * H * W * (C + 4) * 4 + (size_t)C32_THREADS * 16;
+    if (whole <= 150 * 1024) { *halo = 0; return H; }
+    *halo = 4;
+    for (int R = H / 2; R >= 8; R /= 2)
+        if (H % R == 0 && 2ull * (R + 8) * W * (C + 4) * 4 + (size_t)C32_THREADS * 16 <= 150 * 1024) return R;
+    return -1;
+}
+
+extern "C" int ss_op32_chains_bands(int H, int W, int C)
+{
+    if (H < 1 || W < 1 || !(C == 16 || C == 24 || C == 32)) return SS_ERR_INVALID;
+    int halo;
+    const int R = chains_rows(H, W, C, &halo);
+    return R < 1 ? SS_ERR_CAPACITY : H / R;
+}
+
+extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, const void* d_w9, const void* d_bias, void* const* d_ys,
+                              float* d_psum, int N, int H, int W, int C, const int* d_nvalid)
+{
+    if (!d_x1 || !d_w1 || !d_w9 || !d_bias || !d_ys || !d_psum || N < 1 || N > 65535 || (H * W) % 16) return SS_ERR_INVALID;
+    int halo;
+    const int R = chains_rows(H, W, C, &halo);
+    if (R < 1) return SS_ERR_CAPACITY;
+    const size_t lds = 2ull * (R + 2 * halo) * W * (C + 4) * 4 + (size_t)(C32_THREADS / (C / 4)) * C * 4;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(H / R, N);
+    const float *x1 = (const float*)d_x1, *w1 = (const float*)d_w1, *w9 = (const float*)d_w9, *b = (const float*)d_bias;
+    float *y0 = (float*)d_ys[0], *y1 = (float*)d_ys[1], *y2 = (float*)d_ys[2], *y3 = (float*)d_ys[3];
+#define CH32(CC, WW) if (C == CC && W == WW) { \
+        static bool attr = false; \
+        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+        hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
+        OP32_CHECK(); return SS_OK; }
+    CH32(16, 32) CH32(24, 16) CH32(32, 8)
+#undef CH32
+    return SS_ERR_INVALID;
+}
+
+template <int MID, int C2, int C1, int N2, bool POOL>
+static int launch_tail32(hipStream_t st, const void* const* ys, const float* psum, int bands, const float* gw1, const float* gb1,
+                         const float* gw2, const float* gb2, int hidden, const float* w3, const float* b3, const float* xin, const float* wd,
+                         const float* bd, float* out, const float* w4, const float* b4, float* out2, int N, int H, int W, const int* nv)
+{
+    constexpr size_t lds = (size_t)(w_lds_floats<MID, C2>() + (C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0) + w_lds_floats<C2, N2>() + 8 * MID + 16) * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k32_tail<MID, C2, C1, N2, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;
+        attr = true;
+    }
+    const int tiles = H * W / 16;
+    constexpr int WV = T32_THREADS / 64;
+    int tpw = 1;
+    while (tpw < 4 && tiles / (WV * tpw) > 2 && (long long)N * (tiles / (2 * WV * tpw)) >= 2048) tpw *= 2;     // weights are staged per workgroup
+    const dim3 grid((tiles + WV * tpw - 1) / (WV * tpw), N);
+    hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), grid, dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
+                       (const float*)ys[3], psum, bands, 1.0f / (float)(H * W), gw1, gb1, gw2, gb2, hidden, w3, b3, xin, wd, bd, out, w4, b4, out2,
+                       N, H, W, tpw, nv);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+extern "C" int ss_op32_tail(void* stream, const void* const* d_ys, const float* d_psum, int bands, const void* d_gw1, const void* d_gb1,
+                            const void* d_gw2, const void* d_gb2, int hidden, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
+                            const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
+                            int H, int W, int MID, int C2, int N2, const int* d_nvalid)
+{
+    if (!d_ys || !d_psum || !d_gw1 || !d_gb1 || !d_gw2 || !d_gb2 || !d_w3 || !d_b3 || !d_xin || !d_w4 || !d_b4 || !d_out2 || N < 1 || N > 65535 ||
+        bands < 1 || hidden < 1 || hidden > 4 || (H * W) % 16 || (C1 && (!d_wd || !d_bd)) || (pool && (W % 8 || H % 2)))
+        return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+#define TL32(M_, C2_, C1_, N2_, P_) if (MID == M_ && C2 == C2_ && C1 == C1_ && N2 == N2_ && (pool != 0) == P_) \
+        return launch_tail32<M_, C2_, C1_, N2_, P_>(st, d_ys, d_psum, bands, (const float*)d_gw1, (const float*)d_gb1, (const float*)d_gw2, \
+            (const float*)d_gb2, hidden, (const float*)d_w3, (const float*)d_b3, (const float*)d_xin, (const float*)d_wd, (const float*)d_bd, \
+            (float*)d_out, (const float*)d_w4, (const float*)d_b4, (float*)d_out2, N, H, W, d_nvalid)
+    TL32(16, 64, 16, 16, false); TL32(16, 64, 0, 64, true); TL32(24, 96, 64, 24, false); TL32(24, 96, 0, 96, true);
+    TL32(32, 128, 96, 32, false); TL32(32, 128, 0, 128, false);
+#undef TL32
+    return SS_ERR_INVALID;
+}
+
+extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid)
+{
+    if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
+    constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 20) * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k32_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL(k32_stem, dim3(64 / ST_PR, N), dim3(C32_THREADS), lds, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
+                       (const float*)d_bias, (float*)d_y, N, d_nvalid);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+extern "C" int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F,
+                            const int* d_nvalid)
+{
+    if (!d_x || !d_w || !d_bias || !d_out || N < 1 || HW < 1 || C != 128 || F < 1) return SS_ERR_INVALID;
+    hipLaunchKernelGGL(k32_head, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, (const float*)d_w, (const float*)d_bias,
+                       (float*)d_out, N, HW, F, d_nvalid);
+    OP32_CHECK();
+    return SS_OK;
+}

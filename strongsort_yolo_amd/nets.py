@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused
+from . import fused, fused32
 
 
 # --------------------------------------------------------------------------------------------------
@@ -911,9 +911,7 @@ class OSNet(nn.Module):
         """Parts 1, 2, 4, 5, 7, 8: an OSBlock.  On the GPU the block's tail also runs the 1x1 convolution that follows it —
         the next block's conv1 (state becomes (block output, that conv1's output)) or the stage's ConvBR (+ average pool;
         state becomes a 1-tuple: the following part is already applied)."""
-        blk, nxt, pool = {1: (self.conv2[0], self.conv2[1].conv1, False), 2: (self.conv2[1], self.conv2[2], True),
-                          4: (self.conv3[0], self.conv3[1].conv1, False), 5: (self.conv3[1], self.conv3[2], True),
-                          7: (self.conv4[0], self.conv4[1].conv1, False), 8: (self.conv4[1], self.conv5, False)}[k]
+        blk, nxt, pool = self._blocks(k)
         x, x1 = s if isinstance(s, tuple) else (s, None)
         if blk.tail_ok(x, nxt, pool):
             want_out = k in (1, 4, 7)
@@ -921,9 +919,48 @@ class OSNet(nn.Module):
             return (out, o2) if want_out else (o2,)
         return blk(x, x1)
 
+    def _blocks(self, k):
+        return {1: (self.conv2[0], self.conv2[1].conv1, False), 2: (self.conv2[1], self.conv2[2], True),
+                4: (self.conv3[0], self.conv3[1].conv1, False), 5: (self.conv3[1], self.conv3[2], True),
+                7: (self.conv4[0], self.conv4[1].conv1, False), 8: (self.conv4[1], self.conv5, False)}[k]
+
+    def _part32(self, k, s):
+        """Part k with fp32 activations on the hand-written fp32 kernels (fused32.py, csrc/ss_ops32.hip; the accuracy mode).
+        Same states as the half path: part 0 -> (x0, conv1 of the first block); a first block of a stage -> (block output, next
+        block's conv1); a second block -> (the ConvBR after it [+ 2x2 average],); parts 3, 6, 9 only unwrap."""
+        f = fused32
+        if k == 0:
+            x0 = f.stem(s, self.conv1)
+            c1 = self.conv2[0].conv1
+            return (x0, f.pointwise(x0, c1, c1.conv, relu=True))
+        if k in (1, 2, 4, 5, 7, 8):
+            blk, nxt, pool = self._blocks(k)
+            x, x1 = s if (isinstance(s, tuple) and len(s) == 2) else (s[0] if isinstance(s, tuple) else s, None)
+            if x1 is None:
+                x1 = f.pointwise(x, blk.conv1, blk.conv1.conv, relu=True)
+            ys, psum = f.chains(x1, blk)
+            want_out = k in (1, 4, 7)
+            out, o2 = f.tail(ys, psum, blk, x, nxt, pool, want_out)
+            return (out, o2) if want_out else (o2,)
+        assert isinstance(s, tuple) and len(s) == 1           # the previous block's tail already ran this part
+        return s[0]
+
+    def _fp32_kernels(self, x) -> bool:
+        first = x[0] if isinstance(x, tuple) else x
+        if not fused32.usable(first):
+            return False
+        if getattr(self, "_ok32", None) is None:
+            self._ok32 = fused32.osnet_ok(self, torch.empty(1, 3, 256, 128, device=first.device))
+        return self._ok32
+
     def _part(self, k, x):
         """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages.  The state
         between parts is a tensor or a tuple of tensors (see _block_part)."""
+        if self._fp32_kernels(x):
+            first = x[0] if isinstance(x, tuple) else x
+            want = {0: (256, 128), 1: (64, 32), 2: (64, 32), 4: (32, 16), 5: (32, 16), 7: (16, 8), 8: (16, 8)}.get(k)
+            if (want is None and isinstance(x, tuple) and len(x) == 1) or (want is not None and tuple(first.shape[2:]) == want):
+                return self._part32(k, x)
         if k == 0:
             if fused.usable(x) and fused.stem_ok(x, self.conv1.conv) and self.conv1.relu:      # conv + bias + ReLU + pool, one launch
                 c1 = self.conv2[0].conv1
@@ -959,6 +996,8 @@ class OSNet(nn.Module):
             x = self._part(k, x)
         if fused.osnet_head_ok(x, self.fc):                  # average pool + fc + ReLU in one launch
             return fused.osnet_head(x, self.fc)
+        if self._fp32_kernels(x) and x.shape[1] == 128:
+            return fused32.head(x, self.fc)
         return F.relu(self.fc(x.mean((2, 3))))
 
     def forward(self, x):

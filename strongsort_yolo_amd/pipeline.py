@@ -45,9 +45,10 @@ class FramePipeline:
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
         dev = self.dev = self.eng.device
         self.half, self.dtype = half, torch.float16 if half else torch.float32
-        # reid_half=False: the ReID crops and OSNet in fp32 (PyTorch-ROCm's library convolutions; the fused kernels are half-only)
-        # beside a half detector — the accuracy mode: appearance distances then agree with a CPU fp32 OSNet to ~1e-6, which f16
-        # activations do not (bench.py reid_f16_vs_f32; north_star's 1e-4 bound on float distances).  Default: as the detector.
+        # reid_half=False: the ReID crops and OSNet in fp32 on the hand-written fp32 kernels (fused32.py, csrc/ss_ops32.hip:
+        # v_mfma_f32_16x16x4_f32) beside a half detector — the accuracy mode: appearance distances then agree with a CPU fp32
+        # OSNet to ~1e-5, which f16 activations do not (bench.py reid_f16_vs_f32; north_star's 1e-4 bound on float distances;
+        # the reference passes no half=, yolo_multi_model.py:41).  Default: as the detector.
         self.reid_half = half if reid_half is None else bool(reid_half)
         self.reid_dtype = torch.float16 if self.reid_half else torch.float32
         self.det_source, self.feat_source, self.run_nets = det_source, feat_source, run_nets
@@ -311,7 +312,7 @@ class OverlappedPipeline(FramePipeline):
         self.Sv = self.S * self.F
         # packed ReID batches: the group's valid crops contiguous, the OSNet kernels skip the unused slots of the fixed batch
         # (~28 of 32 slots per frame are used at configs[1]); pack_crops=False: A/B switch
-        self.pack = bool(self.reid_half and self.run_nets and pack_crops)
+        self.pack = bool(self.run_nets and pack_crops)
         self.geom_dev = self.geom_dev[:1].repeat(self.Sv, 1).contiguous()
         self.outs = torch.zeros(self.F, self.S, MAX_TRACKS, 8, dtype=torch.float32, device=self.dev)
         self.nouts = torch.zeros(self.F, self.S, dtype=torch.int32, device=self.dev)
@@ -446,12 +447,14 @@ class OverlappedPipeline(FramePipeline):
             b.dets6.copy_(b.dets[:, :, :6])
         if self.run_nets:
             if self.pack:        # the group's valid crops contiguous; the ReID kernels skip the rest of the fixed-size batch
-                e.crop_norm_packed(b.frames, b.dets6, self.RB, b.ndets, b.crop_off, b.crops, half=True)
+                e.crop_norm_packed(b.frames, b.dets6, self.RB, b.ndets, b.crop_off, b.crops, half=self.reid_half)
             else:
                 e.crop_norm_batch(b.frames, b.dets6, self.RB, counts=b.ndets, half=self.reid_half, out=b.crops, channels_last=True)
 
     def _valid(self, b):
-        from . import fused
+        from . import fused, fused32
+        if not self.reid_half:                               # fp32 kernels take the count as a launch argument
+            return fused32.valid_images(b.crop_off[self.Sv:] if self.pack else None)
         return fused.valid_images(b.crop_off[self.Sv:] if self.pack else None, self.Sv * self.RB)
 
     def _select(self, b, emb):
