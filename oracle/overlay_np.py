@@ -46,6 +46,8 @@ def _coverage(p, chars, font, H, W):
                      np.where(tt >= L, 4 * ((xs - x1) ** 2 + (ys - y1) ** 2) <= a2, 4 * cr * cr <= a2 * L))
     elif t == POLY:
         pts = np.frombuffer(chars[a:a + 8 * (b >> 1)].tobytes(), np.int32).reshape(-1, 2)
+        if len(pts) < 3:                                           # a degenerate polygon covers nothing
+            return
         full = polygon_mask_np(pts, H, W)
         m = full[cy0:cy1 + 1, cx0:cx1 + 1]
     else:

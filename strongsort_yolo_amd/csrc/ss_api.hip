@@ -447,18 +447,30 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
         if (c->chains.size() >= 16) {                            // least recently used entry goes
             size_t lru = 0;
             for (size_t i = 1; i < c->chains.size(); ++i) if (c->chains[i].used < c->chains[lru].used) lru = i;
+            // its last replay may still be running (16 other launches is no guarantee on a detached, slow chain): the stream it
+            // was launched on is drained before the executable graph goes
+            HIPCHK(c, hipStreamSynchronize(chain_st));
             (void)hipGraphExecDestroy(c->chains[lru].exec); (void)hipGraphDestroy(c->chains[lru].graph);
             c->chains.erase(c->chains.begin() + lru);
         }
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
-        HIPCHK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
-        ss_launch_group_chain(dev, c->prm, c->cap_stream);
-        hipError_t le = hipGetLastError();
-        hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
-        if (le != hipSuccess || ee != hipSuccess || !graph)
-            return fail(c, SS_ERR_HIP, std::string("capture of the tracker chain failed: ") + hipGetErrorString(le != hipSuccess ? le : ee));
-        HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        // A failed capture / instantiation must not leave the group half-applied (its head, k_group_prep + k_assoc, is already
+        // enqueued): the chain then goes out as plain launches, the captured graph (if any) is released.
+        hipError_t be = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal), le = hipSuccess, ee = hipSuccess, ie = hipSuccess;
+        if (be == hipSuccess) {
+            ss_launch_group_chain(dev, c->prm, c->cap_stream);
+            le = hipGetLastError();
+            ee = hipStreamEndCapture(c->cap_stream, &graph);
+            if (le == hipSuccess && ee == hipSuccess && graph) ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        }
+        if (be != hipSuccess || le != hipSuccess || ee != hipSuccess || !graph || ie != hipSuccess || !exec) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            ss_launch_group_chain(dev, c->prm, chain_st);
+            HIPCHK(c, hipGetLastError());
+            return SS_OK;
+        }
         c->chains.push_back({ key, graph, exec, 0 });
         hit = &c->chains.back();
     }
@@ -547,8 +559,10 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
     else if (n == "frame_caps") {
         // value = tracks and detections k_frame keeps in LDS (cost entries = value^2): 0 restores the maxima (256 tracks, 128 detections, 12288 entries)
-        if (value != 0 && (value < 16 || value > 128 || value % 16)) return fail(c, SS_ERR_INVALID, "frame_caps: 0 or a multiple of 16 in 16..128");
-        c->dev.cap_t = value ? value : SS_MAXT; c->dev.cap_d = value ? value : SS_MAXD; c->dev.cap_cost = value ? value * value : SS_COST_CAP;
+        // (112 is the largest square that fits: 128 x 128 cost entries + the per-track areas would be 173 KB of LDS, past the CU's 160)
+        if (value != 0 && (value < 16 || value > 112 || value % 16)) return fail(c, SS_ERR_INVALID, "frame_caps: 0 or a multiple of 16 in 16..112");
+        c->dev.cap_t = value ? value : SS_MAXT; c->dev.cap_d = value ? value : SS_MAXD;
+        c->dev.cap_cost = value ? (value * value < SS_COST_CAP ? value * value : SS_COST_CAP) : SS_COST_CAP;
     }
     else if (n == "chain_cus") {
         if (value < -1 || value > 128 || (value > 0 && value % 8)) return fail(c, SS_ERR_INVALID, "chain_cus: 0 (off), -1 (detached, no reservation) or a multiple of 8 up to 128");

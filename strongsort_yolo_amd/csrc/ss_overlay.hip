@@ -65,6 +65,7 @@ __device__ __forceinline__ bool ov_covers(const OvPrim& p, int x, int y, const u
         // its right: x < ax + (y - ay)(bx - ax) / (by - ay), cross-multiplied in 64-bit integers (oracle polygon_mask_np)
         if (x < p.x0 || x > p.x1 || y < p.y0 || y > p.y1) return false;
         const int n = p.b >> 1;
+        if (n < 3) return false;                                   // a degenerate polygon covers nothing (and has no last vertex to read)
         const int* pts = reinterpret_cast<const int*>(chars + p.a);
         int cnt = 0, ax = pts[2 * (n - 1)], ay = pts[2 * (n - 1) + 1];
         for (int i = 0; i < n; ++i) {

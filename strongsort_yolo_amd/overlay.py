@@ -82,7 +82,7 @@ class CommandList:
         col = tuple(int(c) for c in color)
         self.blends.append((len(self.rows), q, col))
         if len(q) < 3:
-            self.rows.append((FILL, 1, 1, 0, 0, 0, 0, 0) if False else (POLY, 1, 1, 0, 0, 0, 0, 0))       # empty box: covers nothing, keeps positions
+            self.rows.append((POLY, 1, 1, 0, 0, 0, 0, 0))       # degenerate polygon: 0 vertices, covers nothing (ov_covers: n < 3), keeps positions
             return
         self.chars += b"\0" * (-len(self.chars) % 4)
         self.rows.append((POLY, int(q[:, 0].min()), int(q[:, 1].min()), int(q[:, 0].max()), int(q[:, 1].max()), bgr(*col), len(self.chars), len(q) << 1))

@@ -350,6 +350,10 @@ class OverlappedPipeline(FramePipeline):
         # instead of between their kernels in the dispatcher.  (CU-masked streams have no priority: track_priority does not apply.)
         # chain_cus = -1: detached onto a plain high-priority stream, nothing reserved.
         self.chain_cus = int(chain_cus)
+        if self.chain_cus and tracker_stream:
+            # the tracker-stream branch releases a buffer set on that stream, not behind the detached chain's results stream: the
+            # chain could still be reading the set's detections / features when stage 0 refills it
+            raise ValueError("tracker_stream and chain_cus cannot be combined")
         if self.chain_cus:
             self.eng.set_option("chain_cus", self.chain_cus)
         if self.chain_cus > 0:
