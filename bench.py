@@ -451,6 +451,88 @@ def reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=0, frames=150, reid
                     "one-to-one renumbering"}
 
 
+def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
+    """The detector side of north_star's "box indices bit-exact": how often does the f16 detector (hand-written kernels, the
+    throughput default) give the keep list of the SAME network in fp32 (PyTorch-ROCm's library convolutions on the GPU; the
+    reference passes no half=, yolo_multi_model.py:18-21, :41)?  Rendered synthetic frames -> HIP letterbox -> detector -> HIP NMS,
+    once per precision; compared: the ordered keep-index lists, their symmetric difference, and the box / score deltas of the anchors
+    both kept.  Weights: seeded He weights calibrated to zero-mean / unit-variance layer outputs (calibrate_reid_; no checkpoint
+    exists offline), the class biases shifted so that about `target` anchors per frame pass conf — a random network has no objects,
+    so how many scores sit near the threshold is set by that choice, not by data: the figure is a property of the kernels'
+    rounding on THIS synthetic network, stated as such."""
+    import copy
+    import math
+    import torch
+    from strongsort_yolo_amd import fused, nets
+    from strongsort_yolo_amd.pipeline import FramePipeline
+    from strongsort_yolo_amd.synth import make_stream
+    kw = dict(device=device, reid_batch=32, dcfg=dcfg, det_source="detector", feat_source="injected", graph="none", seed=0)
+    p16 = FramePipeline(detector, 1, (H, W), half=True, **kw)
+    p32 = FramePipeline(detector, 1, (H, W), half=False, **kw)
+    if not hasattr(p32.detector, "detect") or not hasattr(p32.detector.detect, "cv3"):
+        p16.close(); p32.close()
+        return None
+    dev, nc = p32.dev, p32.nc
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+
+    def letterboxed(img):
+        p32.frames[0].copy_(torch.from_numpy(img).to(dev))
+        p32.eng.letterbox_batch(p32.frames, p32.geom, half=False, pad_value=dcfg.pad_value, out=p32.lb, channels_last=True)
+        torch.cuda.synchronize(dev)
+        return p32.lb.float().cpu().contiguous()
+
+    cs = make_stream(2023, W, H, n_ids)
+    xcal = torch.cat([letterboxed(cs.render(cs.next_frame())) for _ in range(2)])
+    det32 = calibrate_reid_(nets.build_detector(detector, 0).float(), xcal)
+    with torch.no_grad():
+        pm = det32(xcal)
+        pm = (pm[0] if isinstance(pm, tuple) else pm)[:, 4:4 + nc].amax(1).flatten().double().clamp(1e-12, 1 - 1e-12)
+        logit = torch.log(pm / (1 - pm)).sort(descending=True).values
+        shift = float(logit[min(2 * target, len(logit) - 1)]) - math.log(dcfg.conf / (1 - dcfg.conf))
+        for lvl in det32.detect.cv3:
+            lvl[2].bias.sub_(shift)
+    for p in (p16, p32):
+        p.detector.load_state_dict(det32.state_dict())
+        fused.clear_prepared(p.detector)
+    st = make_stream(2025, W, H, n_ids)
+    same = same_set = sym = common = n16 = n32 = 0
+    dbox = dconf = 0.0
+    first_diff = None
+    with torch.no_grad():
+        for k in range(frames):
+            img = torch.from_numpy(st.render(st.next_frame())).to(dev)
+            got = []
+            for p in (p16, p32):
+                p.frames[0].copy_(img)
+                p.step(track=False)
+                torch.cuda.synchronize(dev)
+                n = int(p.ndets[0].item())
+                got.append((p.keep[0, :n].cpu().numpy().copy(), p.dets[0, :n, :6].cpu().numpy().copy()))
+            (k16, r16), (k32, r32) = got
+            n16 += len(k16); n32 += len(k32)
+            eq = len(k16) == len(k32) and bool((k16 == k32).all())
+            same += eq
+            same_set += set(k16.tolist()) == set(k32.tolist())
+            sym += len(set(k16.tolist()) ^ set(k32.tolist()))
+            if not eq and first_diff is None:
+                first_diff = k
+            pos32 = {int(a): i for i, a in enumerate(k32)}
+            for i, a in enumerate(k16):
+                j = pos32.get(int(a))
+                if j is not None:
+                    common += 1
+                    dbox = max(dbox, float(np.abs(r16[i, :4] - r32[j, :4]).max()))
+                    dconf = max(dconf, float(abs(r16[i, 4] - r32[j, 4])))
+    p16.close(); p32.close()
+    return {"detector": detector, "frames": frames, "frames_with_identical_keep_list": same, "frames_with_identical_keep_set": same_set,
+            "keep_list_agreement": round(same / frames, 4), "kept_f16_mean": round(n16 / frames, 2), "kept_fp32_mean": round(n32 / frames, 2),
+            "anchors_in_one_list_only": sym, "anchors_in_both": common, "max_box_delta_px": round(dbox, 4), "max_conf_delta": round(dconf, 6),
+            "first_frame_with_different_lists": first_diff, "class_bias_shift": round(shift, 4), "target_kept_per_frame": target,
+            "note": "f16 = hand-written kernels (throughput default); fp32 = the same weights on PyTorch-ROCm's library convolutions; letterbox + NMS "
+                    "are the HIP kernels in both; seeded calibrated random-init network (no checkpoint offline), class biases shifted so that ~target anchors "
+                    "pass conf: near-threshold density is synthetic"}
+
+
 def net_outputs_check(pipe):
     """The benchmark's synthetic workload does not consume the networks' outputs (detections come from a synthetic head tensor,
     features from the identity table), so a convolution kernel that skipped work inside a replayed graph would go unnoticed.
@@ -987,6 +1069,8 @@ def main():
         if world == 1 and not args.no_reid_check and not args.no_nets:
             res["reid_f16_vs_f32"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index)
             res["reid_f16_vs_f32"]["fp32_reid_mode"] = reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=dev_index, reid_half=False)
+        if world == 1 and not args.no_reid_check and not args.no_nets and args.preset in ("c2", "c3", "c5"):
+            res["det_f16_vs_f32"] = det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=dev_index)
         if world == 1 and overlap and not args.no_nets and not args.reid_fp32 and not args.no_accuracy_mode:
             # the configuration that meets north_star's float bound, measured the same way on fewer steps: the whole hot path with the
             # ReID crops + OSNet in fp32 on the hand-written fp32 kernels; its distance error / id rate on the true ReID data path are
