@@ -27,6 +27,7 @@
 // with the fp32 CPU network to rounding (1e-6 relative per layer), not bit for bit: tests/test_gpu_nets32.py states the bounds.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/strongsort_hip.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -238,6 +239,172 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains(const float* __restric
     }
 }
 
+// ---- k32_chains2 ---------------------------------------------------------------------------------------------------------
+// The same four chains with ONE barrier per layer and no second activation buffer.  A wave owns a 16-pixel-wide column strip
+// (tile column xt) over a run of RPW rows.  In the MFMA operand convention lane (kq, n) holds chunks kq + 4 jj of pixel n, and the
+// 1x1 product leaves chunk 4 mt + q of the same pixel in lane (q, n): the depthwise 3x3 of a layer is therefore computed by the lane
+// that needs its result as the B operand of the NEXT layer's 1x1 — per layer a wave reads its 3x3 windows from the current
+// buffer (the only LDS traffic: 3 vectors per row and chunk, a rolling window down the run), applies bias + ReLU, multiplies by
+// the next layer's weights straight out of the registers and writes that product to the other buffer.  A chain's last layer stores
+// to HBM instead and the same phase already computes the next chain's first 1x1 (from x1, prefetched at the phase's start).
+// Channel sums: shuffle-reduced per wave, one LDS row per wave.
+template <int C, int W, int NT, int RPW>
+__global__ __launch_bounds__(NT) void k32_chains2(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
+                                                 const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
+                                                 float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
+                                                 float* __restrict__ y3, float* __restrict__ psum, int Nimg, int H, int R, int HALO,
+                                                 const int* __restrict__ n_img)
+{
+    constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = (C + 15) / 16, PITCH = C + 4, NWV = NT / 64, TC = W / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
+    if (n_img && img >= *n_img) return;
+    const int RB = R + 2 * HALO, r0 = band * R - HALO;          // image row of LDS row 0
+    float* __restrict__ PA = smem32;
+    float* __restrict__ PB = PA + RB * W * PITCH;
+    float* __restrict__ S = PB + RB * W * PITCH;                // [NWV][C] channel sums of a chain's last layer, per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int runs = RB / RPW;                                  // (host: RB * TC == NWV * RPW)
+    const int xt = wave / runs, ra = (wave - xt * runs) * RPW, xx = 16 * xt + n;
+    const float* __restrict__ xi = x1 + (size_t)img * H * W * C;    // image bases are wave-uniform: 32-bit lane offsets below
+
+    auto load_a = [&](int layer, f4 (&a)[MT][JJ]) {
+        const float* wl = w1 + (size_t)layer * C * C;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const int row = 16 * mt + n, c = kq + 4 * jj;
+                a[mt][jj] = (row < C && c < CH) ? ld4(wl + (unsigned)(row * C + 4 * c)) : zero4();
+            }
+    };
+    auto load_x1 = [&](int r, f4 (&b)[JJ]) {
+        const int y = r0 + r;
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) {
+            const int c = kq + 4 * jj;
+            b[jj] = (c < CH && y >= 0 && y < H) ? ld4(xi + (unsigned)((y * W + xx) * C + 4 * c)) : zero4();
+        }
+    };
+    auto pw_store = [&](const f4 (&b)[JJ], const f4 (&a)[MT][JJ], float* __restrict__ Pn, int r) {
+        f4 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[mt] = MFMA4(a[mt][jj][s], b[jj][s], acc[mt]);
+        const int y = r0 + r;
+        const bool inimg = y >= 0 && y < H;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int co = 4 * mt + kq;
+            if (co < CH) st4(Pn + (r * W + xx) * PITCH + 4 * co, inimg ? acc[mt] : zero4());
+        }
+    };
+
+    int layer = 0, cur = 0;
+    {   // first 1x1 of chain 0
+        f4 a[MT][JJ];
+        load_a(0, a);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            f4 b[JJ];
+            load_x1(ra + i, b);
+            pw_store(b, a, PA, ra + i);
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        float* __restrict__ yt = (t == 0 ? y0 : t == 1 ? y1 : t == 2 ? y2 : y3) + (size_t)img * H * W * C;
+#pragma unroll 1
+        for (int d = 0; d <= t; ++d, ++layer) {
+            const bool last = d == t, more = t < 3;
+            const float* __restrict__ Pc = cur ? PB : PA;
+            float* __restrict__ Pn = cur ? PA : PB;
+            f4 a[MT][JJ];
+            f4 bx[RPW][JJ];
+            if (!last || more) load_a(layer + 1, a);             // the next layer of this chain / the first layer of the next chain
+            f4 o[RPW][JJ];
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const int c = kq + 4 * jj;
+                const bool cv = c < CH;
+                const float* __restrict__ w9l = w9 + (size_t)layer * 9 * C;
+                f4 k9[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) k9[i] = cv ? ld4(w9l + (unsigned)(i * C + 4 * c)) : zero4();
+                const f4 bb = cv ? ld4(bs + layer * C + 4 * c) : zero4();
+                auto ld = [&](int r, int x) -> f4 {
+                    return (cv && r >= 0 && r < RB && x >= 0 && x < W) ? ld4(Pc + (r * W + x) * PITCH + 4 * c) : zero4();
+                };
+                f4 t0 = ld(ra - 1, xx - 1), t1 = ld(ra - 1, xx), t2 = ld(ra - 1, xx + 1);
+                f4 m0 = ld(ra, xx - 1), m1 = ld(ra, xx), m2 = ld(ra, xx + 1);
+                f4 n0 = ld(ra + 1, xx - 1), n1 = ld(ra + 1, xx), n2 = ld(ra + 1, xx + 1);
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = ra + i;
+                    const f4 b0 = n0, b1 = n1, b2 = n2;
+                    if (i + 1 < RPW) { n0 = ld(r + 2, xx - 1); n1 = ld(r + 2, xx); n2 = ld(r + 2, xx + 1); }     // next row's taps on the wire during this row's arithmetic
+                    f4 v = bb;
+                    v = fma4(k9[0], t0, v); v = fma4(k9[1], t1, v); v = fma4(k9[2], t2, v);
+                    v = fma4(k9[3], m0, v); v = fma4(k9[4], m1, v); v = fma4(k9[5], m2, v);
+                    v = fma4(k9[6], b0, v); v = fma4(k9[7], b1, v); v = fma4(k9[8], b2, v);
+                    o[i][jj] = relu4(v);
+                    t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+                    __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise hoists every row's loads: 170+ registers and spills)
+                }
+            }
+            if (!last) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) pw_store(o[i], a, Pn, ra + i);
+            } else {
+                if (more)                                            // x1 rows of the next chain's first 1x1: on the wire while the outputs leave
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) load_x1(ra + i, bx[i]);
+                f4 ps[JJ];
+#pragma unroll
+                for (int jj = 0; jj < JJ; ++jj) ps[jj] = zero4();
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = ra + i, y = r0 + r;
+                    if (r >= HALO && r < HALO + R && y >= 0 && y < H) {
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj) {
+                            const int c = kq + 4 * jj;
+                            if (c < CH) { st4(yt + (unsigned)((y * W + xx) * C + 4 * c), o[i][jj]); ps[jj] = ps[jj] + o[i][jj]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < JJ; ++jj) {                    // sum over the wave's 16 columns (lanes n of the same kq)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = ps[jj][j];
+                        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                        ps[jj][j] = v;
+                    }
+                    const int c = kq + 4 * jj;
+                    if (n == 0 && c < CH) st4(S + wave * C + 4 * c, ps[jj]);
+                }
+                if (more)
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) pw_store(bx[i], a, Pn, ra + i);
+            }
+            __syncthreads();
+            if (last && tid < C) {                                   // the band's channel sums of chain t, waves in order
+                float sum = 0.f;
+                for (int wv = 0; wv < NWV; ++wv) sum += S[wv * C + tid];
+                psum[(((size_t)t * Nimg + img) * bands + band) * C + tid] = sum;
+            }
+            cur ^= 1;
+        }
+    }
+}
+
 // ---- k32_tail ------------------------------------------------------------------------------------------------------------
 // Per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chain sums; per pixel: x2 = sum_t gate_t * y_t;
 // o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block input x, C1 channels); o -> d_out when asked;
@@ -371,10 +538,10 @@ __global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict_
 __global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict__ x, const float* __restrict__ w /*[16][148]*/,
                                                       const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img)
 {
-    constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, IN_ROWS = 24, CROWS = 2 * ST_PR + 1, CSP = 20;
+    constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, IN_ROWS = 24, CROWS = 2 * ST_PR + 1, CSP = 16;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     float* __restrict__ In = smem32;                         // [24][404]
-    float* __restrict__ Cs = In + IN_ROWS * ST_ROWP;         // [9][64][20] convolution rows after bias + ReLU
+    float* __restrict__ Cs = In + IN_ROWS * ST_ROWP;         // [9][64][16] convolution rows after bias + ReLU
     const int img = blockIdx.y, band = blockIdx.x;
     if (n_img && img >= *n_img) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
@@ -468,6 +635,7 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
+static bool g_chains_form = true;
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -533,8 +701,26 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
+#define CH32B(CC, WW, NT_, RPW_) if (C == CC && W == WW && g_chains_form) { \
+        const int RB_ = R + 2 * halo, TC_ = WW / 16, NWV_ = NT_ / 64; \
+        if (RB_ * TC_ == NWV_ * RPW_ && RB_ % RPW_ == 0) { \
+            static bool attr = false; \
+            if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains2<CC, WW, NT_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+            const size_t lds2 = 2ull * RB_ * WW * (CC + 4) * 4 + (size_t)NWV_ * CC * 4; \
+            hipLaunchKernelGGL((k32_chains2<CC, WW, NT_, RPW_>), grid, dim3(NT_), lds2, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
+            OP32_CHECK(); return SS_OK; } }
+    CH32B(16, 32, 768, 4) CH32B(24, 16, 512, 4)
+#undef CH32B
     CH32(16, 32) CH32(24, 16) CH32(32, 8)
 #undef CH32
+    return SS_ERR_INVALID;
+}
+
+// A/B switch (tests, measurements): "chains_form" 1 = k32_chains2 where it applies (default), 0 = k32_chains everywhere
+extern "C" int ss_op32_set_option(const char* name, int value)
+{
+    if (!name) return SS_ERR_INVALID;
+    if (!strcmp(name, "chains_form")) { g_chains_form = value != 0; return SS_OK; }
     return SS_ERR_INVALID;
 }
 
@@ -583,7 +769,7 @@ extern "C" int ss_op32_tail(void* stream, const void* const* d_ys, const float* 
 extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid)
 {
     if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
-    constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 20) * 4;
+    constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16) * 4;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)k32_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;

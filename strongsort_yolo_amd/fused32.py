@@ -35,6 +35,11 @@ def _cl(x):
     return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
 
 
+def set_option(name: str, value: int):
+    """Process-wide A/B switch of the fp32 operators (csrc ss_op32_set_option): chains_form 1 (default) / 0."""
+    _ck(_lib.load().ss_op32_set_option(name.encode(), int(value)))
+
+
 def usable(x) -> bool:
     return ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
 

@@ -75,8 +75,19 @@ def _block(c1, c2, seed):
     return blk, g
 
 
+@pytest.mark.parametrize("form", [1, 0])
 @pytest.mark.parametrize("c1,c2,n,h,w", [(16, 64, 3, 64, 32), (64, 96, 3, 32, 16), (96, 128, 5, 16, 8)])
-def test_chains_match_fp64(c1, c2, n, h, w):
+def test_chains_match_fp64(c1, c2, n, h, w, form):
+    """Both kernel forms: 1 = the register-streamed chains (one barrier per layer; 64 x 32 and 32 x 16 maps), 0 = the two-buffer form."""
+    from strongsort_yolo_amd import fused32
+    fused32.set_option("chains_form", form)
+    try:
+        _chains_case(c1, c2, n, h, w)
+    finally:
+        fused32.set_option("chains_form", 1)
+
+
+def _chains_case(c1, c2, n, h, w):
     from strongsort_yolo_amd import fused32
     blk, g = _block(c1, c2, c1 + h)
     mid = c2 // 4
