@@ -497,6 +497,7 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
     st = make_stream(2025, W, H, n_ids)
     same = same_set = sym = common = n16 = n32 = 0
     dbox = dconf = 0.0
+    dboxes, dconfs = [], []
     first_diff = None
     with torch.no_grad():
         for k in range(frames):
@@ -521,12 +522,16 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
                 j = pos32.get(int(a))
                 if j is not None:
                     common += 1
-                    dbox = max(dbox, float(np.abs(r16[i, :4] - r32[j, :4]).max()))
-                    dconf = max(dconf, float(abs(r16[i, 4] - r32[j, 4])))
+                    dboxes.append(float(np.abs(r16[i, :4] - r32[j, :4]).max()))
+                    dconfs.append(float(abs(r16[i, 4] - r32[j, 4])))
+                    dbox, dconf = max(dbox, dboxes[-1]), max(dconf, dconfs[-1])
     p16.close(); p32.close()
     return {"detector": detector, "frames": frames, "frames_with_identical_keep_list": same, "frames_with_identical_keep_set": same_set,
             "keep_list_agreement": round(same / frames, 4), "kept_f16_mean": round(n16 / frames, 2), "kept_fp32_mean": round(n32 / frames, 2),
             "anchors_in_one_list_only": sym, "anchors_in_both": common, "max_box_delta_px": round(dbox, 4), "max_conf_delta": round(dconf, 6),
+            "box_delta_px_p50_p95": [round(float(np.percentile(dboxes, q)), 4) for q in (50, 95)] if dboxes else None,
+            "conf_delta_p50_p95": [round(float(np.percentile(dconfs, q)), 6) for q in (50, 95)] if dconfs else None,
+            "anchors_in_both_within_1px": round(float(np.mean(np.array(dboxes) <= 1.0)), 4) if dboxes else None,
             "first_frame_with_different_lists": first_diff, "class_bias_shift": round(shift, 4), "target_kept_per_frame": target,
             "note": "f16 = hand-written kernels (throughput default); fp32 = the same weights on PyTorch-ROCm's library convolutions; letterbox + NMS "
                     "are the HIP kernels in both; seeded calibrated random-init network (no checkpoint offline), class biases shifted so that ~target anchors "
@@ -758,6 +763,18 @@ def main():
     dev_index = 0 if (world == 1 or one_dev) else local_rank
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    # One process per GPU, each with a Python enqueue loop: give every rank its own contiguous slice of the host cores (the launcher
+    # does not pin; eight loops migrating over all cores would share caches and the same few cores).  SS_BENCH_NO_AFFINITY=1: off.
+    affinity = None
+    if world > 1 and os.environ.get("SS_BENCH_NO_AFFINITY") != "1" and hasattr(os, "sched_setaffinity"):
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+            mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+            os.sched_setaffinity(0, mine)
+            affinity = f"{mine[0]}-{mine[-1]}"
+        except OSError:
+            affinity = None
     if not args.dist_check:
         torch.cuda.set_device(dev_index)
     if world > 1:
@@ -1032,6 +1049,12 @@ def main():
     same, tot, exact_frames, exact_timed, n_timed = id_check(R, nchk)
     out_host, nout_host = R.out_host, R.nout_host
     id_rate = same / max(tot, 1)
+    per_rank_enq = [round(t_enq_cpu / KF * 1e3, 4)]
+    if world > 1:
+        te = torch.tensor([t_enq_cpu / KF * 1e3], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        ge = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(ge, te)
+        per_rank_enq = [round(float(t.item()), 4) for t in ge]
     id_min = torch.tensor([id_rate, float(exact_frames), float(exact_timed)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(id_min, op=dist.ReduceOp.MIN)
@@ -1051,6 +1074,7 @@ def main():
             "per_rank_value": [round(S * KF / t, 2) for t in per_rank_dt], "ranks_in_process_group": dist.get_world_size() if world > 1 else 1,
             "backend": (backend + ("=RCCL" if backend == "nccl" else "")) if world > 1 else None,
             "devices": "one GPU shared by all ranks (SS_BENCH_SINGLE_DEVICE=1: control-flow run)" if (one_dev and world > 1) else "one GPU per rank",
+            "cpu_affinity_rank0": affinity, "per_rank_host_enqueue_cpu_ms_per_frame": per_rank_enq,
             "host_enqueue_ms_per_frame": round(t_enq / KF * 1e3, 4), "host_enqueue_cpu_ms_per_frame": round(t_enq_cpu / KF * 1e3, 4), "id_match_rate": round(id_rate_min, 6), "frames_bit_exact": f"{exact_min}/{nchk}", "frames_bit_exact_timed": f"{exact_timed_min}/{n_timed}",
             "id_check": "every rank vs the oracle on its own stream 0 over prefill + warm-up + ALL timed frames, minimum over ranks",
             "roofline": roofline, "roofline_front": roofline_front, "net_outputs_check": nets_check,

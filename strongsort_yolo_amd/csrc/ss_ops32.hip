@@ -405,6 +405,166 @@ __global__ __launch_bounds__(NT) void k32_chains2(const float* __restrict__ x1, 
     }
 }
 
+// ---- k32_chains3 ---------------------------------------------------------------------------------------------------------
+// k32_chains' two-phase form (1x1 of every tile -> barrier -> depthwise of every pixel -> barrier) with what the first trace asked
+// for (745 us per launch at 1024 crops, 46 us per workgroup for work that issues in 17):
+//  * one lane map for BOTH phases — lane (kq, n) = chunk kq (+ 4 jj) of column n of a 16-pixel row segment — and a pixel pitch
+//    that is 8 mod 16 dwords (24 / 24 / 40 for 16 / 24 / 32 channels): every 16-byte LDS access of the kernel, the depthwise
+//    taps at x - 1, x, x + 1 included, is conflict-free (the chunk-fastest thread order of k32_chains on a C + 4 pitch paid 3x on
+//    its nine taps);
+//  * the weights of a phase are requested one phase ahead (1x1 matrix at the start of the depthwise phase before it, the nine
+//    taps + bias at the start of the 1x1 phase before them), and a chain's first 1x1 reads x1 from registers filled during the
+//    previous chain's last depthwise phase: no phase starts with a dependent global load;
+//  * channel sums by wave shuffles, one LDS vector per (wave, lane row).
+// 24 channels = 6 chunks: waves 0..7 take chunks 0..3 of four rows each, waves 8..11 chunks 4, 5 of TWO row runs at once (lane
+// rows kq < 2 / kq >= 2), so all twelve waves walk four rows.
+template <int C> struct Ch3 {
+    static constexpr int PITCH = (C == 24) ? 24 : C + 8;
+};
+template <int C, int W>
+__global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
+                                                         const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
+                                                         float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
+                                                         float* __restrict__ y3, float* __restrict__ psum, int Nimg, int H, int R, int HALO,
+                                                         const int* __restrict__ n_img)
+{
+    constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = (C + 15) / 16, PITCH = Ch3<C>::PITCH, NWV = C32_THREADS / 64, RPG = 4;
+    constexpr int TPW = (C == 16) ? 4 : 3;                       // 16-pixel tiles of the 1x1 phase per wave (48 / 12, ceil(32 / 12))
+    static_assert((C == 16 && W == 32) || (C == 24 && W == 16), "instantiated for the 64 x 32 x 16 and 32 x 16 x 24 maps");
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
+    if (n_img && img >= *n_img) return;
+    const int RB = R + 2 * HALO, r0 = band * R - HALO;          // image row of LDS row 0 (host: RB == 24 for C 16, 32 for C 24)
+    float* __restrict__ P = smem32;
+    float* __restrict__ Q = P + RB * W * PITCH;
+    float* __restrict__ S = Q + RB * W * PITCH;                 // [NWV][4 lane rows][4] partial channel sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    // depthwise unit of this lane: chunk dc of column dx, rows dra .. dra + 3
+    int dc, dx, dra;
+    if (C == 16) { const int xt = wave / 6; dc = kq; dx = 16 * xt + n; dra = (wave - 6 * xt) * RPG; }
+    else if (wave < 8) { dc = kq; dx = n; dra = wave * RPG; }
+    else { dc = 4 + (kq & 1); dx = n; dra = (2 * (wave - 8) + (kq >> 1)) * RPG; }
+    const int ntiles = RB * W / 16;
+    const float* __restrict__ xi = x1 + (size_t)img * H * W * C;
+
+    auto load_a = [&](int layer, f4 (&a)[MT][JJ]) {
+        const float* wl = w1 + (size_t)layer * C * C;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const int row = 16 * mt + n, c = kq + 4 * jj;
+                a[mt][jj] = (row < C && c < CH) ? ld4(wl + (unsigned)(row * C + 4 * c)) : zero4();
+            }
+    };
+    auto load_x1 = [&](f4 (&b)[TPW][JJ]) {                        // this wave's tiles of the band, straight from the block's conv1 output
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tile = wave + i * NWV, p = tile * 16 + n, r = p / W, y = r0 + r;
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const int c = kq + 4 * jj;
+                b[i][jj] = (tile < ntiles && c < CH && y >= 0 && y < H) ? ld4(xi + (unsigned)((y * W + (p - r * W)) * C + 4 * c)) : zero4();
+            }
+        }
+    };
+    f4 a[MT][JJ], bpre[TPW][JJ];
+    load_a(0, a);
+    load_x1(bpre);
+    int layer = 0;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+        float* __restrict__ yt = (t == 0 ? y0 : t == 1 ? y1 : t == 2 ? y2 : y3) + (size_t)img * H * W * C;
+#pragma unroll 1
+        for (int d = 0; d <= t; ++d, ++layer) {
+            // ---- 1x1 phase (taps + bias of this layer's depthwise requested first)
+            f4 k9[9];
+            const float* __restrict__ w9l = w9 + (size_t)layer * 9 * C;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) k9[i] = ld4(w9l + (unsigned)(i * C + 4 * dc));
+            const f4 bb = ld4(bs + layer * C + 4 * dc);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = wave + i * NWV;
+                if (tile < ntiles) {
+                    const int p = tile * 16 + n, r = p / W, y = r0 + r;
+                    const bool inimg = y >= 0 && y < H;
+                    f4 b[JJ];
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const int c = kq + 4 * jj;
+                        b[jj] = d == 0 ? bpre[i][jj] : (c < CH ? ld4(Q + p * PITCH + 4 * c) : zero4());
+                    }
+                    f4 acc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4();
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int jj = 0; jj < JJ; ++jj)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc[mt] = MFMA4(a[mt][jj][s], b[jj][s], acc[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int co = 4 * mt + kq;
+                        if (co < CH) st4(P + p * PITCH + 4 * co, inimg ? acc[mt] : zero4());
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- depthwise phase (next 1x1 matrix / next chain's x1 tiles requested first)
+            const bool last = d == t;
+            if (layer < 9) load_a(layer + 1, a);
+            if (last && t < 3) load_x1(bpre);
+            f4 psa = zero4();
+            {
+                auto ld = [&](int r, int x) -> f4 {
+                    return (r >= 0 && r < RB && x >= 0 && x < W) ? ld4(P + (r * W + x) * PITCH + 4 * dc) : zero4();
+                };
+                f4 t0 = ld(dra - 1, dx - 1), t1 = ld(dra - 1, dx), t2 = ld(dra - 1, dx + 1);
+                f4 m0 = ld(dra, dx - 1), m1 = ld(dra, dx), m2 = ld(dra, dx + 1);
+#pragma unroll
+                for (int i = 0; i < RPG; ++i) {
+                    const int r = dra + i;
+                    const f4 b0 = ld(r + 1, dx - 1), b1 = ld(r + 1, dx), b2 = ld(r + 1, dx + 1);
+                    f4 o = bb;
+                    o = fma4(k9[0], t0, o); o = fma4(k9[1], t1, o); o = fma4(k9[2], t2, o);
+                    o = fma4(k9[3], m0, o); o = fma4(k9[4], m1, o); o = fma4(k9[5], m2, o);
+                    o = fma4(k9[6], b0, o); o = fma4(k9[7], b1, o); o = fma4(k9[8], b2, o);
+                    o = relu4(o);
+                    st4(Q + (r * W + dx) * PITCH + 4 * dc, o);
+                    const int y = r0 + r;
+                    if (last && r >= HALO && r < HALO + R && y >= 0 && y < H) {
+                        st4(yt + (unsigned)((y * W + dx) * C + 4 * dc), o);
+                        psa = psa + o;
+                    }
+                    t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
+                }
+            }
+            if (last) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = psa[j];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    psa[j] = v;
+                }
+                if (n == 0) st4(S + (wave * 4 + kq) * 4, psa);
+            }
+            __syncthreads();
+            if (last && tid < C) {                                   // channel tid of chain t: the (wave, lane row) partials of its chunk, in order
+                float sum = 0.f;
+                for (int wv = 0; wv < NWV; ++wv)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cq = (C == 16 || wv < 8) ? q : 4 + (q & 1);
+                        if (cq == (tid >> 2)) sum += S[(wv * 4 + q) * 4 + (tid & 3)];
+                    }
+                psum[(((size_t)t * Nimg + img) * bands + band) * C + tid] = sum;
+            }
+        }
+    }
+}
+
 // ---- k32_tail ------------------------------------------------------------------------------------------------------------
 // Per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chain sums; per pixel: x2 = sum_t gate_t * y_t;
 // o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block input x, C1 channels); o -> d_out when asked;
@@ -635,7 +795,7 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
-static bool g_chains_form = true;
+static int g_chains_form = 2;        // 2: k32_chains3, 1: k32_chains2, 0: k32_chains (64 x 32 and 32 x 16 maps; the 16 x 8 maps always take k32_chains)
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -701,7 +861,15 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
-#define CH32B(CC, WW, NT_, RPW_) if (C == CC && W == WW && g_chains_form) { \
+#define CH32C(CC, WW) if (C == CC && W == WW && g_chains_form == 2 && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
+        static bool attr = false; \
+        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+        const size_t lds3 = 2ull * (R + 2 * halo) * WW * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
+        hipLaunchKernelGGL((k32_chains3<CC, WW>), grid, dim3(C32_THREADS), lds3, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
+        OP32_CHECK(); return SS_OK; }
+    CH32C(16, 32) CH32C(24, 16)
+#undef CH32C
+#define CH32B(CC, WW, NT_, RPW_) if (C == CC && W == WW && g_chains_form == 1) { \
         const int RB_ = R + 2 * halo, TC_ = WW / 16, NWV_ = NT_ / 64; \
         if (RB_ * TC_ == NWV_ * RPW_ && RB_ % RPW_ == 0) { \
             static bool attr = false; \
@@ -716,11 +884,11 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
     return SS_ERR_INVALID;
 }
 
-// A/B switch (tests, measurements): "chains_form" 1 = k32_chains2 where it applies (default), 0 = k32_chains everywhere
+// A/B switch (tests, measurements): "chains_form" 2 = k32_chains3 where it applies (default), 1 = k32_chains2, 0 = k32_chains everywhere
 extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
-    if (!strcmp(name, "chains_form")) { g_chains_form = value != 0; return SS_OK; }
+    if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
 
