@@ -419,8 +419,8 @@ int ss_op32_tail(void* stream, const void* const* d_ys, const float* d_psum, int
                  const void* d_gw2, const void* d_gb2, int hidden, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
                  const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
                  int H, int W, int MID, int C2, int N2, const int* d_nvalid);
-/* Process-wide A/B switch of the fp32 operators: "chains_form" 2 (default): k32_chains3 (two phases per layer, conflict-free lane
- * map, weights requested a phase ahead) where it applies, 1: the register-streamed k32_chains2, 0: the first two-buffer form everywhere. */
+/* Process-wide A/B switch of the fp32 operators: "chains_form" 1 (default): k32_chains3 (conflict-free lane map, weights requested a
+ * phase ahead) where it applies, 0: k32_chains everywhere. */
 int ss_op32_set_option(const char* name, int value);
 /* conv 7x7 / 2 (3 -> 16) + bias + ReLU + max pool 3x3 / 2: d_x [N][256][128][3] -> d_y [N][64][32][16]; d_w [16][148] with
  * k = (ky * 7 + kx) * 3 + c and a zero in column 147. */

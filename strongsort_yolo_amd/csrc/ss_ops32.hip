@@ -175,9 +175,9 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains(const float* __restric
 #pragma unroll
                     for (int jj = 0; jj < JJ; ++jj) {
                         const int c = kq + 4 * jj;
-                        if (c >= CH) b[jj] = zero4();
-                        else if (d == 0) b[jj] = inimg ? ld4(x1 + ibase + ((size_t)y * W + (p - r * W)) * C + 4 * c) : zero4();
-                        else b[jj] = ld4(Q + p * PITCH + 4 * c);
+                        const int cc = c < CH ? c : 0, yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+                        const f4 v = d == 0 ? ld4(x1 + ibase + ((size_t)yc * W + (p - r * W)) * C + 4 * cc) : ld4(Q + p * PITCH + 4 * cc);
+                        b[jj] = (c < CH && (d != 0 || inimg)) ? v : zero4();
                     }
                     f4 acc[MT];
 #pragma unroll
@@ -205,8 +205,11 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains(const float* __restric
                 for (int i = 0; i < 9; ++i) k9[i] = ld4(wt + i * C);
                 const f4 bb = ld4(bs + layer * C + 4 * chunk);
                 f4 psa = zero4();
-                auto ld = [&](int r, int x) -> f4 {
-                    return (r >= 0 && r < RB && x >= 0 && x < W) ? ld4(P + (r * W + x) * PITCH + 4 * chunk) : zero4();
+                auto ld = [&](int r, int x) -> f4 {                    // unconditional load from a clamped address + select (no branch per tap)
+                    const bool ok = r >= 0 && r < RB && x >= 0 && x < W;
+                    const int rc = r < 0 ? 0 : (r >= RB ? RB - 1 : r), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+                    const f4 v = ld4(P + (rc * W + xc) * PITCH + 4 * chunk);
+                    return ok ? v : zero4();
                 };
                 if (ra < rb) {
                     f4 t0 = ld(ra - 1, xx - 1), t1 = ld(ra - 1, xx), t2 = ld(ra - 1, xx + 1);
@@ -239,172 +242,6 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains(const float* __restric
     }
 }
 
-// ---- k32_chains2 ---------------------------------------------------------------------------------------------------------
-// The same four chains with ONE barrier per layer and no second activation buffer.  A wave owns a 16-pixel-wide column strip
-// (tile column xt) over a run of RPW rows.  In the MFMA operand convention lane (kq, n) holds chunks kq + 4 jj of pixel n, and the
-// 1x1 product leaves chunk 4 mt + q of the same pixel in lane (q, n): the depthwise 3x3 of a layer is therefore computed by the lane
-// that needs its result as the B operand of the NEXT layer's 1x1 — per layer a wave reads its 3x3 windows from the current
-// buffer (the only LDS traffic: 3 vectors per row and chunk, a rolling window down the run), applies bias + ReLU, multiplies by
-// the next layer's weights straight out of the registers and writes that product to the other buffer.  A chain's last layer stores
-// to HBM instead and the same phase already computes the next chain's first 1x1 (from x1, prefetched at the phase's start).
-// Channel sums: shuffle-reduced per wave, one LDS row per wave.
-template <int C, int W, int NT, int RPW>
-__global__ __launch_bounds__(NT) void k32_chains2(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
-                                                 const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
-                                                 float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
-                                                 float* __restrict__ y3, float* __restrict__ psum, int Nimg, int H, int R, int HALO,
-                                                 const int* __restrict__ n_img)
-{
-    constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = (C + 15) / 16, PITCH = C + 4, NWV = NT / 64, TC = W / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem32[];
-    const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
-    if (n_img && img >= *n_img) return;
-    const int RB = R + 2 * HALO, r0 = band * R - HALO;          // image row of LDS row 0
-    float* __restrict__ PA = smem32;
-    float* __restrict__ PB = PA + RB * W * PITCH;
-    float* __restrict__ S = PB + RB * W * PITCH;                // [NWV][C] channel sums of a chain's last layer, per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
-    const int runs = RB / RPW;                                  // (host: RB * TC == NWV * RPW)
-    const int xt = wave / runs, ra = (wave - xt * runs) * RPW, xx = 16 * xt + n;
-    const float* __restrict__ xi = x1 + (size_t)img * H * W * C;    // image bases are wave-uniform: 32-bit lane offsets below
-
-    auto load_a = [&](int layer, f4 (&a)[MT][JJ]) {
-        const float* wl = w1 + (size_t)layer * C * C;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) {
-                const int row = 16 * mt + n, c = kq + 4 * jj;
-                a[mt][jj] = (row < C && c < CH) ? ld4(wl + (unsigned)(row * C + 4 * c)) : zero4();
-            }
-    };
-    auto load_x1 = [&](int r, f4 (&b)[JJ]) {
-        const int y = r0 + r;
-#pragma unroll
-        for (int jj = 0; jj < JJ; ++jj) {
-            const int c = kq + 4 * jj;
-            b[jj] = (c < CH && y >= 0 && y < H) ? ld4(xi + (unsigned)((y * W + xx) * C + 4 * c)) : zero4();
-        }
-    };
-    auto pw_store = [&](const f4 (&b)[JJ], const f4 (&a)[MT][JJ], float* __restrict__ Pn, int r) {
-        f4 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int jj = 0; jj < JJ; ++jj)
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc[mt] = MFMA4(a[mt][jj][s], b[jj][s], acc[mt]);
-        const int y = r0 + r;
-        const bool inimg = y >= 0 && y < H;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int co = 4 * mt + kq;
-            if (co < CH) st4(Pn + (r * W + xx) * PITCH + 4 * co, inimg ? acc[mt] : zero4());
-        }
-    };
-
-    int layer = 0, cur = 0;
-    {   // first 1x1 of chain 0
-        f4 a[MT][JJ];
-        load_a(0, a);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            f4 b[JJ];
-            load_x1(ra + i, b);
-            pw_store(b, a, PA, ra + i);
-        }
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int t = 0; t < 4; ++t) {
-        float* __restrict__ yt = (t == 0 ? y0 : t == 1 ? y1 : t == 2 ? y2 : y3) + (size_t)img * H * W * C;
-#pragma unroll 1
-        for (int d = 0; d <= t; ++d, ++layer) {
-            const bool last = d == t, more = t < 3;
-            const float* __restrict__ Pc = cur ? PB : PA;
-            float* __restrict__ Pn = cur ? PA : PB;
-            f4 a[MT][JJ];
-            f4 bx[RPW][JJ];
-            if (!last || more) load_a(layer + 1, a);             // the next layer of this chain / the first layer of the next chain
-            f4 o[RPW][JJ];
-#pragma unroll
-            for (int jj = 0; jj < JJ; ++jj) {
-                const int c = kq + 4 * jj;
-                const bool cv = c < CH;
-                const float* __restrict__ w9l = w9 + (size_t)layer * 9 * C;
-                f4 k9[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) k9[i] = cv ? ld4(w9l + (unsigned)(i * C + 4 * c)) : zero4();
-                const f4 bb = cv ? ld4(bs + layer * C + 4 * c) : zero4();
-                auto ld = [&](int r, int x) -> f4 {
-                    return (cv && r >= 0 && r < RB && x >= 0 && x < W) ? ld4(Pc + (r * W + x) * PITCH + 4 * c) : zero4();
-                };
-                f4 t0 = ld(ra - 1, xx - 1), t1 = ld(ra - 1, xx), t2 = ld(ra - 1, xx + 1);
-                f4 m0 = ld(ra, xx - 1), m1 = ld(ra, xx), m2 = ld(ra, xx + 1);
-                f4 n0 = ld(ra + 1, xx - 1), n1 = ld(ra + 1, xx), n2 = ld(ra + 1, xx + 1);
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int r = ra + i;
-                    const f4 b0 = n0, b1 = n1, b2 = n2;
-                    if (i + 1 < RPW) { n0 = ld(r + 2, xx - 1); n1 = ld(r + 2, xx); n2 = ld(r + 2, xx + 1); }     // next row's taps on the wire during this row's arithmetic
-                    f4 v = bb;
-                    v = fma4(k9[0], t0, v); v = fma4(k9[1], t1, v); v = fma4(k9[2], t2, v);
-                    v = fma4(k9[3], m0, v); v = fma4(k9[4], m1, v); v = fma4(k9[5], m2, v);
-                    v = fma4(k9[6], b0, v); v = fma4(k9[7], b1, v); v = fma4(k9[8], b2, v);
-                    o[i][jj] = relu4(v);
-                    t0 = m0; t1 = m1; t2 = m2; m0 = b0; m1 = b1; m2 = b2;
-                    __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise hoists every row's loads: 170+ registers and spills)
-                }
-            }
-            if (!last) {
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) pw_store(o[i], a, Pn, ra + i);
-            } else {
-                if (more)                                            // x1 rows of the next chain's first 1x1: on the wire while the outputs leave
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) load_x1(ra + i, bx[i]);
-                f4 ps[JJ];
-#pragma unroll
-                for (int jj = 0; jj < JJ; ++jj) ps[jj] = zero4();
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    const int r = ra + i, y = r0 + r;
-                    if (r >= HALO && r < HALO + R && y >= 0 && y < H) {
-#pragma unroll
-                        for (int jj = 0; jj < JJ; ++jj) {
-                            const int c = kq + 4 * jj;
-                            if (c < CH) { st4(yt + (unsigned)((y * W + xx) * C + 4 * c), o[i][jj]); ps[jj] = ps[jj] + o[i][jj]; }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int jj = 0; jj < JJ; ++jj) {                    // sum over the wave's 16 columns (lanes n of the same kq)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float v = ps[jj][j];
-                        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                        ps[jj][j] = v;
-                    }
-                    const int c = kq + 4 * jj;
-                    if (n == 0 && c < CH) st4(S + wave * C + 4 * c, ps[jj]);
-                }
-                if (more)
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) pw_store(bx[i], a, Pn, ra + i);
-            }
-            __syncthreads();
-            if (last && tid < C) {                                   // the band's channel sums of chain t, waves in order
-                float sum = 0.f;
-                for (int wv = 0; wv < NWV; ++wv) sum += S[wv * C + tid];
-                psum[(((size_t)t * Nimg + img) * bands + band) * C + tid] = sum;
-            }
-            cur ^= 1;
-        }
-    }
-}
-
 // ---- k32_chains3 ---------------------------------------------------------------------------------------------------------
 // k32_chains' two-phase form (1x1 of every tile -> barrier -> depthwise of every pixel -> barrier) with what the first trace asked
 // for (745 us per launch at 1024 crops, 46 us per workgroup for work that issues in 17):
@@ -421,7 +258,7 @@ __global__ __launch_bounds__(NT) void k32_chains2(const float* __restrict__ x1, 
 template <int C> struct Ch3 {
     static constexpr int PITCH = (C == 24) ? 24 : C + 8;
 };
-template <int C, int W>
+template <int C, int W, bool PRE>
 __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
                                                          const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
                                                          float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
@@ -429,7 +266,7 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
                                                          const int* __restrict__ n_img)
 {
     constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = (C + 15) / 16, PITCH = Ch3<C>::PITCH, NWV = C32_THREADS / 64, RPG = 4;
-    constexpr int TPW = (C == 16) ? 4 : 3;                       // 16-pixel tiles of the 1x1 phase per wave (48 / 12, ceil(32 / 12))
+    constexpr int TPW = 4, PWV = (C == 16) ? 12 : 8;             // 1x1 phase: 4 tiles of 16 pixels per wave on 12 (48 tiles) / 8 (32 tiles) waves
     static_assert((C == 16 && W == 32) || (C == 24 && W == 16), "instantiated for the 64 x 32 x 16 and 32 x 16 x 24 maps");
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
@@ -438,13 +275,12 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
     float* __restrict__ P = smem32;
     float* __restrict__ Q = P + RB * W * PITCH;
     float* __restrict__ S = Q + RB * W * PITCH;                 // [NWV][4 lane rows][4] partial channel sums
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
     // depthwise unit of this lane: chunk dc of column dx, rows dra .. dra + 3
     int dc, dx, dra;
     if (C == 16) { const int xt = wave / 6; dc = kq; dx = 16 * xt + n; dra = (wave - 6 * xt) * RPG; }
     else if (wave < 8) { dc = kq; dx = n; dra = wave * RPG; }
     else { dc = 4 + (kq & 1); dx = n; dra = (2 * (wave - 8) + (kq >> 1)) * RPG; }
-    const int ntiles = RB * W / 16;
     const float* __restrict__ xi = x1 + (size_t)img * H * W * C;
 
     auto load_a = [&](int layer, f4 (&a)[MT][JJ]) {
@@ -454,23 +290,28 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
 #pragma unroll
             for (int jj = 0; jj < JJ; ++jj) {
                 const int row = 16 * mt + n, c = kq + 4 * jj;
-                a[mt][jj] = (row < C && c < CH) ? ld4(wl + (unsigned)(row * C + 4 * c)) : zero4();
+                const f4 v = ld4(wl + (unsigned)((row < C ? row : 0) * C + 4 * (c < CH ? c : 0)));
+                a[mt][jj] = (row < C && c < CH) ? v : zero4();
             }
     };
-    auto load_x1 = [&](f4 (&b)[TPW][JJ]) {                        // this wave's tiles of the band, straight from the block's conv1 output
+    auto load_x1 = [&](f4 (&b)[PRE ? TPW : 1][JJ]) {                        // this wave's tiles of the band, straight from the block's conv1 output
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int tile = wave + i * NWV, p = tile * 16 + n, r = p / W, y = r0 + r;
+        for (int i = 0; i < (PRE ? TPW : 1); ++i) {
+            const int tile = (wave < PWV ? wave : 0) + i * PWV, p = tile * 16 + n, r = p / W, y = r0 + r;
 #pragma unroll
             for (int jj = 0; jj < JJ; ++jj) {
                 const int c = kq + 4 * jj;
-                b[i][jj] = (tile < ntiles && c < CH && y >= 0 && y < H) ? ld4(xi + (unsigned)((y * W + (p - r * W)) * C + 4 * c)) : zero4();
+                const bool ok = c < CH && y >= 0 && y < H;
+                const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), cc = c < CH ? c : 0;
+                const f4 v = ld4(xi + (unsigned)((yc * W + (p - r * W)) * C + 4 * cc));      // unconditional load + select (see the depthwise taps)
+                b[i][jj] = ok ? v : zero4();
             }
         }
     };
-    f4 a[MT][JJ], bpre[TPW][JJ];
+    // PRE: a chain's first 1x1 takes x1 from registers filled one phase earlier (16 / 32 VGPRs); !PRE: it loads x1 in place
+    f4 a[MT][JJ], bpre[PRE ? TPW : 1][JJ];
     load_a(0, a);
-    load_x1(bpre);
+    if (PRE) load_x1(bpre);
     int layer = 0;
 #pragma unroll 1
     for (int t = 0; t < 4; ++t) {
@@ -483,17 +324,24 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
 #pragma unroll
             for (int i = 0; i < 9; ++i) k9[i] = ld4(w9l + (unsigned)(i * C + 4 * dc));
             const f4 bb = ld4(bs + layer * C + 4 * dc);
+            if (wave < PWV) {                                    // (wave-uniform: the tiles below are straight-line code, their LDS reads and MFMA chains interleave)
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) {
-                const int tile = wave + i * NWV;
-                if (tile < ntiles) {
-                    const int p = tile * 16 + n, r = p / W, y = r0 + r;
+                for (int i = 0; i < TPW; ++i) {
+                    const int p = (wave + i * PWV) * 16 + n, r = p / W, y = r0 + r;
                     const bool inimg = y >= 0 && y < H;
                     f4 b[JJ];
 #pragma unroll
                     for (int jj = 0; jj < JJ; ++jj) {
                         const int c = kq + 4 * jj;
-                        b[jj] = d == 0 ? bpre[i][jj] : (c < CH ? ld4(Q + p * PITCH + 4 * c) : zero4());
+                        const int cc = c < CH ? c : 0;
+                        if (PRE) {
+                            const f4 qv = ld4(Q + p * PITCH + 4 * cc);
+                            b[jj] = d == 0 ? bpre[i][jj] : (c < CH ? qv : zero4());
+                        } else {
+                            const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+                            const f4 v = d == 0 ? ld4(xi + (unsigned)((yc * W + (p - r * W)) * C + 4 * cc)) : ld4(Q + p * PITCH + 4 * cc);
+                            b[jj] = (c < CH && (d != 0 || inimg)) ? v : zero4();
+                        }
                     }
                     f4 acc[MT];
 #pragma unroll
@@ -515,11 +363,16 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
             // ---- depthwise phase (next 1x1 matrix / next chain's x1 tiles requested first)
             const bool last = d == t;
             if (layer < 9) load_a(layer + 1, a);
-            if (last && t < 3) load_x1(bpre);
+            if (PRE && last && t < 3) load_x1(bpre);
             f4 psa = zero4();
             {
+                // every tap is an UNCONDITIONAL load from a clamped address + a select: a conditional load is its own exec-masked
+                // branch region, and the 27 of a phase then pay their LDS latencies one after the other (first trace: 127 such regions)
                 auto ld = [&](int r, int x) -> f4 {
-                    return (r >= 0 && r < RB && x >= 0 && x < W) ? ld4(P + (r * W + x) * PITCH + 4 * dc) : zero4();
+                    const bool ok = r >= 0 && r < RB && x >= 0 && x < W;
+                    const int rc = r < 0 ? 0 : (r >= RB ? RB - 1 : r), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+                    const f4 v = ld4(P + (rc * W + xc) * PITCH + 4 * dc);
+                    return ok ? v : zero4();
                 };
                 f4 t0 = ld(dra - 1, dx - 1), t1 = ld(dra - 1, dx), t2 = ld(dra - 1, dx + 1);
                 f4 m0 = ld(dra, dx - 1), m1 = ld(dra, dx), m2 = ld(dra, dx + 1);
@@ -552,13 +405,13 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
             }
             __syncthreads();
             if (last && tid < C) {                                   // channel tid of chain t: the (wave, lane row) partials of its chunk, in order
+                const int cq = tid >> 2, j = tid & 3;
                 float sum = 0.f;
-                for (int wv = 0; wv < NWV; ++wv)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int cq = (C == 16 || wv < 8) ? q : 4 + (q & 1);
-                        if (cq == (tid >> 2)) sum += S[(wv * 4 + q) * 4 + (tid & 3)];
-                    }
+                if (C == 16 || cq < 4) {
+                    for (int wv = 0; wv < (C == 16 ? NWV : 8); ++wv) sum += S[(wv * 4 + cq) * 4 + j];
+                } else {
+                    for (int wv = 8; wv < NWV; ++wv) { sum += S[(wv * 4 + (cq - 4)) * 4 + j]; sum += S[(wv * 4 + (cq - 2)) * 4 + j]; }
+                }
                 psum[(((size_t)t * Nimg + img) * bands + band) * C + tid] = sum;
             }
         }
@@ -795,7 +648,8 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
-static int g_chains_form = 2;        // 2: k32_chains3, 1: k32_chains2, 0: k32_chains (64 x 32 and 32 x 16 maps; the 16 x 8 maps always take k32_chains)
+static int g_chains_pre = 1;          // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead (A/B)
+static int g_chains_form = 1;        // 1: k32_chains3, 0: k32_chains (64 x 32 and 32 x 16 maps; the 16 x 8 maps always take k32_chains)
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -861,34 +715,25 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
-#define CH32C(CC, WW) if (C == CC && W == WW && g_chains_form == 2 && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
+#define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
         static bool attr = false; \
-        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         const size_t lds3 = 2ull * (R + 2 * halo) * WW * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
-        hipLaunchKernelGGL((k32_chains3<CC, WW>), grid, dim3(C32_THREADS), lds3, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
+        hipLaunchKernelGGL((k32_chains3<CC, WW, PRE_>), grid, dim3(C32_THREADS), lds3, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
-    CH32C(16, 32) CH32C(24, 16)
+    CH32C(16, 32, true) CH32C(16, 32, false) CH32C(24, 16, true) CH32C(24, 16, false)
 #undef CH32C
-#define CH32B(CC, WW, NT_, RPW_) if (C == CC && W == WW && g_chains_form == 1) { \
-        const int RB_ = R + 2 * halo, TC_ = WW / 16, NWV_ = NT_ / 64; \
-        if (RB_ * TC_ == NWV_ * RPW_ && RB_ % RPW_ == 0) { \
-            static bool attr = false; \
-            if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains2<CC, WW, NT_, RPW_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
-            const size_t lds2 = 2ull * RB_ * WW * (CC + 4) * 4 + (size_t)NWV_ * CC * 4; \
-            hipLaunchKernelGGL((k32_chains2<CC, WW, NT_, RPW_>), grid, dim3(NT_), lds2, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
-            OP32_CHECK(); return SS_OK; } }
-    CH32B(16, 32, 768, 4) CH32B(24, 16, 512, 4)
-#undef CH32B
     CH32(16, 32) CH32(24, 16) CH32(32, 8)
 #undef CH32
     return SS_ERR_INVALID;
 }
 
-// A/B switch (tests, measurements): "chains_form" 2 = k32_chains3 where it applies (default), 1 = k32_chains2, 0 = k32_chains everywhere
+// A/B switch (tests, measurements): "chains_form" 1 = k32_chains3 where it applies (default), 0 = k32_chains everywhere
 extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
-    if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
+    if (!strcmp(name, "chains_pre")) { g_chains_pre = value != 0; return SS_OK; }
+    if (!strcmp(name, "chains_form")) { if (value < 0 || value > 1) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
 

@@ -4,6 +4,8 @@ usage: python tools/osnet32_time.py [reps=20] [crops=1024] [eager_pass=0|1: one 
 import os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd import nets, fused32
+if "SS32_CHAINS_PRE" in os.environ:
+    fused32.set_option("chains_pre", int(os.environ["SS32_CHAINS_PRE"]))
 if "SS32_CHAINS_FORM" in os.environ:
     fused32.set_option("chains_form", int(os.environ["SS32_CHAINS_FORM"]))
 dev = torch.device("cuda", 0)
@@ -34,7 +36,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps
 
 
-out = {"crops": N, "chains_form": os.environ.get("SS32_CHAINS_FORM", "1"), "osnet_fp32_own_kernels_ms": round(timed(lambda: r32(c32)), 4)}
+out = {"crops": N, "chains_form": os.environ.get("SS32_CHAINS_FORM", "1"), "chains_pre": os.environ.get("SS32_CHAINS_PRE", "1"), "osnet_fp32_own_kernels_ms": round(timed(lambda: r32(c32)), 4)}
 fused32.ENABLED = False
 out["osnet_fp32_library_ms"] = round(timed(lambda: r32(c32)), 4)
 fused32.ENABLED = True
