@@ -377,8 +377,24 @@ class YOLO:
         return [Results(image, self.names, Boxes(rows[:, :4], rows[:, 6], rows[:, 5], rows[:, 4]),
                         None if kpts is None else Keypoints(kpts[di]), None if masks is None else masks[di])]
 
+    TRACKERS = ("strongsort.yaml", "strongsort", "botsort.yaml", "bytetrack.yaml")
+
+    def _check_tracker(self, tracker):
+        """`tracker=`: this library has ONE tracker, StrongSORT (BASELINE north_star).  The reference passes "botsort.yaml"
+        (yolo_multi_model.py:41) — the Ultralytics tracker configurations are accepted and answered by StrongSORT, once with a
+        warning that says so; any other value is an error instead of being ignored."""
+        name = os.path.basename(str(tracker))
+        if name not in self.TRACKERS:
+            raise ValueError(f"tracker={tracker!r}: this library tracks with StrongSORT only (accepted: {', '.join(self.TRACKERS)})")
+        if not name.startswith("strongsort") and not getattr(self, "_tracker_warned", False):
+            import warnings
+            self._tracker_warned = True
+            warnings.warn(f"tracker={tracker!r} is an Ultralytics configuration; tracking runs StrongSORT (OSNet-x0.25 appearance + NSA Kalman), "
+                          f"its parameters are strongsort_yolo_amd.config.StrongSortConfig", RuntimeWarning, stacklevel=3)
+
     @torch.no_grad()
     def track(self, image, verbose=False, device=0, persist=True, tracker="strongsort.yaml", **kw) -> List[Results]:
+        self._check_tracker(tracker)
         if not persist and self._pipe is not None:
             self._pipe.eng.reset(-1)
         return self._run(image, device, True)

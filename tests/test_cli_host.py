@@ -133,3 +133,22 @@ def test_result_rows_index_like_tensors():
         b[3]
     with pytest.raises(IndexError):
         b[-4]
+
+
+def test_tracker_argument_is_checked_not_ignored():
+    """`tracker=` (yolo_multi_model.py:41 passes "botsort.yaml"): Ultralytics configurations are answered by StrongSORT with one
+    warning, anything else raises; the CLI's default weights are the reference's (`:17`)."""
+    import warnings
+    import pytest
+    from strongsort_yolo_amd import cli
+    from strongsort_yolo_amd.yolo import YOLO
+    assert cli.DEFAULT_WEIGHTS == "yolo11n-pose.pt"
+    m = YOLO("yolov8n.pt", random_init_ok=True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m._check_tracker("botsort.yaml")
+        m._check_tracker("botsort.yaml")
+        m._check_tracker("strongsort.yaml")
+    assert len([x for x in w if issubclass(x.category, RuntimeWarning)]) == 1
+    with pytest.raises(ValueError):
+        m._check_tracker("deepsort.yaml")

@@ -24,13 +24,13 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if not k.startswith("k_"): continue
+        if not k.startswith("k"): continue
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = {}
 for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Name"].split("(")[0].replace("void ", "")
-        if k.startswith("k_"): dur[k] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]), float(r["Percentage"]))
+        if k.startswith("k"): dur[k] = (float(r["AverageNs"]) / 1e3, int(r["Calls"]), float(r["Percentage"]))
 res = {}
 for k, c in agg.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
