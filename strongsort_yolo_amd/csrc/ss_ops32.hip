@@ -32,6 +32,8 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define MFMA4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// workgroup barrier that orders LDS traffic only: global loads requested for a later phase stay in flight across it
+#define LDS_BARRIER32() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 static __device__ __forceinline__ f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 static __device__ __forceinline__ void st4(float* p, const f4 v) { *reinterpret_cast<f4*>(p) = v; }
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
                     }
                 }
             }
-            __syncthreads();
+            LDS_BARRIER32();
             // ---- depthwise phase (next 1x1 matrix / next chain's x1 tiles requested first)
             const bool last = d == t;
             if (layer < 9) load_a(layer + 1, a);
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
                 }
                 if (n == 0) st4(S + (wave * 4 + kq) * 4, psa);
             }
-            __syncthreads();
+            LDS_BARRIER32();
             if (last && tid < C) {                                   // channel tid of chain t: the (wave, lane row) partials of its chunk, in order
                 const int cq = tid >> 2, j = tid & 3;
                 float sum = 0.f;
