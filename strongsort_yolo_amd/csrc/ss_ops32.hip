@@ -274,8 +274,11 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
     const int img = blockIdx.y, band = blockIdx.x, bands = gridDim.x;
     if (n_img && img >= *n_img) return;
     const int RB = R + 2 * HALO, r0 = band * R - HALO;          // image row of LDS row 0 (host: RB == 24 for C 16, 32 for C 24)
-    float* __restrict__ P = smem32;
-    float* __restrict__ Q = P + RB * W * PITCH;
+    // P carries a one-pixel ZERO border (rows -1 and RB, columns -1 and W): the nine taps of a pixel are nine plain loads at
+    // immediate offsets from one lane base — no bounds test, no clamp, no select (they were 60 % of the kernel's vector instructions)
+    constexpr int PW = W + 2;
+    float* __restrict__ P = smem32;                             // [(RB + 2)][W + 2][PITCH]
+    float* __restrict__ Q = P + (RB + 2) * PW * PITCH;          // [RB][W][PITCH]
     float* __restrict__ S = Q + RB * W * PITCH;                 // [NWV][4 lane rows][4] partial channel sums
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
     // depthwise unit of this lane: chunk dc of column dx, rows dra .. dra + 3
@@ -314,6 +317,8 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
     f4 a[MT][JJ], bpre[PRE ? TPW : 1][JJ];
     load_a(0, a);
     if (PRE) load_x1(bpre);
+    for (int i = threadIdx.x; i < (RB + 2) * PW * PITCH / 4; i += C32_THREADS) st4(P + 4 * i, zero4());     // the border (the interior is rewritten)
+    LDS_BARRIER32();
     int layer = 0;
 #pragma unroll 1
     for (int t = 0; t < 4; ++t) {
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int co = 4 * mt + kq;
-                        if (co < CH) st4(P + p * PITCH + 4 * co, inimg ? acc[mt] : zero4());
+                        if (co < CH) st4(P + ((r + 1) * PW + (p - r * W) + 1) * PITCH + 4 * co, inimg ? acc[mt] : zero4());
                     }
                 }
             }
@@ -368,20 +373,14 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
             if (PRE && last && t < 3) load_x1(bpre);
             f4 psa = zero4();
             {
-                // every tap is an UNCONDITIONAL load from a clamped address + a select: a conditional load is its own exec-masked
-                // branch region, and the 27 of a phase then pay their LDS latencies one after the other (first trace: 127 such regions)
-                auto ld = [&](int r, int x) -> f4 {
-                    const bool ok = r >= 0 && r < RB && x >= 0 && x < W;
-                    const int rc = r < 0 ? 0 : (r >= RB ? RB - 1 : r), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
-                    const f4 v = ld4(P + (rc * W + xc) * PITCH + 4 * dc);
-                    return ok ? v : zero4();
-                };
-                f4 t0 = ld(dra - 1, dx - 1), t1 = ld(dra - 1, dx), t2 = ld(dra - 1, dx + 1);
-                f4 m0 = ld(dra, dx - 1), m1 = ld(dra, dx), m2 = ld(dra, dx + 1);
+                const float* __restrict__ pb = P + (dra * PW + dx) * PITCH + 4 * dc;        // tap (row dra - 1, column dx - 1)
+                auto ld = [&](int i, int j) -> f4 { return ld4(pb + (i * PW + j) * PITCH); };
+                f4 t0 = ld(0, 0), t1 = ld(0, 1), t2 = ld(0, 2);
+                f4 m0 = ld(1, 0), m1 = ld(1, 1), m2 = ld(1, 2);
 #pragma unroll
                 for (int i = 0; i < RPG; ++i) {
                     const int r = dra + i;
-                    const f4 b0 = ld(r + 1, dx - 1), b1 = ld(r + 1, dx), b2 = ld(r + 1, dx + 1);
+                    const f4 b0 = ld(i + 2, 0), b1 = ld(i + 2, 1), b2 = ld(i + 2, 2);
                     f4 o = bb;
                     o = fma4(k9[0], t0, o); o = fma4(k9[1], t1, o); o = fma4(k9[2], t2, o);
                     o = fma4(k9[3], m0, o); o = fma4(k9[4], m1, o); o = fma4(k9[5], m2, o);
@@ -720,7 +719,7 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
 #define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
         static bool attr = false; \
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
-        const size_t lds3 = 2ull * (R + 2 * halo) * WW * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
+        const size_t lds3 = ((size_t)(R + 2 * halo + 2) * (WW + 2) + (size_t)(R + 2 * halo) * WW) * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
         hipLaunchKernelGGL((k32_chains3<CC, WW, PRE_>), grid, dim3(C32_THREADS), lds3, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
     CH32C(16, 32, true) CH32C(16, 32, false) CH32C(24, 16, true) CH32C(24, 16, false)
