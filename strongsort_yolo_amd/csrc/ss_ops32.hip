@@ -649,7 +649,8 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
-static int g_chains_pre = 1;          // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead (A/B)
+static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
+                                      // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
 static int g_chains_form = 1;        // 1: k32_chains3, 0: k32_chains (64 x 32 and 32 x 16 maps; the 16 x 8 maps always take k32_chains)
 
 template <int K, int N>
@@ -716,7 +717,7 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
-#define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
+#define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre < 0 ? CC == 16 : g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
         static bool attr = false; \
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
         const size_t lds3 = ((size_t)(R + 2 * halo + 2) * (WW + 2) + (size_t)(R + 2 * halo) * WW) * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
@@ -733,7 +734,7 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
 extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
-    if (!strcmp(name, "chains_pre")) { g_chains_pre = value != 0; return SS_OK; }
+    if (!strcmp(name, "chains_pre")) { g_chains_pre = value < 0 ? -1 : (value != 0); return SS_OK; }
     if (!strcmp(name, "chains_form")) { if (value < 0 || value > 1) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
