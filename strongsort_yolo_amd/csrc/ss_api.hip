@@ -176,12 +176,13 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     d.S = (int)S;
     d.budget = cfg->nn_budget;
     d.cap_cost = SS_COST_CAP; d.cap_t = SS_MAXT; d.cap_d = SS_MAXD;
+    d.chain_merge = 1;
     int rc = SS_OK;
 #define A(field, n) if (rc == SS_OK) rc = dalloc(c, &d.field, (n))
     A(n_tracks, S); A(next_id, S); A(frame, S); A(err, S); A(order, S * T);
     A(slot_used, S * T); A(track_id, S * T); A(state, S * T); A(hits, S * T); A(age, S * T); A(tsu, S * T);
     A(class_id, S * T); A(det_idx, S * T); A(gal_count, S * T); A(gal_head, S * T); A(conf, S * T);
-    A(mean, S * T * 8); A(cov, S * T * 64); A(smooth, S * T * SS_F);
+    A(mean, S * T * 8); A(cov, S * T * 64); A(smooth, S * T * 2 * SS_F); A(smooth_sel, S * T);
     A(gallery, S * T * SS_NRT * SS_TILE_FLOATS);
     const size_t FM = SS_FMAX;
     A(feat_unit, FM * S * D * SS_F); A(feat_frag, FM * S * SS_NCT * SS_TILE_FLOATS);
@@ -557,6 +558,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     else if (n == "nms_fused") ss_nms_fused = value != 0;       // process-wide: one workgroup per image after the filter (1, default) or sort / mask / scan launches
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
+    else if (n == "chain_merge") c->dev.chain_merge = value != 0;       // k_post + k_newrow of a frame as one launch (default) / two launches
     else if (n == "frame_caps") {
         // value = tracks and detections k_frame keeps in LDS (cost entries = value^2): 0 restores the maxima (256 tracks, 128 detections, 12288 entries)
         // (112 is the largest square that fits: 128 x 128 cost entries + the per-track areas would be 173 KB of LDS, past the CU's 160)
@@ -820,7 +822,11 @@ extern "C" int ss_get_tracks(ss_ctx* c, int s, int cap, int* n_tracks, int* next
         const size_t g = sb + order[i];
         if (mean) HIPCHK(c, hipMemcpy(mean + (size_t)i * 8, d.mean + g * 8, 64, hipMemcpyDeviceToHost));
         if (cov) HIPCHK(c, hipMemcpy(cov + (size_t)i * 64, d.cov + g * 64, 512, hipMemcpyDeviceToHost));
-        if (smooth) HIPCHK(c, hipMemcpy(smooth + (size_t)i * SS_F, d.smooth + g * SS_F, SS_F * 4, hipMemcpyDeviceToHost));
+        if (smooth) {
+            int sel = 0;
+            HIPCHK(c, hipMemcpy(&sel, d.smooth_sel + g, 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(smooth + (size_t)i * SS_F, d.smooth + (g * 2 + (sel & 1)) * SS_F, SS_F * 4, hipMemcpyDeviceToHost));
+        }
     }
     return SS_OK;
 }

@@ -68,7 +68,9 @@ struct SSDev {
     int *slot_used, *track_id, *state, *hits, *age, *tsu, *class_id, *det_idx, *gal_count, *gal_head;
     float* conf;
     double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]
-    float* smooth;              // [S][MAXT][512]
+    float* smooth;              // [S][MAXT][2][512] EMA feature, double-buffered: the row in use is [smooth_sel]; an update reads it and
+                                //   writes the other half, so the new-row units of the SAME launch (k_postnew) can still read the old one
+    int* smooth_sel;            // [S][MAXT] 0 / 1
     float* gallery;             // [S][MAXT][NRT][TILE_FLOATS]  fragment-major ring of nn_budget rows
     // group inputs / outputs (caller's buffers)
     const float* dets;          // [F][S][MAXD][6]
@@ -95,7 +97,9 @@ struct SSDev {
     // per-frame hand-off k_frame -> k_post -> k_newrow
     int4* post;                 // [S][MAXT] surviving tracks in list order {slot, det or -1, flags, aux}
     int* n_post;                // [S]
-    int* rowlist;               // [S][MAXT] slot | first_row<<16 of every gallery row appended this frame
+    int* rowlist;               // [S][MAXT] every gallery row appended this frame: slot | first_row<<16 | smooth_sel at frame start<<17 |
+                                //   matched<<18 | matched detection<<19 (the row = EMA(smooth[sel], feature of that detection), or smooth[sel] itself)
+    int chain_merge;            // 1: k_post and k_newrow of a frame as ONE launch (k_postnew), 0: two launches (A/B, ss_set_option "chain_merge")
     int* n_rows;                // [S]
     const double* cmc;          // [F][S][8] camera-motion warps of the group (ss_track_set_cmc) or NULL
     double* cost_spill;         // [S][MAXT*MAXD] cost matrices that do not fit the LDS

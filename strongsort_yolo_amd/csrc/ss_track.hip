@@ -1309,7 +1309,8 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         if (emit) { fl |= SS_P_EMIT; aux |= epos << 8; }
         m.neworder[pos] = myslot;
         dev.post[sb + pos] = make_int4(myslot, md, fl, aux);
-        if (doapp) dev.rowlist[sb + apos] = myslot | ((fl & SS_P_FIRSTROW) ? 1 << 16 : 0);
+        if (doapp) dev.rowlist[sb + apos] = myslot | ((fl & SS_P_FIRSTROW) ? 1 << 16 : 0) | ((dev.smooth_sel[sb + myslot] & 1) << 17) |
+                                           ((fl & SS_P_MATCHED) ? (1 << 18) | (md << 19) : 0);
     }
     // births: unmatched detections in ascending index take the free slots in ascending order
     int nNew, nFree, rank;
@@ -1347,95 +1348,134 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
 // NSA Kalman update across the wave's 64 lanes (one covariance entry each), EMA feature, Kalman initiation of new
 // tracks, gallery append (fragment-major) and the output row.  grid = (streams, SS_POST_BLOCKS).
 #define SS_POST_BLOCKS 16
+// one surviving / new track, by one wave (ws: 72 doubles, rowbuf: 512 floats of this wave)
+__device__ __forceinline__ void post_track(const SSDev& dev, const SSParams& prm, int s, int f, int k, double* ws, float* rowbuf)
+{
+    const int l = threadIdx.x & 63, S = dev.S;
+    const size_t sb = (size_t)s * SS_MAXT;
+    const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;
+    const int4 e = dev.post[sb + k];
+    const int slot = __builtin_amdgcn_readfirstlane(e.x), d = __builtin_amdgcn_readfirstlane(e.y);
+    const int fl = __builtin_amdgcn_readfirstlane(e.z), aux = __builtin_amdgcn_readfirstlane(e.w);
+    const size_t g = sb + slot;
+    const int sel = __builtin_amdgcn_readfirstlane(dev.smooth_sel[g]) & 1;
+    const float* sm = dev.smooth + (g * 2 + sel) * SS_F;          // the EMA row in use
+    const float* src = sm;                                        // the row a confirmed track appends
+    if (fl & SS_P_MATCHED) {
+        const double* zz = dev.xyah + (fb + d) * 4;
+        const double z[4] = { zz[0], zz[1], zz[2], zz[3] };
+        const float* fu = dev.feat_unit + (fb + d) * SS_F;
+        float sv[8], fv[8];                                       // EMA operands on the wire before the Kalman arithmetic
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sv[j] = sm[l + 64 * j]; fv[j] = fu[l + 64 * j]; }
+        ss_kf_update_wave(dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws);
+        ema_regs(sv, fv, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf);
+        SS_WAVE_SYNC();
+        // the new row goes to the OTHER half: new-row units of this launch (k_postnew) may still be reading the old one
+        float* sn = dev.smooth + (g * 2 + (sel ^ 1)) * SS_F;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sn[l + 64 * j] = rowbuf[l + 64 * j];
+        if (l == 0) dev.smooth_sel[g] = sel ^ 1;
+        src = rowbuf;
+    } else if (fl & SS_P_BIRTH) {
+        const double* zz = dev.xyah + (fb + d) * 4;
+        const double h = zz[3];
+        const int r = l >> 3, c = l & 7;
+        // ss_kf_initiate, one covariance entry per lane
+        const double sd = (r == 2) ? 1e-2 : (r == 6) ? 1e-5 : (r < 4) ? 2.0 * prm.wp * h : 10.0 * prm.wv * h;
+        dev.cov[g * 64 + l] = (r == c) ? sd * sd : 0.0;
+        if (l < 8) dev.mean[g * 8 + l] = (l < 4) ? zz[l] : 0.0;
+        const float* fu = dev.feat_unit + (fb + d) * SS_F;
+        float* sw = dev.smooth + (g * 2 + sel) * SS_F;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sw[l + 64 * j] = fu[l + 64 * j];
+    }
+    if (fl & SS_P_APPEND) gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, aux & 0xff, src);
+    if ((fl & SS_P_EMIT) && l == 0) {
+        double mm[4];
+        if (fl & SS_P_MATCHED) { mm[0] = ws[64]; mm[1] = ws[65]; mm[2] = ws[66]; mm[3] = ws[67]; }
+        else { const double* gm = dev.mean + g * 8; mm[0] = gm[0]; mm[1] = gm[1]; mm[2] = gm[2]; mm[3] = gm[3]; }
+        const double wd = mm[2] * mm[3];
+        const double x = mm[0] - wd / 2, y = mm[1] - mm[3] / 2;
+        const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];
+        const int x1 = max((int)x, 0), y1 = max((int)y, 0);
+        const int x2 = min((int)(x + wd), W - 1), y2 = min((int)(y + mm[3]), H - 1);
+        float* o = dev.out_rows + (fs * SS_MAXT + (aux >> 8)) * 8;
+        o[0] = (float)x1; o[1] = (float)y1; o[2] = (float)x2; o[3] = (float)y2;
+        o[4] = (float)dev.track_id[g]; o[5] = (float)dev.class_id[g]; o[6] = dev.conf[g];
+        o[7] = (float)dev.det_idx[g];
+    }
+    SS_WAVE_SYNC();                                               // rowbuf / ws are reused by the next track
+}
+
 __global__ __launch_bounds__(256) void k_post(SSDev dev, SSParams prm, int f)
 {
     __shared__ double ws[4][72];
     __shared__ __attribute__((aligned(16))) float rowbuf[4][SS_F];
-    const int s = blockIdx.x, w = threadIdx.x >> 6, l = threadIdx.x & 63, S = dev.S;
-    const size_t sb = (size_t)s * SS_MAXT;
-    const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;
+    const int s = blockIdx.x, w = threadIdx.x >> 6;
     const int n = dev.n_post[s];
-    for (int k = blockIdx.y * 4 + w; k < n; k += gridDim.y * 4) {
-        const int4 e = dev.post[sb + k];
-        const int slot = __builtin_amdgcn_readfirstlane(e.x), d = __builtin_amdgcn_readfirstlane(e.y);
-        const int fl = __builtin_amdgcn_readfirstlane(e.z), aux = __builtin_amdgcn_readfirstlane(e.w);
-        const size_t g = sb + slot;
-        float* sm = dev.smooth + g * SS_F;
-        const float* src = sm;                                        // the row a confirmed track appends
-        if (fl & SS_P_MATCHED) {
-            const double* zz = dev.xyah + (fb + d) * 4;
-            const double z[4] = { zz[0], zz[1], zz[2], zz[3] };
-            const float* fu = dev.feat_unit + (fb + d) * SS_F;
-            float sv[8], fv[8];                                       // EMA operands on the wire before the Kalman arithmetic
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { sv[j] = sm[l + 64 * j]; fv[j] = fu[l + 64 * j]; }
-            ss_kf_update_wave(dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws[w]);
-            ema_regs(sv, fv, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf[w]);
-            SS_WAVE_SYNC();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sm[l + 64 * j] = rowbuf[w][l + 64 * j];
-            src = rowbuf[w];
-        } else if (fl & SS_P_BIRTH) {
-            const double* zz = dev.xyah + (fb + d) * 4;
-            const double h = zz[3];
-            const int r = l >> 3, c = l & 7;
-            // ss_kf_initiate, one covariance entry per lane
-            const double sd = (r == 2) ? 1e-2 : (r == 6) ? 1e-5 : (r < 4) ? 2.0 * prm.wp * h : 10.0 * prm.wv * h;
-            dev.cov[g * 64 + l] = (r == c) ? sd * sd : 0.0;
-            if (l < 8) dev.mean[g * 8 + l] = (l < 4) ? zz[l] : 0.0;
-            const float* fu = dev.feat_unit + (fb + d) * SS_F;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sm[l + 64 * j] = fu[l + 64 * j];
-        }
-        if (fl & SS_P_APPEND) gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, aux & 0xff, src);
-        if ((fl & SS_P_EMIT) && l == 0) {
-            double mm[4];
-            if (fl & SS_P_MATCHED) { mm[0] = ws[w][64]; mm[1] = ws[w][65]; mm[2] = ws[w][66]; mm[3] = ws[w][67]; }
-            else { const double* gm = dev.mean + g * 8; mm[0] = gm[0]; mm[1] = gm[1]; mm[2] = gm[2]; mm[3] = gm[3]; }
-            const double wd = mm[2] * mm[3];
-            const double x = mm[0] - wd / 2, y = mm[1] - mm[3] / 2;
-            const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];
-            const int x1 = max((int)x, 0), y1 = max((int)y, 0);
-            const int x2 = min((int)(x + wd), W - 1), y2 = min((int)(y + mm[3]), H - 1);
-            float* o = dev.out_rows + (fs * SS_MAXT + (aux >> 8)) * 8;
-            o[0] = (float)x1; o[1] = (float)y1; o[2] = (float)x2; o[3] = (float)y2;
-            o[4] = (float)dev.track_id[g]; o[5] = (float)dev.class_id[g]; o[6] = dev.conf[g];
-            o[7] = (float)dev.det_idx[g];
-        }
-        SS_WAVE_SYNC();                                               // rowbuf / ws are reused by the next track
-    }
+    for (int k = blockIdx.y * 4 + w; k < n; k += gridDim.y * 4) post_track(dev, prm, s, f, k, ws[w], rowbuf[w]);
 }
 
 // =================================================================================================
 // k_newrow — distances of the gallery rows appended in frame f to the detections of the later frames of the group
 // =================================================================================================
 // Unit = (16 appended rows = 16 tracks, pair of column tiles of a frame f2 > f): the k-split MFMA form
-// (cosine_dots), A gathered straight from the row-major EMA features.  Every (track, detection) entry is kept:
+// (cosine_dots), A gathered from the 16 rows' EMA features.  Every (track, detection) entry is kept:
 // M[slot][f2][d] = min(M, 1 - dot), or just 1 - dot for a gallery's first row.
-__global__ __launch_bounds__(512) void k_newrow(SSDev dev, int f)
+// OWN_ROWS (k_postnew: the update of the same frame runs beside this unit): the 16 rows are computed HERE, from the row list's
+// (smooth half at frame start, matched detection) — the same ema_regs arithmetic on the same operands as post_track — into LDS;
+// !OWN_ROWS (k_newrow after k_post): they are read from the half post_track wrote.
+template <bool OWN_ROWS>
+__device__ __forceinline__ void newrow_units(const SSDev& dev, const SSParams& prm, int s, int f, int u0, int ustep, float* lds_part /*[2*8*4*64]*/,
+                                             int* s_slot /*[16]*/, float* rows /*[16][SS_F], OWN_ROWS*/)
 {
-    __shared__ float lds_part[2 * 8 * 4 * 64];
-    __shared__ int s_slot[16];
     const int S = dev.S, w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int s = blockIdx.y;                                            // grid = (units in flight per stream, streams)
     const int nrt = (dev.n_rows[s] + 15) / 16;
     const int p0 = dev.pf[s * (SS_FMAX + 1) + f + 1], np = dev.n_pl[s] - p0;
-    for (int u = blockIdx.x; u < nrt * np; u += gridDim.x) {
+    const size_t sb = (size_t)s * SS_MAXT, fb = ((size_t)f * S + s) * SS_MAXD;
+    int have = -1;                                                       // row tile whose rows are in `rows`
+    for (int u = u0; u < nrt * np; u += ustep) {
         const int rti = u / np, p = p0 + u % np;                         // row tile major, pair fastest
-        const size_t sb = (size_t)s * SS_MAXT;
         const int2 pr = dev.pl[(size_t)s * SS_PLMAX + p];
         const int f2 = pr.x, ct0 = pr.y & 0xff, D2 = pr.y >> 16;
         const bool two = (pr.y >> 8) & 1;
         const int nrow = min(16, dev.n_rows[s] - rti * 16);
-        __syncthreads();                                              // the previous unit is done with s_slot / lds_part
+        __syncthreads();                                              // the previous unit is done with s_slot / lds_part / rows
         if (threadIdx.x < 16) s_slot[threadIdx.x] = (int)threadIdx.x < nrow ? dev.rowlist[sb + rti * 16 + threadIdx.x] : -1;
         __syncthreads();
+        if (OWN_ROWS && have != rti) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                              // wave w: rows 2w, 2w + 1
+                const int i = 2 * w + q, e = s_slot[i];
+                float* out = rows + i * SS_F;
+                if (e >= 0) {
+                    const float* sm = dev.smooth + ((sb + (e & 0xffff)) * 2 + ((e >> 17) & 1)) * SS_F;
+                    float sv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sv[j] = sm[l + 64 * j];
+                    if ((e >> 18) & 1) {
+                        const float* fu = dev.feat_unit + (fb + ((e >> 19) & 0x7f)) * SS_F;
+                        float fv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) fv[j] = fu[l + 64 * j];
+                        ema_regs(sv, fv, prm.ema_alpha, prm.ema_one_minus_alpha, out);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) out[l + 64 * j] = sv[j];
+                    }
+                }
+            }
+            have = rti;
+            __syncthreads();
+        }
         // A: element k = 16(4w+j) + 4c + ks of row i, lane = ks*16 + i (the fragment-major float4 #((4w+j)*64 + lane))
         const int i = l & 15, ks = l >> 4;
         const int si = s_slot[i];
         float4 a[4];
         if (si >= 0) {
-            const float* row = dev.smooth + (sb + (si & 0xffff)) * SS_F + ks;
+            const float* row = OWN_ROWS ? rows + i * SS_F + ks
+                                        : dev.smooth + ((sb + (si & 0xffff)) * 2 + (dev.smooth_sel[sb + (si & 0xffff)] & 1)) * SS_F + ks;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float* q = row + 16 * (4 * w + j);
@@ -1454,9 +1494,37 @@ __global__ __launch_bounds__(512) void k_newrow(SSDev dev, int f)
             const int sl = s_slot[row];
             int* mp = dev.M + ((sb + (sl & 0xffff)) * SS_FMAX + f2) * SS_MAXD + d;
             const int key = ss_fkey(1.0f - tot);
-            *mp = (sl >> 16) ? key : min(*mp, key);
+            *mp = ((sl >> 16) & 1) ? key : min(*mp, key);
         }
     }
+}
+
+__global__ __launch_bounds__(512) void k_newrow(SSDev dev, SSParams prm, int f)
+{
+    __shared__ float lds_part[2 * 8 * 4 * 64];
+    __shared__ int s_slot[16];
+    newrow_units<false>(dev, prm, blockIdx.y, f, blockIdx.x, gridDim.x, lds_part, s_slot, nullptr);
+}
+
+// k_post and k_newrow of a frame in ONE launch (the chain of a group is 2 F dependent launches instead of 3 F - 1): workgroups
+// 0 .. SS_PN_POST - 1 of a stream run post_track (8 waves each), the others the new-row units, which do not wait for them:
+// they compute the rows they need themselves from the half of `smooth` that this launch does not write.
+#define SS_PN_POST 8
+#define SS_PN_NEW 64
+__global__ __launch_bounds__(512) void k_postnew(SSDev dev, SSParams prm, int f, int with_new)
+{
+    __shared__ __attribute__((aligned(16))) float pn_lds[2 * 8 * 4 * 64 + 16 * SS_F];      // new-row role: partial sums + the 16 rows; post role: ws + row buffers
+    __shared__ int s_slot[16];
+    const int s = blockIdx.y;
+    if (blockIdx.x < SS_PN_POST) {
+        const int w = threadIdx.x >> 6, n = dev.n_post[s];
+        double* ws = reinterpret_cast<double*>(pn_lds) + w * 72;                           // 8 x 72 doubles = 4608 B
+        float* rowbuf = pn_lds + 8 * 72 * 2 + w * SS_F;
+        for (int k = blockIdx.x * 8 + w; k < n; k += SS_PN_POST * 8) post_track(dev, prm, s, f, k, ws, rowbuf);
+        return;
+    }
+    if (!with_new) return;
+    newrow_units<true>(dev, prm, s, f, blockIdx.x - SS_PN_POST, SS_PN_NEW, pn_lds, s_slot, pn_lds + 2 * 8 * 4 * 64);
 }
 
 // =================================================================================================
@@ -1611,8 +1679,13 @@ void ss_launch_group_chain(const SSDev& dev, const SSParams& prm, hipStream_t st
 {
     for (int f = 0; f < dev.F; ++f) {
         hipLaunchKernelGGL(k_frame, dim3(dev.S), dim3(256), ss_frame_lds_bytes(dev.cap_cost, dev.cap_t, dev.cap_d), st, dev, prm, f);
-        hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);
-        if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(64, dev.S), dim3(512), 0, st, dev, f);
+        if (dev.chain_merge) {
+            const int with_new = f + 1 < dev.F;
+            hipLaunchKernelGGL(k_postnew, dim3(SS_PN_POST + (with_new ? SS_PN_NEW : 0), dev.S), dim3(512), 0, st, dev, prm, f, with_new);
+        } else {
+            hipLaunchKernelGGL(k_post, dim3(dev.S, SS_POST_BLOCKS), dim3(256), 0, st, dev, prm, f);
+            if (f + 1 < dev.F) hipLaunchKernelGGL(k_newrow, dim3(64, dev.S), dim3(512), 0, st, dev, prm, f);
+        }
     }
 }
 

@@ -171,12 +171,33 @@ def test_assoc_operand_staging_variants(stage, S, F, frames, ids):
     _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + s), frames, F=F, wh=wh, opts={"assoc_stage": stage % 100, "assoc_xcd_map": stage // 100})
 
 
-@pytest.mark.parametrize("caps,ids,wh", [(32, 30, (1280, 720)), (16, 30, (1280, 720)), (64, 100, (1920, 1080)), (0, 100, (1920, 1080)), (32, 12, (640, 480))])
+def test_frame_caps_beyond_the_lds_are_rejected():
+    """128 x 128 cost entries + the per-track areas would need 173 KB of LDS: the option refuses it (112 is the largest that fits)."""
+    from strongsort_yolo_amd.lib import SSError
+    eng = engine(StrongSortConfig())
+    with pytest.raises(SSError):
+        eng.set_option("frame_caps", 128)
+    eng.set_option("frame_caps", 112)
+    eng.close()
+
+
+@pytest.mark.parametrize("caps,ids,wh", [(32, 30, (1280, 720)), (16, 30, (1280, 720)), (64, 100, (1920, 1080)), (0, 100, (1920, 1080)), (32, 12, (640, 480)),
+                                         (112, 100, (1920, 1080))])
 def test_frame_kernel_work_areas_in_lds_or_global_scratch(caps, ids, wh):
     """`frame_caps`: k_frame keeps its f64 work arrays (Cholesky factors, predicted boxes, detection vectors, cost matrix) in LDS up to
     that many tracks / detections and takes them from the stream's global scratch beyond — 30 and 100 identities against caps of 16,
     32, 64 and the maxima: tracks over, detections over, cost matrix spilled, everything inside; every frame and intermediate equal."""
     _run_streams(2, lambda s: ids + 2 * s, 45, F=5, wh=wh, opts={"frame_caps": caps})
+
+
+@pytest.mark.parametrize("merge", [1, 0])
+@pytest.mark.parametrize("S,F,frames,ids", [(1, 32, 150, 30), (3, 8, 64, 12), (2, 5, 45, 100)])
+def test_post_and_newrow_as_one_launch_or_two(merge, S, F, frames, ids):
+    """k_postnew (the update of a frame and the distances of its new gallery rows in ONE launch, the rows recomputed by the
+    new-row units from the double-buffered EMA feature) against the two-launch form: both equal the oracle in every intermediate;
+    incl. (100, 100) shapes and groups where tracks are confirmed / die inside the group."""
+    wh = (1920, 1080) if ids >= 100 else (1280, 720)
+    _run_streams(S, lambda s: ids + 3 * s, frames, F=F, wh=wh, opts={"chain_merge": merge}, stream_kw=dict(p_vanish=0.05, vanish_max=6))
 
 
 @pytest.mark.parametrize("graph", [1, 0])
