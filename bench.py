@@ -495,7 +495,9 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
         p.detector.load_state_dict(det32.state_dict())
         fused.clear_prepared(p.detector)
     st = make_stream(2025, W, H, n_ids)
-    same = same_set = sym = common = n16 = n32 = 0
+    from oracle import cexact
+    same = same_set = sym = common = n16 = n32 = cpu_same = 0
+    cpu_frames = min(8, frames)
     dbox = dconf = 0.0
     dboxes, dconfs = [], []
     first_diff = None
@@ -510,6 +512,11 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
                 n = int(p.ndets[0].item())
                 got.append((p.keep[0, :n].cpu().numpy().copy(), p.dets[0, :n, :6].cpu().numpy().copy()))
             (k16, r16), (k32, r32) = got
+            if k < cpu_frames:                              # the fp32 side against the CPU network + the oracle's NMS (the reference-style path)
+                pc = det32(p32.lb.float().cpu().contiguous())
+                pc = (pc[0] if isinstance(pc, tuple) else pc)[0, :4 + nc].numpy()
+                kc, _ = cexact.nms(pc, nc, dcfg.conf, dcfg.iou, dcfg.agnostic_nms, dcfg.max_wh, dcfg.max_nms, p32.max_det)
+                cpu_same += int(len(kc) == len(k32) and bool((np.asarray(kc) == k32).all()))
             n16 += len(k16); n32 += len(k32)
             eq = len(k16) == len(k32) and bool((k16 == k32).all())
             same += eq
@@ -532,7 +539,7 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
             "box_delta_px_p50_p95": [round(float(np.percentile(dboxes, q)), 4) for q in (50, 95)] if dboxes else None,
             "conf_delta_p50_p95": [round(float(np.percentile(dconfs, q)), 6) for q in (50, 95)] if dconfs else None,
             "anchors_in_both_within_1px": round(float(np.mean(np.array(dboxes) <= 1.0)), 4) if dboxes else None,
-            "first_frame_with_different_lists": first_diff, "class_bias_shift": round(shift, 4), "target_kept_per_frame": target,
+            "first_frame_with_different_lists": first_diff, "fp32_gpu_vs_cpu_fp32_identical_keep_lists": f"{cpu_same}/{cpu_frames}", "class_bias_shift": round(shift, 4), "target_kept_per_frame": target,
             "note": "f16 = hand-written kernels (throughput default); fp32 = the same weights on PyTorch-ROCm's library convolutions; letterbox + NMS "
                     "are the HIP kernels in both; seeded calibrated random-init network (no checkpoint offline), class biases shifted so that ~target anchors "
                     "pass conf: near-threshold density is synthetic"}
@@ -734,6 +741,7 @@ def main():
     ap.add_argument("--no-api-path", action="store_true", help="skip the YOLO.track / track_stream measurement")
     ap.add_argument("--no-reid-check", action="store_true", help="skip the f16 HIP OSNet vs CPU fp32 OSNet measurement on the true feat_source='reid' path")
     ap.add_argument("--reid-fp32", action="store_true", help="the ACCURACY MODE as the measured configuration: ReID crops + OSNet-x0.25 with fp32 activations on the hand-written fp32 kernels (csrc/ss_ops32.hip); the default line carries the same measurement on fewer steps as `accuracy_mode`")
+    ap.add_argument("--det-fp32", action="store_true", help="with --reid-fp32: the detector in fp32 too (PyTorch-ROCm's library convolutions; north_star files the detector under PyTorch-ROCm) — every network operation of the path in fp32")
     ap.add_argument("--no-accuracy-mode", action="store_true", help="skip the second, shorter timed run with the fp32 ReID network (`accuracy_mode`)")
     ap.add_argument("--accuracy-steps", type=int, default=10, help="timed steps of the `accuracy_mode` run")
     ap.add_argument("--check-frames", type=int, default=-1, help="frames (from the start of the run) compared with the oracle; -1: all of them, the timed ones included")
@@ -811,12 +819,12 @@ def main():
     PipeCls = OverlappedPipeline if overlap else FramePipeline
     from types import SimpleNamespace
 
-    def timed_pipeline(reid_half, K, Wm):
+    def timed_pipeline(reid_half, K, Wm, half=True):
         """PREFILL + Wm warm-up + exactly K timed steps of the whole hot path with the ReID network in half (throughput default) or
         fp32 (accuracy mode); returns everything the line is built from.  The pipeline stays open (caller closes R.pipe)."""
         KF, WF = K * FPS, Wm * FPS                          # timed / warm-up frames per stream
         total = PREFILL + WF + KF
-        pipe = PipeCls(detector, S, (H, W), device=dev_index, half=True, reid_batch=rb, cfg=cfg, dcfg=dcfg,
+        pipe = PipeCls(detector, S, (H, W), device=dev_index, half=half, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                        det_source="synthetic", feat_source="by_anchor", graph=args.graph, reid_half=reid_half,
                        run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
         for kv in args.opt:
@@ -956,7 +964,7 @@ def main():
                 n_timed += 1
         return same, tot, exact_frames, exact_timed, n_timed
 
-    R = timed_pipeline(not args.reid_fp32, args.steps, args.warmup)
+    R = timed_pipeline(not args.reid_fp32, args.steps, args.warmup, half=not (args.det_fp32 and args.reid_fp32))
     pipe, K, Wm, KF, WF, total, dt, per_rank_dt, t_enq, t_enq_cpu, wls, gs, nc, A, dev = (R.pipe, R.K, R.Wm, R.KF, R.WF, R.total, R.dt, R.per_rank_dt, R.t_enq, R.t_enq_cpu,
                                                                                    R.wls, R.gs, R.nc, R.A, R.dev)
     step_ms, assoc_ms, assoc_n, assoc_order_us, assoc_each_us, assoc_ik_us, assoc_ik_n = R.step_ms, R.assoc_ms, R.assoc_n, R.assoc_order_us, R.assoc_each_us, R.assoc_ik_us, R.assoc_ik_n
@@ -1105,6 +1113,13 @@ def main():
             on_own = bool(getattr(A2.pipe.reid, "_ok32", False))
             A2.pipe.close()
             tp = (res.get("reid_f16_vs_f32") or {}).get("fp32_reid_mode") or {}
+            # ... and with the detector in fp32 as well (library convolutions): no f16 arithmetic left on the path
+            A3 = timed_pipeline(False, max(2, args.accuracy_steps // 2), 2, half=False)
+            b_same, b_tot, b_exact, b_exact_timed, b_ntimed = id_check(A3, A3.total)
+            A3.pipe.close()
+            all32 = {"detector": "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels", "frames_per_s": round(S * A3.KF / A3.dt, 2),
+                     "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
+                     "frames_bit_exact": f"{b_exact}/{A3.total}"}
             res["accuracy_mode"] = {
                 "reid_precision": "fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)",
                 "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
@@ -1113,6 +1128,7 @@ def main():
                 "distance_err": tp.get("cost_matrix_cosine_max_abs_err"), "embedding_err": tp.get("embedding_unit_max_abs_err"),
                 "true_path_id_match_rate": tp.get("id_match_rate"), "within_north_star_bound_1e-4": tp.get("within_bound"),
                 "net_outputs_check": a_nets,
+                "all_fp32": all32,
                 "note": "same workload, same pipeline, same checks as the default line with reid_half=False; distance_err / true_path_id_match_rate: "
                         "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32.fp32_reid_mode)"}
         if world == 1 and not args.no_cpu_baseline:
