@@ -21,6 +21,7 @@
 #define SS_FMAX 32            // frames of a stream that one tracker call (group) may carry
 #define SS_TLMAX (SS_MAXT * SS_NRT)          // gallery tiles of a stream
 #define SS_PLMAX (SS_FMAX * SS_NCT / 2)      // column-tile pairs of a stream's group
+#define SS_NCTP (SS_FMAX * SS_NCT)           // packed column tiles of a stream's group at most (every detection of every frame)
 #define SS_RECT 32            // gallery tiles per association work record at most (the record carries their tile words)
 #define SS_RECW (4 + SS_RECT) // ints per record: {stream, frame, pair word, tiles<<16 | composite<<31} + SS_RECT words (144 bytes)
 #define SS_RECI4 (SS_RECW / 4)
@@ -82,6 +83,10 @@ struct SSDev {
     // group scratch
     float* feat_unit;           // [FMAX][S][MAXD][512]
     float* feat_frag;           // [FMAX][S][NCT][TILE_FLOATS]
+    float* feat_pack;           // [S][NCTP][TILE_FLOATS] the group's detections PACKED across frames (column g = detections of the earlier
+                                //   frames + d): k_assoc's B operand when assoc_pack — 28 column-tile pairs instead of 32 at ~28 det/frame
+    int* colmap;                // [S][FMAX*MAXD + 64] packed column g -> frame<<8 | detection, -1 behind the last one
+    int assoc_pack;             // 1: k_assoc works on packed pairs (ss_set_option "assoc_pack"), 0: pairs of one frame's column tiles
     double *tlwh, *xyah;        // [FMAX][S][MAXD][4]
     int* M;                     // [S][MAXT][FMAX][MAXD] ordered-int keys (ss_fkey) of the appearance distance
                                 //   min over the gallery rows of (slot) that are valid in frame f of the group

@@ -595,6 +595,21 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
             }
         }
         if (tid == 0) { dev.pf[s * (SS_FMAX + 1) + F] = ptot; dev.n_pl[s] = ptot; }
+        // assoc_pack: k_assoc's pairs run over the group's detections PACKED across frames (column g = detections of the frames
+        // before + d, written by the detection-prep waves below): ceil(ceil(sum D / 16) / 2) pairs instead of sum ceil(ceil(D / 16) / 2)
+        // — 28 instead of 32 at ~28 detections per frame, one step less for every wave of the launch.  k_newrow keeps the per-frame pairs.
+        int coff, Dtot;
+        block_scan_sum256(tid < F ? D : 0, wtot, coff, Dtot);
+        const bool pack = dev.assoc_pack != 0;
+        const int nctp = (Dtot + SS_TILE - 1) / SS_TILE, ppk = (nctp + 1) / 2;
+        if (pack) {
+            __syncthreads();                                             // plw: the per-frame pairs are in global memory now
+            if (tid < ppk) plw[tid] = make_int2(0, (2 * tid) | ((2 * tid + 1 < nctp) ? 256 : 0) | (Dtot << 16));
+            for (int g = Dtot + tid; g < 32 * ppk + 64; g += 256) dev.colmap[(size_t)s * (SS_FMAX * SS_MAXD + 64) + g] = -1;
+            for (int g = Dtot + (tid >> 6); g < nctp * SS_TILE; g += 4)   // zero rows behind the last packed detection
+                frag_write_row(reinterpret_cast<float4*>(dev.feat_pack + ((size_t)s * SS_NCTP + g / SS_TILE) * SS_TILE_FLOATS), g % SS_TILE, nullptr, true);
+        }
+        const int pta = pack ? ppk : ptot;                               // pairs the association records are cut from
         // Work records (one workgroup of k_assoc each) = (column-tile pair of one frame, range of <= SS_RECT gallery tiles).
         // A pair is cut into n_g ranges of (almost) equal length: n_g = the workgroups a pair can have when the launch's
         // cos_grid workgroups are shared evenly by the S*F frames and the frame's pairs, but ranges of at least 8 tiles (one
@@ -607,11 +622,11 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         if (tid < F) npf[tid] = np;
         if (tid < 8) lcnt[tid] = 0;
         __syncthreads();
-        const int n_sf = max(1, dev.cos_grid / (S * F));
+        const int n_sf = max(1, dev.cos_grid / (S * F)), n_pp = max(1, dev.cos_grid / (S * max(ppk, 1)));
         int ng = 0, nr = 0;
-        if (tid < ptot) {
+        if (tid < pta) {
             if (ttot > 0) {
-                ng = min(max(n_sf / npf[plw[tid].x] - ncrec, 1), max(1, ttot / 8));
+                ng = min(max((pack ? n_pp : n_sf / npf[plw[tid].x]) - ncrec, 1), max(1, ttot / 8));
                 ng = max(ng, (ttot + SS_RECT - 1) / SS_RECT);
             }
             ngs[tid] = ng;
@@ -619,12 +634,12 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         }
         int ro, NR;
         block_scan_sum256(nr, wtot, ro, NR);
-        if (tid < ptot) roff[tid] = ro;
-        if (tid == 0) roff[ptot] = NR;
+        if (tid < pta) roff[tid] = ro;
+        if (tid == 0) roff[pta] = NR;
         __syncthreads();
         for (int pass = 0; pass < 2; ++pass) {
             for (int r = tid; r < NR; r += 256) {
-                int lo = 0, hi = ptot;                                 // pair of record r: roff[lo] <= r < roff[lo + 1]
+                int lo = 0, hi = pta;                                  // pair of record r: roff[lo] <= r < roff[lo + 1]
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (roff[mid] <= r) lo = mid; else hi = mid; }
                 const int pp = lo, j = r - roff[pp], nrp = roff[pp + 1] - roff[pp], ngp = ngs[pp];
                 // list = XCD: range j of stream s always on the same XCD (its part of the gallery stays in that XCD's L2 for every
@@ -703,6 +718,14 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
         for (int j = 0; j < 8; ++j) { float u = n > 0.0f ? v[j] / n : 0.0f; unit[l + 64 * j] = u; rowbuf[w][l + 64 * j] = u; }   // all-zero row stays zero (D-17)
         SS_WAVE_SYNC();
         frag_write_row(frag, jj, rowbuf[w], false);
+        if (dev.assoc_pack) {                                           // the same row as column g of the group's packed detections
+            int cb = l < f ? min(dev.n_dets[(size_t)l * S + s], SS_MAXD) : 0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) cb += __shfl_xor(cb, off);
+            const int g = cb + d;
+            frag_write_row(reinterpret_cast<float4*>(dev.feat_pack + ((size_t)s * SS_NCTP + g / SS_TILE) * SS_TILE_FLOATS), g % SS_TILE, rowbuf[w], false);
+            if (l == 0) dev.colmap[(size_t)s * (SS_FMAX * SS_MAXD + 64) + g] = (f << 8) | d;
+        }
         if (l == 0) {
             const float* b = dev.dets + (fs * SS_MAXD + d) * 6;
             double x1 = b[0], y1 = b[1], x2 = b[2], y2 = b[3];
@@ -755,6 +778,14 @@ __device__ __forceinline__ void ss_glds16(const void* gsrc, unsigned lds_dst)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// ... and of 64 dwords (lane l's dword lands at lds_dst + 4 l): the record's column map
+__device__ __forceinline__ void ss_glds4(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 #define SS_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // NP: how the record's detection operand B (2 x 32 KiB) reaches the LDS.  0: through registers, one barrier (round 3).
@@ -773,6 +804,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float4* bl = reinterpret_cast<float4*>(smem);                  // [2][32][64] float4 = 64 KiB: B of the record's pair
     float4* hand = bl + 4096;                                      // [7][2][64] float4 = 14 KiB: running sums wave w -> wave w+1
     int* hflag = reinterpret_cast<int*>(hand + 7 * 128);           // [8] record number whose sum is in the slot
+    int* cmap = hflag + 16;                                        // [64] assoc_pack: frame<<8 | detection of the record's 32 packed columns (-1: none)
+    const bool pack = dev.assoc_pack != 0;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int wu = __builtin_amdgcn_readfirstlane(w);
     if (threadIdx.x < 8) hflag[threadIdx.x] = 0;                    // ordered before its first use by the staging barriers
@@ -859,7 +892,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         float4 ra[4][4];                                              // 4-deep ring of segment pieces
         // B of (frame f, stream s, column tiles ct0, ct0+1)
-        const float4* ff = reinterpret_cast<const float4*>(dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
+        const float4* ff = reinterpret_cast<const float4*>(pack ? dev.feat_pack + ((size_t)s * SS_NCTP + ct0) * SS_TILE_FLOATS
+                                                                  : dev.feat_frag + (((size_t)f * dev.S + s) * SS_NCT + ct0) * SS_TILE_FLOATS);
+        // the record's column map by LDS-DMA, issued by wave 0 before its first piece of B: loads return in order, so the first
+        // awaited piece covers it, and the barrier after that piece publishes it (an uncounted older operation: no wait count changes)
+        const int* cmsrc = dev.colmap + (size_t)s * (SS_FMAX * SS_MAXD + 64) + ct0 * SS_TILE + l;
         // (a lone column tile is staged twice: branch-free, and the second copy's results are never stored)
         const float4* ff1 = two ? ff + 4 * 512 : ff;
         const int tx = threadIdx.x;
@@ -872,7 +909,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (has) { ld(0, ra[0]); ld(1, ra[1]); }                  // on the wire before the B staging (nsteps >= 8)
             const float4 t00 = ff[tx], t01 = ff[tx + 512], t02 = ff[tx + 1024], t03 = ff[tx + 1536];
             const float4 t10 = ff1[tx], t11 = ff1[tx + 512], t12 = ff1[tx + 1024], t13 = ff1[tx + 1536];
+            const int cmv = (pack && tx < 64) ? *cmsrc : 0;
             __syncthreads();                                         // the previous record's readers are done with bl / hand
+            if (pack && tx < 64) cmap[tx] = cmv;
             SS_TL(2);                                                // first gallery pieces + B landed
             bl[tx] = t00; bl[tx + 512] = t01; bl[tx + 1024] = t02; bl[tx + 1536] = t03;
             bl[tx + 2048] = t10; bl[tx + 2560] = t11; bl[tx + 3072] = t12; bl[tx + 3584] = t13;
@@ -880,6 +919,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             SS_TL(3);                                                // B staged
         } else {
             if (seq > 1) SS_LDS_BARRIER();                           // the previous record's readers are done with bl / hand
+            if (pack && wu == 0) ss_glds4(cmsrc, (unsigned)(reinterpret_cast<char*>(cmap) - smem));
             if (!has) {
                 // a wave without a run (records of fewer than 8 tiles) only moves its rows of B and takes part in the barriers —
                 // the same number of them as the waves with a run execute (the hardware barrier counts arrivals, not places)
@@ -965,39 +1005,56 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     // 1 - dot, rows not in the ring at frame f masked to +inf, min over the tile's 16 rows
                     const int tw = __builtin_amdgcn_readlane(cur, 4 + q);
                     const int slot = tw & 0xff, rt = (tw >> 8) & 7, count = (tw >> 12) & 0xff, head = (tw >> 20) & 0x7f;
+                    // packed columns: the frame a row must still be in the ring for is the COLUMN's (column l & 15 of either tile)
+                    int cm0 = 0, cm1 = 0, f0 = f, f1 = f;
+                    if (pack) { cm0 = cmap[l & 15]; cm1 = cmap[16 + (l & 15)]; f0 = cm0 >> 8; f1 = cm1 >> 8; }
                     float m0 = INFINITY, m1 = INFINITY;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int pos = rt * SS_TILE + 4 * (l >> 4) + r;
                         int jrel = pos - head;
                         if (jrel < 0) jrel += budget;
-                        const bool valid = pos < count && jrel >= f;
-                        m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
-                        m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                        const bool in_ring = pos < count;
+                        m0 = fminf(m0, (in_ring && jrel >= f0) ? 1.0f - tot0[r] : INFINITY);
+                        m1 = fminf(m1, (in_ring && jrel >= f1) ? 1.0f - tot1[r] : INFINITY);
                     }
                     m0 = fminf(m0, __shfl_xor(m0, 16)); m0 = fminf(m0, __shfl_xor(m0, 32));
                     m1 = fminf(m1, __shfl_xor(m1, 16)); m1 = fminf(m1, __shfl_xor(m1, 32));
-                    int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
-                    if (l < 16) { if (ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m0)); }
-                    else if (l < 32) { if (two && ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m1)); }
+                    if (!pack) {
+                        int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE;
+                        if (l < 16) { if (ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m0)); }
+                        else if (l < 32) { if (two && ct0 * SS_TILE + l < D) ss_atomic_min_nr(out + l, ss_fkey(m1)); }
+                    } else if (l < 32) {                             // lane l < 16: column l of the first tile, else column l - 16 of the second
+                        const int cm = l < 16 ? cm0 : cm1;
+                        if (cm >= 0 && (l < 16 || two))
+                            ss_atomic_min_nr(dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + (cm >> 8)) * SS_MAXD + (cm & 0xff), ss_fkey(l < 16 ? m0 : m1));
+                    }
                 }
                 if (sg == 7 && comp) {
                     // composite tile: this lane's four accumulator rows are the four rows of group l/16 — one track, no shuffles
                     const int gw = group_word(q, l >> 4);
                     const int slot = gw & 0xff, rt = (gw >> 8) & 7, r4 = (gw >> 11) & 3, count = (gw >> 13) & 0xff, head = (gw >> 21) & 0x7f;
+                    int cm0 = 0, cm1 = 0, f0 = f, f1 = f;
+                    if (pack) { cm0 = cmap[l & 15]; cm1 = cmap[16 + (l & 15)]; f0 = cm0 >> 8; f1 = cm1 >> 8; }
                     float m0 = INFINITY, m1 = INFINITY;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int pos = rt * SS_TILE + 4 * r4 + r;
                         int jrel = pos - head;
                         if (jrel < 0) jrel += budget;
-                        const bool valid = pos < count && jrel >= f;
-                        m0 = fminf(m0, valid ? 1.0f - tot0[r] : INFINITY);
-                        m1 = fminf(m1, valid ? 1.0f - tot1[r] : INFINITY);
+                        const bool in_ring = pos < count;
+                        m0 = fminf(m0, (in_ring && jrel >= f0) ? 1.0f - tot0[r] : INFINITY);
+                        m1 = fminf(m1, (in_ring && jrel >= f1) ? 1.0f - tot1[r] : INFINITY);
                     }
-                    int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE + (l & 15);
-                    if (count > 0 && ct0 * SS_TILE + (l & 15) < D) ss_atomic_min_nr(out, ss_fkey(m0));
-                    if (count > 0 && two && ct0 * SS_TILE + SS_TILE + (l & 15) < D) ss_atomic_min_nr(out + SS_TILE, ss_fkey(m1));
+                    if (!pack) {
+                        int* out = dev.M + (((size_t)s * SS_MAXT + slot) * SS_FMAX + f) * SS_MAXD + ct0 * SS_TILE + (l & 15);
+                        if (count > 0 && ct0 * SS_TILE + (l & 15) < D) ss_atomic_min_nr(out, ss_fkey(m0));
+                        if (count > 0 && two && ct0 * SS_TILE + SS_TILE + (l & 15) < D) ss_atomic_min_nr(out + SS_TILE, ss_fkey(m1));
+                    } else {
+                        int* mrow = dev.M + ((size_t)s * SS_MAXT + slot) * SS_FMAX * SS_MAXD;
+                        if (count > 0 && cm0 >= 0) ss_atomic_min_nr(mrow + (cm0 >> 8) * SS_MAXD + (cm0 & 0xff), ss_fkey(m0));
+                        if (count > 0 && two && cm1 >= 0) ss_atomic_min_nr(mrow + (cm1 >> 8) * SS_MAXD + (cm1 & 0xff), ss_fkey(m1));
+                    }
                 }
             };
             int i = 0;
@@ -1637,7 +1694,7 @@ __global__ void k_kat_iou(const double* ttlwh, int T, const double* dtlwh, int D
 
 // ---- launch helpers used by ss_api.hip -------------------------------------------------------------
 size_t ss_lsap_lds_bytes() { return 256 * 4; }
-size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 7 * 2048 + 64; }
+size_t ss_assoc_lds_bytes() { return 2 * SS_TILE_FLOATS * 4 + 7 * 2048 + 64 + 256; }       // B pair, hand-over slots, flags, column map
 
 extern "C" void ss_step_kernel_attr()
 {

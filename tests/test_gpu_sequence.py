@@ -190,6 +190,18 @@ def test_frame_kernel_work_areas_in_lds_or_global_scratch(caps, ids, wh):
     _run_streams(2, lambda s: ids + 2 * s, 45, F=5, wh=wh, opts={"frame_caps": caps})
 
 
+@pytest.mark.parametrize("pack", [0, 1])
+@pytest.mark.parametrize("S,F,frames,ids,wh", [(1, 32, 150, 30, (1280, 720)), (4, 16, 64, 0, (1280, 720)), (2, 8, 48, 100, (1920, 1080)), (3, 5, 40, 3, (640, 480))])
+def test_association_on_packed_or_per_frame_columns(pack, S, F, frames, ids, wh):
+    """assoc_pack: k_assoc's column-tile pairs over the group's detections packed across frames (a pair's 32 columns may belong to
+    several frames: per-column ring validity and M address) against pairs of one frame's tiles: every intermediate of every frame
+    equals the oracle either way; mixed identity counts, frames without detections, (100, 100) shapes, tiny streams (a group's
+    detections fit one pair)."""
+    mixed = (30, 8, 100, 3)
+    _run_streams(S, (lambda s: mixed[s % 4]) if ids == 0 else (lambda s: ids + s), frames, F=F, wh=wh, opts={"assoc_pack": pack},
+                 stream_kw=dict(p_vanish=0.05, vanish_max=6), empty_every=7 if ids == 3 else 0)
+
+
 @pytest.mark.parametrize("merge", [1, 0])
 @pytest.mark.parametrize("S,F,frames,ids", [(1, 32, 150, 30), (3, 8, 64, 12), (2, 5, 45, 100)])
 def test_post_and_newrow_as_one_launch_or_two(merge, S, F, frames, ids):
