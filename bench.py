@@ -1018,8 +1018,10 @@ def main():
             full, rem = rows // 16, rows % 16
             groups = 0 if (rem == 0 or rem > 12) else -(-rem // 4)
             tiles += Tc * (full + (1 if rem > 12 else 0)) + -(-(Tc * groups) // 4)
-        pairs = -(-int(-(-Dm // 16)) // 2)
-        mfma_floor_us = tiles * pairs * frames_launch * 256 * 32 / (1024 * 2.4e9) * 1e6
+        packed = not any(kv.replace(" ", "") == "assoc_pack=0" for kv in args.opt)       # detection columns packed across the frames of a launch (library default)
+        pairs_launch = -(-int(-(-(Dm * frames_launch) // 16)) // 2) if packed else -(-int(-(-Dm // 16)) // 2) * frames_launch
+        pairs = pairs_launch / frames_launch
+        mfma_floor_us = tiles * pairs_launch * 256 * 32 / (1024 * 2.4e9) * 1e6
         basis = ("SURVEY §8(d): FP32-bound shape (c4)" if args.preset == "c4" else
                  f"measured HBM traffic / algorithmic bytes = {traffic / max(alg_bytes, 1):.3f} (profiles/{PMC_FILE})" if traffic is not None else
                  f"no PMC entry for this shape; the gallery is read once per {frames_launch:.0f}-frame group, so HBM traffic is ~1/{frames_launch:.0f} of the algorithmic bytes")
@@ -1043,7 +1045,7 @@ def main():
                                        "note": "SURVEY §8(d) algorithmic bytes x frames per launch / launch time: what a frame-by-frame implementation would have to move"},
                     "hbm_equivalent_GBps": round(ach_b, 1), "frac_of_hbm_peak": round(ach_b / 8000.0, 4),
                     "f32_mfma_TFLOPs": round(ach_f, 2), "frac_of_f32_mfma_peak": round(ach_f / 157.3, 4),
-                    "mfma_floor_us": round(mfma_floor_us, 2), "mfma_tiles_per_frame": int(tiles * pairs),
+                    "mfma_floor_us": round(mfma_floor_us, 2), "mfma_tiles_per_frame": round(tiles * pairs, 1), "column_pairs_per_launch": int(pairs_launch), "columns_packed_across_frames": packed,
                     "inkernel_mean_us": round(assoc_ik_us, 2), "inkernel_launches": assoc_ik_n,
                     "frac_inkernel": (round((flops / t_ik / 1e12 / 157.3) if fp32_bound else (alg_bytes / t_ik / 1e9 / 8000.0), 4) if t_ik > 0 else None),
                     "tracks_confirmed_per_stream": [t for t, _ in T_conf], "gallery_rows": [round(b, 1) for _, b in T_conf]}
