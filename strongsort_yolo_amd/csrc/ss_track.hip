@@ -648,7 +648,10 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
                 // instead of ~1 GB, L2 hit rate 0.33)
                 // (assoc_xcd_map 1: all ranges of a pair on ONE XCD instead — each XCD then stages 1/8 of the detection operands and
                 // streams the whole gallery; for launches of few pairs, where the operands' fabric traffic is the start-up burst)
-                const int x = dev.xcd_map ? ((pp + s) & 7) : ((j + s * nrp + (nrp < 8 ? (pp % ((8 + nrp - 1) / nrp)) * nrp : 0)) & 7);
+                // (records per pair not a multiple of 8: the ranges past the last full eight rotate over the XCDs from pair to pair — with
+                //  17 per pair, j = 16 of EVERY pair landed on list 0: 87 records for 64 workgroups there, 58 on the other lists)
+                const int jx = (nrp >= 8 && j >= (nrp & ~7)) ? j + pp * (nrp & 7) : j;
+                const int x = dev.xcd_map ? ((pp + s) & 7) : ((jx + s * nrp + (nrp < 8 ? (pp % ((8 + nrp - 1) / nrp)) * nrp : 0)) & 7);
                 const int pos = atomicAdd(&lcnt[x], 1);
                 if (pass == 0) continue;
                 if (lbase[x] + pos >= dev.items_cap) { dev.err[s] = SS_ERR_CAPACITY; continue; }
