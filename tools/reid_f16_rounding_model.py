@@ -5,6 +5,7 @@ and rendered crops, fp32 arithmetic with explicit roundings to half:
               depthwise + bias + ReLU) as one fused unit; the gate-weighted sum, pools and the head likewise
   unfused     torch-f16's rounding points: the convolution rounded before the bias / activation pass, the 1x1 of a LightConv rounded
               before its depthwise, every elementwise step rounded (what the fused HIP kernels reproduce bit for bit)
+  hybrid      f16 storage ('once') for the stem and the first stage only, fp32 from the second stage on
 Prints the max abs error of the unit embeddings and of the pairwise cosine distances against fp32.  usage: python tools/reid_f16_rounding_model.py [crops=96]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -74,6 +75,16 @@ def block(b, x, mode):
 
 
 def forward(net, x, mode):
+    if mode == "hybrid":                                    # f16 storage (one rounding per tensor) for the stem and the 64 x 32 stage — 60 % of the
+        x = h(x)                                            # network's time — fp32 from the 32 x 16 stage on
+        x = h(F.max_pool2d(convbr(net.conv1, x, "once"), 3, 2, 1))
+        x = block(net.conv2[0], x, "once"); x = block(net.conv2[1], x, "once")
+        x = h(F.avg_pool2d(convbr(net.conv2[2], x, "once"), 2, 2))
+        x = block(net.conv3[0], x, "fp32"); x = block(net.conv3[1], x, "fp32")
+        x = F.avg_pool2d(convbr(net.conv3[2], x, "fp32"), 2, 2)
+        x = block(net.conv4[0], x, "fp32"); x = block(net.conv4[1], x, "fp32")
+        x = convbr(net.conv5, x, "fp32")
+        return F.relu(F.linear(x.mean((2, 3)), net.fc.weight, net.fc.bias))
     r = (lambda t: t) if mode == "fp32" else h
     x = r(x)
     x = r(F.max_pool2d(convbr(net.conv1, x, mode), 3, 2, 1))
@@ -91,7 +102,7 @@ with torch.no_grad():
     assert torch.allclose(ref, net(x), atol=1e-4, rtol=1e-4)          # the model below IS the module
     u = lambda e: (e / e.norm(dim=1, keepdim=True)).double()
     out = {"crops": N}
-    for mode in ("once", "unfused"):
+    for mode in ("once", "unfused", "hybrid"):
         e = forward(net, x, mode)
         out[mode] = {"embedding_unit_max_abs_err": round(float((u(e) - u(ref)).abs().max()), 5),
                      "cosine_distance_max_abs_err": round(float(((1 - u(e) @ u(e).T) - (1 - u(ref) @ u(ref).T)).abs().max()), 5)}
