@@ -475,39 +475,24 @@ __global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict_
     const size_t pbase = (size_t)img * HW;
     const float* const ys[4] = { y0, y1, y2, y3 };
     const int tile0 = (blockIdx.x * (T32_THREADS / 64) + wave) * tpw;
-    auto pix = [&](int tile) -> int {                        // pixel of this lane inside the image
-        if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; return (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
-        return tile * 16 + n;
-    };
-    // the four chain outputs of a tile are requested one tile ahead (unconditional loads: chunks past the channel count re-read chunk 0)
-    auto load_y = [&](int tile, f4 (&y)[4][JM]) {
-        const size_t px = pbase + pix(tile);
-#pragma unroll
-        for (int jj = 0; jj < JM; ++jj) {
-            const int c = kq + 4 * jj, cc = c < CHM ? c : 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) y[t][jj] = ld4(ys[t] + px * MID + 4 * cc);
-        }
-    };
-    f4 ycur[4][JM];
-    if (tile0 < tiles_img) load_y(tile0, ycur);
     for (int it = 0; it < tpw; ++it) {
         const int tile = tile0 + it;
         if (tile >= tiles_img) break;
-        const int pl = pix(tile);
+        int pl;                                              // pixel of this lane inside the image
+        if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; pl = (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
+        else pl = tile * 16 + n;
         const size_t px = pbase + pl;
-        const bool more = it + 1 < tpw && tile + 1 < tiles_img;
-        f4 ynxt[4][JM];
-        if (more) load_y(tile + 1, ynxt);
         // x2 chunks
         f4 bm[JM];
 #pragma unroll
         for (int jj = 0; jj < JM; ++jj) {
-            const int c = kq + 4 * jj, cc = c < CHM ? c : 0;
-            f4 v = ld4(G + 4 * cc) * ycur[0][jj];
+            const int c = kq + 4 * jj;
+            if (c < CHM) {
+                f4 v = ld4(G + 4 * c) * ld4(ys[0] + px * MID + 4 * c);
 #pragma unroll
-            for (int t = 1; t < 4; ++t) v = v + ld4(G + t * MID + 4 * cc) * ycur[t][jj];
-            bm[jj] = c < CHM ? v : zero4();
+                for (int t = 1; t < 4; ++t) v = v + ld4(G + t * MID + 4 * c) * ld4(ys[t] + px * MID + 4 * c);
+                bm[jj] = v;
+            } else bm[jj] = zero4();
         }
         f4 acc[MT3];
 #pragma unroll
@@ -552,12 +537,6 @@ __global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict_
                     st4(out2 + po * N2 + oc, s);
                 }
             } else if (4 * mt + kq < CH4) st4(out2 + px * N2 + oc, v);
-        }
-        if (more) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int jj = 0; jj < JM; ++jj) ycur[t][jj] = ynxt[t][jj];
         }
     }
 }
@@ -773,10 +752,8 @@ static int launch_tail32(hipStream_t st, const void* const* ys, const float* psu
     }
     const int tiles = H * W / 16;
     constexpr int WV = T32_THREADS / 64;
-    // a workgroup stages the weights and computes the image's gates before its first tile (three barriers, ~2 us): as many tiles per
-    // wave as still leave >= 768 workgroups (3 per CU); at 1 024 crops that is ONE workgroup per image on every map size
     int tpw = 1;
-    while (tpw < 16 && WV * tpw < tiles && (long long)N * ((tiles + 2 * WV * tpw - 1) / (2 * WV * tpw)) >= 768) tpw *= 2;
+    while (tpw < 4 && tiles / (WV * tpw) > 2 && (long long)N * (tiles / (2 * WV * tpw)) >= 2048) tpw *= 2;     // weights are staged per workgroup
     const dim3 grid((tiles + WV * tpw - 1) / (WV * tpw), N);
     hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), grid, dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
                        (const float*)ys[3], psum, bands, 1.0f / (float)(H * W), gw1, gb1, gw2, gb2, hidden, w3, b3, xin, wd, bd, out, w4, b4, out2,
