@@ -177,13 +177,14 @@ extern "C" int ss_create(const ss_config* cfg, int device, ss_ctx** out)
     d.budget = cfg->nn_budget;
     d.cap_cost = SS_COST_CAP; d.cap_t = SS_MAXT; d.cap_d = SS_MAXD;
     d.chain_merge = 1;
+    d.pred_ahead = 1;
     d.assoc_pack = 1;
     int rc = SS_OK;
 #define A(field, n) if (rc == SS_OK) rc = dalloc(c, &d.field, (n))
     A(n_tracks, S); A(next_id, S); A(frame, S); A(err, S); A(order, S * T);
     A(slot_used, S * T); A(track_id, S * T); A(state, S * T); A(hits, S * T); A(age, S * T); A(tsu, S * T);
     A(class_id, S * T); A(det_idx, S * T); A(gal_count, S * T); A(gal_head, S * T); A(conf, S * T);
-    A(mean, S * T * 8); A(cov, S * T * 64); A(smooth, S * T * 2 * SS_F); A(smooth_sel, S * T);
+    A(mean, S * T * 8); A(cov, S * T * 64); A(mean_p, S * T * 8); A(cov_p, S * T * 64); A(smooth, S * T * 2 * SS_F); A(smooth_sel, S * T);
     A(gallery, S * T * SS_NRT * SS_TILE_FLOATS);
     const size_t FM = SS_FMAX;
     A(feat_unit, FM * S * D * SS_F); A(feat_frag, FM * S * SS_NCT * SS_TILE_FLOATS);
@@ -561,6 +562,7 @@ extern "C" int ss_set_option(ss_ctx* c, const char* name, int value)
     else if (n == "assoc_comp_rows") { if (value < 0 || value > 12) return fail(c, SS_ERR_INVALID, "assoc_comp_rows: 0..12"); c->comp_rows = value; }
     else if (n == "assoc_stage") { if (value != 0 && value != 1 && value != 2 && value != 4 && value != 5) return fail(c, SS_ERR_INVALID, "assoc_stage: 0, 1, 2, 4 or 5"); c->assoc_stage = value; }
     else if (n == "assoc_pack") c->dev.assoc_pack = value != 0;         // association on detection columns packed across the group's frames (default) / per-frame pairs
+    else if (n == "pred_ahead") c->dev.pred_ahead = value != 0;         // k_frame takes the predicted state post_track left (default) / predicts itself
     else if (n == "chain_merge") c->dev.chain_merge = value != 0;       // k_post + k_newrow of a frame as one launch (default) / two launches
     else if (n == "frame_caps") {
         // value = tracks and detections k_frame keeps in LDS (cost entries = value^2): 0 restores the maxima (256 tracks, 128 detections, 12288 entries)

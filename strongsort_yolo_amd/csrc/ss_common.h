@@ -68,7 +68,10 @@ struct SSDev {
     // persistent per slot  [S][MAXT]
     int *slot_used, *track_id, *state, *hits, *age, *tsu, *class_id, *det_idx, *gal_count, *gal_head;
     float* conf;
-    double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]
+    double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]: a track's state after its last frame
+    double *mean_p, *cov_p;     // the same PREDICTED one frame ahead (written by post_track for every live track): with pred_ahead and no
+                                //   camera motion k_frame only reads the 24 values its gate needs instead of loading, predicting and storing 72
+    int pred_ahead;             // ss_set_option "pred_ahead" (default 1)
     float* smooth;              // [S][MAXT][2][512] EMA feature, double-buffered: the row in use is [smooth_sel]; an update reads it and
                                 //   writes the other half, so the new-row units of the SAME launch (k_postnew) can still read the old one
     int* smooth_sel;            // [S][MAXT] 0 / 1
@@ -303,12 +306,14 @@ __device__ inline void ss_kf_update(double* mean, double* cov, const double z[4]
 // the operations the oracle performs for that entry (the gain rows r and c, column c of S K^T), so every result bit
 // equals the one-thread form.  ws = 72 doubles of per-wave LDS (covariance, then mean; the new mean is left in
 // ws[64..71]).  gmean / gcov are updated in place.
-__device__ inline void ss_kf_update_wave(double* gmean, double* gcov, const double z[4], double conf, double wp, double* ws)
+// (imean / icov: the state it starts from — the same arrays, or the predicted copies; the new covariance is ALSO left in ws[0..63])
+__device__ inline void ss_kf_update_wave(const double* imean, const double* icov, double* gmean, double* gcov, const double z[4], double conf,
+                                         double wp, double* ws)
 {
     const int l = threadIdx.x & 63, r = l >> 3, c = l & 7;
-    const double p = gcov[l];
+    const double p = icov[l];
     ws[l] = p;
-    if (l < 8) ws[64 + l] = gmean[l];
+    if (l < 8) ws[64 + l] = imean[l];
     SS_WAVE_SYNC();
     const double* cov = ws;
     const double* mean = ws + 64;
@@ -353,9 +358,36 @@ __device__ inline void ss_kf_update_wave(double* gmean, double* gcov, const doub
 #pragma unroll
     for (int k = 0; k < 4; ++k) a2 = fma(z[k] - m4[k], Kr[k], a2);
     SS_WAVE_SYNC();                                 // every lane has read the old state
-    gcov[l] = p - acc;
+    const double pn = p - acc;
+    gcov[l] = pn;
+    ws[l] = pn;
     if (c == 0) { const double nm = mr + a2; gmean[r] = nm; ws[64 + r] = nm; }
     SS_WAVE_SYNC();
+}
+
+// Kalman prediction of a state held in ws (covariance [64], mean [8]) by the 64 lanes of a wave, lane l = entry (l >> 3, l & 7):
+// exactly the operations ss_kf_predict performs for that entry (A = P F^T on the left half, B = F A on the top half, + Q on the
+// diagonal; h = the mean's height BEFORE the step).  -> pmean[8], pcov[64] (global).
+__device__ inline void ss_kf_predict_wave(const double* ws, double wp, double wv, double* pmean, double* pcov)
+{
+    const int l = threadIdx.x & 63, i = l >> 3, j = l & 7;
+    const double* P = ws;
+    const double* mean = ws + 64;
+    const double h = mean[3];
+    const double sp = wp * h, sv = wv * h;
+    double a = P[i * 8 + j];
+    if (j < 4) a = a + P[i * 8 + j + 4];
+    if (i < 4) {
+        double a4 = P[(i + 4) * 8 + j];
+        if (j < 4) a4 = a4 + P[(i + 4) * 8 + j + 4];
+        a = a + a4;
+    }
+    if (i == j) {
+        const double sd = (i == 2) ? 1e-2 : (i == 6) ? 1e-5 : (i < 4) ? sp : sv;
+        a = a + sd * sd;
+    }
+    pcov[l] = a;
+    if (l < 8) pmean[l] = l < 4 ? mean[l] + mean[l + 4] : mean[l];
 }
 
 // camera-motion warp m (2x3, full-frame pixels) applied to a track's box (oracle so_camera_update, D-18)

@@ -1197,19 +1197,32 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         myslot = dev.order[sb + tid];
         const size_t g = sb + myslot;
         double mean[8], cov[64];
+        if (dev.pred_ahead && !dev.cmc) {
+            // the prediction was made by post_track of the previous frame (one wave per track, beside the new-row units): only the
+            // values the gate needs are read here (mean, the 4x4 block of the covariance), nothing is stored — post_track takes the
+            // predicted state from the same arrays.  (This thread-per-track form loads, predicts and stores 72 doubles per track at a
+            // 512-byte lane stride: 2-3 us of k_frame's 11.)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
+            for (int i = 0; i < 8; ++i) mean[i] = dev.mean_p[g * 8 + i];
 #pragma unroll
-        for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
-        if (dev.cmc) {                                               // N4: camera motion between frame f-1 and f, before predicting
-            const double* wm = dev.cmc + fs * 8;
-            if (wm[6] >= 1.0) { const double m6[6] = { wm[0], wm[1], wm[2], wm[3], wm[4], wm[5] }; ss_camera_update(mean, m6); }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cov[i * 8 + j] = dev.cov_p[g * 64 + i * 8 + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mean[i] = dev.mean[g * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) cov[i] = dev.cov[g * 64 + i];
+            if (dev.cmc) {                                           // N4: camera motion between frame f-1 and f, before predicting
+                const double* wm = dev.cmc + fs * 8;
+                if (wm[6] >= 1.0) { const double m6[6] = { wm[0], wm[1], wm[2], wm[3], wm[4], wm[5] }; ss_camera_update(mean, m6); }
+            }
+            ss_kf_predict(mean, cov, prm.wp, prm.wv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
         }
-        ss_kf_predict(mean, cov, prm.wp, prm.wv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dev.mean[g * 8 + i] = mean[i];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
         dev.age[g] += 1;
         mytsu = dev.tsu[g] + 1;
         dev.tsu[g] = mytsu;
@@ -1421,6 +1434,10 @@ __device__ __forceinline__ void post_track(const SSDev& dev, const SSParams& prm
     const int sel = __builtin_amdgcn_readfirstlane(dev.smooth_sel[g]) & 1;
     const float* sm = dev.smooth + (g * 2 + sel) * SS_F;          // the EMA row in use
     const float* src = sm;                                        // the row a confirmed track appends
+    // the state this frame starts from: what k_frame predicted in place, or the prediction the previous frame's post_track left
+    const bool use_pred = dev.pred_ahead && !dev.cmc;
+    const double* imean = use_pred ? dev.mean_p + g * 8 : dev.mean + g * 8;
+    const double* icov = use_pred ? dev.cov_p + g * 64 : dev.cov + g * 64;
     if (fl & SS_P_MATCHED) {
         const double* zz = dev.xyah + (fb + d) * 4;
         const double z[4] = { zz[0], zz[1], zz[2], zz[3] };
@@ -1428,7 +1445,7 @@ __device__ __forceinline__ void post_track(const SSDev& dev, const SSParams& prm
         float sv[8], fv[8];                                       // EMA operands on the wire before the Kalman arithmetic
 #pragma unroll
         for (int j = 0; j < 8; ++j) { sv[j] = sm[l + 64 * j]; fv[j] = fu[l + 64 * j]; }
-        ss_kf_update_wave(dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws);
+        ss_kf_update_wave(imean, icov, dev.mean + g * 8, dev.cov + g * 64, z, (double)dev.dets[(fb + d) * 6 + 4], prm.wp, ws);
         ema_regs(sv, fv, prm.ema_alpha, prm.ema_one_minus_alpha, rowbuf);
         SS_WAVE_SYNC();
         // the new row goes to the OTHER half: new-row units of this launch (k_postnew) may still be reading the old one
@@ -1443,18 +1460,26 @@ __device__ __forceinline__ void post_track(const SSDev& dev, const SSParams& prm
         const int r = l >> 3, c = l & 7;
         // ss_kf_initiate, one covariance entry per lane
         const double sd = (r == 2) ? 1e-2 : (r == 6) ? 1e-5 : (r < 4) ? 2.0 * prm.wp * h : 10.0 * prm.wv * h;
-        dev.cov[g * 64 + l] = (r == c) ? sd * sd : 0.0;
-        if (l < 8) dev.mean[g * 8 + l] = (l < 4) ? zz[l] : 0.0;
+        const double c0 = (r == c) ? sd * sd : 0.0;
+        dev.cov[g * 64 + l] = c0; ws[l] = c0;
+        if (l < 8) { const double m0 = (l < 4) ? zz[l] : 0.0; dev.mean[g * 8 + l] = m0; ws[64 + l] = m0; }
         const float* fu = dev.feat_unit + (fb + d) * SS_F;
         float* sw = dev.smooth + (g * 2 + sel) * SS_F;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sw[l + 64 * j] = fu[l + 64 * j];
     }
+    else {                                                        // a track without a detection keeps the predicted state
+        const double cv = icov[l];
+        ws[l] = cv;
+        if (use_pred) dev.cov[g * 64 + l] = cv;
+        if (l < 8) { const double mv = imean[l]; ws[64 + l] = mv; if (use_pred) dev.mean[g * 8 + l] = mv; }
+    }
+    SS_WAVE_SYNC();                                               // ws = the track's state after this frame
+    ss_kf_predict_wave(ws, prm.wp, prm.wv, dev.mean_p + g * 8, dev.cov_p + g * 64);
     if (fl & SS_P_APPEND) gallery_append_wave(dev.gallery + g * SS_NRT * SS_TILE_FLOATS, aux & 0xff, src);
     if ((fl & SS_P_EMIT) && l == 0) {
         double mm[4];
-        if (fl & SS_P_MATCHED) { mm[0] = ws[64]; mm[1] = ws[65]; mm[2] = ws[66]; mm[3] = ws[67]; }
-        else { const double* gm = dev.mean + g * 8; mm[0] = gm[0]; mm[1] = gm[1]; mm[2] = gm[2]; mm[3] = gm[3]; }
+        { mm[0] = ws[64]; mm[1] = ws[65]; mm[2] = ws[66]; mm[3] = ws[67]; }
         const double wd = mm[2] * mm[3];
         const double x = mm[0] - wd / 2, y = mm[1] - mm[3] / 2;
         const int H = dev.img_hw[s * 2], W = dev.img_hw[s * 2 + 1];

@@ -202,6 +202,16 @@ def test_association_on_packed_or_per_frame_columns(pack, S, F, frames, ids, wh)
                  stream_kw=dict(p_vanish=0.05, vanish_max=6), empty_every=7 if ids == 3 else 0)
 
 
+@pytest.mark.parametrize("ahead", [1, 0])
+@pytest.mark.parametrize("S,F,frames,ids", [(1, 32, 150, 30), (3, 8, 64, 12), (2, 5, 45, 100)])
+def test_prediction_one_frame_ahead_or_inside_the_frame_kernel(ahead, S, F, frames, ids):
+    """pred_ahead: post_track leaves every live track's state predicted for the next frame (one wave per track, the per-entry operations
+    of ss_kf_predict) and k_frame reads only what its gate needs, against k_frame loading, predicting and storing the whole state:
+    every intermediate and the track tables (mean / covariance bit for bit) equal the oracle either way; births, deaths, unmatched tracks."""
+    wh = (1920, 1080) if ids >= 100 else (1280, 720)
+    _run_streams(S, lambda s: ids + 3 * s, frames, F=F, wh=wh, opts={"pred_ahead": ahead}, stream_kw=dict(p_vanish=0.05, vanish_max=6))
+
+
 @pytest.mark.parametrize("merge", [1, 0])
 @pytest.mark.parametrize("S,F,frames,ids", [(1, 32, 150, 30), (3, 8, 64, 12), (2, 5, 45, 100)])
 def test_post_and_newrow_as_one_launch_or_two(merge, S, F, frames, ids):
