@@ -65,6 +65,10 @@ int  ss_synchronize(ss_ctx* ctx);
  * memory, e.g. the array cv2 returned) into device memory through the context's write-combined pinned staging ring,
  * asynchronously on `hip_stream`.  The host buffer may be reused as soon as the call returns. */
 int ss_upload(ss_ctx* ctx, void* hip_stream, void* d_dst, const void* h_src, size_t bytes);
+/* A frame GROUP at once (the throughput form of ss_upload, for the reference's `cap.read()` loop at yolo_multi_model.py:270-278 fed
+ * `batch` frames at a time): n host buffers of bytes_each bytes are staged by `threads` host threads in one write-combined area and
+ * leave in ONE asynchronous copy to d_dst, where the frames lie contiguously; h_srcs may be reused on return. */
+int ss_upload_batch(ss_ctx* ctx, void* hip_stream, void* d_dst, const void* const* h_srcs, int n, size_t bytes_each, int threads);
 
 /* ... and back: device -> host through a pinned staging buffer; synchronous. */
 int ss_download(ss_ctx* ctx, void* hip_stream, void* h_dst, const void* d_src, size_t bytes);

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ss_common.h"
 
@@ -60,6 +61,8 @@ struct ss_ctx {
     // host -> device upload staging (ss_upload): write-combined pinned buffers, used round robin
     struct Stage { void* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool busy = false; } stage[4];
     int stage_next = 0;
+    Stage bstage[2];            // ss_upload_batch: a whole frame group per staging area
+    int bstage_next = 0;
     uint8_t* font;              // [95][5] overlay font (ss_overlay_set_font)
     // N4 camera-motion compensation
     uint8_t* cmc_small;         // [FMAX+1][S][cmc_stride] down-scaled grey frames (index 0 = last frame of the previous group)
@@ -239,6 +242,7 @@ extern "C" void ss_destroy(ss_ctx* c)
     if (c->ev_chain) (void)hipEventDestroy(c->ev_chain);
     for (void* p : c->allocs) (void)hipFree(p);
     for (auto& st : c->stage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
+    for (auto& st : c->bstage) { if (st.ev) (void)hipEventDestroy(st.ev); if (st.p) (void)hipHostFree(st.p); }
     if (c->back.p) (void)hipHostFree(c->back.p);
     delete c;
 }
@@ -267,6 +271,38 @@ extern "C" int ss_upload(ss_ctx* c, void* hip_stream, void* d_dst, const void* h
     }
     if (!st.ev) HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
     memcpy(st.p, h_src, bytes);
+    HIPCHK(c, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
+    HIPCHK(c, hipEventRecord(st.ev, (hipStream_t)hip_stream));
+    st.busy = true;
+    return SS_OK;
+}
+
+// A group of frames at once: the n host buffers (bytes_each each) are copied into ONE write-combined staging area by `threads`
+// host threads (a single thread fills write-combined memory at ~30 GB/s: 0.09 ms per 720p frame, 2.9 ms for a group of 32 — more
+// than the GPU needs for the group), then leave in one asynchronous copy to d_dst (the frames contiguous there).  Two staging
+// areas alternate; h_srcs may be reused on return.
+extern "C" int ss_upload_batch(ss_ctx* c, void* hip_stream, void* d_dst, const void* const* h_srcs, int n, size_t bytes_each, int threads)
+{
+    if (!c || !d_dst || !h_srcs || n < 0 || threads < 1) return fail(c, SS_ERR_INVALID, "ss_upload_batch: bad argument");
+    if (n == 0 || bytes_each == 0) return SS_OK;
+    for (int i = 0; i < n; ++i) if (!h_srcs[i]) return fail(c, SS_ERR_INVALID, "ss_upload_batch: null frame");
+    ss_ctx::Stage& st = c->bstage[c->bstage_next];
+    c->bstage_next ^= 1;
+    if (st.busy) { HIPCHK(c, hipEventSynchronize(st.ev)); st.busy = false; }
+    const size_t bytes = (size_t)n * bytes_each;
+    if (st.cap < bytes) {
+        if (st.p) { HIPCHK(c, hipHostFree(st.p)); st.p = nullptr; st.cap = 0; }
+        HIPCHK(c, hipHostMalloc(&st.p, bytes, hipHostMallocWriteCombined));
+        st.cap = bytes;
+    }
+    if (!st.ev) HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    const int T = threads < n ? threads : n;
+    char* base = (char*)st.p;
+    auto work = [=](int t) { for (int i = t; i < n; i += T) memcpy(base + (size_t)i * bytes_each, h_srcs[i], bytes_each); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
     HIPCHK(c, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     HIPCHK(c, hipEventRecord(st.ev, (hipStream_t)hip_stream));
     st.busy = true;

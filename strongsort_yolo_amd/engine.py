@@ -113,6 +113,21 @@ class TrackerEngine:
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         self._ck(self.L.ss_upload(self.ctx, C.c_void_p(st.cuda_stream), _ptr(dst), src.ctypes.data_as(C.c_void_p), src.nbytes))
 
+    def upload_batch(self, dst: torch.Tensor, srcs, stream=None, threads: int = 4):
+        """len(srcs) host arrays of one size -> dst[0 .. len(srcs)) (device, contiguous) in ONE asynchronous copy: the arrays are staged
+        by `threads` host threads in a write-combined area (a single thread staging 32 frames of 720p costs more than the GPU needs
+        for them).  The arrays may be reused immediately."""
+        n = len(srcs)
+        if n == 0:
+            return
+        srcs = [np.ascontiguousarray(a) for a in srcs]
+        each = srcs[0].nbytes
+        if any(a.nbytes != each for a in srcs) or not dst.is_contiguous() or dst[0].numel() * dst.element_size() != each or dst.shape[0] < n:
+            raise ValueError("upload_batch: size / layout mismatch")
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        arr = (C.c_void_p * n)(*[a.ctypes.data for a in srcs])
+        self._ck(self.L.ss_upload_batch(self.ctx, C.c_void_p(st.cuda_stream), _ptr(dst), arr, n, each, int(threads)))
+
     def download(self, dst: np.ndarray, src: torch.Tensor, stream=None):
         """Device tensor -> host array (synchronous)."""
         if dst.nbytes != src.numel() * src.element_size() or not src.is_contiguous() or not dst.flags["C_CONTIGUOUS"]:

@@ -20,7 +20,7 @@ DST_F16, DST_HWC = 1, 2
 
 EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
-    "ss_upload", "ss_download", "ss_overlay_set_font", "ss_overlay", "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_nms_set_classes", "ss_crop_norm", "ss_crop_norm_batch",
+    "ss_upload", "ss_upload_batch", "ss_download", "ss_overlay_set_font", "ss_overlay", "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_nms_set_classes", "ss_crop_norm", "ss_crop_norm_batch",
     "ss_track_update", "ss_track_update_group", "ss_cmc_estimate", "ss_track_set_cmc", "ss_crop_norm_packed", "ss_unpack_feats", "ss_op_set_valid_images", "ss_op_set_option", "ss_track_set_assoc_event", "ss_track_update_host",
     "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_project", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
@@ -83,6 +83,7 @@ def load():
     L.ss_reset.argtypes = [vp, i]
     L.ss_synchronize.argtypes = [vp]
     L.ss_upload.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.ss_upload_batch.argtypes = [vp, vp, vp, C.POINTER(vp), i, C.c_size_t, i]
     L.ss_download.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.ss_overlay_set_font.argtypes = [vp, vp]
     L.ss_overlay.argtypes = [vp, vp, vp, i, C.c_longlong, i, i, i, vp, vp, vp]

@@ -485,8 +485,7 @@ class YOLO:
                 g = state["group"]
                 b = pipe.begin_frame()                                    # waits until this buffer set's last group left the tracker
                 with torch.cuda.stream(pipe.s_in):
-                    for f, img in enumerate(chunk):
-                        pipe.eng.upload(b.frames[f], img, pipe.s_in)
+                    pipe.eng.upload_batch(b.frames, chunk, pipe.s_in)      # the group's frames: staged by several host threads, one copy
                     if self._fill is not None:
                         for f in range(len(chunk)):
                             self._fill(b, f, self._frame_index + f)
