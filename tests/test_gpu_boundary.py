@@ -247,17 +247,21 @@ def test_cli_save_draws_on_the_resident_frame_one_upload_per_frame(tmp_path):
     from strongsort_yolo_amd.cli import process_video
     from strongsort_yolo_amd.engine import TrackerEngine
     calls = {"up": 0, "down": 0}
-    up0, down0 = TrackerEngine.upload, TrackerEngine.download
+    up0, down0, upb0 = TrackerEngine.upload, TrackerEngine.download, TrackerEngine.upload_batch
 
     def up(self, *a, **k):
         calls["up"] += 1
         return up0(self, *a, **k)
 
+    def upb(self, dst, srcs, *a, **k):                      # a frame group in one call: counts its frames
+        calls["up"] += len(srcs)
+        return upb0(self, dst, srcs, *a, **k)
+
     def down(self, *a, **k):
         calls["down"] += 1
         return down0(self, *a, **k)
 
-    TrackerEngine.upload, TrackerEngine.download = up, down
+    TrackerEngine.upload, TrackerEngine.download, TrackerEngine.upload_batch = up, down, upb
     try:
         model, frames, ref = _synthetic_model()
         np.save(tmp_path / "clip.npy", np.stack(frames[:24]))
@@ -278,7 +282,7 @@ def test_cli_save_draws_on_the_resident_frame_one_upload_per_frame(tmp_path):
             host.append(ov.draw(frames[k], res, cnt.counts(), fps))
         model2.close()
     finally:
-        TrackerEngine.upload, TrackerEngine.download = up0, down0
+        TrackerEngine.upload, TrackerEngine.download, TrackerEngine.upload_batch = up0, down0, upb0
     # frames 0..8 carry no FPS text in either run (it appears from the 10th processed frame on): identical pixels there
     for k in range(9):
         assert np.array_equal(res_frames[k], host[k]), f"frame {k}"
