@@ -68,6 +68,27 @@ __device__ __forceinline__ void frag_write_row(float4* tile, int i, const float*
     tile[(q * 4 + ks0 + 1) * 16 + i] = make_float4(r[ks0 + 1], r[5 + ks0], r[9 + ks0], r[13 + ks0]);
 }
 
+// three independent flag scans for the price of one (k_frame ran ten scans of two barriers each: 20 of its ~30 barriers)
+__device__ inline void block_scan256_3(int f0, int f1, int f2, int* wtot /*LDS[12]*/, int& p0, int& p1, int& p2, int& t0, int& t1, int& t2)
+{
+    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1), m2 = __ballot(f2);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int i0 = __popcll(m0 & below), i1 = __popcll(m1 & below), i2 = __popcll(m2 & below);
+    __syncthreads();                       // protect wtot from the previous scan's readers
+    if (lane == 0) { wtot[w] = __popcll(m0); wtot[4 + w] = __popcll(m1); wtot[8 + w] = __popcll(m2); }
+    __syncthreads();
+    int o0 = 0, o1 = 0, o2 = 0, s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = wtot[i], c1 = wtot[4 + i], c2 = wtot[8 + i];
+        if (i < w) { o0 += c0; o1 += c1; o2 += c2; }
+        s0 += c0; s1 += c1; s2 += c2;
+    }
+    p0 = o0 + i0; p1 = o1 + i1; p2 = o2 + i2;
+    t0 = s0; t1 = s1; t2 = s2;
+}
+
 // exclusive prefix sum of small non-negative ints over the 256 threads of a block
 __device__ inline void block_scan_sum256(int v, int* wtot /*LDS[4]*/, int& excl, int& total)
 {
@@ -1296,15 +1317,14 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     // ---------------- stage B: IoU association ----------------------------------------------
     int nU, nC1, nCols;
     const int isU = (tid < nT) && (mystate != SS_CONFIRMED);
-    block_scan256(isU, m.wtot, pos, nU);
-    if (isU) m.cand[pos] = tid;
     const int isC1 = (tid < nT) && (mystate == SS_CONFIRMED) && (m.matchdet[tid] < 0) && (mytsu == 1);
-    block_scan256(isC1, m.wtot, pos, nC1);
-    if (isC1) m.cand[nU + pos] = tid;
-    const int nCand = nU + nC1;
     const int isCol = (tid < D) && (m.dettrk[tid] < 0);
-    block_scan256(isCol, m.wtot, pos, nCols);
-    if (isCol) m.cols[pos] = tid;
+    int posC1, posCol;
+    block_scan256_3(isU, isC1, isCol, m.wtot, pos, posC1, posCol, nU, nC1, nCols);
+    if (isU) m.cand[pos] = tid;
+    if (isC1) m.cand[nU + posC1] = tid;
+    const int nCand = nU + nC1;
+    if (isCol) m.cols[posCol] = tid;
     m.asg[tid] = -1; m.rcnt[tid] = 0; m.ccnt[tid] = 0;
     __syncthreads();
     if (prm.debug) {
@@ -1375,9 +1395,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         }
     }
     int nSurv, nApp, nOut, apos, epos;
-    block_scan256(alive, m.wtot, pos, nSurv);
-    block_scan256(doapp, m.wtot, apos, nApp);
-    block_scan256(emit, m.wtot, epos, nOut);
+    block_scan256_3(alive, doapp, emit, m.wtot, pos, apos, epos, nSurv, nApp, nOut);
     if (alive) {
         if (emit) { fl |= SS_P_EMIT; aux |= epos << 8; }
         m.neworder[pos] = myslot;
@@ -1388,9 +1406,9 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     // births: unmatched detections in ascending index take the free slots in ascending order
     int nNew, nFree, rank;
     const int isNew = (tid < D) && (m.dettrk[tid] < 0);
-    block_scan256(isNew, m.wtot, rank, nNew);
-    const int isFree = !m.used[tid];                     // includes the slots freed above (block_scan256 synchronised)
-    block_scan256(isFree, m.wtot, pos, nFree);
+    const int isFree = !m.used[tid];                     // includes the slots freed above (the scan before this one synchronised)
+    int pz, nz;
+    block_scan256_3(isNew, isFree, 0, m.wtot, rank, pos, pz, nNew, nFree, nz);
     if (isFree) m.freelist[pos] = tid;
     __syncthreads();
     if (nSurv + nNew > SS_MAXT || nNew > nFree) { if (tid == 0) dev.err[s] = SS_ERR_CAPACITY; nNew = min(nNew, min(nFree, SS_MAXT - nSurv)); }
