@@ -2064,6 +2064,11 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
     constexpr int IT = C1 > 0 ? 1 : 32 * CG / 64, KS1 = C1 > 0 ? (C1 + 31) / 32 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 Ws4[MT2 * 16 * EP];
     __shared__ __attribute__((aligned(16))) _Float16 Et[128 * EP];
+    // the shortcut's weights and the three bias vectors come with the first round trip too: read from global memory where they are
+    // used (per 16-channel tile, inside the epilogue loops) each of them was a dependent L2 access in a workgroup that lives ~4 us
+    constexpr int WDP = C1 > 0 ? KS1 * 32 + 8 : 8;                            // pitch of a `down` weight row (halfs), zero-padded to whole 32-wide blocks
+    __shared__ __attribute__((aligned(16))) _Float16 Wds[C1 > 0 ? C2 * WDP : 8];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2 * C2 + MT2 * 16];    // b3 | bd | b4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, n = lane & 15;
     const size_t px_wg = (size_t)blockIdx.x * 128, px0 = px_wg + wave * 32;
     const int img = (int)(px_wg / HW);
@@ -2102,6 +2107,20 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
+    for (int i = tid; i < (2 * C2 + MT2 * 16) / 8; i += 256) {                // biases -> LDS
+        const int e = i * 8;
+        h8 v = z8;
+        if (e < C2) v = *reinterpret_cast<const h8*>(b3 + e);
+        else if (e < 2 * C2) { if (C1 > 0) v = *reinterpret_cast<const h8*>(bd + (e - C2)); }
+        else if (e - 2 * C2 < N2) v = *reinterpret_cast<const h8*>(b4 + (e - 2 * C2));
+        *reinterpret_cast<h8*>(Bs + e) = v;
+    }
+    if constexpr (C1 > 0) {
+        for (int i = tid; i < C2 * (KS1 * 4); i += 256) {                   // shortcut weights -> LDS (k >= C1: zeros)
+            const int r = i / (KS1 * 4), c8 = i - r * (KS1 * 4);
+            *reinterpret_cast<h8*>(Wds + r * WDP + c8 * 8) = c8 * 8 < C1 ? *reinterpret_cast<const h8*>(wd + (size_t)r * C1 + c8 * 8) : z8;
+        }
+    }
     for (int i = tid; i < MT2 * 16 * K8; i += 256) {                        // second product's weights -> LDS
         const int r = i / K8, c8 = i - r * K8;
         *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? *reinterpret_cast<const h8*>(w4 + (size_t)r * C2 + c8 * 8) : z8;
@@ -2148,7 +2167,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
                 const int k = ks * 32 + 8 * q;
-                const h8 a = k < C1 ? *reinterpret_cast<const h8*>(wd + (size_t)(mt * 16 + n) * C1 + k) : z8;
+                const h8 a = *reinterpret_cast<const h8*>(Wds + (mt * 16 + n) * WDP + k);
                 const h4 a0 = { a[0], a[1], a[2], a[3] }, a1 = { a[4], a[5], a[6], a[7] };
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) {
@@ -2158,7 +2177,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
                     dd[pt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a1, b1, dd[pt], 0, 0, 0);
                 }
             }
-            const h4 bb3 = *reinterpret_cast<const h4*>(b3 + mt * 16 + 4 * q), bbd = *reinterpret_cast<const h4*>(bd + mt * 16 + 4 * q);
+            const h4 bb3 = *reinterpret_cast<const h4*>(Bs + mt * 16 + 4 * q), bbd = *reinterpret_cast<const h4*>(Bs + C2 + mt * 16 + 4 * q);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 h4 o;
@@ -2194,7 +2213,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
             const int i = it * 64 + lane, row = i / CG, cg = i - row * CG;
             const size_t px = px0 + row;
             const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
-            const h8 bb = *reinterpret_cast<const h8*>(b3 + cg * 8);
+            const h8 bb = *reinterpret_cast<const h8*>(Bs + cg * 8);
             const h8 r = rs[it];
             h8 o;
 #pragma unroll
@@ -2248,7 +2267,7 @@ __global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __
         if (i >= 32 * CG2) break;
         const size_t px = px0 + row;
         const h8 v = *reinterpret_cast<const h8*>(tile + row * EP + cg * 8);
-        const h8 bb = *reinterpret_cast<const h8*>(b4 + cg * 8);
+        const h8 bb = *reinterpret_cast<const h8*>(Bs + 2 * C2 + cg * 8);
         h8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
