@@ -560,15 +560,27 @@ __global__ __launch_bounds__(256) void k_pw_splitk(PwArgs A) { pw_splitk_body<BN
 // set the occupancy of EVERY problem in the launch to 2 waves per SIMD - detector 1.03 -> 1.05 ms.)
 struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int form[PW_GROUP_MAX]; int n; };
 
-template <int BN, bool CONV3>
-__global__ __launch_bounds__(256) void k_pw_group(PwGroup G)
+// SPLITK = false: no problem of the launch takes the split-K form.  That body's 148 VGPRs and 21 KB of LDS set the occupancy of the
+// WHOLE launch (3 waves per SIMD), and at 32 frames no level is small enough to take it: without it the 80-wide 3x3 group is 82 VGPRs /
+// 22 KB (5 waves) - yolov8n on 32 frames 0.954 -> 0.914 ms, same bits.  (Also measured, r05: a level's two first layers, which read the
+// same pixels, as ONE 144-channel problem whose halves the second layers read in place - half the gathers, 1.8x the matrix work per K
+// chunk, but 118 VGPRs / 40 KB: 0.931 ms, slower than the per-branch problems at the higher occupancy.  Not kept.)
+#ifndef SS_GRP_WAVES
+#define SS_GRP_WAVES 6
+#endif
+template <int BN, bool CONV3, bool SPLITK>
+__global__ __launch_bounds__(256)
+#if SS_GRP_WAVES
+__attribute__((amdgpu_waves_per_eu(SS_GRP_WAVES)))
+#endif
+void k_pw_group(PwGroup G)
 {
     __shared__ __attribute__((aligned(16))) _Float16 pw_lds[pw_lds_halfs<BN, 1, true>()];
     int bx = blockIdx.x, p = 0;
     for (int i = 1; i < G.n; ++i) if (bx >= G.start[i]) p = i;
     bx -= G.start[p];
     const int form = G.form[p];
-    if (form == 1) { pw_splitk_body<BN, CONV3>(G.p[p], bx, 0); return; }
+    if constexpr (SPLITK) { if (form == 1) { pw_splitk_body<BN, CONV3>(G.p[p], bx, 0); return; } }
     if (BN == 80 && G.p[p].N <= 64) pw_body<64, 1, CONV3, true>(G.p[p], bx, 0, pw_lds);      // (dead code in the narrower groups)
     else pw_body<BN, 1, CONV3, true>(G.p[p], bx, 0, pw_lds);
 }
@@ -2822,8 +2834,11 @@ extern "C" int ss_op_conv_group_f16(void* stream, int n, const ss_conv_desc* d)
     G.start[PW_GROUP_MAX] = wgs;
     G.n = n;
     hipStream_t st = (hipStream_t)stream;
-#define SS_GRP(BN) do { if (conv3) hipLaunchKernelGGL((k_pw_group<BN, true>), dim3(wgs), dim3(256), 0, st, G);            \
-                        else hipLaunchKernelGGL((k_pw_group<BN, false>), dim3(wgs), dim3(256), 0, st, G); } while (0)
+    bool any_splitk = false;
+    for (int s = 0; s < n; ++s) any_splitk = any_splitk || G.form[s] == 1;
+#define SS_GRP(BN) do { if (conv3 && any_splitk) hipLaunchKernelGGL((k_pw_group<BN, true, true>), dim3(wgs), dim3(256), 0, st, G);            \
+                        else if (conv3) hipLaunchKernelGGL((k_pw_group<BN, true, false>), dim3(wgs), dim3(256), 0, st, G);                    \
+                        else hipLaunchKernelGGL((k_pw_group<BN, false, false>), dim3(wgs), dim3(256), 0, st, G); } while (0)
     if (nmax <= 32) SS_GRP(32);
     else if (nmax <= 64) SS_GRP(64);
     else SS_GRP(80);
