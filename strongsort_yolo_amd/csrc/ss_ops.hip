@@ -431,8 +431,16 @@ __device__ __forceinline__ void pw_body(const PwArgs& A, const int bx, const int
     }
 }
 
+#ifndef SS_TAIL_BUMP
+#define SS_TAIL_BUMP 1
+#endif
+#ifndef SS_PW_BUMP
+#define SS_PW_BUMP 1
+#endif
+// waves per SIMD asked of the register allocator (it otherwise parks the accumulators in AGPRs and stops a few registers above a step)
+template <int BN, int PT, bool CONV3> constexpr int pw_waves() { return !SS_PW_BUMP ? 1 : BN * PT <= 32 ? 8 : (BN == 32 && PT == 2 && CONV3) ? 5 : BN * PT <= 80 ? 6 : BN * PT <= 128 ? 4 : BN * PT <= 160 ? 3 : 2; }   // (<32, 2, 3x3> at 6: spills)
 template <int BN, int PT, bool CONV3, bool VEC_EPI>
-__global__ __launch_bounds__(256) void k_pw(PwArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(pw_waves<BN, PT, CONV3>()))) void k_pw(PwArgs A)
 {
     __shared__ __attribute__((aligned(16))) _Float16 pw_lds[pw_lds_halfs<BN, PT, VEC_EPI>()];
     pw_body<BN, PT, CONV3, VEC_EPI>(A, blockIdx.x, blockIdx.y, pw_lds);
@@ -668,7 +676,7 @@ __device__ __forceinline__ void bn_conv(const _Float16* __restrict__ In, const i
 }
 
 template <int C, int PT1, int PT2>
-__global__ __launch_bounds__(256) void k_bneck(BnArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(!SS_TAIL_BUMP ? 1 : C == 16 ? 6 : 1))) void k_bneck(BnArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) char bn_smem[];
     constexpr int MT = C / 16, P = C + 8, WP = 72;
@@ -2063,7 +2071,7 @@ __global__ __launch_bounds__(128) void k_gate_vec(const float* __restrict__ psum
 // as one more MFMA product (weights wd [C2][C1], bias bd) and applies it in the accumulator layout — the `down` launch
 // (56 us at stage 1 / 512 crops) and 0.1 GB of shortcut reads disappear.  Same products, roundings and order as k_pw.
 template <int MID, int C2, int N2, int C1>
-__global__ __launch_bounds__(256) void k_osnet_tail(GatePtrs ys, const float* __restrict__ gv,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(!SS_TAIL_BUMP ? 1 : MID == 16 ? 4 : MID == 24 ? 3 : 2))) void k_osnet_tail(GatePtrs ys, const float* __restrict__ gv,
                                                    const __half* __restrict__ w3, const __half* __restrict__ b3,
                                                    const __half* __restrict__ idn, const __half* __restrict__ wd,
                                                    const __half* __restrict__ bd, __half* __restrict__ out,
