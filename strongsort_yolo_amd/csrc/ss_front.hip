@@ -179,12 +179,24 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     const int nrows = rb1 - ra0 + 1;
     const size_t rowb = (size_t)x1 * 3;
     const int mis = (int)(rowb & 3), ndw = (mis + cw * 3 + 3) >> 2, pitch = ndw + 1;
-    const bool staged = (stride & 3) == 0 && ((uintptr_t)src & 3) == 0 && (size_t)nrows * pitch * 4 <= CROP_LDS_BYTES;
-    if (staged) {
-        const size_t end = (size_t)H * stride;
+    // mode 2: the band's source rows fit the LDS and are staged once; mode 1 (tall / wide boxes): staged per 16 output rows; mode 0
+    // (boxes of which not even that fits, unaligned frames): byte loads from global memory
+    const bool aligned = (stride & 3) == 0 && ((uintptr_t)src & 3) == 0;
+    bool fit_sub = aligned;
+#pragma unroll
+    for (int rr = 0; rr < CROP_RPT; ++rr) {
+        int a0, a1, b0, b1; float f0, f1;
+        ss_axis(yb + 16 * rr, sy, ch, a0, a1, f0);
+        ss_axis(yb + 16 * rr + 15, sy, ch, b0, b1, f1);
+        fit_sub = fit_sub && (size_t)(b1 - a0 + 1) * pitch * 4 <= CROP_LDS_BYTES;
+    }
+    const int mode = (aligned && (size_t)nrows * pitch * 4 <= CROP_LDS_BYTES) ? 2 : fit_sub ? 1 : 0;
+    const bool staged = mode != 0;
+    const size_t end = (size_t)H * stride;
+    auto stage = [&](const int r_first, const int nr) {
         // eight loads in flight per thread before the first LDS store (a load -> store loop pays one memory latency per
         // iteration: 22 iterations for a 64-row band of a 120-pixel box, the kernel's whole duration)
-        const int tot = nrows * ndw;
+        const int tot = nr * ndw;
         for (int i0 = tid; i0 < tot; i0 += 256 * 8) {
             uint32_t v[8];
             int la[8];
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
                 v[u] = 0; la[u] = -1;
                 if (i < tot) {
                     const int rr = i / ndw, dw = i - rr * ndw;
-                    const size_t off = (size_t)(y1 + ra0 + rr) * stride + (rowb - mis) + (size_t)dw * 4;
+                    const size_t off = (size_t)(y1 + r_first + rr) * stride + (rowb - mis) + (size_t)dw * 4;
                     la[u] = rr * pitch + dw;
                     if (off + 4 <= end) v[u] = *reinterpret_cast<const uint32_t*>(src + off);
                     else { for (int k = 0; k < 4 && off + k < end; ++k) v[u] |= (uint32_t)src[off + k] << (8 * k); }
@@ -203,7 +215,8 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (la[u] >= 0) Ls[la[u]] = v[u];
         }
-    }
+    };
+    if (mode == 2) stage(ra0, nrows);
     __syncthreads();
     const size_t slot = d_off ? (size_t)d_off[img] + d : (size_t)blockIdx.z;     // packed: image i's crops follow image i-1's
     // the column taps of this thread's 8 pixels are the same for every row of the band: byte offsets of the two taps in a staged
@@ -223,8 +236,17 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     ss_axis(y, sy, ch, yy0, yy1, fy);
     __attribute__((aligned(16))) T o[24];
     if (staged) {
-        const uint32_t* l0 = Ls + (yy0 - ra0) * pitch;
-        const uint32_t* l1 = Ls + (yy1 - ra0) * pitch;
+        int row0 = ra0;
+        if (mode == 1) {                                                      // (uniform) this sub-band's rows replace the previous one's
+            int a1, b0, b1; float f0, f1;
+            ss_axis(yb + 16 * rr, sy, ch, row0, a1, f0);
+            ss_axis(yb + 16 * rr + 15, sy, ch, b0, b1, f1);
+            if (rr) __syncthreads();
+            stage(row0, b1 - row0 + 1);
+            __syncthreads();
+        }
+        const uint32_t* l0 = Ls + (yy0 - row0) * pitch;
+        const uint32_t* l1 = Ls + (yy1 - row0) * pitch;
         auto px = [&](const uint32_t* row, int ob) -> uint32_t {             // bytes 0..2 = B, G, R of the source pixel at byte ob
             const int dw = ob >> 2;
             const uint64_t two = ((uint64_t)row[dw + 1] << 32) | row[dw];
@@ -243,9 +265,12 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
             }
         }
     } else {
+        // boxes whose rows do not fit the LDS budget: byte loads from global memory, one pixel at a time (rolled: unrolled, its 96 loads in
+        // flight set the kernel's register count - 174 VGPRs, 2 waves per SIMD - for the staged boxes as well)
         const uint8_t* r0 = src + (size_t)(y1 + yy0) * stride + rowb;
         const uint8_t* r1 = src + (size_t)(y1 + yy1) * stride + rowb;
-#pragma unroll
+        T* od = dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3;
+#pragma unroll 1
         for (int p = 0; p < 8; ++p) {
             int xx0, xx1; float fx;
             ss_axis(xg + p, sx, cw, xx0, xx1, fx);
@@ -253,9 +278,10 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
             for (int c = 0; c < 3; ++c) {
                 const int sc = 2 - c;
                 const float p00 = r0[xx0 * 3 + sc], p01 = r0[xx1 * 3 + sc], p10 = r1[xx0 * 3 + sc], p11 = r1[xx1 * 3 + sc];
-                o[p * 3 + c] = lut[c * 256 + (int)ss_bilerp_u8(p00, p01, p10, p11, fx, fy)];
+                od[p * 3 + c] = lut[c * 256 + (int)ss_bilerp_u8(p00, p01, p10, p11, fx, fy)];
             }
         }
+        continue;
     }
     constexpr int NV = 24 * sizeof(T) / 16;
     uint4* out = reinterpret_cast<uint4*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);

@@ -237,7 +237,11 @@ def test_crop_norm_batch_bit_exact(eng, half, hwc):
     dets[1, 0, :4] = [30.0, 300.0, 500.0, 301.2]
     for j in range(2, 6):
         dets[2, j, :4] = [200.0 + j, 100.0, 260.0 + 2 * j, 290.0]
-    counts[0], counts[1], counts[2] = max(counts[0], 2), max(counts[1], 2), max(counts[2], 6)
+    # tall boxes whose 64-row band does not fit the LDS but whose 16-row sub-bands do (staged four times per workgroup), at two
+    # byte alignments, the second one touching the last row of the frame
+    dets[0, 2, :4] = [300.0, 60.0, 520.0, 560.0]
+    dets[1, 2, :4] = [701.0, 150.0, 990.0, H + 4.0]
+    counts[0], counts[1], counts[2] = max(counts[0], 3), max(counts[1], 3), max(counts[2], 6)
     out = torch.full((B * n, 3, 256, 128), 7.0, dtype=torch.float16 if half else torch.float32, device=eng.device)
     if hwc:
         out = out.contiguous(memory_format=torch.channels_last)
