@@ -572,15 +572,15 @@ struct PwGroup { PwArgs p[PW_GROUP_MAX]; int start[PW_GROUP_MAX + 1]; int form[P
 // WHOLE launch (3 waves per SIMD), and at 32 frames no level is small enough to take it: without it the 80-wide 3x3 group is 82 VGPRs /
 // 22 KB (5 waves) - yolov8n on 32 frames 0.954 -> 0.914 ms, same bits.  (Also measured, r05: a level's two first layers, which read the
 // same pixels, as ONE 144-channel problem whose halves the second layers read in place - half the gathers, 1.8x the matrix work per K
-// chunk, but 118 VGPRs / 40 KB: 0.931 ms, slower than the per-branch problems at the higher occupancy.  Not kept.)
+// chunk, but 118 VGPRs / 40 KB: 0.931 ms, slower than the per-branch problems at the higher occupancy.  Not kept.
+// Also measured and not kept (r05, detector at 0.87 ms): the split-K form for the plain 3x3 launches up to 8 192 pixels (0.91 ms), 128-wide K
+// chunks for the long K walks of the stride-32 level (neutral), 8 x 8 instead of 8 x 16 bottleneck tiles at the stride-8 level (0.88-0.89 ms).)
 #ifndef SS_GRP_WAVES
 #define SS_GRP_WAVES 6
 #endif
 template <int BN, bool CONV3, bool SPLITK>
 __global__ __launch_bounds__(256)
-#if SS_GRP_WAVES
-__attribute__((amdgpu_waves_per_eu(SS_GRP_WAVES)))
-#endif
+__attribute__((amdgpu_waves_per_eu(SPLITK || !SS_GRP_WAVES ? 1 : SS_GRP_WAVES)))
 void k_pw_group(PwGroup G)
 {
     __shared__ __attribute__((aligned(16))) _Float16 pw_lds[pw_lds_halfs<BN, 1, true>()];
