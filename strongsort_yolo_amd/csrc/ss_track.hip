@@ -1190,13 +1190,36 @@ __device__ inline int frame_assign(int n_rows, int n_cols, bool big, const doubl
     return 2;
 }
 
+// -DSS_FRAME_STAMPS (a profiling build, tools/frame_phases.py): wall-clock time (100 MHz) of k_frame's phases and of k_postnew's two roles,
+// summed per stream-0 launch into rows 3000-3002 of dev.timeline
+#ifdef SS_FRAME_STAMPS
+#define SS_FS(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = wall_clock64(); dev.timeline[3000 * 16 + (i)] += t_ - fs_t; fs_t = t_; } } while (0)
+#define SS_FSV(i, val) do { asm volatile("" :: "v"(val)); if (threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = wall_clock64(); dev.timeline[3003 * 16 + (i)] += t_ - fs_t0; } } while (0)
+#else
+#define SS_FS(i) do { } while (0)
+#define SS_FSV(i, val) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
 {
+#ifdef SS_FRAME_STAMPS
+    long long fs_t = wall_clock64();
+    const long long fs_t0 = fs_t;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int s = blockIdx.x, tid = threadIdx.x, S = dev.S;
     const size_t sb = (size_t)s * SS_MAXT;
     const size_t fs = (size_t)f * S + s, fb = fs * SS_MAXD;        // (frame, stream) and its detection base
+    // what does not depend on the counts is requested with them: every dependent load of a freshly launched workgroup is ~0.5-1 us (the
+    // previous kernel's data comes from the memory side of the L2s), and the detection boxes used to be requested last, after the track block
+    const int slot_raw = dev.order[sb + tid];
+    double zraw[4], draw[4];
+    {
+        const size_t dz = (fb + (tid < SS_MAXD ? tid : SS_MAXD - 1)) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { zraw[i] = dev.xyah[dz + i]; draw[i] = dev.tlwh[dz + i]; }
+    }
     const int nT = dev.n_tracks[s], D = min(dev.n_dets[fs], SS_MAXD);
+    SS_FSV(0, nT + D);
     const FrameLds m = carve_frame(smem, dev, s, nT, D);
     if (s == 0 && tid == 0) {
 #pragma unroll
@@ -1215,7 +1238,8 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     // ---------------- predict every live track (thread = position in the track list) -----------------------
     int myslot = -1, mystate = 0, mytsu = 0, confirmed = 0;
     if (tid < nT) {
-        myslot = dev.order[sb + tid];
+        myslot = slot_raw;
+        SS_FSV(1, myslot);
         const size_t g = sb + myslot;
         double mean[8], cov[64];
         if (dev.pred_ahead && !dev.cmc) {
@@ -1244,8 +1268,10 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
 #pragma unroll
             for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
         }
+        SS_FSV(2, (int)__double2loint(mean[0]) ^ (int)__double2loint(cov[27]));
         dev.age[g] += 1;
         mytsu = dev.tsu[g] + 1;
+        SS_FSV(3, mytsu);
         dev.tsu[g] = mytsu;
         dev.det_idx[g] = -1;
         // gate factorisation (projection with conf = 0) and predicted box
@@ -1259,20 +1285,24 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         const double wd = mean[2] * mean[3];
         double* tb = m.ttl + tid * 4;
         tb[0] = mean[0] - wd / 2; tb[1] = mean[1] - mean[3] / 2; tb[2] = wd; tb[3] = mean[3];
+        SS_FSV(4, (int)__double2loint(tb[0]));
         mystate = dev.state[g];
         confirmed = mystate == SS_CONFIRMED;
+        SS_FSV(5, mystate);
     }
     m.slot_l[tid] = myslot;
     m.tsu_l[tid] = mytsu;
     if (tid < D) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { m.zs[tid * 4 + i] = dev.xyah[(fb + tid) * 4 + i]; m.dtl[tid * 4 + i] = dev.tlwh[(fb + tid) * 4 + i]; }
+        for (int i = 0; i < 4; ++i) { m.zs[tid * 4 + i] = zraw[i]; m.dtl[tid * 4 + i] = draw[i]; }
     }
+    SS_FS(0);
     int pos, nC;
     block_scan256(confirmed, m.wtot, pos, nC);
     if (confirmed) m.conf_l[pos] = tid;
     __syncthreads();
 
+    SS_FS(1);
     // ---------------- stage A: appearance + motion cost, LSAP --------------------------------
     double* spill = dev.cost_spill + (size_t)s * SS_MAXT * SS_MAXD;
     if (nC > 0 && D > 0) {
@@ -1280,10 +1310,24 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         const int nr = tr ? D : nC, nc = tr ? nC : D;
         const bool big = nr * nc > dev.cap_cost;
         double* cost = big ? spill : m.cost;
-        for (int idx = tid; idx < nC * D; idx += 256) {
+        // the appearance distances of a thread's next four entries are requested together: one exposed round trip to the association
+        // kernel's output per 1 024 entries instead of one per 256 (at 30 x 30: 4 -> 1; each was ~0.6 us of this ~2.7 us phase)
+        const int nE = nC * D;
+        for (int base = 0; base < nE; base += 1024) {
+        int keys[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = min(base + tid + 256 * j, nE - 1);           // clamped: an unconditional load (a predicated one would wait alone)
+            const int r = idx / D, d = idx - r * D;
+            keys[j] = dev.M[((sb + m.slot_l[m.conf_l[r]]) * SS_FMAX + f) * SS_MAXD + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = base + tid + 256 * j;
+            if (idx >= nE) break;
             const int r = idx / D, d = idx % D;
             const int ti = m.conf_l[r];
-            const float c = ss_fkey_inv(dev.M[((sb + m.slot_l[ti]) * SS_FMAX + f) * SS_MAXD + d]);
+            const float c = ss_fkey_inv(keys[j]);
             const double* ch = m.chol + ti * 14;
             double Lm[16] = { ch[0], 0, 0, 0, ch[1], ch[2], 0, 0, ch[3], ch[4], ch[5], 0, ch[6], ch[7], ch[8], ch[9] };
             double m4[4] = { ch[10], ch[11], ch[12], ch[13] };
@@ -1298,8 +1342,10 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
                 dev.dbg_cos[o] = c; dev.dbg_maha[o] = maha; dev.dbg_gated[o] = (uint8_t)gt; dev.dbg_cost_a[o] = v;
             }
         }
+        }
         if (big) __threadfence();                        // the spilled matrix is read back by another wave
         __syncthreads();
+        SS_FS(2);
         const int path = frame_assign(nC, D, big, m.cost, spill, m, dev.err + s);
         if (prm.debug && tid == 0) dev.dbg_counts[fs * 8 + 4] = path;
         if (tid < nC) {
@@ -1314,6 +1360,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     }
     __syncthreads();
 
+    SS_FS(3);
     // ---------------- stage B: IoU association ----------------------------------------------
     int nU, nC1, nCols;
     const int isU = (tid < nT) && (mystate != SS_CONFIRMED);
@@ -1332,6 +1379,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         if (tid < nCols) dev.dbg_lists[(fs * 4 + 2) * SS_MAXT + tid] = m.cols[tid];
         if (tid == 0) { int* c = dev.dbg_counts + fs * 8; c[0] = nC; c[1] = nCand; c[2] = nCols; c[3] = D; c[5] = 0; if (!(nC > 0 && D > 0)) c[4] = 0; }
     }
+    SS_FS(4);
     if (nCand > 0 && nCols > 0) {
         const bool tr = nCols < nCand;
         const int nr = tr ? nCols : nCand, nc = tr ? nCand : nCols;
@@ -1364,6 +1412,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
     }
     __syncthreads();
 
+    SS_FS(5);
     // ---------------- stage C: track states, survivors, gallery ring positions, output slots -----------------
     int alive = 0, md = -1, fl = 0, aux = 0, doapp = 0, emit = 0;
     if (tid < nT) {
@@ -1394,6 +1443,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
             emit = mytsu <= 1;
         }
     }
+    SS_FS(6);
     int nSurv, nApp, nOut, apos, epos;
     block_scan256_3(alive, doapp, emit, m.wtot, pos, apos, epos, nSurv, nApp, nOut);
     if (alive) {
@@ -1403,6 +1453,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         if (doapp) dev.rowlist[sb + apos] = myslot | ((fl & SS_P_FIRSTROW) ? 1 << 16 : 0) | ((dev.smooth_sel[sb + myslot] & 1) << 17) |
                                            ((fl & SS_P_MATCHED) ? (1 << 18) | (md << 19) : 0);
     }
+    SS_FS(7);
     // births: unmatched detections in ascending index take the free slots in ascending order
     int nNew, nFree, rank;
     const int isNew = (tid < D) && (m.dettrk[tid] < 0);
@@ -1425,12 +1476,17 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         dev.post[sb + nSurv + rank] = make_int4(slot, tid, SS_P_BIRTH, 0);
     }
     __syncthreads();
+    SS_FS(8);
     const int nTot = nSurv + nNew;
     if (tid < nTot) dev.order[sb + tid] = m.neworder[tid];
     if (tid == 0) {
         dev.n_tracks[s] = nTot; dev.next_id[s] = nid0 + nNew; dev.frame[s] += 1;
         dev.n_post[s] = nTot; dev.n_rows[s] = nApp; dev.n_out[fs] = nOut;
     }
+    SS_FS(9);
+#ifdef SS_FRAME_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x == 0) dev.timeline[3000 * 16 + 15] += 1;
+#endif
 }
 
 // =================================================================================================
@@ -1619,15 +1675,25 @@ __global__ __launch_bounds__(512) void k_postnew(SSDev dev, SSParams prm, int f,
     __shared__ __attribute__((aligned(16))) float pn_lds[2 * 8 * 4 * 64 + 16 * SS_F];      // new-row role: partial sums + the 16 rows; post role: ws + row buffers
     __shared__ int s_slot[16];
     const int s = blockIdx.y;
+#ifdef SS_FRAME_STAMPS
+    const long long pn_t = wall_clock64();
+#endif
     if (blockIdx.x < SS_PN_POST) {
         const int w = threadIdx.x >> 6, n = dev.n_post[s];
         double* ws = reinterpret_cast<double*>(pn_lds) + w * 72;                           // 8 x 72 doubles = 4608 B
         float* rowbuf = pn_lds + 8 * 72 * 2 + w * SS_F;
         for (int k = blockIdx.x * 8 + w; k < n; k += SS_PN_POST * 8) post_track(dev, prm, s, f, k, ws, rowbuf);
+#ifdef SS_FRAME_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x == 0 && s == 0) { dev.timeline[3001 * 16 + 0] += wall_clock64() - pn_t; dev.timeline[3001 * 16 + 15] += 1; }
+#endif
         return;
     }
     if (!with_new) return;
     newrow_units<true>(dev, prm, s, f, blockIdx.x - SS_PN_POST, SS_PN_NEW, pn_lds, s_slot, pn_lds + 2 * 8 * 4 * 64);
+#ifdef SS_FRAME_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == SS_PN_POST && s == 0) { dev.timeline[3002 * 16 + 0] += wall_clock64() - pn_t; dev.timeline[3002 * 16 + 15] += 1; }
+#endif
 }
 
 // =================================================================================================
