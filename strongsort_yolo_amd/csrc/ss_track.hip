@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
 
     // ---------------- predict every live track (thread = position in the track list) -----------------------
     int myslot = -1, mystate = 0, mytsu = 0, confirmed = 0;
+    int pre_hits = 0, pre_head = 0, pre_cnt = 0;                     // stage C's per-track counters, requested here with the rest of the state
     if (tid < nT) {
         myslot = slot_raw;
         SS_FSV(1, myslot);
@@ -1269,6 +1270,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
             for (int i = 0; i < 64; ++i) dev.cov[g * 64 + i] = cov[i];
         }
         SS_FSV(2, (int)__double2loint(mean[0]) ^ (int)__double2loint(cov[27]));
+        pre_hits = dev.hits[g]; pre_head = dev.gal_head[g]; pre_cnt = dev.gal_count[g];
         dev.age[g] += 1;
         mytsu = dev.tsu[g] + 1;
         SS_FSV(3, mytsu);
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
             const float* det = dev.dets + (fb + md) * 6;
             dev.conf[g] = det[4];
             dev.class_id[g] = (int)det[5];
-            const int h = dev.hits[g] + 1;
+            const int h = pre_hits + 1;
             dev.hits[g] = h;
             dev.tsu[g] = 0; mytsu = 0;
             dev.det_idx[g] = md;
@@ -1434,7 +1436,7 @@ __global__ __launch_bounds__(256) void k_frame(SSDev dev, SSParams prm, int f)
         if (!alive) { dev.slot_used[g] = 0; m.used[myslot] = 0; dev.gal_count[g] = 0; dev.gal_head[g] = 0; }
         else if (mystate == SS_CONFIRMED) {
             // every confirmed track appends its (possibly just updated) EMA feature to its gallery ring (D-05)
-            const int head = dev.gal_head[g], cnt = dev.gal_count[g];
+            const int head = pre_head, cnt = pre_cnt;
             dev.gal_head[g] = (head + 1 == prm.nn_budget) ? 0 : head + 1;
             dev.gal_count[g] = min(cnt + 1, prm.nn_budget);
             doapp = 1;
