@@ -21,6 +21,9 @@ python tools/osnet_sequence.py "$t" > $out/r05_osnet_sequence.txt 2>&1
 python tools/trace_busy.py "$t" 16 > $out/r05_gpu_busy_c2_s1.txt 2>&1
 find $out/prof_bench -name "*.csv" -size +2M -delete
 tail -3 $out/r05_rocprofv3_kernel_trace_k_assoc_pipeline_c2_s1.csv; cat $out/bench_c2_time.txt
+python tools/crop_time.py > $out/r05_crop_time.txt 2>&1
+SS_LIB_PATH=$PWD/ab_tmp/stamps.so python tools/frame_phases.py > $out/r05_frame_phases.txt 2>&1
+python tools/osnet_time.py 40 32 > $out/r05_nets_time.txt 2>&1
 for f in $out/r05_bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
