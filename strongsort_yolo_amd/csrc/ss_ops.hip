@@ -1038,11 +1038,27 @@ __global__ __launch_bounds__(256) void k_osnet_stem(const __half* __restrict__ x
     // ---- stage the input rows: 16-byte chunks, zeros outside the image and in the margins ----
     const __half* xi = x + (size_t)img * H * STEM_W * 3;
     constexpr int CH = STEM_PITCH / 8;                                                 // 52 chunks per LDS row
-    for (int i = tid; i < STEM_IN_ROWS * CH; i += 256) {
-        const int rr = i / CH, ch = i - rr * CH, gr = in_r0 + rr;
-        const bool ok = ch >= STEM_M / 8 && ch < STEM_M / 8 + STEM_W * 3 / 8 && gr >= 0 && gr < H;
-        *reinterpret_cast<h8*>(In + rr * STEM_PITCH + ch * 8) =
-            ok ? *reinterpret_cast<const h8*>(xi + (size_t)gr * STEM_W * 3 + (ch - STEM_M / 8) * 8) : z8;
+    {
+        // all of a thread's chunks are requested before the first LDS store, from clamped addresses (rolled, with a predicated load per
+        // iteration, this loop paid five full memory round trips per workgroup - most of a workgroup's life)
+        constexpr int NIT = (STEM_IN_ROWS * CH + 255) / 256;
+        h8 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = min(tid + 256 * it, STEM_IN_ROWS * CH - 1);
+            const int rr = i / CH, ch = i - rr * CH;
+            const int gr = min(max(in_r0 + rr, 0), H - 1), cc = min(max(ch - STEM_M / 8, 0), STEM_W * 3 / 8 - 1);
+            v[it] = *reinterpret_cast<const h8*>(xi + (size_t)gr * STEM_W * 3 + cc * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + 256 * it;
+            if (i < STEM_IN_ROWS * CH) {
+                const int rr = i / CH, ch = i - rr * CH, gr = in_r0 + rr;
+                const bool ok = ch >= STEM_M / 8 && ch < STEM_M / 8 + STEM_W * 3 / 8 && gr >= 0 && gr < H;
+                *reinterpret_cast<h8*>(In + rr * STEM_PITCH + ch * 8) = ok ? v[it] : z8;
+            }
+        }
     }
     if (tid < STEM_CR * 2) *reinterpret_cast<h8a4*>(Cv + (tid >> 1) * STEM_CW * STEM_CP + (tid & 1) * 8) = z8;      // left pad column
     // weights of this wave's residue: A operand, lane (q, oc = n): k = 8q..8q+7 of every ky
@@ -2127,23 +2143,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(!SS_TAIL_BU
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a3[mt] = kval ? *reinterpret_cast<const h8*>(w3 + (size_t)(mt * 16 + n) * MID + 8 * q) : z8;
-    for (int i = tid; i < (2 * C2 + MT2 * 16) / 8; i += 256) {                // biases -> LDS
-        const int e = i * 8;
-        h8 v = z8;
-        if (e < C2) v = *reinterpret_cast<const h8*>(b3 + e);
-        else if (e < 2 * C2) { if (C1 > 0) v = *reinterpret_cast<const h8*>(bd + (e - C2)); }
-        else if (e - 2 * C2 < N2) v = *reinterpret_cast<const h8*>(b4 + (e - 2 * C2));
-        *reinterpret_cast<h8*>(Bs + e) = v;
+    // weights and biases -> LDS: every vector of a thread is requested (from a clamped, always valid address) before the first LDS store.
+    // (As rolled `load -> store` loops with a predicated load each, these cost one full L2 round trip per 256 vectors - two to eight of
+    // them back to back in a workgroup that otherwise lives for one.)
+    constexpr int NB = (2 * C2 + MT2 * 16) / 8, NW4 = MT2 * 16 * K8, NWD = C1 > 0 ? C2 * (KS1 * 4) : 0;
+    constexpr int IB = (NB + 255) / 256, IW4 = (NW4 + 255) / 256, IWD = (NWD + 255) / 256;
+    h8 vb[IB], vw4[IW4], vwd[IWD > 0 ? IWD : 1];
+#pragma unroll
+    for (int it = 0; it < IB; ++it) {
+        const int e = min(tid + 256 * it, NB - 1) * 8;
+        const __half* src = e < C2 ? b3 + e : e < 2 * C2 ? (C1 > 0 ? bd + (e - C2) : b3) : b4 + min(e - 2 * C2, N2 - 8);
+        vb[it] = *reinterpret_cast<const h8*>(src);
     }
-    if constexpr (C1 > 0) {
-        for (int i = tid; i < C2 * (KS1 * 4); i += 256) {                   // shortcut weights -> LDS (k >= C1: zeros)
-            const int r = i / (KS1 * 4), c8 = i - r * (KS1 * 4);
-            *reinterpret_cast<h8*>(Wds + r * WDP + c8 * 8) = c8 * 8 < C1 ? *reinterpret_cast<const h8*>(wd + (size_t)r * C1 + c8 * 8) : z8;
+#pragma unroll
+    for (int it = 0; it < IWD; ++it) {
+        const int i = min(tid + 256 * it, NWD - 1), r = i / (KS1 * 4), c8 = i - r * (KS1 * 4);
+        vwd[it] = *reinterpret_cast<const h8*>(wd + (size_t)r * C1 + min(c8 * 8, C1 - 8));
+    }
+#pragma unroll
+    for (int it = 0; it < IW4; ++it) {
+        const int i = min(tid + 256 * it, NW4 - 1), r = i / K8, c8 = i - r * K8;
+        vw4[it] = *reinterpret_cast<const h8*>(w4 + (size_t)min(r, N2 - 1) * C2 + c8 * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < IB; ++it) {
+        const int i = tid + 256 * it, e = i * 8;
+        if (i < NB) {
+            const bool ok = e < C2 || (e < 2 * C2 ? C1 > 0 : e - 2 * C2 < N2);
+            *reinterpret_cast<h8*>(Bs + e) = ok ? vb[it] : z8;
         }
     }
-    for (int i = tid; i < MT2 * 16 * K8; i += 256) {                        // second product's weights -> LDS
-        const int r = i / K8, c8 = i - r * K8;
-        *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? *reinterpret_cast<const h8*>(w4 + (size_t)r * C2 + c8 * 8) : z8;
+#pragma unroll
+    for (int it = 0; it < IWD; ++it) {
+        const int i = tid + 256 * it, r = i / (KS1 * 4), c8 = i - r * (KS1 * 4);
+        if (i < NWD) *reinterpret_cast<h8*>(Wds + r * WDP + c8 * 8) = c8 * 8 < C1 ? vwd[it] : z8;     // (k >= C1: zeros)
+    }
+#pragma unroll
+    for (int it = 0; it < IW4; ++it) {
+        const int i = tid + 256 * it, r = i / K8, c8 = i - r * K8;
+        if (i < NW4) *reinterpret_cast<h8*>(Ws4 + r * EP + c8 * 8) = r < N2 ? vw4[it] : z8;
     }
     __syncthreads();
 
