@@ -410,9 +410,15 @@ __global__ __launch_bounds__(512) void k_nms_filter(NmsBatch nb, int N, int nc, 
     const int a = blockIdx.x * 64 + l;
     float best = -INFINITY; int bc = 0x7fffffff;
     if (a < N)
-        for (int k = g; k < nc; k += 8) {
-            float s = pred[(size_t)(4 + k) * N + a];
-            if (s > best) { best = s; bc = k; }
+        for (int k0 = g; k0 < nc; k0 += 80) {                       // ten class rows in flight per thread (80 classes: one round trip, was ten)
+            float s[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) s[j] = pred[(size_t)(4 + min(k0 + 8 * j, nc - 1)) * N + a];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int k = k0 + 8 * j;
+                if (k < nc && s[j] > best) { best = s[j]; bc = k; }
+            }
         }
     sbest[g][l] = best; scls[g][l] = bc;
     __syncthreads();
