@@ -57,11 +57,21 @@ template <int K, int N, int NTHR>
 static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const float* __restrict__ w, int tid)
 {
     constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 4, NP = (N + 15) / 16 * 16;
-    for (int i = tid; i < NP * (KP / 4); i += NTHR) {
-        const int r = i / (KP / 4), c = i - r * (KP / 4);
-        f4 v = zero4();
-        if (r < N && c < CH) v = ld4(w + (size_t)r * K + 4 * c);
-        st4(Ws + r * KP + 4 * c, v);
+    // up to eight vectors of a thread are requested (from clamped, always valid addresses) before the first LDS store: the rolled
+    // `predicated load -> store` loop paid one L2 round trip per NTHR vectors - 3 to 17 of them back to back at the start of a workgroup
+    constexpr int TOT = NP * (KP / 4), NIT = (TOT + NTHR - 1) / NTHR, UB = NIT < 8 ? NIT : 8;
+    for (int i0 = tid; i0 < TOT; i0 += UB * NTHR) {
+        f4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = min(i0 + u * NTHR, TOT - 1), r = i / (KP / 4), c = i - r * (KP / 4);
+            v[u] = ld4(w + (size_t)min(r, N - 1) * K + 4 * min(c, CH - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int i = i0 + u * NTHR, r = i / (KP / 4), c = i - r * (KP / 4);
+            if (i < TOT) st4(Ws + r * KP + 4 * c, (r < N && c < CH) ? v[u] : zero4());
+        }
     }
 }
 template <int K, int N>
@@ -453,14 +463,28 @@ __global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict_
     if (tid < 4 * MID) {                                     // channel means of the four chain outputs (bands in order)
         const int t = tid / MID, c = tid - t * MID;
         float s = 0.f;
-        for (int b = 0; b < bands; ++b) s += psum[(((size_t)t * Nimg + img) * bands + b) * MID + c];
+        const float* ps = psum + (((size_t)t * Nimg + img) * bands) * MID + c;
+        for (int b0 = 0; b0 < bands; b0 += 8) {                // eight band sums per round trip (clamped index), added in band order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ps[(size_t)min(b0 + u, bands - 1) * MID];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b0 + u < bands) s += v[u];
+        }
         Mn[tid] = s * scale;
     }
     __syncthreads();
     if (tid < 4 * hidden) {
         const int t = tid / hidden, j = tid - t * hidden;
         float s = gb1[j];
-        for (int c = 0; c < MID; ++c) s = __builtin_fmaf(gw1[j * MID + c], Mn[t * MID + c], s);
+        f4 wv[MID / 4];                                        // the row in MID / 4 vector loads, one round trip (was MID dependent scalar loads)
+#pragma unroll
+        for (int q4 = 0; q4 < MID / 4; ++q4) wv[q4] = ld4(gw1 + j * MID + 4 * q4);
+#pragma unroll
+        for (int q4 = 0; q4 < MID / 4; ++q4) {
+            s = __builtin_fmaf(wv[q4][0], Mn[t * MID + 4 * q4], s); s = __builtin_fmaf(wv[q4][1], Mn[t * MID + 4 * q4 + 1], s);
+            s = __builtin_fmaf(wv[q4][2], Mn[t * MID + 4 * q4 + 2], s); s = __builtin_fmaf(wv[q4][3], Mn[t * MID + 4 * q4 + 3], s);
+        }
         Hd[t * 4 + j] = s > 0.f ? s : 0.f;
     }
     __syncthreads();
