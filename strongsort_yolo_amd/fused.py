@@ -79,16 +79,24 @@ class valid_images:
         self.n_dev, self.batch = n_dev, int(batch)
         self._stream = None
 
+    active = 0          # nesting depth of `with valid_images(...)` blocks that carry a count (this thread's launches skip images)
+
     def __enter__(self):
         if self.n_dev is not None:
             self._stream = C.c_void_p(torch.cuda.current_stream(self.n_dev.device).cuda_stream)
             _ck(_lib.load().ss_op_set_valid_images(self._stream, _p(self.n_dev), self.batch))
+            valid_images.active += 1
         return self
 
     def __exit__(self, *a):
         if self.n_dev is not None:
+            valid_images.active -= 1
             _ck(_lib.load().ss_op_set_valid_images(self._stream, None, 0))
         return False
+
+
+def _nv_active() -> bool:
+    return valid_images.active > 0
 
 
 def set_option(name: str, value: int):
@@ -636,7 +644,8 @@ def osnet_head_ok(x, fc) -> bool:
 def osnet_head(x, fc):
     """relu(fc(mean_hw(x))): x [N, 128, H, W] channels-last half -> [N, F] half."""
     n, c, h, w = x.shape
-    out = torch.empty((n, fc.out_features), dtype=x.dtype, device=x.device)
+    # rows of images past the valid count of a packed batch are not computed: zeros, not uninitialised memory, for whoever reads the full tensor
+    out = torch.zeros((n, fc.out_features), dtype=x.dtype, device=x.device) if _nv_active() else torch.empty((n, fc.out_features), dtype=x.dtype, device=x.device)
     _ck(_lib.load().ss_op_osnet_head_f16(_st(x), _p(x), _p(fc.weight), _p(fc.bias), _p(out), n, h * w, c, fc.out_features))
     return out
 

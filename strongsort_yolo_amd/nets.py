@@ -484,7 +484,8 @@ class Attention(nn.Module):
             y = fused.psa_attention(qkv, self.pe(v), self.num_heads, self.scale)
             pc = self.proj.conv
             if res is not None and fused.pointwise_ok(pc):                               # PSABlock's x + attn(x) in the projection's epilogue
-                return fused.pointwise(y, fused.weight_nk(self.proj, pc), pc.bias, "none", res=res)
+                # res_after: the projection is rounded to half BEFORE the shortcut is added, as `res + self.proj(y)` rounds it
+                return fused.pointwise(y, fused.weight_nk(self.proj, pc), pc.bias, "none", res=res, res_after=True)
             return self.proj(y) if res is None else res + self.proj(y)
         qkv = self.qkv(x).contiguous().view(B, self.num_heads, self.key_dim * 2 + self.head_dim, N)
         q, k, v = qkv.split([self.key_dim, self.key_dim, self.head_dim], dim=2)
@@ -509,9 +510,9 @@ class PSABlock(nn.Module):
         f1 = self.ffn[1].conv
         if fused.usable(x) and fused.pointwise_ok(f1):                                   # x + ffn(x) in the second 1x1's epilogue
             if out is not None:
-                fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x, out=out, c_off=c_off)
+                fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x, res_after=True, out=out, c_off=c_off)
                 return None
-            return fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x)
+            return fused.pointwise(self.ffn[0](x), fused.weight_nk(self.ffn[1], f1), f1.bias, "none", res=x, res_after=True)   # (two roundings, as x + ffn(x))
         y = x + self.ffn(x)
         if out is not None:
             out[:, c_off:c_off + y.shape[1]] = y
