@@ -60,7 +60,7 @@ CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4, "c6": None}
 # where the two HIP streams' stages are cut inside OSNet.  c2, r03 sweep after the detector got faster (40 steps, two runs each): split 2:
 # 11 232 / 11 244, 4: 11 701 / 11 531, 5: 11 720 / 11 785, 6: 11 509 / 11 014 frames/s.  The larger detectors keep the earlier cut (30 steps, one
 # run each): c3 cut 2: 7 981, cut 5: 7 938; c5 (pose head) cut 2: 9 267, cut 5: 8 446; c4 (yolov7: the detector is the long stage) was only measured at 2
-REID_SPLIT = {"c1": 4, "c2": 5, "c3": 2, "c4": 2, "c5": 5, "c6": 2}
+REID_SPLIT = {"c1": 4, "c2": 6, "c3": 2, "c4": 2, "c5": 5, "c6": 2}     # c2 re-measured with the round-5 kernels (detector 0.87, OSNet 1.16 ms): 6 over 5 by 3-9 % in two paired runs
 PMC_FILE = "r05_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by tracker workload / streams / frames (tools/pmc_assoc.sh)
 PMC_WORKLOAD = {"c1": None, "c2": "c2", "c3": "c2", "c5": "c2", "c6": "c2", "c4": "c4"}   # presets that differ only in the detector share a tracker workload
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
