@@ -210,7 +210,7 @@ def _run_groups(pipe, items, fb):
 
 
 @pytest.mark.parametrize("detector,w,h,n_ids,reid_batch,n_frames,split", [
-    ("yolov8n", 1280, 720, 30, 32, 176, 5),    # bench.py default = BASELINE configs[1]: 5 groups of 32 + a partial group of 16
+    ("yolov8n", 1280, 720, 30, 32, 176, 6),    # bench.py default = BASELINE configs[1]: 5 groups of 32 + a partial group of 16 (cut after OSNet part 6)
     ("yolov7", 1920, 1080, 100, 128, 80, 2),   # bench.py --preset c4 = configs[3]: 2 groups of 32 + 16
     ("yolov8s", 1280, 720, 30, 32, 144, 2),    # --preset c3 = configs[2] per GPU: the stage cut the larger detectors keep (OSNet part 2)
     ("yolov8n-pose", 1280, 720, 30, 32, 144, 5),   # --preset c5 = configs[4] per GPU: 51 keypoint columns ride through NMS with the kept rows
