@@ -429,6 +429,271 @@ __global__ __launch_bounds__(C32_THREADS) void k32_chains3(const float* __restri
     }
 }
 
+// ---- k32_chainsR ---------------------------------------------------------------------------------------------------------
+// The chains as a REGISTER-resident row stream (round 6): no activation ever touches LDS.  k32_chains3 spends its time moving every
+// layer's 1x1 output through LDS (write 16 B per (pixel, chunk), read it back 4.5 times) with the LDS, vector and matrix phases of
+// a layer one after the other behind workgroup barriers and one workgroup per CU (profiles/r05_pmc_osnet32.json: MFMA-busy 0.19,
+// 1.2 TB/s).  The operand convention makes all of that unnecessary:
+//   * after the 1x1 of a 16-pixel row segment lane (kq, n) holds output chunk kq (+ 4 mt) of column n — the depthwise 3x3 is per
+//     channel, so its column neighbours are the SAME register of lanes n - 1 / n + 1 of the same 16-lane DPP row (row_shr:1 /
+//     row_shl:1; the image's left / right zero padding is DPP's bound_ctrl zero), its row neighbours are the same lane one and
+//     two steps ago,
+//   * and the depthwise output of lane (kq, n) IS the B operand of the next layer's MFMAs.
+// A WAVE walks down the rows of ONE image for ONE chain: when the 1x1 row p of a layer arrives it finishes output row p - 1
+// (+ ky = 2 taps), continues row p (+ ky = 1) and starts row p + 1 (bias + ky = 0) — two partial accumulators per layer, summed in
+// the order bias, ky 0, 1, 2 (kx 0, 1, 2 inside) — and hands the finished row to the next layer in the same step.  State per layer:
+// 2 x NT x MT f4 accumulators (+ the 1x1 matrix when it lives in registers); the nine taps + bias of a layer are read from the
+// workgroup's LDS table in every step (16-lane broadcast reads; kept out of registers on purpose: the first register-stream attempt
+// of round 5 died of spills because every chain's state and taps lived in one wave).
+// Work split: a wave runs chain 3 (4 layers) then chain 0 (1 layer), its partner chain 2 (3) then chain 1 (2): five layer passes
+// each, so the two waves of an image and the two images of a workgroup finish together; no barrier after the table is staged, no
+// halo (a wave owns the whole image height), channel sums in registers (psum has ONE band).
+#define R32_THREADS 256
+static __device__ __forceinline__ float dppf_shr1_z(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true)); }
+static __device__ __forceinline__ float dppf_shl1_z(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)); }
+
+template <int C> struct ChR {
+    static constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = JJ, CP = 16 * JJ, KP = CP + 4, NPR = (C % 16) ? C + 1 : C;   // NPR: rows of a staged 1x1 matrix (+ one zero row)
+    static constexpr int TAB = 10 * 10 * CP;                       // floats: [layer][9 taps + bias][CP]
+};
+
+// One chain of L layers (global layer indices l0 .. l0 + L - 1) over the H rows of one image, by one wave.
+// Columns: with two segments per row (W = 32) segment t holds the columns 2 n + t (even / odd), so the left neighbour of an even
+// column is the odd segment shifted by one lane and its right neighbour the odd segment itself (and mirrored for the odd columns):
+// two DPP moves per value instead of six, no seam between the segments.
+// ONE loop, ONE body: a layer runs from the step its first row arrives (a scalar compare per layer); after its last row it runs on
+// ZERO rows, which is what the zero padding below the image asks for; "is this row inside the image" is the third operand of the
+// ReLU, v_med3_f32(x, 0, lim) with the wave-uniform lim = +inf / 0, so the masking costs no instruction.  (Compile experiments of
+// round 6: separate prologue / steady / epilogue copies of the body made the register allocator spill 400-800 values, a body with no
+// branch at all 40-560; the per-layer guards keep the layers separate basic blocks and the allocation spill-free.)
+// Also measured and not kept: a layer consuming the row the one before finished in the PREVIOUS step (so that one wave's 1x1 of layer
+// l + 1 runs beside its depthwise of layer l): 32 more live registers, 36-300 spilled values, 340 instead of 284 us; three waves per
+// SIMD at 24 channels (168 registers): 236 spilled values, 538 instead of 198 us.
+template <int C, int W, int L, bool ALDS>
+struct ChainState {
+    static constexpr int JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = W / 16;
+    f4 a[ALDS ? 1 : L][MT][JJ];
+    f4 accA[L][NT][MT], accB[L][NT][MT], sum[MT];
+};
+
+// P[.][mt] = rows 16 mt .. of W_l x (this lane's part of the layer's input row)
+template <int C, int W, int L, bool ALDS>
+static __device__ __forceinline__ void chain_mm(const ChainState<C, W, L, ALDS>& S, int l, int mt, int wl0, int n,
+                                                const f4 (&in)[W / 16][ChR<C>::JJ], f4 (&P)[W / 16][ChR<C>::MT])
+{
+    constexpr int JJ = ChR<C>::JJ, NT = W / 16, KP = ChR<C>::KP, NPR = ChR<C>::NPR;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    int wo = wl0 + l * NPR * KP;
+    if (ALDS) asm volatile("" : "+v"(wo));                                      // the matrix reads stay inside the step (not hoisted into registers)
+    const float* wp = smem32 + wo;
+    f4 am[JJ];
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+        const int row = 16 * mt + n;
+        am[jj] = ALDS ? ld4(wp + (row < C ? row : C) * KP + 16 * jj) : S.a[ALDS ? 0 : l][mt][jj];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) P[t][mt] = zero4();
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj)                                              // the segments' chains side by side: a dependent MFMA is 40 cycles behind its
+#pragma unroll
+        for (int s = 0; s < 4; ++s)                                              // predecessor, an independent one 32
+#pragma unroll
+            for (int t = 0; t < NT; ++t) P[t][mt] = MFMA4(am[jj][s], in[t][jj][s], P[t][mt]);
+}
+
+// the 1x1 row P of layer l arrives: finish the output row above (-> out = med3(., 0, lim): ReLU, or zero when that row is outside
+// the image), continue this row, start the next
+template <int C, int W, int L, bool ALDS>
+static __device__ __forceinline__ void chain_dw(ChainState<C, W, L, ALDS>& S, int l, int mt, int tl0, float lim, const f4 (&P)[W / 16][ChR<C>::MT],
+                                                f4 (&out)[W / 16][ChR<C>::MT])
+{
+    constexpr int NT = W / 16, CP = ChR<C>::CP;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    int to = tl0 + l * 10 * CP;
+    asm volatile("" : "+v"(to));                                                // the table reads stay inside the step (not hoisted into registers)
+    const float* tp = smem32 + to;
+    f4 k9[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) k9[k] = ld4(tp + k * CP + 16 * mt);
+    f4 lf[NT], rt[NT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (NT == 1) { lf[0][s] = dppf_shr1_z(P[0][mt][s]); rt[0][s] = dppf_shl1_z(P[0][mt][s]); }
+        else {
+            lf[0][s] = dppf_shr1_z(P[NT - 1][mt][s]); rt[0][s] = P[NT - 1][mt][s];
+            lf[NT - 1][s] = P[0][mt][s];              rt[NT - 1][s] = dppf_shl1_z(P[0][mt][s]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f4 fin = S.accB[l][t][mt];
+        fin = fma4(k9[6], lf[t], fin); fin = fma4(k9[7], P[t][mt], fin); fin = fma4(k9[8], rt[t], fin);
+        f4 mid = S.accA[l][t][mt];
+        mid = fma4(k9[3], lf[t], mid); mid = fma4(k9[4], P[t][mt], mid); mid = fma4(k9[5], rt[t], mid);
+        f4 top = k9[9];
+        top = fma4(k9[0], lf[t], top); top = fma4(k9[1], P[t][mt], top); top = fma4(k9[2], rt[t], top);
+        S.accB[l][t][mt] = mid;
+        S.accA[l][t][mt] = top;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) out[t][mt][s] = __builtin_amdgcn_fmed3f(fin[s], 0.f, lim);
+    }
+}
+
+template <int C, int W, int L, bool ALDS>
+static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, float* __restrict__ yo, float* __restrict__ ps,
+                                                  const float* __restrict__ w1g, int l0, int H, int kq, int n, int probe)
+{
+    constexpr int CH = ChR<C>::CH, JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = W / 16, CP = ChR<C>::CP, KP = ChR<C>::KP, NPR = ChR<C>::NPR;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];          // the workgroup's tables: [10][10][CP] taps + bias, then (ALDS) [10][NPR][KP] 1x1 matrices
+    ChainState<C, W, L, ALDS> S;
+    if (!ALDS) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jj = 0; jj < JJ; ++jj) {
+                    const int row = 16 * mt + n, c = kq + 4 * jj;
+                    const f4 v = ld4(w1g + (size_t)(l0 + l) * C * C + (unsigned)((row < C ? row : 0) * C + 4 * (c < CH ? c : 0)));
+                    S.a[l][mt][jj] = (row < C && c < CH) ? v : zero4();
+                }
+    }
+    const int tl0 = l0 * 10 * CP + 4 * kq;                                     // this lane's chunk of the chain's first tap row (float offset)
+    const int wl0 = ChR<C>::TAB + l0 * NPR * KP + 4 * kq;
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const f4 bb = ld4(smem32 + tl0 + (l * 10 + 9) * CP + 16 * mt);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { S.accA[l][t][mt] = bb; S.accB[l][t][mt] = zero4(); }
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) S.sum[mt] = zero4();
+    // this lane's part of an input row: chunks kq + 4 jj of columns NT n + t
+    auto ldrow = [&](int r, f4 (&d)[NT][JJ]) {
+        const int rc = r < H ? r : H - 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const int c = kq + 4 * jj;
+                d[t][jj] = ld4(xi + (unsigned)((rc * W + NT * n + t) * C + 4 * (c < CH ? c : 0)));
+            }
+    };
+    auto inside = [&](int r) -> float { return (r >= 0 && r < H) ? __builtin_inff() : 0.f; };
+    f4 in0[NT][JJ];
+    const int iend = H + L;                                       // the chain's last row leaves in step iend - 1
+    {
+        // Two row buffers used in turn by the two halves of the loop body (no register copies: a copy of a loaded value would wait
+        // for it one step after it was requested), rows requested two steps ahead, and the output store of a step UNCONDITIONAL
+        // (a row that is not there yet is all zeros — med3's lim — and goes to row 0, which the real row 0 overwrites later): the
+        // number of memory operations between a request and its use is fixed, so the wait before the use is a COUNTED vmcnt instead
+        // of vmcnt(0) — which was a full memory round trip (and the previous step's stores) in every step, 236 of the kernel's 283 us.
+        f4 X[2][NT][JJ];
+        const int i0 = -(iend & 1);                                            // an odd number of steps starts with a step that does nothing
+        ldrow(i0 < 0 ? 0 : i0, X[0]);
+        ldrow(i0 + 1, X[1]);
+        auto step = [&](int i, f4 (&Xc)[NT][JJ]) {                             // row i enters, row i - L leaves
+            const float lim0 = inside(i);
+            f4 cur[2][NT][MT], last[NT][MT];                                    // last: the chain's row of this step (zero until the last layer runs)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) last[t][mt] = zero4();
+#pragma unroll
+            for (int jj = 0; jj < JJ; ++jj) {
+                const float lj = (JJ * 4 == CH || kq + 4 * jj < CH) ? lim0 : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) in0[t][jj][s] = __builtin_amdgcn_fmed3f(Xc[t][jj][s], 0.f, lj);   // x1 >= 0 (a ReLU output)
+            }
+            ldrow(i + 2, Xc);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                if (i >= l) {                                                  // (also what keeps one layer's tables in registers at a time)
+                    f4 P[NT][MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) chain_mm<C, W, L, ALDS>(S, l, mt, wl0, n, l == 0 ? in0 : cur[(l - 1) & 1], P);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) chain_dw<C, W, L, ALDS>(S, l, mt, tl0, inside(i - l - 1), P, l + 1 < L ? cur[l & 1] : last);
+                }
+            }
+            const int o = i - L < 0 ? 0 : i - L;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (MT * 4 == CH || kq + 4 * mt < CH) {
+                        if (!(probe & 1)) st4(yo + (unsigned)((o * W + NT * n + t) * C + 4 * (kq + 4 * mt)), last[t][mt]);
+                        S.sum[mt] = S.sum[mt] + last[t][mt];
+                    }
+        };
+#pragma unroll 1
+        for (int i = i0; i < iend; i += 2) {
+            step(i, X[0]);
+            step(i + 1, X[1]);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        f4 v = S.sum[mt];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = v[j];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            v[j] = s;
+        }
+        if (n == 0 && (MT * 4 == CH || kq + 4 * mt < CH)) st4(ps + 4 * (kq + 4 * mt), v);
+    }
+}
+
+template <int C, int W, bool ALDS>
+__global__ __launch_bounds__(R32_THREADS, 2) void k32_chainsR(const float* __restrict__ x1, const float* __restrict__ w1 /*[10][C][C]*/,
+                                                              const float* __restrict__ w9 /*[10][9][C]*/, const float* __restrict__ bs /*[10][C]*/,
+                                                              float* __restrict__ y0, float* __restrict__ y1, float* __restrict__ y2,
+                                                              float* __restrict__ y3, float* __restrict__ psum, int Nimg, int H,
+                                                              const int* __restrict__ n_img, int probe)
+{
+    constexpr int CH = ChR<C>::CH, CP = ChR<C>::CP, KP = ChR<C>::KP, NPR = ChR<C>::NPR, TAB = ChR<C>::TAB;
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* __restrict__ T = smem32;                              // [10][10][CP]: taps 0..8, bias; zero in the padding channels
+    float* __restrict__ Wl = T + TAB;                            // ALDS: [10][NPR][KP], row C (when C % 16) and the padding columns zero
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TAB; i += R32_THREADS) {
+        const int c = i % CP, k = (i / CP) % 10, l = i / (10 * CP);
+        float v = 0.f;
+        if (c < C) v = k < 9 ? w9[(l * 9 + k) * C + c] : bs[l * C + c];
+        T[i] = v;
+    }
+    if (ALDS) {
+        for (int i = tid; i < 10 * NPR * (KP / 4); i += R32_THREADS) {
+            const int c4 = i % (KP / 4), r = (i / (KP / 4)) % NPR, l = i / ((KP / 4) * NPR);
+            f4 v = zero4();
+            if (r < C && c4 < CH) v = ld4(w1 + (size_t)(l * C + r) * C + 4 * c4);
+            st4(Wl + (l * NPR + r) * KP + 4 * c4, v);
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
+    const int img = blockIdx.x * 2 + (wave >> 1), pair = wave & 1;
+    int nv = Nimg;
+    if (n_img && *n_img < nv) nv = *n_img;
+    if (img >= nv) return;
+    const size_t ib = (size_t)img * H * W * C;
+    const float* xi = x1 + ib;
+    auto ps = [&](int t) { return psum + ((size_t)t * Nimg + img) * C; };
+    if (pair == 0) {
+        chain_rows<C, W, 4, ALDS>(xi, y3 + ib, ps(3), w1, 6, H, kq, n, probe);
+        chain_rows<C, W, 1, ALDS>(xi, y0 + ib, ps(0), w1, 0, H, kq, n, probe);
+    } else {
+        chain_rows<C, W, 3, ALDS>(xi, y2 + ib, ps(2), w1, 3, H, kq, n, probe);
+        chain_rows<C, W, 2, ALDS>(xi, y1 + ib, ps(1), w1, 1, H, kq, n, probe);
+    }
+}
+
 // ---- k32_tail ------------------------------------------------------------------------------------------------------------
 // Per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chain sums; per pixel: x2 = sum_t gate_t * y_t;
 // o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block input x, C1 channels); o -> d_out when asked;
@@ -675,7 +940,9 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
                                       // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
-static int g_chains_form = 1;        // 1: k32_chains3, 0: k32_chains (64 x 32 and 32 x 16 maps; the 16 x 8 maps always take k32_chains)
+static int g_chains_form = 2;        // 2: k32_chainsR (register row stream; 64 x 32 x 16 and 32 x 16 x 24 maps), 1: k32_chains3, 0: k32_chains (the 16 x 8 maps always take k32_chains)
+static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
+static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16)) && H >= 9; }
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -719,6 +986,7 @@ static int chains_rows(int H, int W, int C, int* halo)
 extern "C" int ss_op32_chains_bands(int H, int W, int C)
 {
     if (H < 1 || W < 1 || !(C == 16 || C == 24 || C == 32)) return SS_ERR_INVALID;
+    if (chains_rowstream(H, W, C)) return 1;
     int halo;
     const int R = chains_rows(H, W, C, &halo);
     return R < 1 ? SS_ERR_CAPACITY : H / R;
@@ -728,14 +996,22 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
                               float* d_psum, int N, int H, int W, int C, const int* d_nvalid)
 {
     if (!d_x1 || !d_w1 || !d_w9 || !d_bias || !d_ys || !d_psum || N < 1 || N > 65535 || (H * W) % 16) return SS_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const float *x1 = (const float*)d_x1, *w1 = (const float*)d_w1, *w9 = (const float*)d_w9, *b = (const float*)d_bias;
+    float *y0 = (float*)d_ys[0], *y1 = (float*)d_ys[1], *y2 = (float*)d_ys[2], *y3 = (float*)d_ys[3];
+    if (chains_rowstream(H, W, C)) {                          // two images (four waves) per workgroup
+#define CHR(CC, WW, AL) if (C == CC && W == WW) { \
+        const size_t ldsr = (size_t)(ChR<CC>::TAB + (AL ? 10 * ChR<CC>::NPR * ChR<CC>::KP : 0)) * 4; \
+        hipLaunchKernelGGL((k32_chainsR<CC, WW, AL>), dim3((N + 1) / 2), dim3(R32_THREADS), ldsr, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, d_nvalid, g_chains_probe); \
+        OP32_CHECK(); return SS_OK; }
+        CHR(16, 32, false) CHR(24, 16, true)
+#undef CHR
+    }
     int halo;
     const int R = chains_rows(H, W, C, &halo);
     if (R < 1) return SS_ERR_CAPACITY;
     const size_t lds = 2ull * (R + 2 * halo) * W * (C + 4) * 4 + (size_t)(C32_THREADS / (C / 4)) * C * 4;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 grid(H / R, N);
-    const float *x1 = (const float*)d_x1, *w1 = (const float*)d_w1, *w9 = (const float*)d_w9, *b = (const float*)d_bias;
-    float *y0 = (float*)d_ys[0], *y1 = (float*)d_ys[1], *y2 = (float*)d_ys[2], *y3 = (float*)d_ys[3];
 #define CH32(CC, WW) if (C == CC && W == WW) { \
         static bool attr = false; \
         if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
@@ -754,12 +1030,13 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
     return SS_ERR_INVALID;
 }
 
-// A/B switch (tests, measurements): "chains_form" 1 = k32_chains3 where it applies (default), 0 = k32_chains everywhere
+// A/B switch (tests, measurements): "chains_form" 2 = k32_chainsR where it applies (default), 1 = k32_chains3, 0 = k32_chains everywhere
 extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
     if (!strcmp(name, "chains_pre")) { g_chains_pre = value < 0 ? -1 : (value != 0); return SS_OK; }
-    if (!strcmp(name, "chains_form")) { if (value < 0 || value > 1) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
+    if (!strcmp(name, "chains_probe")) { g_chains_probe = value; return SS_OK; }
+    if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
 

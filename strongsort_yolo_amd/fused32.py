@@ -36,7 +36,7 @@ def _cl(x):
 
 
 def set_option(name: str, value: int):
-    """Process-wide A/B switch of the fp32 operators (csrc ss_op32_set_option): chains_form 1 (default) / 0."""
+    """Process-wide A/B switch of the fp32 operators (csrc ss_op32_set_option): chains_form 2 (default) / 1 / 0."""
     _ck(_lib.load().ss_op32_set_option(name.encode(), int(value)))
 
 

@@ -75,16 +75,18 @@ def _block(c1, c2, seed):
     return blk, g
 
 
-@pytest.mark.parametrize("form", [1, 0])
-@pytest.mark.parametrize("c1,c2,n,h,w", [(16, 64, 3, 64, 32), (64, 96, 3, 32, 16), (96, 128, 5, 16, 8)])
+@pytest.mark.parametrize("form", [2, 1, 0])
+@pytest.mark.parametrize("c1,c2,n,h,w", [(16, 64, 3, 64, 32), (64, 96, 3, 32, 16), (96, 128, 5, 16, 8), (16, 64, 4, 64, 32), (64, 96, 1, 32, 16)])
 def test_chains_match_fp64(c1, c2, n, h, w, form):
-    """Both kernel forms: 1 = k32_chains3 (conflict-free lane map, weights requested a phase ahead; 64 x 32 and 32 x 16 maps), 0 = k32_chains (always for 16 x 8)."""
+    """Every kernel form: 2 = k32_chainsR (register-resident row stream, one chain per wave, two images per workgroup: odd and even
+    image counts; 64 x 32 and 32 x 16 maps — the default), 1 = k32_chains3 (LDS phases, conflict-free lane map), 0 = k32_chains
+    (always for 16 x 8)."""
     from strongsort_yolo_amd import fused32
     fused32.set_option("chains_form", form)
     try:
         _chains_case(c1, c2, n, h, w)
     finally:
-        fused32.set_option("chains_form", 1)
+        fused32.set_option("chains_form", 2)
 
 
 def _chains_case(c1, c2, n, h, w):

@@ -3,7 +3,7 @@ usage: python tools/osnet32_eager.py [passes=3] [crops=1024]; SS32_CHAINS_FORM /
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd import nets, fused32
-for k, o in (("SS32_CHAINS_FORM", "chains_form"), ("SS32_CHAINS_PRE", "chains_pre")):
+for k, o in (("SS32_CHAINS_FORM", "chains_form"), ("SS32_CHAINS_PRE", "chains_pre"), ("SS32_CHAINS_PROBE", "chains_probe")):
     if k in os.environ:
         fused32.set_option(o, int(os.environ[k]))
 dev = torch.device("cuda", 0)

@@ -8,6 +8,9 @@ if "SS32_CHAINS_PRE" in os.environ:
     fused32.set_option("chains_pre", int(os.environ["SS32_CHAINS_PRE"]))
 if "SS32_CHAINS_FORM" in os.environ:
     fused32.set_option("chains_form", int(os.environ["SS32_CHAINS_FORM"]))
+for k, o in (("SS32_CHAINS_PROBE", "chains_probe"),):
+    if k in os.environ:
+        fused32.set_option(o, int(os.environ[k]))
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
@@ -36,7 +39,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps
 
 
-out = {"crops": N, "chains_form": os.environ.get("SS32_CHAINS_FORM", "1"), "chains_pre": os.environ.get("SS32_CHAINS_PRE", "1"), "osnet_fp32_own_kernels_ms": round(timed(lambda: r32(c32)), 4)}
+out = {"crops": N, "chains_form": os.environ.get("SS32_CHAINS_FORM", "2"), "chains_pre": os.environ.get("SS32_CHAINS_PRE", "1"), "osnet_fp32_own_kernels_ms": round(timed(lambda: r32(c32)), 4)}
 fused32.ENABLED = False
 out["osnet_fp32_library_ms"] = round(timed(lambda: r32(c32)), 4)
 fused32.ENABLED = True
