@@ -416,15 +416,17 @@ int ss_op32_pointwise(void* stream, const void* d_x, const void* d_w, const void
 int ss_op32_chains_bands(int H, int W, int C);
 int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, const void* d_w9, const void* d_bias, void* const* d_ys,
                    float* d_psum, int N, int H, int W, int C, const int* d_nvalid);
-/* OSBlock tail + the 1x1 ConvBR after it: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) (fc1 [hidden][MID], fc2 [MID][hidden]),
- * x2 = sum_t gate_t * ys[t], o = relu(w3 x2 + b3 + shortcut) -> d_out (may be NULL), o2 = relu(w4 o + b4) -> d_out2, 2x2-averaged
- * when pool.  shortcut = d_xin [N][H][W][C2] (C1 == 0) or wd d_xin + bd with d_xin [N][H][W][C1]. */
+/* OSBlock tail + the 1x1 ConvBR after it, two launches: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) (fc1 [hidden][MID], fc2
+ * [MID][hidden]) -> d_gates [4][N][MID] (caller's workspace); then x2 = sum_t gate_t * ys[t], o = relu(w3 x2 + b3 + shortcut) -> d_out
+ * (may be NULL), o2 = relu(w4 o + b4) -> d_out2, 2x2-averaged when pool.  shortcut = d_xin [N][H][W][C2] (C1 == 0) or wd d_xin + bd
+ * with d_xin [N][H][W][C1]. */
 int ss_op32_tail(void* stream, const void* const* d_ys, const float* d_psum, int bands, const void* d_gw1, const void* d_gb1,
-                 const void* d_gw2, const void* d_gb2, int hidden, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
+                 const void* d_gw2, const void* d_gb2, int hidden, float* d_gates, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
                  const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
                  int H, int W, int MID, int C2, int N2, const int* d_nvalid);
-/* Process-wide A/B switch of the fp32 operators: "chains_form" 1 (default): k32_chains3 (conflict-free lane map, weights requested a
- * phase ahead) where it applies, 0: k32_chains everywhere. */
+/* Process-wide A/B switches of the fp32 operators: "chains_form" 2 (default): k32_chainsR (register-resident row stream) where it
+ * applies, 1: k32_chains3 (LDS phases), 0: k32_chains everywhere; "tail_wgs" n: workgroups of the persistent tail grid (0 = default);
+ * "chains_probe" (measurement only, bit 0: the row-stream kernel does not store its outputs). */
 int ss_op32_set_option(const char* name, int value);
 /* conv 7x7 / 2 (3 -> 16) + bias + ReLU + max pool 3x3 / 2: d_x [N][256][128][3] -> d_y [N][64][32][16]; d_w [16][148] with
  * k = (ky * 7 + kx) * 3 + c and a zero in column 147. */

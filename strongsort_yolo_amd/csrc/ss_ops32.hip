@@ -694,39 +694,20 @@ __global__ __launch_bounds__(R32_THREADS, 2) void k32_chainsR(const float* __res
     }
 }
 
-// ---- k32_tail ------------------------------------------------------------------------------------------------------------
-// Per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chain sums; per pixel: x2 = sum_t gate_t * y_t;
-// o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block input x, C1 channels); o -> d_out when asked;
-// o2 = relu(W4 o + b4) -> d_out2, averaged over 2x2 pixels when POOL.  A wave owns 16-pixel tiles (POOL: 2 rows x 8 columns).
-#define T32_THREADS 512
-template <int MID, int C2, int C1, int N2, bool POOL>
-__global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
-                                                const float* __restrict__ y3, const float* __restrict__ psum, int bands, float scale,
-                                                const float* __restrict__ gw1, const float* __restrict__ gb1, const float* __restrict__ gw2,
-                                                const float* __restrict__ gb2, int hidden, const float* __restrict__ w3,
-                                                const float* __restrict__ b3, const float* __restrict__ xin, const float* __restrict__ wd,
-                                                const float* __restrict__ bd, float* __restrict__ out, const float* __restrict__ w4,
-                                                const float* __restrict__ b4, float* __restrict__ out2, int Nimg, int H, int W, int tpw,
-                                                const int* __restrict__ n_img)
+// ---- k32_gates, k32_tail -----------------------------------------------------------------------------------------------------
+// k32_gates, per image: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) from the chains' channel sums (bands in order) -> gates
+// [4][N][MID].  One 128-thread workgroup per image.  (Round 5 computed them at the start of EVERY tail workgroup: three barriers and
+// three levels of dependent global loads, four times per image, in front of 2 us of streaming.)
+template <int MID>
+__global__ __launch_bounds__(128) void k32_gates(const float* __restrict__ psum, int bands, float scale, const float* __restrict__ gw1,
+                                                 const float* __restrict__ gb1, const float* __restrict__ gw2, const float* __restrict__ gb2,
+                                                 int hidden, float* __restrict__ gates, int Nimg, const int* __restrict__ n_img)
 {
-    constexpr int CHM = MID / 4, JM = (CHM + 3) / 4, MT3 = C2 / 16, CH1 = C1 / 4, J1 = (CH1 + 3) / 4, MT4 = (N2 + 15) / 16, CH4 = N2 / 4;
-    constexpr int L3 = w_lds_floats<MID, C2>(), LD = C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0, L4 = w_lds_floats<C2, N2>();
-    static_assert(C2 % 16 == 0, "C2");
-    extern __shared__ __attribute__((aligned(16))) float smem32[];
-    float* __restrict__ W3s = smem32;
-    float* __restrict__ Wds = W3s + L3;
-    float* __restrict__ W4s = Wds + LD;
-    float* __restrict__ G = W4s + L4;                      // [4][MID] gates, then [4][MID] means, [4][4] hidden
-    float* __restrict__ Mn = G + 4 * MID;
-    float* __restrict__ Hd = Mn + 4 * MID;
-    const int img = blockIdx.y;
+    __shared__ float Mn[4 * MID], Hd[16];
+    const int img = blockIdx.x, tid = threadIdx.x;
     if (n_img && img >= *n_img) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
-    stage_w<MID, C2, T32_THREADS>(W3s, w3, tid);
-    if (C1) stage_w<(C1 ? C1 : 16), C2, T32_THREADS>(Wds, wd, tid);
-    stage_w<C2, N2, T32_THREADS>(W4s, w4, tid);
-    if (tid < 4 * MID) {                                     // channel means of the four chain outputs (bands in order)
-        const int t = tid / MID, c = tid - t * MID;
+    const int t = tid >> 5, c = tid & 31;
+    if (c < MID) {                                            // channel means of the four chain outputs (bands in order)
         float s = 0.f;
         const float* ps = psum + (((size_t)t * Nimg + img) * bands) * MID + c;
         for (int b0 = 0; b0 < bands; b0 += 8) {                // eight band sums per round trip (clamped index), added in band order
@@ -736,96 +717,144 @@ __global__ __launch_bounds__(T32_THREADS) void k32_tail(const float* __restrict_
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (b0 + u < bands) s += v[u];
         }
-        Mn[tid] = s * scale;
+        Mn[t * MID + c] = s * scale;
     }
     __syncthreads();
     if (tid < 4 * hidden) {
-        const int t = tid / hidden, j = tid - t * hidden;
+        const int tt = tid / hidden, j = tid - tt * hidden;
         float s = gb1[j];
-        f4 wv[MID / 4];                                        // the row in MID / 4 vector loads, one round trip (was MID dependent scalar loads)
+        f4 wv[MID / 4];
 #pragma unroll
         for (int q4 = 0; q4 < MID / 4; ++q4) wv[q4] = ld4(gw1 + j * MID + 4 * q4);
 #pragma unroll
         for (int q4 = 0; q4 < MID / 4; ++q4) {
-            s = __builtin_fmaf(wv[q4][0], Mn[t * MID + 4 * q4], s); s = __builtin_fmaf(wv[q4][1], Mn[t * MID + 4 * q4 + 1], s);
-            s = __builtin_fmaf(wv[q4][2], Mn[t * MID + 4 * q4 + 2], s); s = __builtin_fmaf(wv[q4][3], Mn[t * MID + 4 * q4 + 3], s);
+            s = __builtin_fmaf(wv[q4][0], Mn[tt * MID + 4 * q4], s); s = __builtin_fmaf(wv[q4][1], Mn[tt * MID + 4 * q4 + 1], s);
+            s = __builtin_fmaf(wv[q4][2], Mn[tt * MID + 4 * q4 + 2], s); s = __builtin_fmaf(wv[q4][3], Mn[tt * MID + 4 * q4 + 3], s);
         }
-        Hd[t * 4 + j] = s > 0.f ? s : 0.f;
+        Hd[tt * 4 + j] = s > 0.f ? s : 0.f;
     }
     __syncthreads();
-    if (tid < 4 * MID) {
-        const int t = tid / MID, c = tid - t * MID;
+    if (c < MID) {
         float s = gb2[c];
         for (int j = 0; j < hidden; ++j) s = __builtin_fmaf(gw2[c * hidden + j], Hd[t * 4 + j], s);
-        G[tid] = 1.0f / (1.0f + expf(-s));
+        gates[((size_t)t * Nimg + img) * MID + c] = 1.0f / (1.0f + expf(-s));
     }
+}
+
+// k32_tail, per pixel: x2 = sum_t gate_t * y_t; o = relu(W3 x2 + b3 + shortcut), shortcut = idn (C1 == 0) or Wd x + bd (the block
+// input x, C1 channels); o -> d_out when asked; o2 = relu(W4 o + b4) -> d_out2, averaged over 2x2 pixels when POOL.  A wave owns
+// 16-pixel tiles (POOL: 2 rows x 8 columns).  PERSISTENT: the grid is a fixed number of workgroups (two per CU when the weights
+// allow), each stages the three weight matrices ONCE and then walks its share of the images (all tiles of an image by its eight
+// waves), so the staging is paid once per CU instead of once per 8-32 tiles.
+#define T32_THREADS 512
+template <int MID, int C2, int C1, int N2, bool POOL>
+__global__ __launch_bounds__(T32_THREADS, 4) void k32_tail(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
+                                                const float* __restrict__ y3, const float* __restrict__ gates, const float* __restrict__ w3,
+                                                const float* __restrict__ b3, const float* __restrict__ xin, const float* __restrict__ wd,
+                                                const float* __restrict__ bd, float* __restrict__ out, const float* __restrict__ w4,
+                                                const float* __restrict__ b4, float* __restrict__ out2, int Nimg, int H, int W,
+                                                const int* __restrict__ n_img)
+{
+    constexpr int CHM = MID / 4, JM = (CHM + 3) / 4, MT3 = C2 / 16, CH1 = C1 / 4, J1 = (CH1 + 3) / 4, MT4 = (N2 + 15) / 16, CH4 = N2 / 4;
+    constexpr int L3 = w_lds_floats<MID, C2>(), LD = C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0, WV = T32_THREADS / 64;
+    static_assert(C2 % 16 == 0, "C2");
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    constexpr int L4 = w_lds_floats<C2, N2>(), LB = L3 + LD + L4, GP = 16 * JM;     // biases behind the matrices, then one gate table per wave
+    float* __restrict__ W3s = smem32;
+    float* __restrict__ Wds = W3s + L3;
+    float* __restrict__ W4s = Wds + LD;
+    float* __restrict__ Bs = smem32 + LB;                        // [C2] b3 (+ bd), [16 MT4] b4 (zero past N2)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    float* __restrict__ Gw = Bs + C2 + 16 * MT4 + wave * 4 * GP; // this wave's copy of the image's gates: [4][GP], zero in the padding chunks
+    int nv = Nimg;
+    if (n_img && *n_img < nv) nv = *n_img;
+    const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x, img0 = blockIdx.x * per, img1 = min(img0 + per, nv);
+    if (img0 >= img1) return;
+    stage_w<MID, C2, T32_THREADS>(W3s, w3, tid);
+    if (C1) stage_w<(C1 ? C1 : 16), C2, T32_THREADS>(Wds, wd, tid);
+    stage_w<C2, N2, T32_THREADS>(W4s, w4, tid);
+    if (tid < C2) Bs[tid] = b3[tid] + (C1 ? bd[tid] : 0.f);
+    if (tid < 16 * MT4) Bs[C2 + tid] = tid < N2 ? b4[tid] : 0.f;
     __syncthreads();
     const int HW = H * W, tiles_img = HW / 16;
-    const size_t pbase = (size_t)img * HW;
     const float* const ys[4] = { y0, y1, y2, y3 };
-    const int tile0 = (blockIdx.x * (T32_THREADS / 64) + wave) * tpw;
-    for (int it = 0; it < tpw; ++it) {
-        const int tile = tile0 + it;
-        if (tile >= tiles_img) break;
-        int pl;                                              // pixel of this lane inside the image
-        if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; pl = (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
-        else pl = tile * 16 + n;
-        const size_t px = pbase + pl;
-        // x2 chunks
-        f4 bm[JM];
-#pragma unroll
-        for (int jj = 0; jj < JM; ++jj) {
-            const int c = kq + 4 * jj;
-            if (c < CHM) {
-                f4 v = ld4(G + 4 * c) * ld4(ys[0] + px * MID + 4 * c);
-#pragma unroll
-                for (int t = 1; t < 4; ++t) v = v + ld4(G + t * MID + 4 * c) * ld4(ys[t] + px * MID + 4 * c);
-                bm[jj] = v;
-            } else bm[jj] = zero4();
+    for (int img = img0; img < img1; ++img) {
+        // the image's four gate vectors -> this wave's LDS table (a wave reads only what it wrote: no barrier)
+        for (int i = lane; i < 4 * GP; i += 64) {
+            const int t = i / GP, c = i - t * GP;
+            Gw[i] = c < MID ? gates[((size_t)t * Nimg + img) * MID + c] : 0.f;
         }
-        f4 acc[MT3];
+        const size_t pbase = (size_t)img * HW;
+        for (int tile = wave; tile < tiles_img; tile += WV) {
+            int pl;                                              // pixel of this lane inside the image
+            if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; pl = (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
+            else pl = tile * 16 + n;
+            const size_t px = pbase + pl;
+            // every operand of the tile requested before the first is used
+            f4 yv[4][JM], xv[C1 ? (J1 ? J1 : 1) : MT3];
 #pragma unroll
-        for (int mt = 0; mt < MT3; ++mt) acc[mt] = zero4();
-        mm_tile<MID, C2>(W3s, bm, acc, kq, n);
-        if (C1) {                                            // shortcut = Wd x + bd as a second product into the same accumulators
-            f4 bx[J1 ? J1 : 1];
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int jj = 0; jj < J1; ++jj) {
-                const int c = kq + 4 * jj;
-                bx[jj] = c < CH1 ? ld4(xin + px * C1 + 4 * c) : zero4();
+                for (int jj = 0; jj < JM; ++jj) { const int c = kq + 4 * jj; yv[t][jj] = ld4(ys[t] + px * MID + 4 * (c < CHM ? c : 0)); }
+            if (C1) {
+#pragma unroll
+                for (int jj = 0; jj < J1; ++jj) { const int c = kq + 4 * jj; xv[jj] = ld4(xin + px * C1 + 4 * (c < CH1 ? c : 0)); }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT3; ++mt) xv[mt] = ld4(xin + px * C2 + 16 * mt + 4 * kq);
             }
-            mm_tile<(C1 ? C1 : 16), C2>(Wds, bx, acc, kq, n);
-        }
+            // (the weight fragments, biases and gates are re-read from LDS for every tile: an offset the compiler cannot see through keeps
+            //  it from hoisting the loop-invariant reads into registers — 256 registers and 110-290 spilled values when it did)
+            int o3 = 0, od = L3, o4 = L3 + LD, ob = LB + 4 * kq, og = LB + C2 + 16 * MT4 + wave * 4 * GP + 4 * kq;
+            asm volatile("" : "+v"(o3), "+v"(od), "+v"(o4), "+v"(ob), "+v"(og));
+            f4 bm[JM];
 #pragma unroll
-        for (int mt = 0; mt < MT3; ++mt) {
-            const int oc = 16 * mt + 4 * kq;
-            f4 v = acc[mt] + ld4(b3 + oc);
-            if (C1) v = v + ld4(bd + oc);
-            else v = v + ld4(xin + px * C2 + oc);
-            v = relu4(v);
-            acc[mt] = v;
-            if (out) st4(out + px * C2 + oc, v);
-        }
-        // the 1x1 ConvBR that follows: the block output's accumulators are its B chunks
-        f4 acc2[MT4];
+            for (int jj = 0; jj < JM; ++jj) {
+                f4 v = ld4(smem32 + og + 16 * jj) * yv[0][jj];
 #pragma unroll
-        for (int mt = 0; mt < MT4; ++mt) acc2[mt] = zero4();
-        mm_tile<C2, N2>(W4s, acc, acc2, kq, n);
+                for (int t = 1; t < 4; ++t) v = v + ld4(smem32 + og + t * GP + 16 * jj) * yv[t][jj];
+                bm[jj] = v;                                      // (padding chunks: gate 0 -> 0)
+            }
+            f4 acc[MT3];
 #pragma unroll
-        for (int mt = 0; mt < MT4; ++mt) {
-            const int oc = 16 * mt + 4 * kq;
-            f4 v = zero4();
-            if (4 * mt + kq < CH4) v = relu4(acc2[mt] + ld4(b4 + oc));
-            if (POOL) {
-                f4 s;
+            for (int mt = 0; mt < MT3; ++mt) acc[mt] = zero4();
+            mm_tile<MID, C2>(smem32 + o3, bm, acc, kq, n);
+            if (C1) {                                            // shortcut = Wd x + bd as a second product into the same accumulators
+                f4 bx[J1 ? J1 : 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { float a = v[j]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 8); s[j] = a * 0.25f; }
-                if (4 * mt + kq < CH4 && n < 8 && !(n & 1)) {
-                    const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw;
-                    const size_t po = (size_t)img * (HW / 4) + (size_t)ty * (W / 2) + 4 * tx + (n >> 1);
-                    st4(out2 + po * N2 + oc, s);
-                }
-            } else if (4 * mt + kq < CH4) st4(out2 + px * N2 + oc, v);
+                for (int jj = 0; jj < J1; ++jj) bx[jj] = kq + 4 * jj < CH1 ? xv[jj] : zero4();
+                mm_tile<(C1 ? C1 : 16), C2>(smem32 + od, bx, acc, kq, n);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT3; ++mt) {
+                const int oc = 16 * mt + 4 * kq;
+                f4 v = acc[mt] + ld4(smem32 + ob + 16 * mt);
+                if (!C1) v = v + xv[mt];
+                v = relu4(v);
+                acc[mt] = v;
+                if (out) st4(out + px * C2 + oc, v);
+            }
+            // the 1x1 ConvBR that follows: the block output's accumulators are its B chunks
+            f4 acc2[MT4];
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt) acc2[mt] = zero4();
+            mm_tile<C2, N2>(smem32 + o4, acc, acc2, kq, n);
+#pragma unroll
+            for (int mt = 0; mt < MT4; ++mt) {
+                const int oc = 16 * mt + 4 * kq;
+                f4 v = zero4();
+                if (4 * mt + kq < CH4) v = relu4(acc2[mt] + ld4(smem32 + ob + C2 + 16 * mt));
+                if (POOL) {
+                    f4 s;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { float a = v[j]; a += __shfl_xor(a, 1); a += __shfl_xor(a, 8); s[j] = a * 0.25f; }
+                    if (4 * mt + kq < CH4 && n < 8 && !(n & 1)) {
+                        const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw;
+                        const size_t po = (size_t)img * (HW / 4) + (size_t)ty * (W / 2) + 4 * tx + (n >> 1);
+                        st4(out2 + po * N2 + oc, s);
+                    }
+                } else if (4 * mt + kq < CH4) st4(out2 + px * N2 + oc, v);
+            }
         }
     }
 }
@@ -941,6 +970,7 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
                                       // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
 static int g_chains_form = 2;        // 2: k32_chainsR (register row stream; 64 x 32 x 16 and 32 x 16 x 24 maps), 1: k32_chains3, 0: k32_chains (the 16 x 8 maps always take k32_chains)
+static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
 static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16)) && H >= 9; }
 
@@ -1035,47 +1065,52 @@ extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
     if (!strcmp(name, "chains_pre")) { g_chains_pre = value < 0 ? -1 : (value != 0); return SS_OK; }
+    if (!strcmp(name, "tail_wgs")) { if (value < 0 || value > 65535) return SS_ERR_INVALID; g_tail_wgs = value; return SS_OK; }
     if (!strcmp(name, "chains_probe")) { g_chains_probe = value; return SS_OK; }
     if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
 
 template <int MID, int C2, int C1, int N2, bool POOL>
-static int launch_tail32(hipStream_t st, const void* const* ys, const float* psum, int bands, const float* gw1, const float* gb1,
-                         const float* gw2, const float* gb2, int hidden, const float* w3, const float* b3, const float* xin, const float* wd,
-                         const float* bd, float* out, const float* w4, const float* b4, float* out2, int N, int H, int W, const int* nv)
+static int launch_tail32(hipStream_t st, const void* const* ys, const float* gates, const float* w3, const float* b3, const float* xin,
+                         const float* wd, const float* bd, float* out, const float* w4, const float* b4, float* out2, int N, int H, int W, const int* nv)
 {
-    constexpr size_t lds = (size_t)(w_lds_floats<MID, C2>() + (C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0) + w_lds_floats<C2, N2>() + 8 * MID + 16) * 4;
-    static bool attr = false;
-    if (!attr) {
+    constexpr size_t lds = (size_t)(w_lds_floats<MID, C2>() + (C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0) + w_lds_floats<C2, N2>() + C2 + (N2 + 15) / 16 * 16 +
+                                    (T32_THREADS / 64) * 4 * 16 * ((MID / 4 + 3) / 4)) * 4;
+    static int wgs = 0;                                        // workgroups of the persistent grid: what fits on the chip at once (<= 4 per CU)
+    if (!wgs) {
         if (hipFuncSetAttribute((const void*)k32_tail<MID, C2, C1, N2, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;
-        attr = true;
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k32_tail<MID, C2, C1, N2, POOL>, T32_THREADS, lds) != hipSuccess || cus < 1 || per_cu < 1)
+            return SS_ERR_HIP;
+        wgs = cus * (per_cu > 4 ? 4 : per_cu);
     }
-    const int tiles = H * W / 16;
-    constexpr int WV = T32_THREADS / 64;
-    int tpw = 1;
-    while (tpw < 4 && tiles / (WV * tpw) > 2 && (long long)N * (tiles / (2 * WV * tpw)) >= 2048) tpw *= 2;     // weights are staged per workgroup
-    const dim3 grid((tiles + WV * tpw - 1) / (WV * tpw), N);
-    hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), grid, dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
-                       (const float*)ys[3], psum, bands, 1.0f / (float)(H * W), gw1, gb1, gw2, gb2, hidden, w3, b3, xin, wd, bd, out, w4, b4, out2,
-                       N, H, W, tpw, nv);
+    const int grid = g_tail_wgs > 0 ? g_tail_wgs : (N < wgs ? N : wgs);
+    hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), dim3(grid), dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
+                       (const float*)ys[3], gates, w3, b3, xin, wd, bd, out, w4, b4, out2, N, H, W, nv);
     OP32_CHECK();
     return SS_OK;
 }
 
 extern "C" int ss_op32_tail(void* stream, const void* const* d_ys, const float* d_psum, int bands, const void* d_gw1, const void* d_gb1,
-                            const void* d_gw2, const void* d_gb2, int hidden, const void* d_w3, const void* d_b3, const void* d_xin, int C1,
-                            const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
+                            const void* d_gw2, const void* d_gb2, int hidden, float* d_gates, const void* d_w3, const void* d_b3, const void* d_xin,
+                            int C1, const void* d_wd, const void* d_bd, void* d_out, const void* d_w4, const void* d_b4, void* d_out2, int pool, int N,
                             int H, int W, int MID, int C2, int N2, const int* d_nvalid)
 {
-    if (!d_ys || !d_psum || !d_gw1 || !d_gb1 || !d_gw2 || !d_gb2 || !d_w3 || !d_b3 || !d_xin || !d_w4 || !d_b4 || !d_out2 || N < 1 || N > 65535 ||
-        bands < 1 || hidden < 1 || hidden > 4 || (H * W) % 16 || (C1 && (!d_wd || !d_bd)) || (pool && (W % 8 || H % 2)))
+    if (!d_ys || !d_psum || !d_gw1 || !d_gb1 || !d_gw2 || !d_gb2 || !d_gates || !d_w3 || !d_b3 || !d_xin || !d_w4 || !d_b4 || !d_out2 || N < 1 ||
+        N > 65535 || bands < 1 || hidden < 1 || hidden > 4 || (H * W) % 16 || (C1 && (!d_wd || !d_bd)) || (pool && (W % 8 || H % 2)))
         return SS_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    const float scale = 1.0f / (float)(H * W);
+#define GT32(M_) if (MID == M_) hipLaunchKernelGGL((k32_gates<M_>), dim3(N), dim3(128), 0, st, d_psum, bands, scale, (const float*)d_gw1, (const float*)d_gb1, \
+        (const float*)d_gw2, (const float*)d_gb2, hidden, d_gates, N, d_nvalid)
+    GT32(16); else GT32(24); else GT32(32); else return SS_ERR_INVALID;
+#undef GT32
+    OP32_CHECK();
 #define TL32(M_, C2_, C1_, N2_, P_) if (MID == M_ && C2 == C2_ && C1 == C1_ && N2 == N2_ && (pool != 0) == P_) \
-        return launch_tail32<M_, C2_, C1_, N2_, P_>(st, d_ys, d_psum, bands, (const float*)d_gw1, (const float*)d_gb1, (const float*)d_gw2, \
-            (const float*)d_gb2, hidden, (const float*)d_w3, (const float*)d_b3, (const float*)d_xin, (const float*)d_wd, (const float*)d_bd, \
-            (float*)d_out, (const float*)d_w4, (const float*)d_b4, (float*)d_out2, N, H, W, d_nvalid)
+        return launch_tail32<M_, C2_, C1_, N2_, P_>(st, d_ys, d_gates, (const float*)d_w3, (const float*)d_b3, (const float*)d_xin, (const float*)d_wd, \
+            (const float*)d_bd, (float*)d_out, (const float*)d_w4, (const float*)d_b4, (float*)d_out2, N, H, W, d_nvalid)
     TL32(16, 64, 16, 16, false); TL32(16, 64, 0, 64, true); TL32(24, 96, 64, 24, false); TL32(24, 96, 0, 96, true);
     TL32(32, 128, 96, 32, false); TL32(32, 128, 0, 128, false);
 #undef TL32

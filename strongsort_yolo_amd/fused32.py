@@ -146,7 +146,7 @@ def chains(x1, blk):
 
 def tail(ys, psum, blk, x, nxt, pool, want_out):
     """-> (o or None, o2): o = relu(conv3(sum_t gate_t * ys[t]) + shortcut(x)), o2 = relu(nxt(o)) (2x2-averaged when pool);
-    shortcut = x or blk.down(x).  One launch."""
+    shortcut = x or blk.down(x).  Two launches (gates per image, then the persistent tail)."""
     x = _cl(x)
     n, mid, h, w = ys[0].shape
     c3, c4 = blk.conv3.conv, nxt.conv
@@ -159,7 +159,8 @@ def tail(ys, psum, blk, x, nxt, pool, want_out):
     oh, ow = (h // 2, w // 2) if pool else (h, w)
     out2 = torch.empty((n, n2, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
-    _ck(_lib.load().ss_op32_tail(_st(x), arr, _p(psum), psum.shape[2], _p(gw1), _p(gb1), _p(gw2), _p(gb2), gw1.shape[0],
+    gates = torch.empty(4, n, mid, dtype=torch.float32, device=x.device)            # workspace of the gate launch
+    _ck(_lib.load().ss_op32_tail(_st(x), arr, _p(psum), psum.shape[2], _p(gw1), _p(gb1), _p(gw2), _p(gb2), gw1.shape[0], _p(gates),
                                  _p(_w_nk(blk.conv3, c3)), _p(c3.bias), _p(x), c1, _p(wd), _p(bd), _p(out), _p(_w_nk(nxt, c4)), _p(c4.bias),
                                  _p(out2), int(pool), n, h, w, mid, c2, n2, _p(_nv)))
     return out, out2
