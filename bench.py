@@ -61,6 +61,8 @@ CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4, "c6": None}
 # 11 232 / 11 244, 4: 11 701 / 11 531, 5: 11 720 / 11 785, 6: 11 509 / 11 014 frames/s.  The larger detectors keep the earlier cut (30 steps, one
 # run each): c3 cut 2: 7 981, cut 5: 7 938; c5 (pose head) cut 2: 9 267, cut 5: 8 446; c4 (yolov7: the detector is the long stage) was only measured at 2
 REID_SPLIT = {"c1": 4, "c2": 6, "c3": 2, "c4": 2, "c5": 5, "c6": 2}     # c2 re-measured with the round-5 kernels (detector 0.87, OSNet 1.16 ms): 6 over 5 by 3-9 % in two paired runs
+# the same cut with the fp32 ReID network (the default since round 6: OSNet ~2.5x the f16 one, so the first stage keeps fewer of its parts)
+REID_SPLIT_FP32 = {"c1": 2, "c2": 2, "c3": 1, "c4": 1, "c5": 2, "c6": 1}
 PMC_FILE = "r05_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by tracker workload / streams / frames (tools/pmc_assoc.sh)
 PMC_WORKLOAD = {"c1": None, "c2": "c2", "c3": "c2", "c5": "c2", "c6": "c2", "c4": "c4"}   # presets that differ only in the detector share a tracker workload
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
@@ -740,10 +742,11 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the 32-stream association-kernel measurement")
     ap.add_argument("--no-api-path", action="store_true", help="skip the YOLO.track / track_stream measurement")
     ap.add_argument("--no-reid-check", action="store_true", help="skip the f16 HIP OSNet vs CPU fp32 OSNet measurement on the true feat_source='reid' path")
-    ap.add_argument("--reid-fp32", action="store_true", help="the ACCURACY MODE as the measured configuration: ReID crops + OSNet-x0.25 with fp32 activations on the hand-written fp32 kernels (csrc/ss_ops32.hip); the default line carries the same measurement on fewer steps as `accuracy_mode`")
-    ap.add_argument("--det-fp32", action="store_true", help="with --reid-fp32: the detector in fp32 too (PyTorch-ROCm's library convolutions; north_star files the detector under PyTorch-ROCm) — every network operation of the path in fp32")
-    ap.add_argument("--no-accuracy-mode", action="store_true", help="skip the second, shorter timed run with the fp32 ReID network (`accuracy_mode`)")
-    ap.add_argument("--accuracy-steps", type=int, default=10, help="timed steps of the `accuracy_mode` run")
+    ap.add_argument("--reid-f16", action="store_true", help="the THROUGHPUT MODE as the measured configuration: ReID crops + OSNet-x0.25 with f16 activations (csrc/ss_ops.hip) — misses north_star's 1e-4 on the float distances (3e-2); the default line carries the same measurement on fewer steps as `throughput_mode`")
+    ap.add_argument("--reid-fp32", action="store_true", help="(the default since round 6) ReID crops + OSNet-x0.25 with fp32 activations on the hand-written fp32 kernels (csrc/ss_ops32.hip): the configuration that meets north_star's 1e-4 on the true ReID path")
+    ap.add_argument("--det-fp32", action="store_true", help="the detector in fp32 too — every network operation of the path in fp32 (the default line carries this measurement as `all_fp32`)")
+    ap.add_argument("--no-accuracy-mode", action="store_true", help="skip the second, shorter timed run in the other ReID precision (`throughput_mode`; `accuracy_mode` with --reid-f16) and `all_fp32`")
+    ap.add_argument("--accuracy-steps", type=int, default=10, help="timed steps of that second run")
     ap.add_argument("--check-frames", type=int, default=-1, help="frames (from the start of the run) compared with the oracle; -1: all of them, the timed ones included")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--defer-track", type=int, default=1, help="1: the tracker call of a group is enqueued after the last stage's stream has waited for stage 0 of the next group (it then runs beside the start of that group, away from the OSNet row-stream kernel)")
@@ -754,6 +757,9 @@ def main():
     ap.add_argument("--pipe", action="append", default=[], help="A/B switch of the frame pipeline name=0|1: pack_crops, assoc_gate, track_priority; chain_cus=N (compute units reserved for the detached tracker chain)")
     ap.add_argument("--overlap", type=int, default=2, help="N>1: N-stage frame pipeline on N HIP streams (2 or 4; stateless detector / OSNet stages of later frames overlap the tracker of earlier ones); 0/1: strictly sequential")
     args = ap.parse_args()
+    if args.reid_f16 and (args.reid_fp32 or args.det_fp32):
+        ap.error("--reid-f16 excludes --reid-fp32 / --det-fp32")
+    args.reid_fp32 = not args.reid_f16                 # round 6: the parity-meeting precision is the headline (VERDICT r5 'next' 1a; yolo_multi_model.py:41 passes no half=)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -809,8 +815,9 @@ def main():
         fused.set_flags(**{kv.split("=")[0]: kv.split("=")[1] != "0" for kv in args.fused})
     pipe_sw = {kv.split("=")[0]: (int(kv.split("=")[1]) if kv.split("=")[0] == "chain_cus" else kv.split("=")[1] != "0") for kv in args.pipe}
     detector, W, H, n_ids, rb = PRESETS[args.preset]
-    if args.reid_split == -2:
-        args.reid_split = REID_SPLIT[args.preset]
+    split_auto = args.reid_split == -2
+    if split_auto:
+        args.reid_split = (REID_SPLIT_FP32 if args.reid_fp32 else REID_SPLIT)[args.preset]
     cfg, dcfg = StrongSortConfig(), DetectConfig()
     overlap = args.overlap > 1 and args.graph != "none" and not args.no_nets
     FB = args.frame_batch if overlap else 1
@@ -820,13 +827,14 @@ def main():
     from types import SimpleNamespace
 
     def timed_pipeline(reid_half, K, Wm, half=True):
-        """PREFILL + Wm warm-up + exactly K timed steps of the whole hot path with the ReID network in half (throughput default) or
-        fp32 (accuracy mode); returns everything the line is built from.  The pipeline stays open (caller closes R.pipe)."""
+        """PREFILL + Wm warm-up + exactly K timed steps of the whole hot path with the ReID network in fp32 (the default: meets the
+        float bound) or half (throughput mode); returns everything the line is built from.  The pipeline stays open (caller closes R.pipe)."""
         KF, WF = K * FPS, Wm * FPS                          # timed / warm-up frames per stream
         total = PREFILL + WF + KF
+        split = (REID_SPLIT if reid_half else REID_SPLIT_FP32)[args.preset] if split_auto else args.reid_split
         pipe = PipeCls(detector, S, (H, W), device=dev_index, half=half, reid_batch=rb, cfg=cfg, dcfg=dcfg,
                        det_source="synthetic", feat_source="by_anchor", graph=args.graph, reid_half=reid_half,
-                       run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if args.reid_split < 0 else args.reid_split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
+                       run_nets=not args.no_nets, **({"n_stages": args.overlap, "frame_batch": args.frame_batch, "reid_split": None if split < 0 else split, "tracker_stream": args.tracker_stream, "defer_track": bool(args.defer_track), "keep_net_outputs": True, **pipe_sw} if overlap else {}))
         for kv in args.opt:
             pipe.eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         gs = scale_geometry(pipe.geom, H, W)
@@ -1074,8 +1082,8 @@ def main():
             "metric": f"tracked frames/sec (whole node), {W}x{H}@{n_ids}det",
             "value": round(world * S * KF / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "frames_per_step": FPS, "ms_per_step": round(dt / K * 1e3, 4), "ms_per_step_distribution": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 association / f64 Kalman+LSAP (f16 detector convs, fp32 ReID network on own v_mfma_f32 kernels: accuracy mode)" if args.reid_fp32 else
-                      "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs)"), "data": "synthetic",
+            "dtype": ("f32 association / f64 Kalman+LSAP (" + ("fp32 detector convs" if args.det_fp32 else "f16 detector convs") + ", fp32 ReID network on own v_mfma_f32 kernels)" if args.reid_fp32 else
+                      "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs: throughput mode, misses the 1e-4 float bound)"), "data": "synthetic",
             "reid_precision": "fp32 (hand-written kernels, csrc/ss_ops32.hip)" if args.reid_fp32 else "f16 (hand-written kernels, csrc/ss_ops.hip)",
             "config": {"workload": (f"configs[{CONFIG_INDEX[args.preset]}]" if CONFIG_INDEX[args.preset] is not None else "reference default model (yolo_multi_model.py:17)") + f": {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
@@ -1115,39 +1123,46 @@ def main():
             res["reid_f16_vs_f32"]["fp32_reid_mode"] = leg(reid_f16_vs_f32, detector, W, H, n_ids, cfg, dcfg, device=dev_index, reid_half=False)
         if world == 1 and not args.no_reid_check and not args.no_nets and args.preset in ("c2", "c3", "c5"):
             res["det_f16_vs_f32"] = leg(det_f16_vs_f32, detector, W, H, n_ids, dcfg, device=dev_index)
-        if world == 1 and overlap and not args.no_nets and not args.reid_fp32 and not args.no_accuracy_mode:
-            # the configuration that meets north_star's float bound, measured the same way on fewer steps: the whole hot path with the
-            # ReID crops + OSNet in fp32 on the hand-written fp32 kernels; its distance error / id rate on the true ReID data path are
-            # the fp32_reid_mode figures above
-            def accuracy_mode():
-                A2 = timed_pipeline(False, max(2, args.accuracy_steps), 2)
+        if world == 1 and overlap and not args.no_nets and not args.no_accuracy_mode:
+            # the OTHER ReID precision, measured the same way on fewer steps.  Default line (fp32 ReID, the configuration that meets
+            # north_star's float bound): `throughput_mode` = f16 ReID kernels; with --reid-f16: `accuracy_mode` = fp32 ReID kernels.
+            # `all_fp32`: the detector in fp32 as well (no f16 arithmetic left on the path).
+            tp = (res.get("reid_f16_vs_f32") or {})
+            tp32, tp16 = tp.get("fp32_reid_mode") or {}, tp
+
+            def other_mode(other_half):
+                A2 = timed_pipeline(other_half, max(2, args.accuracy_steps), 2)
                 a_same, a_tot, a_exact, a_exact_timed, a_ntimed = id_check(A2, A2.total)
                 a_nets = net_outputs_check(A2.pipe)
                 on_own = bool(getattr(A2.pipe.reid, "_ok32", False))
                 A2.pipe.close()
-                tp = (res.get("reid_f16_vs_f32") or {}).get("fp32_reid_mode") or {}
-                # ... and with the detector in fp32 as well (library convolutions): no f16 arithmetic left on the path
-                try:
-                    A3 = timed_pipeline(False, max(2, args.accuracy_steps // 2), 2, half=False)
-                    b_same, b_tot, b_exact, b_exact_timed, b_ntimed = id_check(A3, A3.total)
-                    A3.pipe.close()
-                    all32 = {"detector": "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels", "frames_per_s": round(S * A3.KF / A3.dt, 2),
-                             "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
-                             "frames_bit_exact": f"{b_exact}/{A3.total}"}
-                except Exception as e:                          # a side measurement never takes the line down
-                    all32 = {"error": f"{type(e).__name__}: {e}"[:300]}
+                t = tp16 if other_half else tp32
                 return {
-                    "reid_precision": "fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)",
+                    "reid_precision": ("f16 activations, hand-written kernels (csrc/ss_ops.hip)" if other_half else
+                                       ("fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)")),
                     "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
                     "ratio_to_default": round((S * A2.KF / A2.dt) / (S * KF / dt), 4),
                     "id_match_rate": round(a_same / max(a_tot, 1), 6), "frames_bit_exact": f"{a_exact}/{A2.total}", "frames_bit_exact_timed": f"{a_exact_timed}/{a_ntimed}",
-                    "distance_err": tp.get("cost_matrix_cosine_max_abs_err"), "embedding_err": tp.get("embedding_unit_max_abs_err"),
-                    "true_path_id_match_rate": tp.get("id_match_rate"), "within_north_star_bound_1e-4": tp.get("within_bound"),
+                    "distance_err": t.get("cost_matrix_cosine_max_abs_err"), "embedding_err": t.get("embedding_unit_max_abs_err"),
+                    "true_path_id_match_rate": t.get("id_match_rate"), "within_north_star_bound_1e-4": t.get("within_bound"),
                     "net_outputs_check": a_nets,
-                    "all_fp32": all32,
-                    "note": "same workload, same pipeline, same checks as the default line with reid_half=False; distance_err / true_path_id_match_rate: "
-                            "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32.fp32_reid_mode)"}
-            res["accuracy_mode"] = leg(accuracy_mode)
+                    "note": "same workload, same pipeline, same checks as the default line in the other ReID precision; distance_err / true_path_id_match_rate: "
+                            "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32)"}
+
+            def all_fp32():
+                A3 = timed_pipeline(False, max(2, args.accuracy_steps // 2), 2, half=False)
+                b_same, b_tot, b_exact, b_exact_timed, b_ntimed = id_check(A3, A3.total)
+                det_own = bool(getattr(A3.pipe.detector, "_own32", False))
+                A3.pipe.close()
+                return {"detector": "fp32, hand-written kernels (csrc/ss_det32.hip)" if det_own else "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels",
+                        "frames_per_s": round(S * A3.KF / A3.dt, 2), "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
+                        "frames_bit_exact": f"{b_exact}/{A3.total}"}
+            res["throughput_mode" if args.reid_fp32 else "accuracy_mode"] = leg(other_mode, args.reid_fp32)
+            if not args.det_fp32:
+                res["all_fp32"] = leg(all_fp32)
+            res["fp32_reid_true_path"] = {"distance_err": tp32.get("cost_matrix_cosine_max_abs_err"), "embedding_err": tp32.get("embedding_unit_max_abs_err"),
+                                          "id_match_rate": tp32.get("id_match_rate"), "within_north_star_bound_1e-4": tp32.get("within_bound"),
+                                          "what": "the default line's ReID precision on the true ReID data path (150 rendered frames, CPU fp32 network + C-oracle tracker as the checker)"}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = leg(cpu_baseline, W, H, n_ids, nc, A, detector)
         print(json.dumps(res), flush=True)

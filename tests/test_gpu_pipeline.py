@@ -218,7 +218,21 @@ def _run_groups(pipe, items, fb):
     ("yolo11n-pose", 1280, 720, 30, 32, 112, 2),   # --preset c6: the reference's default weights file (yolo_multi_model.py:17), C3k2 / C2PSA graph, pose head
 ])
 def test_benchmarked_configuration_equals_oracle(detector, w, h, n_ids, reid_batch, n_frames, split):
+    """The f16-ReID form of every preset (bench.py --reid-f16, the `throughput_mode` of the default line)."""
     _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, split)
+
+
+@pytest.mark.parametrize("detector,w,h,n_ids,reid_batch,n_frames", [
+    ("yolov8n", 1280, 720, 30, 32, 176),       # bench.py's default line since round 6: configs[1] with the fp32 ReID network on its own kernels
+    ("yolov7", 1920, 1080, 100, 128, 80),      # --preset c4
+    ("yolov8n-pose", 1280, 720, 30, 32, 112),  # --preset c5
+])
+def test_benchmarked_default_configuration_fp32_reid_equals_oracle(detector, w, h, n_ids, reid_batch, n_frames):
+    """bench.py's headline configuration: the same pipeline with reid_half=False (crops + OSNet-x0.25 in fp32 on csrc/ss_ops32.hip) and
+    the stage cut bench.REID_SPLIT_FP32 names."""
+    import bench
+    preset = {v[0]: k for k, v in bench.PRESETS.items()}[detector]
+    _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, bench.REID_SPLIT_FP32[preset], reid_half=False)
 
 
 def test_detached_tracker_chain_on_reserved_compute_units_equals_oracle():
@@ -236,9 +250,11 @@ def _benchmarked(detector, w, h, n_ids, reid_batch, n_frames, split, **pipe_kw):
     import bench
     from strongsort_yolo_amd.pipeline import OverlappedPipeline
     preset = {v[0]: k for k, v in bench.PRESETS.items()}[detector]
-    assert bench.REID_SPLIT[preset] == split and bench.PRESETS[preset][1:] == (w, h, n_ids, reid_batch)
-    pipe = OverlappedPipeline(detector, 1, (h, w), half=True, reid_batch=reid_batch, det_source="synthetic",
+    reid_half = pipe_kw.pop("reid_half", True)
+    assert (bench.REID_SPLIT if reid_half else bench.REID_SPLIT_FP32)[preset] == split and bench.PRESETS[preset][1:] == (w, h, n_ids, reid_batch)
+    pipe = OverlappedPipeline(detector, 1, (h, w), half=True, reid_batch=reid_batch, det_source="synthetic", reid_half=reid_half,
                               feat_source="by_anchor", graph="front", n_stages=2, frame_batch=32, reid_split=split, defer_track=True, **pipe_kw)
+    assert pipe.reid_half == reid_half
     assert pipe.pack and pipe.defer and pipe.assoc_ev is not None and pipe.nb == 3 and pipe.eng.max_group_frames == 32
     assert (pipe.sR is not None) == bool(pipe_kw.get("chain_cus"))
     gs = scale_geometry(pipe.geom, h, w)

@@ -216,6 +216,7 @@ def test_bottleneck_launch_eligibility():
 def test_bench_stage_cut_defaults_cover_every_preset():
     import bench
     assert set(bench.REID_SPLIT) == set(bench.PRESETS) and all(0 <= v <= nets.OSNet.N_PARTS for v in bench.REID_SPLIT.values())
+    assert set(bench.REID_SPLIT_FP32) == set(bench.PRESETS) and all(0 <= v <= nets.OSNet.N_PARTS for v in bench.REID_SPLIT_FP32.values())
 
 
 @pytest.mark.parametrize("name,published", [
