@@ -453,6 +453,35 @@ def reid_f16_vs_f32(detector, W, H, n_ids, cfg, dcfg, device=0, frames=150, reid
                     "one-to-one renumbering"}
 
 
+def calibrated_detector(detector, W, H, n_ids, dcfg, p32, target=40):
+    """-> (CPU fp32 detector, class-bias shift): seeded He weights calibrated to zero-mean / unit-variance layer outputs on two rendered
+    frames (letterboxed by the HIP kernel of the fp32 pipeline `p32`), the class biases shifted so that about `target` anchors per frame
+    pass conf.  The network det_f16_vs_f32 and tests/test_gpu_detector32.py compare precisions on (no checkpoint exists offline)."""
+    import math
+    import torch
+    from strongsort_yolo_amd import nets
+    from strongsort_yolo_amd.synth import make_stream
+    dev, nc = p32.dev, p32.nc
+
+    def letterboxed(img):
+        p32.frames[0].copy_(torch.from_numpy(img).to(dev))
+        p32.eng.letterbox_batch(p32.frames, p32.geom, half=False, pad_value=dcfg.pad_value, out=p32.lb, channels_last=True)
+        torch.cuda.synchronize(dev)
+        return p32.lb.float().cpu().contiguous()
+
+    cs = make_stream(2023, W, H, n_ids)
+    xcal = torch.cat([letterboxed(cs.render(cs.next_frame())) for _ in range(2)])
+    det32 = calibrate_reid_(nets.build_detector(detector, 0).float(), xcal)
+    with torch.no_grad():
+        pm = det32(xcal)
+        pm = (pm[0] if isinstance(pm, tuple) else pm)[:, 4:4 + nc].amax(1).flatten().double().clamp(1e-12, 1 - 1e-12)
+        logit = torch.log(pm / (1 - pm)).sort(descending=True).values
+        shift = float(logit[min(2 * target, len(logit) - 1)]) - math.log(dcfg.conf / (1 - dcfg.conf))
+        for lvl in det32.detect.cv3:
+            lvl[2].bias.sub_(shift)
+    return det32, shift
+
+
 def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
     """The detector side of north_star's "box indices bit-exact": how often does the f16 detector (hand-written kernels, the
     throughput default) give the keep list of the SAME network in fp32 (PyTorch-ROCm's library convolutions on the GPU; the
@@ -476,23 +505,7 @@ def det_f16_vs_f32(detector, W, H, n_ids, dcfg, device=0, frames=48, target=40):
         return None
     dev, nc = p32.dev, p32.nc
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-
-    def letterboxed(img):
-        p32.frames[0].copy_(torch.from_numpy(img).to(dev))
-        p32.eng.letterbox_batch(p32.frames, p32.geom, half=False, pad_value=dcfg.pad_value, out=p32.lb, channels_last=True)
-        torch.cuda.synchronize(dev)
-        return p32.lb.float().cpu().contiguous()
-
-    cs = make_stream(2023, W, H, n_ids)
-    xcal = torch.cat([letterboxed(cs.render(cs.next_frame())) for _ in range(2)])
-    det32 = calibrate_reid_(nets.build_detector(detector, 0).float(), xcal)
-    with torch.no_grad():
-        pm = det32(xcal)
-        pm = (pm[0] if isinstance(pm, tuple) else pm)[:, 4:4 + nc].amax(1).flatten().double().clamp(1e-12, 1 - 1e-12)
-        logit = torch.log(pm / (1 - pm)).sort(descending=True).values
-        shift = float(logit[min(2 * target, len(logit) - 1)]) - math.log(dcfg.conf / (1 - dcfg.conf))
-        for lvl in det32.detect.cv3:
-            lvl[2].bias.sub_(shift)
+    det32, shift = calibrated_detector(detector, W, H, n_ids, dcfg, p32, target)
     for p in (p16, p32):
         p.detector.load_state_dict(det32.state_dict())
         fused.clear_prepared(p.detector)
