@@ -434,6 +434,15 @@ int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_b
 /* d_out[n][f] = relu(sum_c d_w[f][c] * mean_hw(d_x[n][.][c]) + d_bias[f]), C == 128. */
 int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F,
                  const int* d_nvalid);
+/* The detector's convolutions in fp32 (csrc/ss_ops32.hip k32_conv / k32_conv0; the arithmetic of the detector forward behind
+ * /root/reference/yolo_multi_model.py:41, :173, which passes no half=).  ss_op32_conv: d_x NHWC [N][H][W][.] with pixel stride xs
+ * floats (a channel slice of a wider tensor when xs > Cin), d_w [Cout][ks][ks][Cin], d_out NHWC [N][OH][OW][.] with pixel stride os,
+ * d_res (may be NULL; added AFTER the activation) with pixel stride rs; ks 1 | 3, stride 1 | 2 (1x1: 1), pad ks / 2; act 1 = SiLU,
+ * 0 = none; Cin, Cout multiples of 16, pointers 16-byte aligned, strides multiples of 4.  ss_op32_conv0: the first convolution,
+ * 3 -> 16 channels, 3x3, stride 2, pad 1, d_x dense NHWC [N][H][W][3], d_w [16][3][3][3]. */
+int ss_op32_conv(void* stream, const void* d_x, int xs, const void* d_w, const void* d_bias, const void* d_res, int rs, void* d_out,
+                 int os, int N, int H, int W, int Cin, int Cout, int ks, int stride, int act);
+int ss_op32_conv0(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int os, int N, int H, int W, int act);
 
 /* ---- profiling support ----------------------------------------------------------------------- */
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last

@@ -965,6 +965,156 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
     }
 }
 
+// ---- k32_conv, k32_conv0: the DETECTOR's convolutions in fp32 ---------------------------------------------------------------
+// The reference runs its detector in fp32 (no half=: /root/reference/yolo_multi_model.py:18-21, :41) and the f16 kernels of ss_ops.hip
+// do not reproduce the fp32 network's NMS keep lists — a CPU rounding model says the loss is in the backbone, so "f16 backbone + fp32
+// head" does not help (tools/det_f16_rounding_model.py, profiles/r06_det_f16_rounding_model.txt).  Until round 6 the fp32 detector ran
+// on the library convolutions with bias / SiLU / concat as separate passes (6 ms per 32 frames).  k32_conv is ONE implicit-GEMM kernel
+// for every 1x1 and 3x3 (stride 1 / 2, pad k / 2) convolution of the YOLO graphs whose channel counts are multiples of 16:
+//   out[p][co] = act(bias[co] + sum_{ky,kx,ci} w[co][(ky, kx, ci)] x[p * s + (ky, kx) - pad][ci]) (+ res[p][co] after the activation)
+// NHWC fp32 with a PIXEL STRIDE per tensor, so input, output and shortcut may be channel slices of wider tensors: a C2f block runs
+// without a single chunk / add / cat pass.  Same operand convention as the ReID kernels (lane (kq, n): chunk kq + 4 j of pixel n; the
+// weights are the A operand from LDS).  K is walked in groups of 64 (four 16-channel chunks of one tap or of consecutive taps); the
+// weight slice of the next group and the next group's pixel vectors are requested before the matrix work of the current one (registers
+// / the other LDS buffer), one barrier per group.
+template <int KS, int STRIDE, int MT, int PT>
+__global__ __launch_bounds__(256) void k32_conv(const float* __restrict__ x, int xs, const float* __restrict__ w, const float* __restrict__ bias,
+                                                const float* __restrict__ res, int rs, float* __restrict__ out, int os, int N, int H, int W, int OH,
+                                                int OW, int Cin, int Cout, int act)
+{
+    constexpr int ROWS = 16 * MT, PITCH = 68, WPT = ROWS * 16 / 256;      // WPT: weight vectors a thread stages per group
+    __shared__ __attribute__((aligned(16))) float Ws[2][ROWS * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
+    const int co0 = blockIdx.y * ROWS, K = KS * KS * Cin, c16s = Cin >> 4, NKC = K >> 4, G = (NKC + 3) >> 2;
+    const long long M = (long long)N * OH * OW;
+    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * PT;
+    long long p[PT];
+    int oy[PT], ox[PT];
+    const float* xim[PT];
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        p[t] = (tile0 + t) * 16 + n;
+        valid[t] = p[t] < M;
+        const long long pc = valid[t] ? p[t] : 0;
+        const int img = (int)(pc / (OH * OW)), r = (int)(pc - (long long)img * (OH * OW));
+        oy[t] = r / OW; ox[t] = r - oy[t] * OW;
+        xim[t] = x + (size_t)img * H * W * xs + 4 * kq;
+    }
+    auto load_b = [&](int g, f4 (&b)[PT][4]) {                        // this lane's chunk of the four k-chunks of group g, per pixel tile
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc) {
+            const int kc = 4 * g + jc, kcc = kc < NKC ? kc : NKC - 1, tap = kcc / c16s, c16 = kcc - tap * c16s, ky = tap / KS, kx = tap - ky * KS;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const int iy = oy[t] * STRIDE + ky - KS / 2, ix = ox[t] * STRIDE + kx - KS / 2;
+                const bool ok = valid[t] && kc < NKC && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                const f4 v = ld4(xim[t] + (size_t)(iyc * W + ixc) * xs + 16 * c16);
+                b[t][jc] = ok ? v : zero4();
+            }
+        }
+    };
+    auto load_w = [&](int g, f4 (&wr)[WPT]) {                          // rows co0 .. of the weight matrix, columns 64 g .. 64 g + 63
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int i = tid + u * 256, row = i >> 4, c4 = i & 15, k = 64 * g + 4 * c4;
+            const bool ok = k < K && co0 + row < Cout;
+            const f4 v = ld4(w + (size_t)(ok ? co0 + row : 0) * K + (ok ? k : 0));
+            wr[u] = ok ? v : zero4();
+        }
+    };
+    auto store_w = [&](int buf, const f4 (&wr)[WPT]) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) { const int i = tid + u * 256; st4(&Ws[buf][(i >> 4) * PITCH + 4 * (i & 15)], wr[u]); }
+    };
+    f4 acc[MT][PT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) acc[mt][t] = zero4();
+    auto mma = [&](int buf, const f4 (&b)[PT][4]) {
+#pragma unroll
+        for (int jc = 0; jc < 4; ++jc)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f4 a = ld4(&Ws[buf][(16 * mt + n) * PITCH + 16 * jc + 4 * kq]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) acc[mt][t] = MFMA4(a[s], b[t][jc][s], acc[mt][t]);
+            }
+    };
+    f4 b0[PT][4], b1[PT][4], wr[WPT];
+    load_b(0, b0);
+    load_w(0, wr);
+    store_w(0, wr);
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < G; g += 2) {
+        if (g + 1 < G) { load_b(g + 1, b1); load_w(g + 1, wr); }
+        mma(0, b0);
+        if (g + 1 < G) store_w(1, wr);
+        __syncthreads();
+        if (g + 1 >= G) break;
+        if (g + 2 < G) { load_b(g + 2, b0); load_w(g + 2, wr); }
+        mma(1, b1);
+        if (g + 2 < G) store_w(0, wr);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int oc = co0 + 16 * mt + 4 * kq;
+        if (oc >= Cout) continue;
+        const f4 bv = ld4(bias + oc);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            if (!valid[t]) continue;
+            f4 v = acc[mt][t] + bv;
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));          // SiLU
+            }
+            if (res) v = v + ld4(res + (size_t)p[t] * rs + oc);
+            st4(out + (size_t)p[t] * os + oc, v);
+        }
+    }
+}
+
+// The first convolution (3 input channels, 3x3, stride 2, pad 1): a thread computes the 16 output channels of one pixel from its 27
+// input values; the weights [16][27] are wave-uniform (scalar loads).  x NHWC [N][H][W][3] dense, out NHWC with a pixel stride.
+__global__ __launch_bounds__(256) void k32_conv0(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ out, int os, int N, int H, int W, int OH, int OW, int act)
+{
+    const long long M = (long long)N * OH * OW, pp = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pp >= M) return;
+    const int img = (int)(pp / (OH * OW)), r = (int)(pp - (long long)img * (OH * OW)), oy = r / OW, ox = r - oy * OW;
+    float v[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float* q = x + ((size_t)img * H * W + (size_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[(ky * 3 + kx) * 3 + c] = ok ? q[c] : 0.f;
+        }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = 4 * c4 + j;
+            float s = bias[co];
+#pragma unroll
+            for (int k = 0; k < 27; ++k) s = __builtin_fmaf(w[co * 27 + k], v[k], s);
+            o[j] = act ? s / (1.0f + expf(-s)) : s;
+        }
+        st4(out + (size_t)pp * os + 4 * c4, o);
+    }
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
@@ -1138,6 +1288,49 @@ extern "C" int ss_op32_head(void* stream, const void* d_x, const void* d_w, cons
     if (!d_x || !d_w || !d_bias || !d_out || N < 1 || HW < 1 || C != 128 || F < 1) return SS_ERR_INVALID;
     hipLaunchKernelGGL(k32_head, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, (const float*)d_w, (const float*)d_bias,
                        (float*)d_out, N, HW, F, d_nvalid);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+/* fp32 convolution of the detector graphs (k32_conv): d_x NHWC [N][H][W][.] with pixel stride xs floats (>= Cin, a channel slice of a
+ * wider tensor when larger), d_w [Cout][ks][ks][Cin], d_out NHWC [N][OH][OW][.] with pixel stride os, d_res (may be NULL, added AFTER
+ * the activation) with pixel stride rs; ks 1 | 3, stride 1 | 2, pad ks / 2; act 1 = SiLU, 0 = none; Cin, Cout multiples of 16 and every
+ * base pointer / stride a multiple of 4 floats. */
+extern "C" int ss_op32_conv(void* stream, const void* d_x, int xs, const void* d_w, const void* d_bias, const void* d_res, int rs, void* d_out,
+                            int os, int N, int H, int W, int Cin, int Cout, int ks, int stride, int act)
+{
+    if (!d_x || !d_w || !d_bias || !d_out || N < 1 || H < 1 || W < 1 || Cin < 16 || Cin % 16 || Cout < 16 || Cout % 16 || xs < Cin || os < Cout ||
+        (xs | os | rs) % 4 || (d_res && rs < Cout) || !(ks == 1 || ks == 3) || !(stride == 1 || stride == 2) || (ks == 1 && stride != 1) ||
+        (((uintptr_t)d_x | (uintptr_t)d_out | (uintptr_t)d_res | (uintptr_t)d_w | (uintptr_t)d_bias) & 15))
+        return SS_ERR_INVALID;
+    const int OH = (H + 2 * (ks / 2) - ks) / stride + 1, OW = (W + 2 * (ks / 2) - ks) / stride + 1;
+    const long long M = (long long)N * OH * OW, tiles = (M + 15) / 16;
+    hipStream_t st = (hipStream_t)stream;
+    const int mt = Cout % 80 == 0 && Cout <= 80 ? 5 : (Cout % 64 == 0 ? 4 : (Cout % 32 == 0 ? 2 : 1));
+    // enough workgroups for the chip: one pixel tile per wave on the small maps
+    const int pt = tiles / 8 * ((Cout + 16 * mt - 1) / (16 * mt)) >= 1024 ? 2 : 1;
+    const dim3 grid((unsigned)((tiles + 4 * pt - 1) / (4 * pt)), (unsigned)((Cout + 16 * mt - 1) / (16 * mt)));
+#define CV32(KS_, ST_, MT_, PT_) if (ks == KS_ && stride == ST_ && mt == MT_ && pt == PT_) { \
+        hipLaunchKernelGGL((k32_conv<KS_, ST_, MT_, PT_>), grid, dim3(256), 0, st, (const float*)d_x, xs, (const float*)d_w, (const float*)d_bias, \
+                           (const float*)d_res, rs, (float*)d_out, os, N, H, W, OH, OW, Cin, Cout, act); \
+        OP32_CHECK(); return SS_OK; }
+#define CV32M(KS_, ST_) CV32(KS_, ST_, 1, 1) CV32(KS_, ST_, 1, 2) CV32(KS_, ST_, 2, 1) CV32(KS_, ST_, 2, 2) CV32(KS_, ST_, 4, 1) CV32(KS_, ST_, 4, 2) \
+        CV32(KS_, ST_, 5, 1) CV32(KS_, ST_, 5, 2)
+    CV32M(1, 1) CV32M(3, 1) CV32M(3, 2)
+#undef CV32M
+#undef CV32
+    return SS_ERR_INVALID;
+}
+
+/* The first convolution of a detector in fp32 (k32_conv0): 3 -> 16 channels, 3x3, stride 2, pad 1; d_x dense NHWC [N][H][W][3],
+ * d_w [16][3][3][3] (co, ky, kx, ci), d_out NHWC with pixel stride os. */
+extern "C" int ss_op32_conv0(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int os, int N, int H, int W, int act)
+{
+    if (!d_x || !d_w || !d_bias || !d_out || N < 1 || H < 2 || W < 2 || os < 16 || os % 4 || ((uintptr_t)d_out & 15)) return SS_ERR_INVALID;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long M = (long long)N * OH * OW;
+    hipLaunchKernelGGL(k32_conv0, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
+                       (const float*)d_bias, (float*)d_out, os, N, H, W, OH, OW, act);
     OP32_CHECK();
     return SS_OK;
 }

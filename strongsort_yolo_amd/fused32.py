@@ -174,3 +174,65 @@ def head(x, fc):
         torch.empty((n, fc.out_features), dtype=torch.float32, device=x.device)
     _ck(_lib.load().ss_op32_head(_st(x), _p(x), _p(fc.weight), _p(fc.bias), _p(out), n, h * w, c, fc.out_features, _p(_nv)))
     return out
+
+
+# ---- the detector's convolutions in fp32 (csrc k32_conv / k32_conv0) ---------------------------------------------------------
+DET = True              # A/B: False sends the fp32 detector to PyTorch-ROCm's library convolutions (bias / SiLU / concat as separate passes)
+
+
+def _nhwc_view(t):
+    """-> pixel stride (floats) of a channels-last tensor or of a channel slice of one, else None."""
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if sc != 1 or sw < c or sw % 4 or sh != w * sw or (n > 1 and sn != h * sh) or t.data_ptr() % 16:
+        return None
+    return sw
+
+
+def conv_ok(x, conv) -> bool:
+    """k32_conv covers this convolution on this input: fp32 CUDA NHWC (or a channel slice of one), 1x1 / 3x3, stride 1 / 2 (1x1: 1),
+    pad k // 2, no groups / dilation, channel counts multiples of 16, a bias."""
+    if not (DET and usable(x)) or conv.groups != 1 or conv.dilation != (1, 1) or conv.bias is None:
+        return False
+    k, s = conv.kernel_size, conv.stride
+    if k[0] != k[1] or s[0] != s[1] or k[0] not in (1, 3) or s[0] not in (1, 2) or (k[0] == 1 and s[0] != 1) or conv.padding != (k[0] // 2, k[0] // 2):
+        return False
+    return conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and x.shape[1] == conv.in_channels and _nhwc_view(x) is not None
+
+
+def conv0_ok(x, conv) -> bool:
+    return (DET and usable(x) and conv.in_channels == 3 and conv.out_channels == 16 and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.groups == 1 and conv.bias is not None and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _w_khwc(mod, conv):
+    """[Cout][kh][kw][Cin] copy of the weight (the K order of k32_conv), cached on `mod`."""
+    return _cached(mod, "_w32_khwc", conv.weight, lambda: conv.weight.detach().float().permute(0, 2, 3, 1).contiguous())
+
+
+def conv(x, mod, conv, act="silu", out=None, res=None):
+    """act(conv(x) + b) (+ res, added after the activation) on k32_conv.  x / out / res: channels-last tensors or channel slices of
+    wider channels-last tensors; out (when given) is written in place and returned."""
+    n, ci, h, w = x.shape
+    k, s = conv.kernel_size[0], conv.stride[0]
+    oh, ow = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    co = conv.out_channels
+    if out is None:
+        out = torch.empty((n, co, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    xs, os_ = _nhwc_view(x), _nhwc_view(out)
+    rs = _nhwc_view(res) if res is not None else 0
+    if xs is None or os_ is None or rs is None or tuple(out.shape) != (n, co, oh, ow) or (res is not None and tuple(res.shape) != tuple(out.shape)):
+        raise _lib.SSError(-1, "fp32 convolution: operand is not a channels-last tensor / channel slice of the expected shape")
+    _ck(_lib.load().ss_op32_conv(_st(x), _p(x), xs, _p(_w_khwc(mod, conv)), _p(conv.bias), _p(res), rs, _p(out), os_, n, h, w, ci, co, k, s,
+                                 1 if act == "silu" else 0))
+    return out
+
+
+def conv0(x, mod, conv, act="silu", out=None):
+    """The first convolution (3 -> 16, 3x3, stride 2) on k32_conv0."""
+    n, _, h, w = x.shape
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((n, 16, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op32_conv0(_st(x), _p(x), _p(_w_khwc(mod, conv)), _p(conv.bias), _p(out), _nhwc_view(out), n, h, w, 1 if act == "silu" else 0))
+    return out

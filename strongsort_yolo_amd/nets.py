@@ -31,7 +31,20 @@ class Conv(nn.Module):
         self.conv = nn.Conv2d(c1, c2, k, s, k // 2 if p is None else p, groups=g, bias=True)
         self.act = nn.SiLU(inplace=True) if act else nn.Identity()
 
-    def forward(self, x):
+    def forward(self, x, out=None, res=None):
+        """out / res (fp32 kernels only): write into this channels-last tensor / channel slice; add `res` after the activation."""
+        act = "silu" if isinstance(self.act, nn.SiLU) else ("none" if isinstance(self.act, nn.Identity) else None)
+        if act is not None and fused32.conv_ok(x, self.conv):       # fp32: one implicit-GEMM launch, bias + SiLU (+ shortcut) in its epilogue
+            return fused32.conv(x, self, self.conv, act, out=out, res=res)
+        if act is not None and fused32.conv0_ok(x, self.conv):
+            return fused32.conv0(x, self, self.conv, act, out=out)
+        if out is not None or res is not None:
+            y = self.act(self.conv(x))
+            y = y if res is None else y + res
+            if out is None:
+                return y
+            out.copy_(y)
+            return out
         if fused.usable(x):
             c = self.conv
             act = "silu" if isinstance(self.act, nn.SiLU) else "none"
@@ -56,7 +69,9 @@ class Bottleneck(nn.Module):
         self.cv1, self.cv2 = Conv(c1, c_, k[0]), Conv(c_, c2, k[1])
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        if out is not None or (self.add and fused32.conv_ok(x, self.cv1.conv)):      # fp32 kernels: the shortcut in the second convolution's epilogue
+            return self.cv2(self.cv1(x), out=out, res=x if self.add else None)
         return x + self.cv2(self.cv1(x)) if self.add else self.cv2(self.cv1(x))
 
 
@@ -76,6 +91,18 @@ class C2f(nn.Module):
         later concat's buffer) by the last 1x1's epilogue — only with the placed path (placed_ok) and a pointwise-capable cv2."""
         if self.placed_ok(x):
             return self._forward_placed(x, also, c_off)
+        if fused32.conv_ok(x, self.cv1.conv) and all(type(m) is Bottleneck for m in self.m):
+            # fp32 kernels: every producer writes its channel slice of the concat buffer, every consumer reads a slice — no chunk / add / cat pass
+            c, n = self.c, len(self.m)
+            B, _, H, W = x.shape
+            cat = torch.empty((B, (2 + n) * c, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+            self.cv1(x, out=cat[:, :2 * c])
+            for i, m in enumerate(self.m):
+                m(cat[:, (1 + i) * c:(2 + i) * c], out=cat[:, (2 + i) * c:(3 + i) * c])
+            y = self.cv2(cat)
+            if also is not None:
+                also[:, c_off:c_off + y.shape[1]] = y
+            return y
         y = list(self.cv1(x).chunk(2, 1))
         for m in self.m:
             y.append(m(y[-1]))
@@ -313,11 +340,17 @@ class Detect(nn.Module):
                                 [last(self.cv3[i], f) for i, f in enumerate(feats)], bb, cb, ext)
         return self._forward_torch(feats)
 
+    @staticmethod
+    def _branch(seq, f):
+        """A head branch (3x3, 3x3, plain 1x1); the last layer on the fp32 kernel too when its widths allow."""
+        t = seq[1](seq[0](f))
+        return fused32.conv(t, seq[2], seq[2], "none") if fused32.conv_ok(t, seq[2]) else seq[2](t)
+
     def _forward_torch(self, feats):
         B = feats[0].shape[0]
-        box = torch.cat([self.cv2[i](f).reshape(B, 64, -1) for i, f in enumerate(feats)], 2)
-        cls = torch.cat([self.cv3[i](f).reshape(B, self.nc, -1) for i, f in enumerate(feats)], 2)
-        if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype:
+        box = torch.cat([self._branch(self.cv2[i], f).reshape(B, 64, -1) for i, f in enumerate(feats)], 2)
+        cls = torch.cat([self._branch(self.cv3[i], f).reshape(B, self.nc, -1) for i, f in enumerate(feats)], 2)
+        if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype or self._anchors[0].device != box.device:
             self._anchors = self._make_anchors(feats)
         anchors, strides = self._anchors
         d = box.view(B, 4, 16, -1).softmax(2)
@@ -391,6 +424,7 @@ class YOLOv8(nn.Module):
         return self.detect([h15, h18, h21])
 
     def forward(self, x):
+        self._own32 = bool(fused32.DET and fused32.usable(x))       # fp32 CUDA input: the convolutions run on csrc k32_conv / k32_conv0
         return self.forward_head(*self.forward_backbone(x))
 
 
