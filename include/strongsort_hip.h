@@ -443,6 +443,9 @@ int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_b
 int ss_op32_conv(void* stream, const void* d_x, int xs, const void* d_w, const void* d_bias, const void* d_res, int rs, void* d_out,
                  int os, int N, int H, int W, int Cin, int Cout, int ks, int stride, int act);
 int ss_op32_conv0(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int os, int N, int H, int W, int act);
+/* cat(upsample2x_nearest(lo), hi) (lo_first != 0) or cat(hi, upsample2x_nearest(lo)) along channels in one pass (the neck's two
+ * upsample + concat pairs), fp32 NHWC: d_lo [N][H/2][W/2][.] pixel stride ls, d_hi [N][H][W][.] pixel stride hs, d_out dense. */
+int ss_op32_upcat(void* stream, const void* d_lo, int ls, int Cl, const void* d_hi, int hs, int Ch, void* d_out, int N, int H, int W, int lo_first);
 
 /* ---- profiling support ----------------------------------------------------------------------- */
 /* Mean duration (ms) of the association (cosine gallery) kernel over the launches since the last

@@ -51,12 +51,14 @@ static __device__ __forceinline__ f4 max4(const f4 a, const f4 b)
     return f4{ a[0] > b[0] ? a[0] : b[0], a[1] > b[1] ? a[1] : b[1], a[2] > b[2] ? a[2] : b[2], a[3] > b[3] ? a[3] : b[3] };
 }
 
-// Weight matrix [N][K] -> LDS rows of KP = 16 JJ + 4 floats (the + 4 keeps the 16-byte operand reads of 16 consecutive rows on
-// distinct banks), zero in the padding columns and in the rows N .. NP - 1 (24 output channels = two M-tiles, the second half empty)
+// Weight matrix [N][K] -> LDS rows of KP = 16 JJ + 8 floats: a row pitch of 8 mod 16 dwords is the one that makes the A-operand read
+// (lane (kq, n): 16 bytes at row n, chunk kq) conflict-free for ds_read_b128's lane groups {0-3, 12-15, 20-27}, .. — the + 4 of round 5
+// was a 2-way conflict on every read (profiles/r06_pmc_det32.json: more conflict cycles than busy cycles).  Zero in the padding columns
+// and in the rows N .. NP - 1 (24 output channels = two M-tiles, the second half empty)
 template <int K, int N, int NTHR>
 static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const float* __restrict__ w, int tid)
 {
-    constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 4, NP = (N + 15) / 16 * 16;
+    constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 8, NP = (N + 15) / 16 * 16;
     // up to eight vectors of a thread are requested (from clamped, always valid addresses) before the first LDS store: the rolled
     // `predicated load -> store` loop paid one L2 round trip per NTHR vectors - 3 to 17 of them back to back at the start of a workgroup
     constexpr int TOT = NP * (KP / 4), NIT = (TOT + NTHR - 1) / NTHR, UB = NIT < 8 ? NIT : 8;
@@ -75,13 +77,13 @@ static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const flo
     }
 }
 template <int K, int N>
-constexpr int w_lds_floats() { return ((N + 15) / 16 * 16) * (16 * ((K / 4 + 3) / 4) + 4); }
+constexpr int w_lds_floats() { return ((N + 15) / 16 * 16) * (16 * ((K / 4 + 3) / 4) + 8); }
 
 // acc[mt] += W[16 mt .. + 15][:] x B for the 16 pixels of the tile; b[jj] = this lane's chunks kq + 4 jj
 template <int K, int N>
 static __device__ __forceinline__ void mm_tile(const float* __restrict__ Ws, const f4 (&b)[(K / 4 + 3) / 4], f4 (&acc)[(N + 15) / 16], int kq, int n)
 {
-    constexpr int JJ = (K / 4 + 3) / 4, KP = 16 * JJ + 4, MT = (N + 15) / 16;
+    constexpr int JJ = (K / 4 + 3) / 4, KP = 16 * JJ + 8, MT = (N + 15) / 16;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -453,7 +455,7 @@ static __device__ __forceinline__ float dppf_shr1_z(float v) { return __builtin_
 static __device__ __forceinline__ float dppf_shl1_z(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)); }
 
 template <int C> struct ChR {
-    static constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = JJ, CP = 16 * JJ, KP = CP + 4, NPR = (C % 16) ? C + 1 : C;   // NPR: rows of a staged 1x1 matrix (+ one zero row)
+    static constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = JJ, CP = 16 * JJ, KP = CP + 8, NPR = (C % 16) ? C + 1 : C;   // NPR: rows of a staged 1x1 matrix (+ one zero row)
     static constexpr int TAB = 10 * 10 * CP;                       // floats: [layer][9 taps + bias][CP]
 };
 
@@ -977,17 +979,19 @@ __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, con
 // weights are the A operand from LDS).  K is walked in groups of 64 (four 16-channel chunks of one tap or of consecutive taps); the
 // weight slice of the next group and the next group's pixel vectors are requested before the matrix work of the current one (registers
 // / the other LDS buffer), one barrier per group.
-template <int KS, int STRIDE, int MT, int PT>
-__global__ __launch_bounds__(256) void k32_conv(const float* __restrict__ x, int xs, const float* __restrict__ w, const float* __restrict__ bias,
+__device__ __attribute__((aligned(16))) float g_zero4[4] = { 0.f, 0.f, 0.f, 0.f };      // (not const: a constant-address-space pointer would turn the selects into generic pointers and the loads into flat loads)   // where the vector of a padding tap / a row past the matrix is read from
+
+template <int KS, int STRIDE, int MT, int PT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k32_conv(const float* __restrict__ x, int xs, const float* __restrict__ w, const float* __restrict__ bias,
                                                 const float* __restrict__ res, int rs, float* __restrict__ out, int os, int N, int H, int W, int OH,
                                                 int OW, int Cin, int Cout, int act)
 {
-    constexpr int ROWS = 16 * MT, PITCH = 68, WPT = ROWS * 16 / 256;      // WPT: weight vectors a thread stages per group
+    constexpr int ROWS = 16 * MT, PITCH = 72, THREADS = 64 * WAVES, WPT = (ROWS * 16 + THREADS - 1) / THREADS;      // WPT: weight vectors a thread stages per group
     __shared__ __attribute__((aligned(16))) float Ws[2][ROWS * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
     const int co0 = blockIdx.y * ROWS, K = KS * KS * Cin, c16s = Cin >> 4, NKC = K >> 4, G = (NKC + 3) >> 2;
     const long long M = (long long)N * OH * OW;
-    const long long tile0 = ((long long)blockIdx.x * 4 + wave) * PT;
+    const long long tile0 = ((long long)blockIdx.x * WAVES + wave) * PT;
     long long p[PT];
     int oy[PT], ox[PT];
     const float* xim[PT];
@@ -1008,25 +1012,26 @@ __global__ __launch_bounds__(256) void k32_conv(const float* __restrict__ x, int
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
                 const int iy = oy[t] * STRIDE + ky - KS / 2, ix = ox[t] * STRIDE + kx - KS / 2;
+                // a tap outside the image (or a k-chunk past K) reads the zero vector: the choice is made on the ADDRESS, so nothing
+                // touches the loaded value before the matrix instructions of the NEXT group do (a select on the value made the
+                // compiler wait for every load right here, i.e. one L2 round trip per 64-wide group in front of the MFMAs)
                 const bool ok = valid[t] && kc < NKC && iy >= 0 && iy < H && ix >= 0 && ix < W;
-                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-                const f4 v = ld4(xim[t] + (size_t)(iyc * W + ixc) * xs + 16 * c16);
-                b[t][jc] = ok ? v : zero4();
+                const float* q = ok ? xim[t] + (size_t)(iy * W + ix) * xs + 16 * c16 : g_zero4;
+                b[t][jc] = ld4(q);
             }
         }
     };
     auto load_w = [&](int g, f4 (&wr)[WPT]) {                          // rows co0 .. of the weight matrix, columns 64 g .. 64 g + 63
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            const int i = tid + u * 256, row = i >> 4, c4 = i & 15, k = 64 * g + 4 * c4;
-            const bool ok = k < K && co0 + row < Cout;
-            const f4 v = ld4(w + (size_t)(ok ? co0 + row : 0) * K + (ok ? k : 0));
-            wr[u] = ok ? v : zero4();
+            const int i = tid + u * THREADS, row = i >> 4, c4 = i & 15, k = 64 * g + 4 * c4;
+            const bool ok = k < K && co0 + row < Cout && row < ROWS;
+            wr[u] = ld4(ok ? w + (size_t)(co0 + row) * K + k : g_zero4);
         }
     };
     auto store_w = [&](int buf, const f4 (&wr)[WPT]) {
 #pragma unroll
-        for (int u = 0; u < WPT; ++u) { const int i = tid + u * 256; st4(&Ws[buf][(i >> 4) * PITCH + 4 * (i & 15)], wr[u]); }
+        for (int u = 0; u < WPT; ++u) { const int i = tid + u * THREADS; if (ROWS * 16 % THREADS == 0 || i < ROWS * 16) st4(&Ws[buf][(i >> 4) * PITCH + 4 * (i & 15)], wr[u]); }
     };
     f4 acc[MT][PT];
 #pragma unroll
@@ -1035,15 +1040,17 @@ __global__ __launch_bounds__(256) void k32_conv(const float* __restrict__ x, int
         for (int t = 0; t < PT; ++t) acc[mt][t] = zero4();
     auto mma = [&](int buf, const f4 (&b)[PT][4]) {
 #pragma unroll
-        for (int jc = 0; jc < 4; ++jc)
+        for (int jc = 0; jc < 4; ++jc) {
+            f4 a[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f4 a = ld4(&Ws[buf][(16 * mt + n) * PITCH + 16 * jc + 4 * kq]);
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(&Ws[buf][(16 * mt + n) * PITCH + 16 * jc + 4 * kq]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)                                  // consecutive MFMAs on different accumulators (a dependent one is 40 cycles behind, an independent 32)
 #pragma unroll
-                    for (int t = 0; t < PT; ++t) acc[mt][t] = MFMA4(a[s], b[t][jc][s], acc[mt][t]);
-            }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) acc[mt][t] = MFMA4(a[mt][s], b[t][jc][s], acc[mt][t]);
+        }
     };
     f4 b0[PT][4], b1[PT][4], wr[WPT];
     load_b(0, b0);
@@ -1115,11 +1122,31 @@ __global__ __launch_bounds__(256) void k32_conv0(const float* __restrict__ x, co
     }
 }
 
+// cat(nearest-2x-upsample(lo), hi) (lo_first) or cat(hi, up(lo)) along channels in one pass: a thread moves one 16-byte chunk of an
+// output pixel.  lo [N][H/2][W/2][.] pixel stride ls, hi [N][H][W][.] pixel stride hs (channel slices allowed), out dense [N][H][W][Cl + Ch].
+__global__ __launch_bounds__(256) void k32_upcat(const float* __restrict__ lo, int ls, int Cl, const float* __restrict__ hi, int hs, int Ch,
+                                                 float* __restrict__ out, int N, int H, int W, int lo_first)
+{
+    const int C4 = (Cl + Ch) >> 2;
+    const long long tot = (long long)N * H * W * C4, i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tot) return;
+    const int c4 = (int)(i % C4);
+    const long long px = i / C4;
+    const int x = (int)(px % W), y = (int)((px / W) % H), img = (int)(px / ((long long)W * H));
+    const int c = 4 * c4, cl = lo_first ? c : c - Ch;                   // channel inside lo (when in its range)
+    f4 v;
+    if (cl >= 0 && cl < Cl) v = ld4(lo + ((size_t)(img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * ls + cl);
+    else v = ld4(hi + (size_t)px * hs + (lo_first ? c - Cl : c));
+    st4(out + (size_t)px * (Cl + Ch) + c, v);
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
                                       // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
 static int g_chains_form = 2;        // 2: k32_chainsR (register row stream; 64 x 32 x 16 and 32 x 16 x 24 maps), 1: k32_chains3, 0: k32_chains (the 16 x 8 maps always take k32_chains)
+static int g_conv_mt = 0, g_conv_min = 768;    // k32_conv: 16-channel output tiles per workgroup forced (A/B) / the workgroup count below which fewer are taken
+static int g_conv_waves = 0, g_conv_wgs = 1024; // k32_conv: waves per workgroup (0 = 8 when that still leaves g_conv_wgs workgroups, else 4); A/B
 static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
 static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16)) && H >= 9; }
@@ -1215,6 +1242,10 @@ extern "C" int ss_op32_set_option(const char* name, int value)
 {
     if (!name) return SS_ERR_INVALID;
     if (!strcmp(name, "chains_pre")) { g_chains_pre = value < 0 ? -1 : (value != 0); return SS_OK; }
+    if (!strcmp(name, "conv_mt")) { if (value < 0 || value > 5 || value == 3) return SS_ERR_INVALID; g_conv_mt = value; return SS_OK; }
+    if (!strcmp(name, "conv_min")) { if (value < 0) return SS_ERR_INVALID; g_conv_min = value; return SS_OK; }
+    if (!strcmp(name, "conv_waves")) { if (!(value == 0 || value == 4 || value == 8)) return SS_ERR_INVALID; g_conv_waves = value; return SS_OK; }
+    if (!strcmp(name, "conv_wgs")) { if (value < 1) return SS_ERR_INVALID; g_conv_wgs = value; return SS_OK; }
     if (!strcmp(name, "tail_wgs")) { if (value < 0 || value > 65535) return SS_ERR_INVALID; g_tail_wgs = value; return SS_OK; }
     if (!strcmp(name, "chains_probe")) { g_chains_probe = value; return SS_OK; }
     if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
@@ -1306,16 +1337,21 @@ extern "C" int ss_op32_conv(void* stream, const void* d_x, int xs, const void* d
     const int OH = (H + 2 * (ks / 2) - ks) / stride + 1, OW = (W + 2 * (ks / 2) - ks) / stride + 1;
     const long long M = (long long)N * OH * OW, tiles = (M + 15) / 16;
     hipStream_t st = (hipStream_t)stream;
-    const int mt = Cout % 80 == 0 && Cout <= 80 ? 5 : (Cout % 64 == 0 ? 4 : (Cout % 32 == 0 ? 2 : 1));
+    // output channels per workgroup: 64 (80 for the 80-wide head layers) on the large maps; on the small ones fewer, so that the launch
+    // still has ~g_conv_min workgroups (a 12 x 20 map of 32 frames is 480 pixel tiles: 120 workgroups of 64 channels would leave the chip 7/8 idle)
+    int mt = Cout % 80 == 0 && Cout <= 80 ? 5 : (Cout % 64 == 0 ? 4 : (Cout % 32 == 0 ? 2 : 1));
+    if (g_conv_mt) mt = (Cout % (16 * g_conv_mt) == 0) ? g_conv_mt : mt;
+    else while (mt > 1 && (tiles / 4) * ((Cout + 16 * mt - 1) / (16 * mt)) < g_conv_min) mt = mt == 5 ? 1 : mt / 2;
     // enough workgroups for the chip: one pixel tile per wave on the small maps
-    const int pt = tiles / 8 * ((Cout + 16 * mt - 1) / (16 * mt)) >= 1024 ? 2 : 1;
-    const dim3 grid((unsigned)((tiles + 4 * pt - 1) / (4 * pt)), (unsigned)((Cout + 16 * mt - 1) / (16 * mt)));
-#define CV32(KS_, ST_, MT_, PT_) if (ks == KS_ && stride == ST_ && mt == MT_ && pt == PT_) { \
-        hipLaunchKernelGGL((k32_conv<KS_, ST_, MT_, PT_>), grid, dim3(256), 0, st, (const float*)d_x, xs, (const float*)d_w, (const float*)d_bias, \
+    const int pt = 1;                                          // (two pixel tiles per wave measured slower everywhere: 4.25 vs 3.68 ms per 32 frames)
+    const int wv = g_conv_waves ? g_conv_waves : (tiles / 8 * ((Cout + 16 * mt - 1) / (16 * mt)) >= g_conv_wgs ? 8 : 4);
+    const dim3 grid((unsigned)((tiles + wv * pt - 1) / (wv * pt)), (unsigned)((Cout + 16 * mt - 1) / (16 * mt)));
+#define CV32(KS_, ST_, MT_, WV_) if (ks == KS_ && stride == ST_ && mt == MT_ && wv == WV_) { \
+        hipLaunchKernelGGL((k32_conv<KS_, ST_, MT_, 1, WV_>), grid, dim3(64 * WV_), 0, st, (const float*)d_x, xs, (const float*)d_w, (const float*)d_bias, \
                            (const float*)d_res, rs, (float*)d_out, os, N, H, W, OH, OW, Cin, Cout, act); \
         OP32_CHECK(); return SS_OK; }
-#define CV32M(KS_, ST_) CV32(KS_, ST_, 1, 1) CV32(KS_, ST_, 1, 2) CV32(KS_, ST_, 2, 1) CV32(KS_, ST_, 2, 2) CV32(KS_, ST_, 4, 1) CV32(KS_, ST_, 4, 2) \
-        CV32(KS_, ST_, 5, 1) CV32(KS_, ST_, 5, 2)
+#define CV32M(KS_, ST_) CV32(KS_, ST_, 1, 4) CV32(KS_, ST_, 1, 8) CV32(KS_, ST_, 2, 4) CV32(KS_, ST_, 2, 8) CV32(KS_, ST_, 4, 4) CV32(KS_, ST_, 4, 8) \
+        CV32(KS_, ST_, 5, 4) CV32(KS_, ST_, 5, 8)
     CV32M(1, 1) CV32M(3, 1) CV32M(3, 2)
 #undef CV32M
 #undef CV32
@@ -1331,6 +1367,20 @@ extern "C" int ss_op32_conv0(void* stream, const void* d_x, const void* d_w, con
     const long long M = (long long)N * OH * OW;
     hipLaunchKernelGGL(k32_conv0, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
                        (const float*)d_bias, (float*)d_out, os, N, H, W, OH, OW, act);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+/* cat(upsample2x_nearest(lo), hi) (lo_first != 0) or cat(hi, upsample2x_nearest(lo)) along channels, fp32 NHWC: d_lo [N][H/2][W/2][.]
+ * pixel stride ls, d_hi [N][H][W][.] pixel stride hs, d_out dense [N][H][W][Cl + Ch]; Cl, Ch multiples of 4, H and W even. */
+extern "C" int ss_op32_upcat(void* stream, const void* d_lo, int ls, int Cl, const void* d_hi, int hs, int Ch, void* d_out, int N, int H, int W, int lo_first)
+{
+    if (!d_lo || !d_hi || !d_out || N < 1 || H < 2 || W < 2 || (H | W) & 1 || Cl < 4 || Ch < 4 || (Cl | Ch | ls | hs) % 4 || ls < Cl || hs < Ch ||
+        (((uintptr_t)d_lo | (uintptr_t)d_hi | (uintptr_t)d_out) & 15))
+        return SS_ERR_INVALID;
+    const long long tot = (long long)N * H * W * ((Cl + Ch) / 4);
+    hipLaunchKernelGGL(k32_upcat, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d_lo, ls, Cl, (const float*)d_hi, hs, Ch,
+                       (float*)d_out, N, H, W, lo_first);
     OP32_CHECK();
     return SS_OK;
 }

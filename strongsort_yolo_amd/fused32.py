@@ -236,3 +236,19 @@ def conv0(x, mod, conv, act="silu", out=None):
         out = torch.empty((n, 16, oh, ow), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _ck(_lib.load().ss_op32_conv0(_st(x), _p(x), _p(_w_khwc(mod, conv)), _p(conv.bias), _p(out), _nhwc_view(out), n, h, w, 1 if act == "silu" else 0))
     return out
+
+
+def upcat_ok(lo, hi) -> bool:
+    if not (DET and usable(lo) and usable(hi)) or _nhwc_view(lo) is None or _nhwc_view(hi) is None:
+        return False
+    n, cl, h, w = lo.shape
+    return tuple(hi.shape[2:]) == (2 * h, 2 * w) and hi.shape[0] == n and cl % 4 == 0 and hi.shape[1] % 4 == 0
+
+
+def upcat(lo, hi, lo_first=True):
+    """cat(upsample2x_nearest(lo), hi) (or cat(hi, up(lo))) along channels, one launch (k32_upcat)."""
+    n, cl, h, w = lo.shape
+    ch = hi.shape[1]
+    out = torch.empty((n, cl + ch, 2 * h, 2 * w), dtype=torch.float32, device=lo.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op32_upcat(_st(lo), _p(lo), _nhwc_view(lo), cl, _p(hi), _nhwc_view(hi), ch, _p(out), n, 2 * h, 2 * w, int(lo_first)))
+    return out

@@ -99,10 +99,9 @@ class C2f(nn.Module):
             self.cv1(x, out=cat[:, :2 * c])
             for i, m in enumerate(self.m):
                 m(cat[:, (1 + i) * c:(2 + i) * c], out=cat[:, (2 + i) * c:(3 + i) * c])
-            y = self.cv2(cat)
-            if also is not None:
-                also[:, c_off:c_off + y.shape[1]] = y
-            return y
+            if also is not None:         # the last 1x1 writes its slice of a later concat's buffer; the block's output is that slice
+                return self.cv2(cat, out=also[:, c_off:c_off + self.cv2.conv.out_channels])
+            return self.cv2(cat)
         y = list(self.cv1(x).chunk(2, 1))
         for m in self.m:
             y.append(m(y[-1]))
@@ -415,6 +414,20 @@ class YOLOv8(nn.Module):
             x21 = torch.empty((B, c19.out_channels + p5.shape[1], p5.shape[2], p5.shape[3]), dtype=p3.dtype, device=p3.device,
                               memory_format=torch.channels_last)
             fused.conv3x3(h18, fused.weight_n9k(self.h19, c19), c19.bias, 2, "silu", out=x21, c_off=0)
+            x21[:, c19.out_channels:] = p5
+            return self.detect([h15, h18, self.h21(x21)])
+        if fused32.conv_ok(p3, c16) and fused32.conv_ok(p4, c19):
+            # fp32 kernels: the two down-path concats as placement — h12 lands in h18's input from its own last 1x1, the stride-2
+            # convolutions write their slices; only p5 is copied
+            B = p3.shape[0]
+            new = lambda c, like: torch.empty((B, c, like.shape[2], like.shape[3]), dtype=p3.dtype, device=p3.device, memory_format=torch.channels_last)
+            x18 = new(c16.out_channels + self.h12.cv2.conv.out_channels, p4)
+            h12 = self.h12(_upcat(p5, p4), also=x18, c_off=c16.out_channels)
+            h15 = self.h15(_upcat(h12, p3))
+            self.h16(h15, out=x18[:, :c16.out_channels])
+            h18 = self.h18(x18)
+            x21 = new(c19.out_channels + p5.shape[1], p5)
+            self.h19(h18, out=x21[:, :c19.out_channels])
             x21[:, c19.out_channels:] = p5
             return self.detect([h15, h18, self.h21(x21)])
         h12 = self.h12(_upcat(p5, p4))
@@ -1043,6 +1056,8 @@ def _upcat(lo, hi, lo_first=True):
     """cat(upsample2x(lo), hi) (or cat(hi, upsample2x(lo))) along channels."""
     if fused.upcat_ok(lo, hi):
         return fused.upcat(lo, hi, lo_first)
+    if fused32.upcat_ok(lo, hi):
+        return fused32.upcat(lo, hi, lo_first)
     up = F.interpolate(lo, scale_factor=2.0, mode="nearest")
     return torch.cat((up, hi) if lo_first else (hi, up), 1)
 

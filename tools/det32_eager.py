@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd import nets, fused32
 if os.environ.get("SS32_DET") == "0":
     fused32.DET = False
+for kv in os.environ.get("SS32_OPTS", "").split(","):
+    if "=" in kv:
+        fused32.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 name = sys.argv[3] if len(sys.argv) > 3 else "yolov8n"
