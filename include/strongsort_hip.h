@@ -445,6 +445,12 @@ int ss_op32_conv(void* stream, const void* d_x, int xs, const void* d_w, const v
 int ss_op32_conv0(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int os, int N, int H, int W, int act);
 /* cat(upsample2x_nearest(lo), hi) (lo_first != 0) or cat(hi, upsample2x_nearest(lo)) along channels in one pass (the neck's two
  * upsample + concat pairs), fp32 NHWC: d_lo [N][H/2][W/2][.] pixel stride ls, d_hi [N][H][W][.] pixel stride hs, d_out dense. */
+/* YOLOv8 head decode in fp32 (DFL expectation, dist2bbox, stride scale, class sigmoid, level concat; the third branch as keypoint
+ * triplets (ext_mode 1) or raw (0)): dense NHWC float branch outputs with their bias -> d_pred [B][4 + nc + n_ext][A]. */
+int ss_op32_v8_decode(void* stream, const void* const* d_box, const void* const* d_cls, const void* const* d_ext, int n_ext, int ext_ld,
+                      int ext_mode, const int* H, const int* W, const int* strides, int B, int nc, int cls_ld, float* d_pred);
+/* SPPF's three chained 5x5 max pools + concat in one pass, fp32: d_x NHWC [N][H][W][.] (pixel stride xs) -> d_out dense [N][H][W][4 C]. */
+int ss_op32_sppf_pools(void* stream, const void* d_x, int xs, void* d_out, int N, int H, int W, int C);
 int ss_op32_upcat(void* stream, const void* d_lo, int ls, int Cl, const void* d_hi, int hs, int Ch, void* d_out, int N, int H, int W, int lo_first);
 
 /* ---- profiling support ----------------------------------------------------------------------- */

@@ -1140,6 +1140,89 @@ __global__ __launch_bounds__(256) void k32_upcat(const float* __restrict__ lo, i
     st4(out + (size_t)px * (Cl + Ch) + c, v);
 }
 
+// SPPF's three chained 5x5 / stride 1 / pad 2 max pools and the concat in one pass: out [N][H][W][4 C] = (x, pool5(x), pool5^2(x),
+// pool5^3(x)) = x and its maxima over the 5x5, 9x9 and 13x13 windows (clipped at the border, as -inf padding does).  A thread makes
+// one 16-byte chunk of the four slices of one pixel.  x may be a channel slice (pixel stride xs).
+__global__ __launch_bounds__(256) void k32_sppf(const float* __restrict__ x, int xs, float* __restrict__ out, int N, int H, int W, int C)
+{
+    const int C4 = C >> 2;
+    const long long tot = (long long)N * H * W * C4, i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= tot) return;
+    const int c = 4 * (int)(i % C4);
+    const long long px = i / C4;
+    const int x0 = (int)(px % W), y0 = (int)((px / W) % H), img = (int)(px / ((long long)W * H));
+    const float* xi = x + (size_t)img * H * W * xs + c;
+    const f4 ninf = f4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+    f4 m5 = ninf, m9 = ninf, m13 = ninf;
+    for (int dy = -6; dy <= 6; ++dy) {
+        const int yy = y0 + dy;
+        if (yy < 0 || yy >= H) continue;
+        const int ay = dy < 0 ? -dy : dy;
+        for (int dx = -6; dx <= 6; ++dx) {
+            const int xx = x0 + dx;
+            if (xx < 0 || xx >= W) continue;
+            const int ax = dx < 0 ? -dx : dx, r = ax > ay ? ax : ay;
+            const f4 v = ld4(xi + (size_t)(yy * W + xx) * xs);
+            m13 = max4(m13, v);
+            if (r <= 4) m9 = max4(m9, v);
+            if (r <= 2) m5 = max4(m5, v);
+        }
+    }
+    float* o = out + (size_t)px * 4 * C + c;
+    st4(o, ld4(xi + (size_t)(y0 * W + x0) * xs)); st4(o + C, m5); st4(o + 2 * C, m9); st4(o + 3 * C, m13);
+}
+
+// YOLOv8 anchor-free head decode in fp32, one pass (DFL softmax expectation, dist2bbox, stride scale, class sigmoid, level concat):
+// the branch outputs of the three levels (NHWC float, bias included) -> pred [B][4 + nc + n_ext][A] float, the layout ss_nms reads.
+// Thread = one anchor of one image.  ext: the third branch (keypoints: ext_mode 1, Ultralytics Pose.kpts_decode; mask coefficients:
+// 0, raw).  The fp32 twin of ss_ops.hip's k_v8_decode, with expf instead of the fast exponential.
+struct V8Levels32 {
+    const float* box[3]; const float* cls[3]; const float* ext[3];   // [B][H][W][64], [B][H][W][cls_ld], [B][H][W][ext_ld]
+    int H[3], W[3], stride[3];
+    int n_ext, ext_ld, ext_mode, cls_ld;
+};
+
+__global__ __launch_bounds__(128) void k32_v8_decode(V8Levels32 L, int B, int nc, int A, float* __restrict__ pred)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (a >= A) return;
+    int l = 0, a0 = 0;
+    while (l < 2 && a >= a0 + L.H[l] * L.W[l]) { a0 += L.H[l] * L.W[l]; ++l; }
+    const int p = a - a0, hw = L.H[l] * L.W[l];
+    const int py = p / L.W[l], px = p - py * L.W[l];
+    const float* bx = L.box[l] + ((size_t)b * hw + p) * 64;
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16], m = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 t = ld4(bx + 16 * s + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[4 * q + k] = t[k]; m = fmaxf(m, t[k]); }
+        }
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float e = expf(v[k] - m); se += e; sw += e * (float)k; }
+        d[s] = sw / se;
+    }
+    const float ax = (float)px + 0.5f, ay = (float)py + 0.5f, st = (float)L.stride[l];
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    float* o = pred + (size_t)b * (4 + nc + L.n_ext) * A + a;
+    o[0] = (x1 + x2) * 0.5f * st; o[(size_t)A] = (y1 + y2) * 0.5f * st;
+    o[(size_t)2 * A] = (x2 - x1) * st; o[(size_t)3 * A] = (y2 - y1) * st;
+    if (L.n_ext) {
+        const float* e = L.ext[l] + ((size_t)b * hw + p) * L.ext_ld;
+        float* oe = o + (size_t)(4 + nc) * A;
+        for (int k = 0, j = 0; k < L.n_ext; ++k, j = j == 2 ? 0 : j + 1) {
+            const float v = e[k];
+            oe[(size_t)k * A] = L.ext_mode == 0 ? v : j == 0 ? (v * 2.0f + (float)px) * st : j == 1 ? (v * 2.0f + (float)py) * st : 1.0f / (1.0f + expf(-v));
+        }
+    }
+    const float* cl = L.cls[l] + ((size_t)b * hw + p) * L.cls_ld;
+    for (int k = 0; k < nc; ++k) o[(size_t)(4 + k) * A] = 1.0f / (1.0f + expf(-cl[k]));
+}
+
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
@@ -1381,6 +1464,38 @@ extern "C" int ss_op32_upcat(void* stream, const void* d_lo, int ls, int Cl, con
     const long long tot = (long long)N * H * W * ((Cl + Ch) / 4);
     hipLaunchKernelGGL(k32_upcat, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d_lo, ls, Cl, (const float*)d_hi, hs, Ch,
                        (float*)d_out, N, H, W, lo_first);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+/* YOLOv8 head decode in fp32: the three levels' branch outputs (dense NHWC float, bias included: box [B][H][W][64], cls [B][H][W][cls_ld]
+ * with the first nc channels used, ext [B][H][W][ext_ld] with the first n_ext used, ext_mode 1 = keypoint triplets, 0 = raw) ->
+ * d_pred [B][4 + nc + n_ext][A], A = sum of H * W. */
+extern "C" int ss_op32_v8_decode(void* stream, const void* const* d_box, const void* const* d_cls, const void* const* d_ext, int n_ext, int ext_ld,
+                                 int ext_mode, const int* H, const int* W, const int* strides, int B, int nc, int cls_ld, float* d_pred)
+{
+    if (!d_box || !d_cls || !H || !W || !strides || !d_pred || B < 1 || B > 65535 || nc < 1 || cls_ld < nc || n_ext < 0 || (n_ext && (!d_ext || ext_ld < n_ext)))
+        return SS_ERR_INVALID;
+    V8Levels32 L;
+    int A = 0;
+    for (int l = 0; l < 3; ++l) {
+        if (!d_box[l] || !d_cls[l] || (n_ext && !d_ext[l]) || H[l] < 1 || W[l] < 1 || ((uintptr_t)d_box[l] & 15)) return SS_ERR_INVALID;
+        L.box[l] = (const float*)d_box[l]; L.cls[l] = (const float*)d_cls[l]; L.ext[l] = n_ext ? (const float*)d_ext[l] : nullptr;
+        L.H[l] = H[l]; L.W[l] = W[l]; L.stride[l] = strides[l];
+        A += H[l] * W[l];
+    }
+    L.n_ext = n_ext; L.ext_ld = ext_ld; L.ext_mode = ext_mode; L.cls_ld = cls_ld;
+    hipLaunchKernelGGL(k32_v8_decode, dim3((A + 127) / 128, B), dim3(128), 0, (hipStream_t)stream, L, B, nc, A, d_pred);
+    OP32_CHECK();
+    return SS_OK;
+}
+
+/* SPPF's pools + concat in fp32: d_x NHWC [N][H][W][.] pixel stride xs -> d_out dense [N][H][W][4 C] = (x, pool5 x, pool5 pool5 x, ...). */
+extern "C" int ss_op32_sppf_pools(void* stream, const void* d_x, int xs, void* d_out, int N, int H, int W, int C)
+{
+    if (!d_x || !d_out || N < 1 || H < 1 || W < 1 || C < 4 || (C | xs) % 4 || xs < C || (((uintptr_t)d_x | (uintptr_t)d_out) & 15)) return SS_ERR_INVALID;
+    const long long tot = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(k32_sppf, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)d_x, xs, (float*)d_out, N, H, W, C);
     OP32_CHECK();
     return SS_OK;
 }

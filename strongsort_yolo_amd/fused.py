@@ -353,7 +353,7 @@ def weight_dw9(mod, conv):
 
 
 PREPARED = ("_w_nk", "_w_n9k", "_w_dw9", "_w_t", "_w_c0", "_w_stem", "_w1", "_w9", "_padded", "_padded_last", "_w12_", "_w_pair_", "_sw", "_gw",
-            "_w32_stem", "_w32_nk", "_sw32")       # ... and the fp32 accuracy mode's copies (fused32.py)
+            "_w32_stem", "_w32_nk", "_sw32", "_w32_khwc")       # ... and the fp32 accuracy mode's copies (fused32.py)
 
 
 def clear_prepared(module):

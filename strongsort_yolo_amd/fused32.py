@@ -252,3 +252,26 @@ def upcat(lo, hi, lo_first=True):
     out = torch.empty((n, cl + ch, 2 * h, 2 * w), dtype=torch.float32, device=lo.device, memory_format=torch.channels_last)
     _ck(_lib.load().ss_op32_upcat(_st(lo), _p(lo), _nhwc_view(lo), cl, _p(hi), _nhwc_view(hi), ch, _p(out), n, 2 * h, 2 * w, int(lo_first)))
     return out
+
+
+def v8_decode(boxes, clss, strides, nc, ext=None, n_ext=0, ext_mode=0):
+    """DFL + dist2bbox + sigmoid + level concat of the anchor-free head in one launch (k32_v8_decode) -> [B, 4 + nc (+ n_ext), A] float32.
+    boxes / clss / ext: the branches' outputs per level (bias included), made dense channels-last here if they are not."""
+    boxes, clss = [_cl(t) for t in boxes], [_cl(t) for t in clss]
+    ext = [_cl(t) for t in ext] if n_ext else None
+    B = boxes[0].shape[0]
+    A = sum(t.shape[2] * t.shape[3] for t in boxes)
+    pred = torch.empty(B, 4 + nc + n_ext, A, dtype=torch.float32, device=boxes[0].device)
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    ints = lambda v: (C.c_int * 3)(*v)
+    _ck(_lib.load().ss_op32_v8_decode(_st(pred), arr(boxes), arr(clss), arr(ext) if n_ext else None, n_ext, ext[0].shape[1] if n_ext else 0, ext_mode,
+                                      ints([t.shape[2] for t in boxes]), ints([t.shape[3] for t in boxes]), ints(strides), B, nc, clss[0].shape[1], _p(pred)))
+    return pred
+
+
+def sppf_pools(x):
+    """cat(x, pool5(x), pool5(pool5(x)), pool5^3(x)) along channels, one launch (k32_sppf)."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, 4 * c, h, w), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _ck(_lib.load().ss_op32_sppf_pools(_st(x), _p(x), _nhwc_view(x), _p(out), n, h, w, c))
+    return out

@@ -220,6 +220,8 @@ class SPPF(nn.Module):
         y = [self.cv1(x)]
         if fused.sppf_pools_ok(y[0]):                        # the three pools and the concat in one launch
             return self.cv2(fused.sppf_pools(y[0]))
+        if fused32.DET and fused32.usable(y[0]) and self.m.kernel_size == 5 and y[0].shape[1] % 4 == 0 and fused32._nhwc_view(y[0]) is not None:
+            return self.cv2(fused32.sppf_pools(y[0]))
         pool = (lambda t: fused.maxpool(t, 5, 1, 2)) if fused.usable(x) else self.m
         y.extend(pool(y[-1]) for _ in range(3))
         return self.cv2(torch.cat(y, 1))
@@ -347,6 +349,13 @@ class Detect(nn.Module):
 
     def _forward_torch(self, feats):
         B = feats[0].shape[0]
+        if fused32.DET and fused32.usable(feats[0]) and len(feats) == 3 and all(fused32.conv_ok(f, self.cv2[i][0].conv) for i, f in enumerate(feats)):
+            # fp32 kernels: the branches on k32_conv, the decode (DFL, dist2bbox, sigmoid, level concat, keypoints / coefficients) in one launch
+            box = [self._branch(self.cv2[i], f) for i, f in enumerate(feats)]
+            cls = [self._branch(self.cv3[i], f) for i, f in enumerate(feats)]
+            ext = [self._branch(self.cv4[i], f) for i, f in enumerate(feats)] if (self.nk or self.nm) else None
+            pred = fused32.v8_decode(box, cls, self.strides, self.nc, ext, self.nk or self.nm, 1 if self.nk else 0)
+            return (pred, self.proto(feats[0])) if self.nm else pred
         box = torch.cat([self._branch(self.cv2[i], f).reshape(B, 64, -1) for i, f in enumerate(feats)], 2)
         cls = torch.cat([self._branch(self.cv3[i], f).reshape(B, self.nc, -1) for i, f in enumerate(feats)], 2)
         if self._anchors is None or self._anchors[0].shape[-1] != box.shape[-1] or self._anchors[0].dtype != box.dtype or self._anchors[0].device != box.device:

@@ -177,7 +177,7 @@ def test_conv0_32_matches_fp64():
         _close(md(xd), ref)
 
 
-@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov8n-pose", "yolov5n"])
+@pytest.mark.parametrize("name", ["yolov8n", "yolov8s", "yolov8n-pose", "yolov8n-seg", "yolov5n", "yolo11n"])
 def test_fp32_detector_on_own_kernels_matches_the_cpu_fp32_network(name):
     """Whole networks: fp32 CUDA (k32_conv / k32_conv0 behind every Conv block they cover) against the same modules on the CPU."""
     from strongsort_yolo_amd import nets
