@@ -181,7 +181,8 @@ class ClassCounter:
         for votes in self.votes.values():
             top = max(votes.values())
             c[min(k for k, v in votes.items() if v == top)] += 1     # ties -> lowest class id (pandas mode()[0])
-        return {self.names.get(k, str(k)): v for k, v in sorted(c.items(), key=lambda kv: -kv[1])}
+        # the plate's order is the reference's: sorted by class NAME (yolo_multi_model.py:305; testing.jpg shows {'backpack': 1, 'bicycle': 4, ...})
+        return dict(sorted(((self.names.get(k, str(k)), v) for k, v in c.items()), key=lambda item: item[0]))
 
 
 DEFAULT_WEIGHTS = "yolo11n-pose.pt"       # the model file the reference loads (/root/reference/yolo_multi_model.py:17)

@@ -26,6 +26,12 @@ def test_labels_and_counts(tmp_path):
     out = process_video({"source": "synthetic:5", "track": True, "count": True, "outdir": str(tmp_path)}, StubModel())
     assert out["frames"] == 5
     assert out["counts"] == {"person": 1, "car": 2}               # id 3: class 2 in 3 of 5 frames
+    # the plate is drawn as str(dict) with the classes in NAME order (yolo_multi_model.py:305, :313), not by count
+    assert str(out["counts"]) == "{'car': 2, 'person': 1}"
+    c = ClassCounter({0: "person", 1: "bicycle", 24: "backpack"})
+    for tid, cls in ((1, 0), (2, 0), (3, 0), (4, 1), (5, 24), (6, 1)):
+        c.votes[tid][cls] += 1
+    assert str(c.counts()) == "{'backpack': 1, 'bicycle': 2, 'person': 3}"
     lines = open(tmp_path / "synthetic:5_labels.txt").read().strip().split("\n")
     assert len(lines) == 15
     f = lines[-1].split()
