@@ -83,7 +83,7 @@ struct ss_ctx {
     size_t ev_used;
     std::vector<float> ev_ms;   // the durations behind the last ss_assoc_timing mean
     // the per-frame chain of a group (3 F - 1 launches) as captured HIP graphs, one per distinct kernel-argument set
-    struct Chain { std::vector<char> key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; };
+    struct Chain { std::vector<char> key; hipGraph_t graph; hipGraphExec_t exec; unsigned long long used; hipStream_t last_st; };   // last_st: the stream of its last replay
     std::vector<Chain> chains;
     hipStream_t cap_stream;     // capture-only stream (nothing ever executes on it)
     int track_graph;            // option "track_graph": 1 (default) replay the chain as a graph for groups of >= 2 frames, 0 plain launches
@@ -286,8 +286,7 @@ extern "C" int ss_upload_batch(ss_ctx* c, void* hip_stream, void* d_dst, const v
     if (!c || !d_dst || !h_srcs || n < 0 || threads < 1) return fail(c, SS_ERR_INVALID, "ss_upload_batch: bad argument");
     if (n == 0 || bytes_each == 0) return SS_OK;
     for (int i = 0; i < n; ++i) if (!h_srcs[i]) return fail(c, SS_ERR_INVALID, "ss_upload_batch: null frame");
-    ss_ctx::Stage& st = c->bstage[c->bstage_next];
-    c->bstage_next ^= 1;
+    ss_ctx::Stage& st = c->bstage[c->bstage_next];                  // (the area is taken for good only when the copy has been enqueued)
     if (st.busy) { HIPCHK(c, hipEventSynchronize(st.ev)); st.busy = false; }
     const size_t bytes = (size_t)n * bytes_each;
     if (st.cap < bytes) {
@@ -296,16 +295,32 @@ extern "C" int ss_upload_batch(ss_ctx* c, void* hip_stream, void* d_dst, const v
         st.cap = bytes;
     }
     if (!st.ev) HIPCHK(c, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-    const int T = threads < n ? threads : n;
+    // small groups are not worth the threads' start + join (tens of microseconds); nothing the standard library throws
+    // (std::system_error when no thread can be started, bad_alloc) may cross the C boundary
+    int T = threads < n ? threads : n;
+    if (bytes < (size_t)4 << 20) T = 1;
     char* base = (char*)st.p;
-    auto work = [=](int t) { for (int i = t; i < n; i += T) memcpy(base + (size_t)i * bytes_each, h_srcs[i], bytes_each); };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(work, t);
-    work(0);
-    for (auto& th : pool) th.join();
+    auto work = [=](int t, int nt) { for (int i = t; i < n; i += nt) memcpy(base + (size_t)i * bytes_each, h_srcs[i], bytes_each); };
+    try {
+        std::vector<std::thread> pool;
+        pool.reserve(T > 1 ? T - 1 : 0);
+        int started = 1;
+        try {
+            for (int t = 1; t < T; ++t) { pool.emplace_back(work, t, T); ++started; }
+        } catch (...) {
+            for (auto& th : pool) th.join();                       // the frames of the threads that never started are copied here
+            for (int t = started; t < T; ++t) work(t, T);
+            pool.clear();
+        }
+        work(0, T);
+        for (auto& th : pool) th.join();
+    } catch (...) {
+        return fail(c, SS_ERR_INVALID, "ss_upload_batch: host staging failed");
+    }
     HIPCHK(c, hipMemcpyAsync(d_dst, st.p, bytes, hipMemcpyHostToDevice, (hipStream_t)hip_stream));
     HIPCHK(c, hipEventRecord(st.ev, (hipStream_t)hip_stream));
     st.busy = true;
+    c->bstage_next ^= 1;
     return SS_OK;
 }
 
@@ -483,13 +498,24 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
             HIPCHK(c, hipGetLastError());
             return SS_OK;
         }
-        if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        // From here on the group's head (k_group_prep + k_assoc) is enqueued: whatever fails below, the chain still goes out (as
+        // plain launches) before the error is reported — a group is never left half-applied.
+        auto plain_then = [&](hipError_t e) -> int {
+            (void)hipGetLastError();
+            ss_launch_group_chain(dev, c->prm, chain_st);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, e);
+            return SS_OK;
+        };
+        if (!c->cap_stream) { const hipError_t e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking); if (e != hipSuccess) { c->cap_stream = nullptr; return plain_then(e); } }
         if (c->chains.size() >= 16) {                            // least recently used entry goes
             size_t lru = 0;
             for (size_t i = 1; i < c->chains.size(); ++i) if (c->chains[i].used < c->chains[lru].used) lru = i;
-            // its last replay may still be running (16 other launches is no guarantee on a detached, slow chain): the stream it
-            // was launched on is drained before the executable graph goes
-            HIPCHK(c, hipStreamSynchronize(chain_st));
+            // its last replay may still be running (16 other launches is no guarantee on a detached, slow chain), and on ANOTHER stream
+            // than today's if chain_cus / ss_set_hip_stream changed in between: the stream it was last launched on is drained before
+            // the executable graph goes
+            const hipError_t e = hipStreamSynchronize(c->chains[lru].last_st);
+            if (e != hipSuccess) return plain_then(e);
             (void)hipGraphExecDestroy(c->chains[lru].exec); (void)hipGraphDestroy(c->chains[lru].graph);
             c->chains.erase(c->chains.begin() + lru);
         }
@@ -511,11 +537,16 @@ extern "C" int ss_track_update_group(ss_ctx* c, int n_frames, const float* d_det
             HIPCHK(c, hipGetLastError());
             return SS_OK;
         }
-        c->chains.push_back({ key, graph, exec, 0 });
+        c->chains.push_back({ key, graph, exec, 0, chain_st });
         hit = &c->chains.back();
     }
     hit->used = ++c->chain_clock;
-    HIPCHK(c, hipGraphLaunch(hit->exec, chain_st));
+    hit->last_st = chain_st;
+    if (hipGraphLaunch(hit->exec, chain_st) != hipSuccess) {     // (the replay did not start: the same kernels as plain launches)
+        (void)hipGetLastError();
+        ss_launch_group_chain(dev, c->prm, chain_st);
+        HIPCHK(c, hipGetLastError());
+    }
     return SS_OK;
 }
 

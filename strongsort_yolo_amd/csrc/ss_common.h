@@ -71,6 +71,10 @@ struct SSDev {
     double *mean, *cov;         // [S][MAXT][8], [S][MAXT][64]: a track's state after its last frame
     double *mean_p, *cov_p;     // the same PREDICTED one frame ahead (written by post_track for every live track): with pred_ahead and no
                                 //   camera motion k_frame only reads the 24 values its gate needs instead of loading, predicting and storing 72
+                                //   INVARIANT: post_track of the previous frame is the ONLY writer of mean_p / cov_p and the device chain the only owner of
+                                //   smooth_sel.  Nothing imports track state from the host today; a path that ever writes mean / cov / smooth from outside
+                                //   (track import, checkpoint restore) must also rebuild mean_p / cov_p (ss_kf_predict) and reset smooth_sel, or switch
+                                //   pred_ahead off for the next frame — k_frame would otherwise gate on stale predictions without any error.
     int pred_ahead;             // ss_set_option "pred_ahead" (default 1)
     float* smooth;              // [S][MAXT][2][512] EMA feature, double-buffered: the row in use is [smooth_sel]; an update reads it and
                                 //   writes the other half, so the new-row units of the SAME launch (k_postnew) can still read the old one

@@ -2958,7 +2958,7 @@ extern "C" int ss_op_bottleneck_f16(void* stream, const void* x, const void* w1,
     const size_t lds = ((size_t)(A.TH + 4) * (A.TW + 4) * P + (((size_t)(A.TH + 2) * (A.TW + 2) * P + 7) & ~(size_t)7) + 2 * (size_t)C * 72) * 2 + 128;
     const dim3 grid((unsigned)(B * A.tiles_x * A.tiles_y));
     hipStream_t st = (hipStream_t)stream;
-#define SS_BN(CC, P1, P2) do { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k_bneck<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
+#define SS_BN(CC, P1, P2) do { static unsigned long long attr = 0; int dv_ = 0; (void)hipGetDevice(&dv_); if (!(attr >> (dv_ & 63) & 1)) { (void)hipFuncSetAttribute((const void*)k_bneck<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr |= 1ull << (dv_ & 63); }   /* the attribute is per DEVICE */ \
                                hipLaunchKernelGGL((k_bneck<CC, P1, P2>), grid, dim3(256), lds, st, A); } while (0)
     if (big) { if (C == 16) SS_BN(16, 3, 2); else if (C == 32) SS_BN(32, 3, 2); else SS_BN(64, 3, 2); }
     else { if (C == 16) SS_BN(16, 2, 1); else if (C == 32) SS_BN(32, 2, 1); else if (C == 64) SS_BN(64, 2, 1); else SS_BN(128, 2, 1); }
@@ -2994,7 +2994,7 @@ extern "C" int ss_op_head_f16(void* stream, const void* x, const void* const* w1
     if (lds > 160 * 1024 - 512) return SS_ERR_INVALID;
     const dim3 grid((unsigned)(B * A.tiles_x * A.tiles_y), 2);
     hipStream_t st = (hipStream_t)stream;
-#define SS_HD(CC, P1, P2) do { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)k_head<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr = true; } \
+#define SS_HD(CC, P1, P2) do { static unsigned long long attr = 0; int dv_ = 0; (void)hipGetDevice(&dv_); if (!(attr >> (dv_ & 63) & 1)) { (void)hipFuncSetAttribute((const void*)k_head<CC, P1, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512); attr |= 1ull << (dv_ & 63); }   /* the attribute is per DEVICE */ \
                                hipLaunchKernelGGL((k_head<CC, P1, P2>), grid, dim3(256), lds, st, A); } while (0)
     if (big) SS_HD(64, 3, 2);
     else if (Cin == 64) SS_HD(64, 2, 1);

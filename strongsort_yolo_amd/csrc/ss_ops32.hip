@@ -1225,6 +1225,17 @@ __global__ __launch_bounds__(128) void k32_v8_decode(V8Levels32 L, int B, int nc
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------------------
 #define OP32_CHECK() do { if (hipGetLastError() != hipSuccess) return SS_ERR_HIP; } while (0)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: `done` is a per-kernel bit set indexed by the current device
+// (a process-wide bool left the second GPU of a process without the attribute: launches asking for > 64 KB of LDS failed there)
+static bool lds_attr_once(const void* fn, unsigned long long& done)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    if (done >> dev & 1) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return false;
+    done |= 1ull << dev;
+    return true;
+}
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
                                       // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
 static int g_chains_form = 2;        // 2: k32_chainsR (register row stream; 64 x 32 x 16 and 32 x 16 x 24 maps), 1: k32_chains3, 0: k32_chains (the 16 x 8 maps always take k32_chains)
@@ -1303,13 +1314,13 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
     const size_t lds = 2ull * (R + 2 * halo) * W * (C + 4) * 4 + (size_t)(C32_THREADS / (C / 4)) * C * 4;
     const dim3 grid(H / R, N);
 #define CH32(CC, WW) if (C == CC && W == WW) { \
-        static bool attr = false; \
-        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains<CC, WW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+        static unsigned long long attr = 0; \
+        if (!lds_attr_once((const void*)k32_chains<CC, WW>, attr)) return SS_ERR_HIP; \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
 #define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre < 0 ? CC == 16 : g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
-        static bool attr = false; \
-        if (!attr) { if (hipFuncSetAttribute((const void*)k32_chains3<CC, WW, PRE_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP; attr = true; } \
+        static unsigned long long attr = 0; \
+        if (!lds_attr_once((const void*)k32_chains3<CC, WW, PRE_>, attr)) return SS_ERR_HIP; \
         const size_t lds3 = ((size_t)(R + 2 * halo + 2) * (WW + 2) + (size_t)(R + 2 * halo) * WW) * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
         hipLaunchKernelGGL((k32_chains3<CC, WW, PRE_>), grid, dim3(C32_THREADS), lds3, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
@@ -1341,15 +1352,18 @@ static int launch_tail32(hipStream_t st, const void* const* ys, const float* gat
 {
     constexpr size_t lds = (size_t)(w_lds_floats<MID, C2>() + (C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0) + w_lds_floats<C2, N2>() + C2 + (N2 + 15) / 16 * 16 +
                                     (T32_THREADS / 64) * 4 * 16 * ((MID / 4 + 3) / 4)) * 4;
-    static int wgs = 0;                                        // workgroups of the persistent grid: what fits on the chip at once (<= 4 per CU)
-    if (!wgs) {
-        if (hipFuncSetAttribute((const void*)k32_tail<MID, C2, C1, N2, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+    static int wgs_dev[64] = { 0 };                            // workgroups of the persistent grid per device: what fits on the chip at once (<= 4 per CU)
+    static unsigned long long attr = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63 || !lds_attr_once((const void*)k32_tail<MID, C2, C1, N2, POOL>, attr)) return SS_ERR_HIP;
+    if (!wgs_dev[dev]) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k32_tail<MID, C2, C1, N2, POOL>, T32_THREADS, lds) != hipSuccess || cus < 1 || per_cu < 1)
             return SS_ERR_HIP;
-        wgs = cus * (per_cu > 4 ? 4 : per_cu);
+        wgs_dev[dev] = cus * (per_cu > 4 ? 4 : per_cu);
     }
+    const int wgs = wgs_dev[dev];
     const int grid = g_tail_wgs > 0 ? g_tail_wgs : (N < wgs ? N : wgs);
     hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), dim3(grid), dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
                        (const float*)ys[3], gates, w3, b3, xin, wd, bd, out, w4, b4, out2, N, H, W, nv);
@@ -1385,11 +1399,8 @@ extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, cons
 {
     if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
     constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16) * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)k32_stem, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) return SS_ERR_HIP;
-        attr = true;
-    }
+    static unsigned long long attr = 0;
+    if (!lds_attr_once((const void*)k32_stem, attr)) return SS_ERR_HIP;
     hipLaunchKernelGGL(k32_stem, dim3(64 / ST_PR, N), dim3(C32_THREADS), lds, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
                        (const float*)d_bias, (float*)d_y, N, d_nvalid);
     OP32_CHECK();

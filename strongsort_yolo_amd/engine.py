@@ -122,8 +122,9 @@ class TrackerEngine:
             return
         srcs = [np.ascontiguousarray(a) for a in srcs]
         each = srcs[0].nbytes
-        if any(a.nbytes != each for a in srcs) or not dst.is_contiguous() or dst[0].numel() * dst.element_size() != each or dst.shape[0] < n:
-            raise ValueError("upload_batch: size / layout mismatch")
+        if (any(a.nbytes != each or a.shape != srcs[0].shape for a in srcs) or not dst.is_contiguous() or dst[0].numel() * dst.element_size() != each
+                or dst.shape[0] < n or tuple(dst.shape[1:]) != tuple(srcs[0].shape)):
+            raise ValueError("upload_batch: size / shape / layout mismatch")
         st = torch.cuda.current_stream(self.device) if stream is None else stream
         arr = (C.c_void_p * n)(*[a.ctypes.data for a in srcs])
         self._ck(self.L.ss_upload_batch(self.ctx, C.c_void_p(st.cuda_stream), _ptr(dst), arr, n, each, int(threads)))

@@ -6,6 +6,7 @@ in nets.py take their plain torch path instead.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -79,24 +80,24 @@ class valid_images:
         self.n_dev, self.batch = n_dev, int(batch)
         self._stream = None
 
-    active = 0          # nesting depth of `with valid_images(...)` blocks that carry a count (this thread's launches skip images)
+    _tls = threading.local()   # .active: nesting depth of THIS thread's `with valid_images(...)` blocks that carry a count (its launches skip images)
 
     def __enter__(self):
         if self.n_dev is not None:
             self._stream = C.c_void_p(torch.cuda.current_stream(self.n_dev.device).cuda_stream)
             _ck(_lib.load().ss_op_set_valid_images(self._stream, _p(self.n_dev), self.batch))
-            valid_images.active += 1
+            valid_images._tls.active = getattr(valid_images._tls, "active", 0) + 1
         return self
 
     def __exit__(self, *a):
         if self.n_dev is not None:
-            valid_images.active -= 1
+            valid_images._tls.active -= 1
             _ck(_lib.load().ss_op_set_valid_images(self._stream, None, 0))
         return False
 
 
 def _nv_active() -> bool:
-    return valid_images.active > 0
+    return getattr(valid_images._tls, "active", 0) > 0
 
 
 def set_option(name: str, value: int):

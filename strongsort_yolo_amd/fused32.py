@@ -8,6 +8,7 @@ throughput default.  Inference only; no CPU path (the modules in nets.py take th
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -15,7 +16,16 @@ from . import lib as _lib
 
 ENABLED = True          # A/B: False sends fp32 CUDA tensors to PyTorch-ROCm's library convolutions (the round-4 accuracy mode)
 
-_nv = None              # device int32[1]: images of the batch that are real (packed ReID batches), set by valid_images
+_tls = threading.local()  # .nv: device int32[1] = images of the batch that are real (packed ReID batches), set by valid_images for THIS thread
+
+
+def _nvp(x):
+    """The valid-image count of this thread's `with valid_images(...)` block as a launch argument; it must live on x's device."""
+    nv = getattr(_tls, "nv", None)
+    if nv is not None and nv.device != x.device:
+        raise _lib.SSError(-1, f"valid_images count on {nv.device}, batch on {x.device}")
+    return _p(nv)
+
 
 
 def _st(x):
@@ -61,13 +71,11 @@ class valid_images:
         self.n_dev = n_dev
 
     def __enter__(self):
-        global _nv
-        self._old, _nv = _nv, self.n_dev
+        self._old, _tls.nv = getattr(_tls, "nv", None), self.n_dev
         return self
 
     def __exit__(self, *a):
-        global _nv
-        _nv = self._old
+        _tls.nv = self._old
         return False
 
 
@@ -93,7 +101,7 @@ def stem(x, cbr):
 
     wk = _cached(cbr, "_w32_stem", conv.weight, build)
     y = torch.empty((n, 16, h // 4, w // 4), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _ck(_lib.load().ss_op32_stem(_st(x), _p(x), _p(wk), _p(conv.bias), _p(y), n, h, w, _p(_nv)))
+    _ck(_lib.load().ss_op32_stem(_st(x), _p(x), _p(wk), _p(conv.bias), _p(y), n, h, w, _nvp(x)))
     return y
 
 
@@ -110,7 +118,7 @@ def pointwise(x, mod, conv, relu=True, res=None):
     if res is not None:
         res = _cl(res)
     _ck(_lib.load().ss_op32_pointwise(_st(x), _p(x), _p(_w_nk(mod, conv)), _p(conv.bias), _p(res), _p(out), n * h * w, k, co, int(relu),
-                                      _p(_nv), h * w))
+                                      _nvp(x), h * w))
     return out
 
 
@@ -140,7 +148,7 @@ def chains(x1, blk):
     ys = [torch.empty_like(x1, memory_format=torch.channels_last) for _ in range(4)]
     psum = torch.empty(4, n, bands, c, dtype=torch.float32, device=x1.device)
     arr = (C.c_void_p * 4)(*[y.data_ptr() for y in ys])
-    _ck(L.ss_op32_chains(_st(x1), _p(x1), _p(w1), _p(w9), _p(b), arr, _p(psum), n, h, w, c, _p(_nv)))
+    _ck(L.ss_op32_chains(_st(x1), _p(x1), _p(w1), _p(w9), _p(b), arr, _p(psum), n, h, w, c, _nvp(x1)))
     return ys, psum
 
 
@@ -162,7 +170,7 @@ def tail(ys, psum, blk, x, nxt, pool, want_out):
     gates = torch.empty(4, n, mid, dtype=torch.float32, device=x.device)            # workspace of the gate launch
     _ck(_lib.load().ss_op32_tail(_st(x), arr, _p(psum), psum.shape[2], _p(gw1), _p(gb1), _p(gw2), _p(gb2), gw1.shape[0], _p(gates),
                                  _p(_w_nk(blk.conv3, c3)), _p(c3.bias), _p(x), c1, _p(wd), _p(bd), _p(out), _p(_w_nk(nxt, c4)), _p(c4.bias),
-                                 _p(out2), int(pool), n, h, w, mid, c2, n2, _p(_nv)))
+                                 _p(out2), int(pool), n, h, w, mid, c2, n2, _nvp(x)))
     return out, out2
 
 
@@ -170,9 +178,9 @@ def head(x, fc):
     """relu(fc(mean_hw(x))): x [N, 128, H, W] channels-last float -> [N, F] float.  Rows of images past the valid count are zero."""
     x = _cl(x)
     n, c, h, w = x.shape
-    out = torch.zeros((n, fc.out_features), dtype=torch.float32, device=x.device) if _nv is not None else \
+    out = torch.zeros((n, fc.out_features), dtype=torch.float32, device=x.device) if getattr(_tls, "nv", None) is not None else \
         torch.empty((n, fc.out_features), dtype=torch.float32, device=x.device)
-    _ck(_lib.load().ss_op32_head(_st(x), _p(x), _p(fc.weight), _p(fc.bias), _p(out), n, h * w, c, fc.out_features, _p(_nv)))
+    _ck(_lib.load().ss_op32_head(_st(x), _p(x), _p(fc.weight), _p(fc.bias), _p(out), n, h * w, c, fc.out_features, _nvp(x)))
     return out
 
 

@@ -353,6 +353,7 @@ class OverlappedPipeline(FramePipeline):
         if self.chain_cus and tracker_stream:
             # the tracker-stream branch releases a buffer set on that stream, not behind the detached chain's results stream: the
             # chain could still be reading the set's detections / features when stage 0 refills it
+            self.eng.close()                                     # (the tracker context exists already: do not leak it)
             raise ValueError("tracker_stream and chain_cus cannot be combined")
         if self.chain_cus:
             self.eng.set_option("chain_cus", self.chain_cus)
