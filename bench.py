@@ -68,6 +68,44 @@ PMC_WORKLOAD = {"c1": None, "c2": "c2", "c3": "c2", "c5": "c2", "c6": "c2", "c4"
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def rank_cpus(local_rank, local_world, dev_index=None, sysfs="/sys"):
+    """Host cores of one rank's Python enqueue loop -> (cpu list, how).  NUMA-aware when the platform says where the rank's GPU hangs:
+    the allowed cores of the GPU's NUMA node (/sys/bus/pci/devices/<bdf>/numa_node, node<k>/cpulist), shared evenly by the ranks whose
+    GPUs sit on that node; otherwise (no GPU index, no sysfs entry, node -1) a contiguous slice of the allowed cores per rank."""
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // max(local_world, 1))
+    fallback = (cores[local_rank * per:(local_rank + 1) * per] or cores, "contiguous slice")
+    if dev_index is None:
+        return fallback
+    try:
+        import torch
+        nodes = []
+        for d in range(torch.cuda.device_count()):
+            pr = torch.cuda.get_device_properties(d)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            nodes.append(int(open(f"{sysfs}/bus/pci/devices/{bdf}/numa_node").read()))
+        node = nodes[dev_index]
+        if node < 0:
+            return fallback
+        node_cpus = [c for c in _cpulist(open(f"{sysfs}/devices/system/node/node{node}/cpulist").read()) if c in set(cores)]
+        mates = [d for d in range(min(local_world, len(nodes))) if nodes[d] == node]          # rank i drives GPU i
+        if not node_cpus or dev_index not in mates:
+            return fallback
+        k, share = mates.index(dev_index), max(1, len(node_cpus) // len(mates))
+        return (node_cpus[k * share:(k + 1) * share] or node_cpus, f"NUMA node {node} of GPU {dev_index}")
+    except Exception:
+        return fallback
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, rendezvous on
     127.0.0.1), exactly the command form the driver uses for N > 1."""
@@ -795,11 +833,9 @@ def main():
     affinity = None
     if world > 1 and os.environ.get("SS_BENCH_NO_AFFINITY") != "1" and hasattr(os, "sched_setaffinity"):
         try:
-            cores = sorted(os.sched_getaffinity(0))
-            per = max(1, len(cores) // int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-            mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+            mine, how = rank_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), None if args.dist_check else dev_index)
             os.sched_setaffinity(0, mine)
-            affinity = f"{mine[0]}-{mine[-1]}"
+            affinity = f"{mine[0]}-{mine[-1]} ({len(mine)} cpus, {how})"
         except OSError:
             affinity = None
     if not args.dist_check:

@@ -73,3 +73,30 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-check"], env=env,
                          capture_output=True, text=True, timeout=600)
     assert json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_rank_affinity_follows_the_gpu_numa_node(tmp_path, monkeypatch):
+    """bench.rank_cpus: a rank's cores come from the NUMA node its GPU hangs on (sysfs), shared by the ranks of that node; without
+    the information a contiguous slice of the allowed cores."""
+    import os
+    import types
+    import bench
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(16)), raising=False)
+    assert bench.rank_cpus(1, 4) == ([4, 5, 6, 7], "contiguous slice")
+    # four GPUs: 0, 1 on node 0 (cpus 0-7), 2, 3 on node 1 (cpus 8-15)
+    import torch
+    props = [types.SimpleNamespace(pci_domain_id=0, pci_bus_id=0x10 + d, pci_device_id=0) for d in range(4)]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: props[d])
+    for d in range(4):
+        p = tmp_path / "bus" / "pci" / "devices" / f"0000:{0x10 + d:02x}:00.0"
+        p.mkdir(parents=True)
+        (p / "numa_node").write_text(f"{d // 2}\n")
+    for k, cl in ((0, "0-7"), (1, "8-15")):
+        p = tmp_path / "devices" / "system" / "node" / f"node{k}"
+        p.mkdir(parents=True)
+        (p / "cpulist").write_text(cl + "\n")
+    assert bench.rank_cpus(0, 4, 0, sysfs=str(tmp_path)) == ([0, 1, 2, 3], "NUMA node 0 of GPU 0")
+    assert bench.rank_cpus(3, 4, 3, sysfs=str(tmp_path)) == ([12, 13, 14, 15], "NUMA node 1 of GPU 3")
+    (tmp_path / "bus" / "pci" / "devices" / "0000:12:00.0" / "numa_node").write_text("-1\n")
+    assert bench.rank_cpus(2, 4, 2, sysfs=str(tmp_path))[1] == "contiguous slice"
