@@ -51,14 +51,14 @@ static __device__ __forceinline__ f4 max4(const f4 a, const f4 b)
     return f4{ a[0] > b[0] ? a[0] : b[0], a[1] > b[1] ? a[1] : b[1], a[2] > b[2] ? a[2] : b[2], a[3] > b[3] ? a[3] : b[3] };
 }
 
-// Weight matrix [N][K] -> LDS rows of KP = 16 JJ + 8 floats: a row pitch of 8 mod 16 dwords is the one that makes the A-operand read
-// (lane (kq, n): 16 bytes at row n, chunk kq) conflict-free for ds_read_b128's lane groups {0-3, 12-15, 20-27}, .. — the + 4 of round 5
-// was a 2-way conflict on every read (profiles/r06_pmc_det32.json: more conflict cycles than busy cycles).  Zero in the padding columns
-// and in the rows N .. NP - 1 (24 output channels = two M-tiles, the second half empty)
+// Weight matrix [N][K] -> LDS rows of KP = 16 JJ + 4 floats, zero in the padding columns and in the rows N .. NP - 1 (24 output channels =
+// two M-tiles, the second half empty).  (The + 4 pitch is a 2-way conflict on the A-operand read — lane (kq, n): 16 bytes at row n, chunk kq,
+// ds_read_b128's lane groups {0-3, 12-15, 20-27}, ..; + 8 is conflict-free and was measured in round 6: no faster anywhere, and the larger
+// tables cost the 24-channel tail its third workgroup per CU, 155 -> 197 us.  k32_conv, whose LDS is small, uses the conflict-free 72.)
 template <int K, int N, int NTHR>
 static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const float* __restrict__ w, int tid)
 {
-    constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 8, NP = (N + 15) / 16 * 16;
+    constexpr int CH = K / 4, JJ = (CH + 3) / 4, KP = 16 * JJ + 4, NP = (N + 15) / 16 * 16;
     // up to eight vectors of a thread are requested (from clamped, always valid addresses) before the first LDS store: the rolled
     // `predicated load -> store` loop paid one L2 round trip per NTHR vectors - 3 to 17 of them back to back at the start of a workgroup
     constexpr int TOT = NP * (KP / 4), NIT = (TOT + NTHR - 1) / NTHR, UB = NIT < 8 ? NIT : 8;
@@ -77,13 +77,13 @@ static __device__ __forceinline__ void stage_w(float* __restrict__ Ws, const flo
     }
 }
 template <int K, int N>
-constexpr int w_lds_floats() { return ((N + 15) / 16 * 16) * (16 * ((K / 4 + 3) / 4) + 8); }
+constexpr int w_lds_floats() { return ((N + 15) / 16 * 16) * (16 * ((K / 4 + 3) / 4) + 4); }
 
 // acc[mt] += W[16 mt .. + 15][:] x B for the 16 pixels of the tile; b[jj] = this lane's chunks kq + 4 jj
 template <int K, int N>
 static __device__ __forceinline__ void mm_tile(const float* __restrict__ Ws, const f4 (&b)[(K / 4 + 3) / 4], f4 (&acc)[(N + 15) / 16], int kq, int n)
 {
-    constexpr int JJ = (K / 4 + 3) / 4, KP = 16 * JJ + 8, MT = (N + 15) / 16;
+    constexpr int JJ = (K / 4 + 3) / 4, KP = 16 * JJ + 4, MT = (N + 15) / 16;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -455,7 +455,7 @@ static __device__ __forceinline__ float dppf_shr1_z(float v) { return __builtin_
 static __device__ __forceinline__ float dppf_shl1_z(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)); }
 
 template <int C> struct ChR {
-    static constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = JJ, CP = 16 * JJ, KP = CP + 8, NPR = (C % 16) ? C + 1 : C;   // NPR: rows of a staged 1x1 matrix (+ one zero row)
+    static constexpr int CH = C / 4, JJ = (CH + 3) / 4, MT = JJ, CP = 16 * JJ, KP = CP + 4, NPR = (C % 16) ? C + 1 : C;   // NPR: rows of a staged 1x1 matrix (+ one zero row)
     static constexpr int TAB = 10 * 10 * CP;                       // floats: [layer][9 taps + bias][CP]
 };
 
@@ -473,7 +473,7 @@ template <int C> struct ChR {
 // SIMD at 24 channels (168 registers): 236 spilled values, 538 instead of 198 us.
 template <int C, int W, int L, bool ALDS>
 struct ChainState {
-    static constexpr int JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = W / 16;
+    static constexpr int JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = (W >= 16 ? W / 16 : 1);
     f4 a[ALDS ? 1 : L][MT][JJ];
     f4 accA[L][NT][MT], accB[L][NT][MT], sum[MT];
 };
@@ -481,9 +481,9 @@ struct ChainState {
 // P[.][mt] = rows 16 mt .. of W_l x (this lane's part of the layer's input row)
 template <int C, int W, int L, bool ALDS>
 static __device__ __forceinline__ void chain_mm(const ChainState<C, W, L, ALDS>& S, int l, int mt, int wl0, int n,
-                                                const f4 (&in)[W / 16][ChR<C>::JJ], f4 (&P)[W / 16][ChR<C>::MT])
+                                                const f4 (&in)[(W >= 16 ? W / 16 : 1)][ChR<C>::JJ], f4 (&P)[(W >= 16 ? W / 16 : 1)][ChR<C>::MT])
 {
-    constexpr int JJ = ChR<C>::JJ, NT = W / 16, KP = ChR<C>::KP, NPR = ChR<C>::NPR;
+    constexpr int JJ = ChR<C>::JJ, NT = (W >= 16 ? W / 16 : 1), KP = ChR<C>::KP, NPR = ChR<C>::NPR;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     int wo = wl0 + l * NPR * KP;
     if (ALDS) asm volatile("" : "+v"(wo));                                      // the matrix reads stay inside the step (not hoisted into registers)
@@ -507,10 +507,10 @@ static __device__ __forceinline__ void chain_mm(const ChainState<C, W, L, ALDS>&
 // the 1x1 row P of layer l arrives: finish the output row above (-> out = med3(., 0, lim): ReLU, or zero when that row is outside
 // the image), continue this row, start the next
 template <int C, int W, int L, bool ALDS>
-static __device__ __forceinline__ void chain_dw(ChainState<C, W, L, ALDS>& S, int l, int mt, int tl0, float lim, const f4 (&P)[W / 16][ChR<C>::MT],
-                                                f4 (&out)[W / 16][ChR<C>::MT])
+static __device__ __forceinline__ void chain_dw(ChainState<C, W, L, ALDS>& S, int l, int mt, int tl0, int n, float lim, const f4 (&P)[(W >= 16 ? W / 16 : 1)][ChR<C>::MT],
+                                                f4 (&out)[(W >= 16 ? W / 16 : 1)][ChR<C>::MT])
 {
-    constexpr int NT = W / 16, CP = ChR<C>::CP;
+    constexpr int NT = (W >= 16 ? W / 16 : 1), CP = ChR<C>::CP;
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     int to = tl0 + l * 10 * CP;
     asm volatile("" : "+v"(to));                                                // the table reads stay inside the step (not hoisted into registers)
@@ -521,7 +521,13 @@ static __device__ __forceinline__ void chain_dw(ChainState<C, W, L, ALDS>& S, in
     f4 lf[NT], rt[NT];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (NT == 1) { lf[0][s] = dppf_shr1_z(P[0][mt][s]); rt[0][s] = dppf_shl1_z(P[0][mt][s]); }
+        if (NT == 1) {
+            lf[0][s] = dppf_shr1_z(P[0][mt][s]); rt[0][s] = dppf_shl1_z(P[0][mt][s]);
+            if (W == 8) {                                        // two 8-wide images share the 16-lane row: no neighbour across the seam
+                lf[0][s] = (n & 7) == 0 ? 0.f : lf[0][s];
+                rt[0][s] = (n & 7) == 7 ? 0.f : rt[0][s];
+            }
+        }
         else {
             lf[0][s] = dppf_shr1_z(P[NT - 1][mt][s]); rt[0][s] = P[NT - 1][mt][s];
             lf[NT - 1][s] = P[0][mt][s];              rt[NT - 1][s] = dppf_shl1_z(P[0][mt][s]);
@@ -544,9 +550,13 @@ static __device__ __forceinline__ void chain_dw(ChainState<C, W, L, ALDS>& S, in
 
 template <int C, int W, int L, bool ALDS>
 static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, float* __restrict__ yo, float* __restrict__ ps,
-                                                  const float* __restrict__ w1g, int l0, int H, int kq, int n, int probe)
+                                                  const float* __restrict__ w1g, int l0, int H, int kq, int n, int probe, bool second = true)
 {
-    constexpr int CH = ChR<C>::CH, JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = W / 16, CP = ChR<C>::CP, KP = ChR<C>::KP, NPR = ChR<C>::NPR;
+    // W == 8: the 16 lanes of a row are TWO images' eight columns (image A: lanes 0-7, image B = the next one: lanes 8-15; `second`
+    // false: there is no image B — its lanes then repeat image A's work on image A's addresses and write nothing of their own)
+    const int col0 = W == 8 ? (n & 7) : 0, po = (W == 8 && second) ? (n >> 3) * H * W * C : 0;
+    xi += po; yo += po;
+    constexpr int CH = ChR<C>::CH, JJ = ChR<C>::JJ, MT = ChR<C>::MT, NT = (W >= 16 ? W / 16 : 1), CP = ChR<C>::CP, KP = ChR<C>::KP, NPR = ChR<C>::NPR;
     extern __shared__ __attribute__((aligned(16))) float smem32[];          // the workgroup's tables: [10][10][CP] taps + bias, then (ALDS) [10][NPR][KP] 1x1 matrices
     ChainState<C, W, L, ALDS> S;
     if (!ALDS) {
@@ -581,7 +591,7 @@ static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, 
 #pragma unroll
             for (int jj = 0; jj < JJ; ++jj) {
                 const int c = kq + 4 * jj;
-                d[t][jj] = ld4(xi + (unsigned)((rc * W + NT * n + t) * C + 4 * (c < CH ? c : 0)));
+                d[t][jj] = ld4(xi + (unsigned)((rc * W + (W == 8 ? col0 : NT * n + t)) * C + 4 * (c < CH ? c : 0)));
             }
     };
     auto inside = [&](int r) -> float { return (r >= 0 && r < H) ? __builtin_inff() : 0.f; };
@@ -620,7 +630,7 @@ static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) chain_mm<C, W, L, ALDS>(S, l, mt, wl0, n, l == 0 ? in0 : cur[(l - 1) & 1], P);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) chain_dw<C, W, L, ALDS>(S, l, mt, tl0, inside(i - l - 1), P, l + 1 < L ? cur[l & 1] : last);
+                    for (int mt = 0; mt < MT; ++mt) chain_dw<C, W, L, ALDS>(S, l, mt, tl0, n, inside(i - l - 1), P, l + 1 < L ? cur[l & 1] : last);
                 }
             }
             const int o = i - L < 0 ? 0 : i - L;
@@ -629,7 +639,7 @@ static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, 
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     if (MT * 4 == CH || kq + 4 * mt < CH) {
-                        if (!(probe & 1)) st4(yo + (unsigned)((o * W + NT * n + t) * C + 4 * (kq + 4 * mt)), last[t][mt]);
+                        if (!(probe & 1)) st4(yo + (unsigned)((o * W + (W == 8 ? col0 : NT * n + t)) * C + 4 * (kq + 4 * mt)), last[t][mt]);
                         S.sum[mt] = S.sum[mt] + last[t][mt];
                     }
         };
@@ -645,10 +655,12 @@ static __device__ __forceinline__ void chain_rows(const float* __restrict__ xi, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = v[j];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            if (W != 8) s += __shfl_xor(s, 8);
             v[j] = s;
         }
-        if (n == 0 && (MT * 4 == CH || kq + 4 * mt < CH)) st4(ps + 4 * (kq + 4 * mt), v);
+        if (W == 8) { if ((n & 7) == 0 && (n == 0 || second)) st4(ps + (n >> 3) * C + 4 * (kq + 4 * mt), v); }      // (psum rows of consecutive images are C apart)
+        else if (n == 0 && (MT * 4 == CH || kq + 4 * mt < CH)) st4(ps + 4 * (kq + 4 * mt), v);
     }
 }
 
@@ -680,19 +692,21 @@ __global__ __launch_bounds__(R32_THREADS, 2) void k32_chainsR(const float* __res
     }
     __syncthreads();
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
-    const int img = blockIdx.x * 2 + (wave >> 1), pair = wave & 1;
+    constexpr int IPW = W == 8 ? 2 : 1;                          // images per wave (two 8-wide images side by side in the 16 lanes of a row)
+    const int img = (blockIdx.x * 2 + (wave >> 1)) * IPW, pair = wave & 1;
     int nv = Nimg;
     if (n_img && *n_img < nv) nv = *n_img;
     if (img >= nv) return;
+    const bool second = img + 1 < nv;
     const size_t ib = (size_t)img * H * W * C;
     const float* xi = x1 + ib;
     auto ps = [&](int t) { return psum + ((size_t)t * Nimg + img) * C; };
     if (pair == 0) {
-        chain_rows<C, W, 4, ALDS>(xi, y3 + ib, ps(3), w1, 6, H, kq, n, probe);
-        chain_rows<C, W, 1, ALDS>(xi, y0 + ib, ps(0), w1, 0, H, kq, n, probe);
+        chain_rows<C, W, 4, ALDS>(xi, y3 + ib, ps(3), w1, 6, H, kq, n, probe, second);
+        chain_rows<C, W, 1, ALDS>(xi, y0 + ib, ps(0), w1, 0, H, kq, n, probe, second);
     } else {
-        chain_rows<C, W, 3, ALDS>(xi, y2 + ib, ps(2), w1, 3, H, kq, n, probe);
-        chain_rows<C, W, 2, ALDS>(xi, y1 + ib, ps(1), w1, 1, H, kq, n, probe);
+        chain_rows<C, W, 3, ALDS>(xi, y2 + ib, ps(2), w1, 3, H, kq, n, probe, second);
+        chain_rows<C, W, 2, ALDS>(xi, y1 + ib, ps(1), w1, 1, H, kq, n, probe, second);
     }
 }
 
@@ -1243,7 +1257,7 @@ static int g_conv_mt = 0, g_conv_min = 768;    // k32_conv: 16-channel output ti
 static int g_conv_waves = 0, g_conv_wgs = 1024; // k32_conv: waves per workgroup (0 = 8 when that still leaves g_conv_wgs workgroups, else 4); A/B
 static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
-static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16)) && H >= 9; }
+static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16) || (C == 32 && W == 8)) && H >= 9; }
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -1303,9 +1317,12 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
     if (chains_rowstream(H, W, C)) {                          // two images (four waves) per workgroup
 #define CHR(CC, WW, AL) if (C == CC && W == WW) { \
         const size_t ldsr = (size_t)(ChR<CC>::TAB + (AL ? 10 * ChR<CC>::NPR * ChR<CC>::KP : 0)) * 4; \
-        hipLaunchKernelGGL((k32_chainsR<CC, WW, AL>), dim3((N + 1) / 2), dim3(R32_THREADS), ldsr, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, d_nvalid, g_chains_probe); \
+        static unsigned long long attr = 0; \
+        if (ldsr > 64 * 1024 && !lds_attr_once((const void*)k32_chainsR<CC, WW, AL>, attr)) return SS_ERR_HIP; \
+        const int ipw = WW == 8 ? 4 : 2;                      /* images per workgroup */ \
+        hipLaunchKernelGGL((k32_chainsR<CC, WW, AL>), dim3((N + ipw - 1) / ipw), dim3(R32_THREADS), ldsr, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, d_nvalid, g_chains_probe); \
         OP32_CHECK(); return SS_OK; }
-        CHR(16, 32, false) CHR(24, 16, true)
+        CHR(16, 32, false) CHR(24, 16, true) CHR(32, 8, true)
 #undef CHR
     }
     int halo;
