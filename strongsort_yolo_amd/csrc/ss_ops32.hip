@@ -895,11 +895,21 @@ __global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kq = lane >> 4, n = lane & 15;
     const int pr0 = band * ST_PR, cy0 = 2 * pr0 - 1, iy0 = 2 * cy0 - 3;
     const float* xi = x + (size_t)img * H * Wd * 3;
-    for (int i = tid; i < IN_ROWS * (ST_ROWP / 4); i += C32_THREADS) {
-        const int lr = i / (ST_ROWP / 4), c4 = i - lr * (ST_ROWP / 4), iy = iy0 + lr;
-        f4 v = zero4();
-        if (iy >= 0 && iy < H && c4 >= 3 && c4 < 99) v = ld4(xi + (size_t)iy * (Wd * 3) + 4 * (c4 - 3));
-        st4(In + lr * ST_ROWP + 4 * c4, v);
+    {   // the band's input rows: every vector of a thread requested (from a clamped, always valid address) before the first LDS store — the
+        // rolled `conditional load -> store` loop was four dependent HBM round trips at the start of every workgroup
+        constexpr int TOT = IN_ROWS * (ST_ROWP / 4), NIT = (TOT + C32_THREADS - 1) / C32_THREADS;
+        f4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = min(tid + u * C32_THREADS, TOT - 1), lr = i / (ST_ROWP / 4), c4 = i - lr * (ST_ROWP / 4), iy = iy0 + lr;
+            const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cc = c4 < 3 ? 0 : (c4 >= 99 ? 95 : c4 - 3);
+            v[u] = ld4(xi + (size_t)iyc * (Wd * 3) + 4 * cc);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * C32_THREADS, lr = i / (ST_ROWP / 4), c4 = i - lr * (ST_ROWP / 4), iy = iy0 + lr;
+            if (i < TOT) st4(In + lr * ST_ROWP + 4 * c4, (iy >= 0 && iy < H && c4 >= 3 && c4 < 99) ? v[u] : zero4());
+        }
     }
     float a[37];
 #pragma unroll
