@@ -63,7 +63,7 @@ CONFIG_INDEX = {"c1": 0, "c2": 1, "c3": 2, "c4": 3, "c5": 4, "c6": None}
 REID_SPLIT = {"c1": 4, "c2": 6, "c3": 2, "c4": 2, "c5": 5, "c6": 2}     # c2 re-measured with the round-5 kernels (detector 0.87, OSNet 1.16 ms): 6 over 5 by 3-9 % in two paired runs
 # the same cut with the fp32 ReID network (the default since round 6: OSNet ~2.5x the f16 one, so the first stage keeps fewer of its parts)
 REID_SPLIT_FP32 = {"c1": 2, "c2": 2, "c3": 1, "c4": 1, "c5": 2, "c6": 1}
-PMC_FILE = "r05_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by tracker workload / streams / frames (tools/pmc_assoc.sh)
+PMC_FILE = "r06_pmc_assoc.json"   # HBM traffic of the association kernel per launch, by tracker workload / streams / frames (tools/pmc_assoc.sh)
 PMC_WORKLOAD = {"c1": None, "c2": "c2", "c3": "c2", "c5": "c2", "c6": "c2", "c4": "c4"}   # presets that differ only in the detector share a tracker workload
 PREFILL = 112      # frames before any timing so galleries hold nn_budget rows (>= 100 + n_init); 7 groups of 16
 
@@ -1199,11 +1199,11 @@ def main():
                             "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32)"}
 
             def all_fp32():
-                A3 = timed_pipeline(False, max(2, args.accuracy_steps // 2), 2, half=False)
+                A3 = timed_pipeline(False, max(2, args.accuracy_steps), 3, half=False)
                 b_same, b_tot, b_exact, b_exact_timed, b_ntimed = id_check(A3, A3.total)
                 det_own = bool(getattr(A3.pipe.detector, "_own32", False))
                 A3.pipe.close()
-                return {"detector": "fp32, hand-written kernels (csrc/ss_det32.hip)" if det_own else "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels",
+                return {"detector": "fp32, hand-written kernels (csrc/ss_ops32.hip k32_conv)" if det_own else "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels",
                         "frames_per_s": round(S * A3.KF / A3.dt, 2), "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
                         "frames_bit_exact": f"{b_exact}/{A3.total}"}
             res["throughput_mode" if args.reid_fp32 else "accuracy_mode"] = leg(other_mode, args.reid_fp32)
