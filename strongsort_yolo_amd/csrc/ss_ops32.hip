@@ -1263,7 +1263,7 @@ static bool lds_attr_once(const void* fn, unsigned long long& done)
 static int g_chains_pre = -1;         // k32_chains3: x1 tiles of a chain's first 1x1 requested a phase ahead: -1 = where it was measured faster (16 channels:
                                       // 618 -> 572 us per launch; 24 channels: 218 -> 330 us, the 32 extra registers spill), 0 / 1 = A/B
 static int g_chains_form = 2;        // 2: k32_chainsR (register row stream; 64 x 32 x 16 and 32 x 16 x 24 maps), 1: k32_chains3, 0: k32_chains (the 16 x 8 maps always take k32_chains)
-static int g_conv_mt = 0, g_conv_min = 768;    // k32_conv: 16-channel output tiles per workgroup forced (A/B) / the workgroup count below which fewer are taken
+static int g_conv_mt = 0, g_conv_min = 0;      // k32_conv: 16-channel output tiles per workgroup forced (A/B) / the workgroup count below which fewer are taken (0: never; measured: 768 -> 3.64 vs 3.59 ms)
 static int g_conv_waves = 0, g_conv_wgs = 1024; // k32_conv: waves per workgroup (0 = 8 when that still leaves g_conv_wgs workgroups, else 4); A/B
 static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
