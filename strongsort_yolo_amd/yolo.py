@@ -220,7 +220,9 @@ class YOLO:
     `model.track(..., persist=False)` would."""
 
     def __init__(self, weights: str = "yolov8n.pt", seed: int = 0, random_init_ok: bool = False, reid_batch: int = 128,
-                 camera_motion: bool = False, reid_weights: Optional[str] = None, reid_fp32: bool = False):
+                 camera_motion: bool = False, reid_weights: Optional[str] = None, reid_fp32: bool = False, half: bool = True):
+        """half=False: the DETECTOR in fp32 as well (the reference's own precision: it passes no half=, yolo_multi_model.py:41) on the
+        fp32 convolution kernels (csrc/ss_ops32.hip k32_conv) — NMS keep lists then equal the CPU fp32 network's; implies reid_fp32."""
         self.weights = weights
         self.reid_weights = reid_weights          # OSNet-x0.25 state_dict; same policy as the detector's (raise unless random init is asked for)
         self.random_init_ok = random_init_ok
@@ -239,8 +241,10 @@ class YOLO:
         # test / bench hooks (synthetic head tensors, no weights exist offline): extra pipeline keywords and a callable
         # fill(buffers, virtual_stream, frame_index) that writes pred_in / anchor_gt / gt_feats before a frame runs
         self._pipe_kw = {"cmc": True} if camera_motion else {}    # N4: ECC camera-motion compensation (off by default)
-        if reid_fp32:                                              # accuracy mode: OSNet in fp32 (pipeline.FramePipeline reid_half)
+        if reid_fp32 or not half:                                  # OSNet in fp32 (pipeline.FramePipeline reid_half): float distances within 1e-4
             self._pipe_kw["reid_half"] = False
+        if not half:
+            self._pipe_kw["half"] = False
         self._fill = None
         self._frame_index = 0
 

@@ -141,6 +141,26 @@ def test_yolo_track_graph_path_equals_oracle(weights, nk):
     model.close()
 
 
+@pytest.mark.parametrize("weights,nk,stream", [("yolov8n.pt", 0, False), ("yolov8n-pose.pt", 51, False), ("yolov8n.pt", 0, True)])
+def test_yolo_all_fp32_equals_oracle(weights, nk, stream):
+    """YOLO(..., half=False): the reference's own precision (it passes no half=, yolo_multi_model.py:41) — detector on the fp32 convolution
+    kernels, ReID crops + OSNet on the fp32 ReID kernels — behind the same drop-in calls, per frame and as a stream; the tracker side equals
+    the oracle chain as in every other mode."""
+    model, frames, ref = _synthetic_model(weights, nk=nk)
+    model._pipe_kw.update(half=False, reid_half=False)
+    if stream:
+        for k, res in enumerate(model.track_stream(frames[:24], batch=8)):
+            _check_tracked(res, ref[k][1], ref[k][2], k)
+        assert k == 23
+        pipe = model._stream_pipe
+    else:
+        for k in range(12):
+            _check_tracked(model.track(frames[k], verbose=False, device=0, persist=True, tracker="botsort.yaml"), ref[k][1], ref[k][2], k)
+        pipe = model._pipe
+    assert pipe.dtype == torch.float32 and pipe.reid_dtype == torch.float32 and getattr(pipe.detector, "_own32", False)
+    model.close()
+
+
 @pytest.mark.parametrize("batch", [1, 4, 16, 32])
 def test_yolo_track_stream_equals_oracle(batch):
     """the throughput form: groups of `batch` frames through the overlapped pipeline, partial last group included"""
