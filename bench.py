@@ -1189,7 +1189,7 @@ def main():
                 return {
                     "reid_precision": ("f16 activations, hand-written kernels (csrc/ss_ops.hip)" if other_half else
                                        ("fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)")),
-                    "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
+                    "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "ms_per_step_distribution": A2.step_ms, "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
                     "ratio_to_default": round((S * A2.KF / A2.dt) / (S * KF / dt), 4),
                     "id_match_rate": round(a_same / max(a_tot, 1), 6), "frames_bit_exact": f"{a_exact}/{A2.total}", "frames_bit_exact_timed": f"{a_exact_timed}/{a_ntimed}",
                     "distance_err": t.get("cost_matrix_cosine_max_abs_err"), "embedding_err": t.get("embedding_unit_max_abs_err"),
@@ -1204,7 +1204,7 @@ def main():
                 det_own = bool(getattr(A3.pipe.detector, "_own32", False))
                 A3.pipe.close()
                 return {"detector": "fp32, hand-written kernels (csrc/ss_ops32.hip k32_conv)" if det_own else "fp32, PyTorch-ROCm library convolutions", "reid": "fp32, hand-written kernels",
-                        "frames_per_s": round(S * A3.KF / A3.dt, 2), "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
+                        "frames_per_s": round(S * A3.KF / A3.dt, 2), "ms_per_step": round(A3.dt / A3.K * 1e3, 4), "ms_per_step_distribution": A3.step_ms, "steps": A3.K, "id_match_rate": round(b_same / max(b_tot, 1), 6),
                         "frames_bit_exact": f"{b_exact}/{A3.total}"}
             res["throughput_mode" if args.reid_fp32 else "accuracy_mode"] = leg(other_mode, args.reid_fp32)
             if not args.det_fp32:
