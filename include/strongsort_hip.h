@@ -411,9 +411,9 @@ int ss_op32_pointwise(void* stream, const void* d_x, const void* d_w, const void
                       long long M, int K, int N, int relu, const int* d_nvalid, int img_px);
 /* The four LightConv chains of an OSBlock (layer = 1x1 linear, depthwise 3x3 + bias + ReLU; chains 1, 2, 3, 4 layers deep, ten
  * layers in that order): d_x1 [N][H][W][C] -> d_ys[0..3] (same shape) and d_psum [4][N][bands][C] = channel sums of each output
- * per band, bands = ss_op32_chains_bands(H, W, C).  d_w1 [10][C][C], d_w9 [10][9][C] (tap-major), d_bias [10][C].
+ * per band, bands = ss_op32_chains_bands(N, H, W, C) (1 for the row-stream kernel, which batches of >= 128 images take).  d_w1 [10][C][C], d_w9 [10][9][C] (tap-major), d_bias [10][C].
  * (C, W) in {(16, 32), (24, 16), (32, 8)}. */
-int ss_op32_chains_bands(int H, int W, int C);
+int ss_op32_chains_bands(int N, int H, int W, int C);
 int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, const void* d_w9, const void* d_bias, void* const* d_ys,
                    float* d_psum, int N, int H, int W, int C, const int* d_nvalid);
 /* OSBlock tail + the 1x1 ConvBR after it, two launches: gate_t = sigmoid(fc2 relu(fc1 mean_t + b1) + b2) (fc1 [hidden][MID], fc2

@@ -195,7 +195,7 @@ def process_video(args: dict, model=None) -> dict:
     if model is None:
         from .yolo import YOLO
         model = YOLO(args.get("weights", DEFAULT_WEIGHTS), random_init_ok=args.get("random_init", False), reid_weights=args.get("reid_weights"),
-                     reid_fp32=args.get("reid_fp32", False), half=not args.get("fp32", False))
+                     reid_fp32=not args.get("reid_f16", False), half=not args.get("fp32", False))
         model.overrides.update(conf=0.3, iou=0.4, agnostic_nms=False, max_det=1000)      # :18-21
     name = os.path.splitext(os.path.basename(str(source)))[0] or "stream"
     writer = LabelsWriter(os.path.join(args.get("outdir", "output"), f"{name}_labels.txt"), args.get("compat", False))
@@ -257,7 +257,8 @@ def main(argv=None):
     p.add_argument("--track", action="store_true")
     p.add_argument("--count", action="store_true")
     p.add_argument("--weights", default=DEFAULT_WEIGHTS, help="detector weights; the reference's default model file (yolo_multi_model.py:17)")
-    p.add_argument("--reid-fp32", action="store_true", help="ReID crops + OSNet in fp32 on the fp32 kernels (float distances within 1e-4 of a CPU fp32 network; about 0.58x the f16 throughput)")
+    p.add_argument("--reid-fp32", action="store_true", help="(the default since round 6) ReID crops + OSNet in fp32 on the fp32 kernels: float distances within 1e-4 of a CPU fp32 network")
+    p.add_argument("--reid-f16", action="store_true", help="throughput mode: ReID crops + OSNet with f16 activations (1.7x the stream rate; appearance distances off by up to 3e-2)")
     p.add_argument("--fp32", action="store_true", help="every network operation in fp32 (the reference passes no half=): detector on the fp32 convolution kernels too — NMS keep lists equal the CPU fp32 network's; about 0.39x the f16 throughput")
     p.add_argument("--reid-weights", default=None, help="OSNet-x0.25 state_dict for the tracker's appearance features (required with --track unless --random-init)")
     p.add_argument("--limit", type=int, default=None)
@@ -265,7 +266,7 @@ def main(argv=None):
     p.add_argument("--batch", type=int, default=16, help="frames per group on the throughput path (1: per-frame model.track calls as in the reference)")
     p.add_argument("--random-init", action="store_true", help="run seeded random-init networks when the weights file is missing")
     a = p.parse_args(argv)
-    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "reid_weights": a.reid_weights, "limit": a.limit, "device": i, "random_init": a.random_init, "batch": a.batch, "reid_fp32": a.reid_fp32, "fp32": a.fp32,
+    jobs = [{"source": s, "track": a.track, "count": a.count, "weights": a.weights, "reid_weights": a.reid_weights, "limit": a.limit, "device": i, "random_init": a.random_init, "batch": a.batch, "reid_f16": a.reid_f16, "fp32": a.fp32,
              "save": (a.save if len(a.source) == 1 else f"{os.path.splitext(a.save)[0]}_{i}{os.path.splitext(a.save)[1]}") if a.save else None}
             for i, s in enumerate(a.source)]
     import torch

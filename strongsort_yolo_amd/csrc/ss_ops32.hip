@@ -769,7 +769,7 @@ __global__ __launch_bounds__(T32_THREADS, 4) void k32_tail(const float* __restri
                                                 const float* __restrict__ b3, const float* __restrict__ xin, const float* __restrict__ wd,
                                                 const float* __restrict__ bd, float* __restrict__ out, const float* __restrict__ w4,
                                                 const float* __restrict__ b4, float* __restrict__ out2, int Nimg, int H, int W,
-                                                const int* __restrict__ n_img)
+                                                const int* __restrict__ n_img, int splits)
 {
     constexpr int CHM = MID / 4, JM = (CHM + 3) / 4, MT3 = C2 / 16, CH1 = C1 / 4, J1 = (CH1 + 3) / 4, MT4 = (N2 + 15) / 16, CH4 = N2 / 4;
     constexpr int L3 = w_lds_floats<MID, C2>(), LD = C1 ? w_lds_floats<(C1 ? C1 : 16), C2>() : 0, WV = T32_THREADS / 64;
@@ -784,8 +784,9 @@ __global__ __launch_bounds__(T32_THREADS, 4) void k32_tail(const float* __restri
     float* __restrict__ Gw = Bs + C2 + 16 * MT4 + wave * 4 * GP; // this wave's copy of the image's gates: [4][GP], zero in the padding chunks
     int nv = Nimg;
     if (n_img && *n_img < nv) nv = *n_img;
-    const int per = (nv + (int)gridDim.x - 1) / (int)gridDim.x, img0 = blockIdx.x * per, img1 = min(img0 + per, nv);
-    if (img0 >= img1) return;
+    // work items = (image, part of its tiles): `splits` parts per image when the batch alone cannot fill the chip (the per-frame call's 32 crops)
+    const int items = nv * splits, per = (items + (int)gridDim.x - 1) / (int)gridDim.x, it0 = blockIdx.x * per, it1 = min(it0 + per, items);
+    if (it0 >= it1) return;
     stage_w<MID, C2, T32_THREADS>(W3s, w3, tid);
     if (C1) stage_w<(C1 ? C1 : 16), C2, T32_THREADS>(Wds, wd, tid);
     stage_w<C2, N2, T32_THREADS>(W4s, w4, tid);
@@ -794,14 +795,15 @@ __global__ __launch_bounds__(T32_THREADS, 4) void k32_tail(const float* __restri
     __syncthreads();
     const int HW = H * W, tiles_img = HW / 16;
     const float* const ys[4] = { y0, y1, y2, y3 };
-    for (int img = img0; img < img1; ++img) {
+    for (int item = it0; item < it1; ++item) {
+        const int img = item / splits, part = item - img * splits;
         // the image's four gate vectors -> this wave's LDS table (a wave reads only what it wrote: no barrier)
         for (int i = lane; i < 4 * GP; i += 64) {
             const int t = i / GP, c = i - t * GP;
             Gw[i] = c < MID ? gates[((size_t)t * Nimg + img) * MID + c] : 0.f;
         }
         const size_t pbase = (size_t)img * HW;
-        for (int tile = wave; tile < tiles_img; tile += WV) {
+        for (int tile = part * WV + wave; tile < tiles_img; tile += WV * splits) {
             int pl;                                              // pixel of this lane inside the image
             if (POOL) { const int tw = W / 8, ty = tile / tw, tx = tile - ty * tw; pl = (2 * ty + (n >> 3)) * W + 8 * tx + (n & 7); }
             else pl = tile * 16 + n;
@@ -1267,7 +1269,12 @@ static int g_conv_mt = 0, g_conv_min = 0;      // k32_conv: 16-channel output ti
 static int g_conv_waves = 0, g_conv_wgs = 1024; // k32_conv: waves per workgroup (0 = 8 when that still leaves g_conv_wgs workgroups, else 4); A/B
 static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
-static bool chains_rowstream(int H, int W, int C) { return g_chains_form == 2 && ((C == 16 && W == 32) || (C == 24 && W == 16) || (C == 32 && W == 8)) && H >= 9; }
+static int g_chains_min_n = 128;     // batches below this take the LDS band forms even with chains_form 2: a row-stream wave walks a whole image (five layer passes,
+                                      // ~200 us whatever the batch), the band forms spread an image over 4 workgroups x 12 waves — the per-frame call's 32-crop batches
+static bool chains_rowstream(int N, int H, int W, int C)
+{
+    return g_chains_form == 2 && N >= g_chains_min_n && ((C == 16 && W == 32) || (C == 24 && W == 16) || (C == 32 && W == 8)) && H >= 9;
+}
 
 template <int K, int N>
 static int launch_pw32(hipStream_t st, const float* x, const float* w, const float* b, const float* res, float* out, long long M, int relu,
@@ -1308,10 +1315,10 @@ static int chains_rows(int H, int W, int C, int* halo)
     return -1;
 }
 
-extern "C" int ss_op32_chains_bands(int H, int W, int C)
+extern "C" int ss_op32_chains_bands(int N, int H, int W, int C)
 {
-    if (H < 1 || W < 1 || !(C == 16 || C == 24 || C == 32)) return SS_ERR_INVALID;
-    if (chains_rowstream(H, W, C)) return 1;
+    if (N < 1 || H < 1 || W < 1 || !(C == 16 || C == 24 || C == 32)) return SS_ERR_INVALID;
+    if (chains_rowstream(N, H, W, C)) return 1;
     int halo;
     const int R = chains_rows(H, W, C, &halo);
     return R < 1 ? SS_ERR_CAPACITY : H / R;
@@ -1324,7 +1331,7 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
     hipStream_t st = (hipStream_t)stream;
     const float *x1 = (const float*)d_x1, *w1 = (const float*)d_w1, *w9 = (const float*)d_w9, *b = (const float*)d_bias;
     float *y0 = (float*)d_ys[0], *y1 = (float*)d_ys[1], *y2 = (float*)d_ys[2], *y3 = (float*)d_ys[3];
-    if (chains_rowstream(H, W, C)) {                          // two images (four waves) per workgroup
+    if (chains_rowstream(N, H, W, C)) {                       // two images (four waves) per workgroup
 #define CHR(CC, WW, AL) if (C == CC && W == WW) { \
         const size_t ldsr = (size_t)(ChR<CC>::TAB + (AL ? 10 * ChR<CC>::NPR * ChR<CC>::KP : 0)) * 4; \
         static unsigned long long attr = 0; \
@@ -1345,7 +1352,7 @@ extern "C" int ss_op32_chains(void* stream, const void* d_x1, const void* d_w1, 
         if (!lds_attr_once((const void*)k32_chains<CC, WW>, attr)) return SS_ERR_HIP; \
         hipLaunchKernelGGL((k32_chains<CC, WW>), grid, dim3(C32_THREADS), lds, st, x1, w1, w9, b, y0, y1, y2, y3, d_psum, N, H, R, halo, d_nvalid); \
         OP32_CHECK(); return SS_OK; }
-#define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form == 1 && (g_chains_pre < 0 ? CC == 16 : g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
+#define CH32C(CC, WW, PRE_) if (C == CC && W == WW && g_chains_form >= 1 && (g_chains_pre < 0 ? CC == 16 : g_chains_pre != 0) == PRE_ && R + 2 * halo == (CC == 16 ? 24 : 32)) { \
         static unsigned long long attr = 0; \
         if (!lds_attr_once((const void*)k32_chains3<CC, WW, PRE_>, attr)) return SS_ERR_HIP; \
         const size_t lds3 = ((size_t)(R + 2 * halo + 2) * (WW + 2) + (size_t)(R + 2 * halo) * WW) * Ch3<CC>::PITCH * 4 + (size_t)(C32_THREADS / 64) * 16 * 4; \
@@ -1369,6 +1376,7 @@ extern "C" int ss_op32_set_option(const char* name, int value)
     if (!strcmp(name, "conv_wgs")) { if (value < 1) return SS_ERR_INVALID; g_conv_wgs = value; return SS_OK; }
     if (!strcmp(name, "tail_wgs")) { if (value < 0 || value > 65535) return SS_ERR_INVALID; g_tail_wgs = value; return SS_OK; }
     if (!strcmp(name, "chains_probe")) { g_chains_probe = value; return SS_OK; }
+    if (!strcmp(name, "chains_min_n")) { if (value < 1) return SS_ERR_INVALID; g_chains_min_n = value; return SS_OK; }
     if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
 }
@@ -1391,9 +1399,12 @@ static int launch_tail32(hipStream_t st, const void* const* ys, const float* gat
         wgs_dev[dev] = cus * (per_cu > 4 ? 4 : per_cu);
     }
     const int wgs = wgs_dev[dev];
-    const int grid = g_tail_wgs > 0 ? g_tail_wgs : (N < wgs ? N : wgs);
+    const int tiles_wv = (H * W / 16 + T32_THREADS / 64 - 1) / (T32_THREADS / 64);      // tiles per wave when one workgroup takes a whole image
+    int splits = 1;
+    while (N * splits * 2 <= wgs && splits * 2 <= tiles_wv) splits *= 2;
+    const int grid = g_tail_wgs > 0 ? g_tail_wgs : (N * splits < wgs ? N * splits : wgs);
     hipLaunchKernelGGL((k32_tail<MID, C2, C1, N2, POOL>), dim3(grid), dim3(T32_THREADS), lds, st, (const float*)ys[0], (const float*)ys[1], (const float*)ys[2],
-                       (const float*)ys[3], gates, w3, b3, xin, wd, bd, out, w4, b4, out2, N, H, W, nv);
+                       (const float*)ys[3], gates, w3, b3, xin, wd, bd, out, w4, b4, out2, N, H, W, nv, splits);
     OP32_CHECK();
     return SS_OK;
 }

@@ -141,7 +141,7 @@ def chains(x1, blk):
     x1 = _cl(x1)
     n, c, h, w = x1.shape
     L = _lib.load()
-    bands = L.ss_op32_chains_bands(h, w, c)
+    bands = L.ss_op32_chains_bands(n, h, w, c)
     if bands < 1:
         raise _lib.SSError(bands, f"fp32 LightConv chains: unsupported map {c} x {h} x {w}")
     w1, w9, b = _block_w(blk, x1)[:3]

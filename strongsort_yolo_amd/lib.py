@@ -158,7 +158,7 @@ def load():
     L.ss_op_maxpool_f16.argtypes = [vp, vp, vp, i, i, i, i, i, i, i]
     L.ss_op_gate_sum_f16.argtypes = [vp, C.POINTER(vp), i, vp, vp, vp, vp, vp, vp, i, i, i, i]
     L.ss_op32_pointwise.argtypes = [vp, vp, vp, vp, vp, vp, ll, i, i, i, vp, i]
-    L.ss_op32_chains_bands.argtypes = [i, i, i]
+    L.ss_op32_chains_bands.argtypes = [i, i, i, i]
     L.ss_op32_chains.argtypes = [vp, vp, vp, vp, vp, C.POINTER(vp), vp, i, i, i, i, vp]
     L.ss_op32_tail.argtypes = [vp, C.POINTER(vp), vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     L.ss_op32_stem.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]

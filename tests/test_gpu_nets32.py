@@ -83,10 +83,12 @@ def test_chains_match_fp64(c1, c2, n, h, w, form):
     (always for 16 x 8)."""
     from strongsort_yolo_amd import fused32
     fused32.set_option("chains_form", form)
+    fused32.set_option("chains_min_n", 1)              # (batches below 128 images would otherwise take the band forms: the per-frame call's batches)
     try:
         _chains_case(c1, c2, n, h, w)
     finally:
         fused32.set_option("chains_form", 2)
+        fused32.set_option("chains_min_n", 128)
 
 
 def _chains_case(c1, c2, n, h, w):
@@ -106,9 +108,20 @@ def _chains_case(c1, c2, n, h, w):
     _close(psum.sum(2), sums, rel=2e-5)
 
 
+@pytest.mark.parametrize("min_n", [1, 128])
 @pytest.mark.parametrize("k", [1, 2, 4, 5, 7, 8])
-def test_block_parts_match_fp64(k):
-    """chains + tail (gates, conv3, shortcut, the following ConvBR [+ average pool]) of every OSBlock position against the modules in fp64."""
+def test_block_parts_match_fp64(k, min_n):
+    """chains + tail (gates, conv3, shortcut, the following ConvBR [+ average pool]) of every OSBlock position against the modules in fp64,
+    with the row-stream chains (what large batches take: min_n 1 forces them for this 3-image batch) and with the band forms small batches take."""
+    from strongsort_yolo_amd import fused32
+    fused32.set_option("chains_min_n", min_n)
+    try:
+        _block_parts_case(k)
+    finally:
+        fused32.set_option("chains_min_n", 128)
+
+
+def _block_parts_case(k):
     from strongsort_yolo_amd import nets
     g = torch.Generator().manual_seed(100 + k)
     net = nets.build_reid(1)

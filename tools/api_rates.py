@@ -13,5 +13,6 @@ p = FramePipeline(detector, 1, (H, W), half=True, reid_batch=rb, cfg=cfg, dcfg=d
 gs, nc, A = scale_geometry(p.geom, H, W), p.nc, p.n_anchors
 p.close()
 for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
-    r = bench.api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg)
-    print(json.dumps({"preset": preset, **{k: r[k] for k in ("per_frame_track_frames_per_s", "track_stream_frames_per_s", "track_stream_batch", "frames_identical_to_oracle")}}), flush=True)
+  for fp32 in (True, False):
+    r = bench.api_path(detector, W, H, n_ids, gs, nc, A, cfg, dcfg, reid_fp32=fp32)
+    print(json.dumps({"preset": preset, "reid_fp32": fp32, **{k: r[k] for k in ("per_frame_track_frames_per_s", "track_stream_frames_per_s", "track_stream_batch", "frames_identical_to_oracle")}}), flush=True)

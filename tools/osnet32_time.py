@@ -11,6 +11,9 @@ if "SS32_CHAINS_FORM" in os.environ:
 for k, o in (("SS32_CHAINS_PROBE", "chains_probe"),):
     if k in os.environ:
         fused32.set_option(o, int(os.environ[k]))
+for kv in os.environ.get("SS32_OPTS", "").split(","):
+    if "=" in kv:
+        fused32.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
