@@ -949,6 +949,139 @@ __global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict_
     }
 }
 
+// ---- k32_stemW: the same operator, a workgroup WALKING down `nb` consecutive bands of one image -------------------------------------
+// k32_stem's workgroups run their phases one after the other (stage 23 rows -> 37 weight loads -> matrix -> pool) and the two workgroups of a
+// CU start together, so they wait together: MFMA-busy 0.41.  Here the 16 NEW input rows of the next band are requested before the current
+// band's matrix phase and stored after it (their HBM latency lies under the MFMAs), the seven rows two bands share stay where they are (the
+// 24 input rows are a RING: local row r of a band is ring row (base + r) mod 24, base += 16 per band; a tile's seven row offsets are
+// wave-uniform scalars), the convolution row two bands share is computed once (Cs is a ring of 9 slots: slot = (row + 1) mod 9), the 37
+// weight registers are loaded once per workgroup, and a wave runs TWO tiles side by side (independent accumulator chains: a dependent MFMA
+// issues 40 cycles after its predecessor, an independent one 32).  Per band: [matrix] barrier [store new rows, pool] barrier.  Every sum
+// keeps k32_stem's order (k = 0 .. 147 into one accumulator), so the two kernels agree bit for bit.
+#define STW_THREADS 512
+__global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const float* __restrict__ x, const float* __restrict__ w /*[16][148]*/,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img, int nb)
+{
+    constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, RING = 24, CSP = 16, RV = Wd * 3 / 4;   // RV: data vectors of an input row (96)
+    extern __shared__ __attribute__((aligned(16))) float smem32[];
+    float* __restrict__ In = smem32;                         // [24][404] ring of input rows
+    float* __restrict__ Cs = In + RING * ST_ROWP;            // [9][64][16] ring of convolution rows after bias + ReLU
+    const int img = blockIdx.y, b0 = blockIdx.x * nb;
+    if (n_img && img >= *n_img) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
+    const float* xi = x + (size_t)img * H * Wd * 3;
+    auto inrow = [&](int iy) { return iy < 0 ? 0 : (iy >= H ? H - 1 : iy); };
+    if (tid < RING * 5) {                                    // the rows' zero borders (3 vectors left, 2 right), written once
+        const int r = tid / 5, j = tid - 5 * r;
+        st4(In + r * ST_ROWP + 4 * (j < 3 ? j : RV + j), zero4());
+    }
+    {   // the first band's 23 rows (ring rows 0 .. 22): every vector requested before the first LDS store
+        constexpr int TOT = 23 * RV, NIT = (TOT + STW_THREADS - 1) / STW_THREADS;
+        const int iy0 = 16 * b0 - 5;
+        f4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = min(tid + u * STW_THREADS, TOT - 1), lr = i / RV, c4 = i - lr * RV;
+            v[u] = ld4(xi + (size_t)inrow(iy0 + lr) * (Wd * 3) + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * STW_THREADS, lr = i / RV, c4 = i - lr * RV, iy = iy0 + lr;
+            if (i < TOT) st4(In + lr * ST_ROWP + 12 + 4 * c4, (iy >= 0 && iy < H) ? v[u] : zero4());
+        }
+    }
+    float a[37];
+#pragma unroll
+    for (int s = 0; s < 37; ++s) a[s] = w[n * 148 + 4 * s + kq];
+    const f4 bb = ld4(bias + 4 * kq);
+#pragma unroll
+    for (int s = 0; s < 37; ++s) asm volatile("" ::"v"(a[s]));
+    asm volatile("" ::"v"(bb[0]), "v"(bb[1]), "v"(bb[2]), "v"(bb[3]));   // the weights have arrived HERE: inside the loop their wait would also cover the rows requested ahead
+    int base = 0;
+    for (int bi = 0; bi < nb; ++bi) {
+        const int band = b0 + bi, cy0 = 8 * band - 1, iy0 = 16 * band - 5;
+        const bool more = bi + 1 < nb;
+        __syncthreads();                                     // this band's rows are in the ring; the previous band's pool is done with Cs
+        f4 pf[3];
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {                    // the next band's 16 new rows: 1 536 vectors
+                const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV;
+                pf[u] = ld4(xi + (size_t)inrow(iy0 + 23 + j) * (Wd * 3) + 4 * c4);
+            }
+        }
+        const int first = bi ? 1 : 0;                        // convolution row 0 of a later band is the previous band's row 8
+        for (int t = 2 * wave; t < (9 - first) * 4; t += 2 * (STW_THREADS / 64)) {
+            const int cyl = first + (t >> 2), cx0 = (t & 3) * 16, cy = cy0 + cyl;
+            if (cy < 0 || cy >= H / 2) continue;
+            const int r0 = base + 2 * cyl;
+            auto ro = [&](int ky) __attribute__((always_inline)) {      // (a function, not an array: a select between two array elements becomes a dynamically indexed stack slot)
+                int r = r0 + ky; r = r >= RING ? r - RING : r; r = r >= RING ? r - RING : r;
+                return r * ST_ROWP - 21 * ky;
+            };
+            const int lb = 3 + 6 * (cx0 + n) + kq;
+            f4 acc0 = zero4(), acc1 = zero4();
+            // B operands four k-steps (eight MFMAs) ahead of their MFMAs (two register groups; the fences keep "request the next group, then
+            // multiply this one" — left alone the scheduler reads each operand right before its use and waits for the LDS every step)
+            constexpr int SG = 4, NG = (37 + SG - 1) / SG;
+            float bv[2][SG][2];
+            auto request = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < SG; ++j) {
+                    const int s = SG * g + j;
+                    if (s < 37) {
+                        const int klo = 4 * s, ky_lo = klo / 21, ky_hi = (klo + 3) / 21 > 6 ? 6 : (klo + 3) / 21;
+                        const int off = (ky_lo == ky_hi) ? ro(ky_lo) : (kq >= 21 * ky_hi - klo ? ro(ky_hi) : ro(ky_lo));
+                        const float* bp = In + lb + off + klo;
+                        bv[g & 1][j][0] = bp[0]; bv[g & 1][j][1] = bp[96];
+                    }
+                }
+            };
+            request(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) request(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < SG; ++j)
+                    if (SG * g + j < 37) { acc0 = MFMA4(a[SG * g + j], bv[g & 1][j][0], acc0); acc1 = MFMA4(a[SG * g + j], bv[g & 1][j][1], acc1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            int slot = (cy + 1) % 9;
+            float* cs = Cs + (slot * OW + cx0 + n) * CSP + 4 * kq;
+            st4(cs, relu4(acc0 + bb));
+            st4(cs + 16 * CSP, relu4(acc1 + bb));
+        }
+        __syncthreads();                                     // Cs complete; local rows 0 .. 15 of the ring are dead
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV, iy = iy0 + 23 + j;
+                int r = base + 23 + j; r = r >= RING ? r - RING : r; r = r >= RING ? r - RING : r;
+                st4(In + r * ST_ROWP + 12 + 4 * c4, (iy >= 0 && iy < H) ? pf[u] : zero4());
+            }
+        }
+        {
+            const int q = tid & 3, pxl = (tid >> 2) & 31, prl = tid >> 7;
+            f4 m = f4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int cy = cy0 + 2 * prl + dy;
+                if (cy < 0 || cy >= H / 2) continue;
+                const int slot = (cy + 1) % 9;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int cx = 2 * pxl - 1 + dx;
+                    if (cx < 0 || cx >= OW) continue;
+                    m = max4(m, ld4(Cs + (slot * OW + cx) * CSP + 4 * q));
+                }
+            }
+            st4(y + (((size_t)img * PH + 4 * band + prl) * PW + pxl) * 16 + 4 * q, m);
+        }
+        base += 16; base = base >= RING ? base - RING : base;
+    }
+}
+
 // ---- k32_head ------------------------------------------------------------------------------------------------------------
 // out[i][f] = relu(b[f] + sum_c w[f][c] * mean_p x[i][p][c]); 4 images per workgroup, C = 128.
 __global__ __launch_bounds__(256) void k32_head(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -1269,6 +1402,7 @@ static int g_conv_mt = 0, g_conv_min = 0;      // k32_conv: 16-channel output ti
 static int g_conv_waves = 0, g_conv_wgs = 1024; // k32_conv: waves per workgroup (0 = 8 when that still leaves g_conv_wgs workgroups, else 4); A/B
 static int g_tail_wgs = 0;           // k32_tail: workgroups of the persistent grid (0 = two per CU where they fit); A/B
 static int g_chains_probe = 0;       // measurement only: bit 0 = k32_chainsR does not store the chain outputs (what the arithmetic alone costs)
+static int g_stem_walk = 0;           // bands per workgroup of the walking stem: 0 = by batch size, -1 = never (k32_stem), 1 / 2 / 4 / 8 / 16 forced
 static int g_chains_min_n = 128;     // batches below this take the LDS band forms even with chains_form 2: a row-stream wave walks a whole image (five layer passes,
                                       // ~200 us whatever the batch), the band forms spread an image over 4 workgroups x 12 waves — the per-frame call's 32-crop batches
 static bool chains_rowstream(int N, int H, int W, int C)
@@ -1376,6 +1510,7 @@ extern "C" int ss_op32_set_option(const char* name, int value)
     if (!strcmp(name, "conv_wgs")) { if (value < 1) return SS_ERR_INVALID; g_conv_wgs = value; return SS_OK; }
     if (!strcmp(name, "tail_wgs")) { if (value < 0 || value > 65535) return SS_ERR_INVALID; g_tail_wgs = value; return SS_OK; }
     if (!strcmp(name, "chains_probe")) { g_chains_probe = value; return SS_OK; }
+    if (!strcmp(name, "stem_walk")) { if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return SS_ERR_INVALID; g_stem_walk = value; return SS_OK; }
     if (!strcmp(name, "chains_min_n")) { if (value < 1) return SS_ERR_INVALID; g_chains_min_n = value; return SS_OK; }
     if (!strcmp(name, "chains_form")) { if (value < 0 || value > 2) return SS_ERR_INVALID; g_chains_form = value; return SS_OK; }
     return SS_ERR_INVALID;
@@ -1437,7 +1572,15 @@ extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, cons
 {
     if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
     constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16) * 4;
-    static unsigned long long attr = 0;
+    static unsigned long long attr = 0, attr_w = 0;
+    const int nb = g_stem_walk > 0 ? g_stem_walk : (g_stem_walk < 0 ? 0 : (N >= 1024 ? 16 : N >= 512 ? 8 : N >= 128 ? 4 : 2));   // bands a workgroup walks down (measured at 1 024 / 860 / 430 / 28 crops: tools/stem32_time.py); -1: one band, k32_stem
+    if (nb) {
+        if (!lds_attr_once((const void*)k32_stemW, attr_w)) return SS_ERR_HIP;
+        hipLaunchKernelGGL(k32_stemW, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
+                           (const float*)d_bias, (float*)d_y, N, d_nvalid, nb);
+        OP32_CHECK();
+        return SS_OK;
+    }
     if (!lds_attr_once((const void*)k32_stem, attr)) return SS_ERR_HIP;
     hipLaunchKernelGGL(k32_stem, dim3(64 / ST_PR, N), dim3(C32_THREADS), lds, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
                        (const float*)d_bias, (float*)d_y, N, d_nvalid);

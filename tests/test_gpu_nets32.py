@@ -65,6 +65,34 @@ def test_stem_matches_fp64():
     _close(got, ref)
 
 
+@pytest.mark.parametrize("walk", [1, 2, 4, 8, 16])
+def test_stem_walking_form_equals_band_form(walk):
+    """k32_stemW (a workgroup walks `walk` bands down an image: input-row ring, shared convolution row kept, next rows requested ahead) keeps
+    k32_stem's summation order: bit-equal outputs, including a valid-image count below the batch."""
+    from strongsort_yolo_amd import fused32, nets
+    g = torch.Generator().manual_seed(11)
+    m = nets.ConvBR(3, 16, 7, 2, 3)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn(m.conv.weight.shape, generator=g) * 0.2)
+        m.conv.bias.copy_(torch.randn(16, generator=g))
+    x = _cl((torch.randn(7, 3, 256, 128, generator=g) * 3).to(DEV))
+    m = m.to(DEV)
+    try:
+        fused32.set_option("stem_walk", -1)
+        ref = fused32.stem(x, m).clone()
+        fused32.set_option("stem_walk", walk)
+        got = fused32.stem(x, m)
+        assert got.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes()
+        ref64 = F.max_pool2d(F.relu(F.conv2d(x.cpu().double(), m.conv.weight.cpu().double(), m.conv.bias.cpu().double(), 2, 3)), 3, 2, 1)
+        _close(got, ref64)
+        nv = torch.tensor([4], dtype=torch.int32, device=DEV)
+        with fused32.valid_images(nv):
+            part = fused32.stem(x, m)
+        assert part[:4].cpu().numpy().tobytes() == ref[:4].cpu().numpy().tobytes()
+    finally:
+        fused32.set_option("stem_walk", 0)
+
+
 def _block(c1, c2, seed):
     from strongsort_yolo_amd import nets
     g = torch.Generator().manual_seed(seed)
