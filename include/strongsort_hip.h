@@ -147,6 +147,14 @@ int ss_crop_norm_packed(ss_ctx* ctx, const uint8_t* d_frames, int batch, long lo
 int ss_unpack_feats(ss_ctx* ctx, const void* d_emb, int emb_half, const int* d_off, const int* d_counts, int batch, int n,
                     float* d_feats, long long feats_image_stride);
 
+/* One frame's results gathered into ONE buffer on the context's stream (the per-frame call of yolo_multi_model.py:41 / :278 reads boxes and
+ * track rows on the host after every frame): dst[0] = n = min(*d_n_dets, det_cap) and dst[1] = m = min(*d_n_out, out_cap) as int32 bit
+ * patterns, n rows of det_ld floats from dst + 2, m rows of out_ld floats from dst + 2 + det_cap * det_ld.  dst: 2 + det_cap * det_ld +
+ * out_cap * out_ld floats of device memory or of pinned (device-accessible) host memory - then the host reads it after synchronising the
+ * stream, with no copy in between.  d_n_out / d_out may both be NULL (detection only: m = 0). */
+int ss_pack_results(ss_ctx* ctx, const int* d_n_dets, const float* d_dets, int det_ld, int det_cap, const int* d_n_out, const float* d_out,
+                    int out_ld, int out_cap, float* dst);
+
 /* Largest n_frames ss_track_update_group / ss_cmc_estimate accept (compile-time SS_FMAX). */
 int ss_max_group_frames(void);
 /* hip_event (a hipEvent_t of the caller, NULL: none) is recorded on the tracker's stream right after the association launch

@@ -33,6 +33,7 @@ void ss_launch_crop_offsets(const int*, int, int, int*, hipStream_t);
 void ss_launch_project(const double*, const double*, const double*, int, double, double*, double*, hipStream_t);
 extern int ss_nms_fused;
 void ss_launch_unpack_feats(const void*, int, const int*, const int*, int, int, float*, long long, hipStream_t);
+void ss_launch_pack_results(const int*, const float*, int, int, const int*, const float*, int, int, float*, hipStream_t);
 void ss_launch_overlay(uint8_t*, int, long long, int, int, int, const void*, const int*, const uint8_t*, const uint8_t*, hipStream_t);
 void ss_launch_cmc(const uint8_t*, int, long long, int, int, int, uint8_t*, long long, int, int, int, int, int, double, int*, const int*, double*, hipStream_t);
 extern "C" void ss_step_kernel_attr();
@@ -848,6 +849,16 @@ extern "C" int ss_unpack_feats(ss_ctx* c, const void* d_emb, int emb_half, const
     if (!c || !d_emb || !d_off || !d_counts || !d_feats || batch < 1 || n < 1 || n > 65535 || batch > 65535)
         return fail(c, SS_ERR_INVALID, "ss_unpack_feats: bad argument");
     ss_launch_unpack_feats(d_emb, emb_half, d_off, d_counts, batch, n, d_feats, feats_image_stride, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_pack_results(ss_ctx* c, const int* d_n_dets, const float* d_dets, int det_ld, int det_cap, const int* d_n_out,
+                               const float* d_out, int out_ld, int out_cap, float* dst)
+{
+    if (!c || !d_n_dets || !d_dets || !dst || det_ld < 1 || det_cap < 1 || ((d_n_out || d_out) && (!d_n_out || !d_out || out_ld < 1 || out_cap < 1)))
+        return fail(c, SS_ERR_INVALID, "ss_pack_results: bad argument");
+    ss_launch_pack_results(d_n_dets, d_dets, det_ld, det_cap, d_n_out, d_out, out_ld, out_cap, dst, c->stream);
     HIPCHK(c, hipGetLastError());
     return SS_OK;
 }

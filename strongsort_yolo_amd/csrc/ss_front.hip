@@ -324,6 +324,26 @@ __global__ __launch_bounds__(128) void k_unpack_feats(const T* __restrict__ emb,
     for (int k = threadIdx.x; k < 512; k += 128) dst[k] = (float)src[k];
 }
 
+// One frame's results in ONE buffer the host reads after its synchronisation: dst[0] = n = min(*n_dets, det_cap), dst[1] = m = min(*n_out, out_cap)
+// (integers, bit-copied), then n detection rows of det_ld floats at dst + 2, then m track rows of out_ld floats at dst + 2 + det_cap * det_ld.
+// dst may be pinned host memory (device-accessible): the per-frame drop-in call used to issue two device copies and three device-to-host
+// copies for the same bytes, 89 us of its ~1 ms.
+__global__ __launch_bounds__(256) void k_pack_results(const int* __restrict__ n_dets, const float* __restrict__ dets, int det_ld, int det_cap,
+                                                      const int* __restrict__ n_out, const float* __restrict__ out, int out_ld, int out_cap,
+                                                      float* __restrict__ dst)
+{
+    const int n = min(max(*n_dets, 0), det_cap), m = (n_out && out) ? min(max(*n_out, 0), out_cap) : 0;
+    if (threadIdx.x == 0) { reinterpret_cast<int*>(dst)[0] = n; reinterpret_cast<int*>(dst)[1] = m; }
+    float* d0 = dst + 2;
+    for (int i = threadIdx.x; i < n * det_ld; i += 256) d0[i] = dets[i];
+    float* d1 = dst + 2 + (size_t)det_cap * det_ld;
+    for (int i = threadIdx.x; i < m * out_ld; i += 256) d1[i] = out[i];
+}
+
+void ss_launch_pack_results(const int* n_dets, const float* dets, int det_ld, int det_cap, const int* n_out, const float* out, int out_ld,
+                            int out_cap, float* dst, hipStream_t st)
+{ hipLaunchKernelGGL(k_pack_results, dim3(1), dim3(256), 0, st, n_dets, dets, det_ld, det_cap, n_out, out, out_ld, out_cap, dst); }
+
 void ss_launch_crop_offsets(const int* counts, int batch, int n, int* off, hipStream_t st)
 { hipLaunchKernelGGL(k_crop_offsets, dim3(1), dim3(1024), 0, st, counts, batch, n, off); }
 

@@ -425,6 +425,18 @@ class TrackerEngine:
         self._ck(self.L.ss_unpack_feats(self.ctx, _ptr(emb), int(emb.dtype == torch.float16), _ptr(offsets), _ptr(counts),
                                         feats.shape[0], n, _ptr(feats), feats.stride(0)))
 
+    def pack_results(self, n_dets: torch.Tensor, dets: torch.Tensor, n_out, out, dst: torch.Tensor):
+        """One frame's counts, detection rows and track rows into `dst` (float32, device or PINNED host memory) on the engine's stream:
+        dst[0:2] = the two counts as int32 bits, then dets rows, then (from 2 + dets.numel()) track rows (csrc ss_pack_results)."""
+        assert dets.is_contiguous() and dets.dim() == 2 and dst.dtype == torch.float32 and dst.is_contiguous()
+        need = 2 + dets.numel() + (out.numel() if out is not None else 0)
+        assert dst.numel() >= need and (dst.is_cuda or dst.is_pinned())
+        if out is not None:
+            assert out.is_contiguous() and out.dim() == 2
+        self._ck(self.L.ss_pack_results(self.ctx, _ptr(n_dets), _ptr(dets), dets.shape[1], dets.shape[0], _ptr(n_out) if out is not None else None,
+                                        _ptr(out) if out is not None else None, out.shape[1] if out is not None else 0,
+                                        out.shape[0] if out is not None else 0, _ptr(dst)))
+
     def nms(self, pred: torch.Tensor, nc: int, dcfg: DetectConfig, gain: float, pad_x: float, pad_y: float,
             w0: int, h0: int, n_extra: int = 0, rows=None, keep=None, count=None):
         """pred: [(4+nc+n_extra), N] float32 on the device."""

@@ -21,7 +21,7 @@ DST_F16, DST_HWC = 1, 2
 EXPORTS = [
     "ss_create", "ss_destroy", "ss_last_error", "ss_set_hip_stream", "ss_reset", "ss_synchronize",
     "ss_upload", "ss_upload_batch", "ss_download", "ss_overlay_set_font", "ss_overlay", "ss_letterbox", "ss_letterbox_batch", "ss_nms", "ss_nms_batch", "ss_nms_set_classes", "ss_crop_norm", "ss_crop_norm_batch",
-    "ss_track_update", "ss_track_update_group", "ss_cmc_estimate", "ss_track_set_cmc", "ss_crop_norm_packed", "ss_unpack_feats", "ss_op_set_valid_images", "ss_op_set_option", "ss_track_set_assoc_event", "ss_track_update_host",
+    "ss_track_update", "ss_track_update_group", "ss_cmc_estimate", "ss_track_set_cmc", "ss_crop_norm_packed", "ss_unpack_feats", "ss_pack_results", "ss_op_set_valid_images", "ss_op_set_option", "ss_track_set_assoc_event", "ss_track_update_host",
     "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_project", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
     "ss_get_gallery", "ss_max_group_frames", "ss_track_join", "ss_stream_create", "ss_stream_destroy", "ss_assoc_timing", "ss_assoc_timing_values", "ss_assoc_inkernel_timing", "ss_assoc_timeline", "ss_op_bias_act_f16", "ss_op_bias_act_place_f16", "ss_op_pointwise_f16", "ss_op_conv3x3_f16", "ss_op_bottleneck_f16", "ss_op_conv_group_f16", "ss_op_head_f16", "ss_op_v8_decode_f16", "ss_op_v8_decode_ext_f16", "ss_op_dwconv3x3_f16", "ss_op_lightconv_f16", "ss_op_osnet_stem_f16", "ss_op_conv0_f16", "ss_op_osnet_streams_f16", "ss_op_osnet_streams_bands", "ss_op_dwtab_bytes", "ss_op_dwtab_f16", "ss_op_gate_apply_f16", "ss_op_osnet_tail_f16", "ss_op_gate_sum_f16", "ss_op_avgpool2_f16", "ss_op_upcat_f16", "ss_op_sppf_pools_f16", "ss_op_psa_attention_f16", "ss_op_osnet_head_f16", "ss_op_maxpool_f16",
@@ -97,6 +97,7 @@ def load():
     L.ss_crop_norm_batch.argtypes = [vp, u8, i, ll, i, i, i, fp, i, ll, i, ip, vp, i]
     L.ss_crop_norm_packed.argtypes = [vp, u8, i, ll, i, i, i, fp, i, ll, i, ip, ip, vp, i]
     L.ss_unpack_feats.argtypes = [vp, vp, i, ip, ip, i, i, fp, ll]
+    L.ss_pack_results.argtypes = [vp, ip, fp, i, i, ip, fp, i, i, fp]
     L.ss_op_set_valid_images.argtypes = [vp, vp, i]
     L.ss_op_set_option.argtypes = [C.c_char_p, i]
     L.ss_track_update.argtypes = [vp, fp, ip, fp, ip, fp, ip]

@@ -96,6 +96,7 @@ class FramePipeline:
         self.anchor_gt = torch.zeros(S, self.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.graph = None
+        self.graph_all = None
         self.graph_mode = graph
         # N4 (optional): ECC camera-motion warps estimated beside the detector, applied by the tracker before predicting
         self.cmc = bool(cmc)
@@ -198,6 +199,13 @@ class FramePipeline:
                         with torch.cuda.graph(gph, stream=st):
                             fn()
                         self.graph.append(gph)
+                    # ... and the three stages once more as ONE graph for the tracking call (model.track, yolo_multi_model.py:41 / :278: the
+                    # only call the reference makes per frame): one replay instead of three, no launch boundary between the stages
+                    self.graph_all = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_all, stream=st):
+                        self._detect_impl()
+                        self._reid_impl()
+                        self._track()
                 else:
                     self.graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph, stream=st):
@@ -208,8 +216,7 @@ class FramePipeline:
             self.eng.use_current_stream()
             self._restore_tracker()          # warm-up frames must not count: streams start fresh
         if self.graph_mode == "split":
-            for gph in (self.graph if track else self.graph[:1]):
-                gph.replay()
+            (self.graph_all if track else self.graph[0]).replay()
             return
         self.graph.replay()
         if self.graph_mode == "front":
@@ -236,6 +243,7 @@ class FramePipeline:
     def close(self):
         torch.cuda.synchronize(self.dev)
         self.graph = None
+        self.graph_all = None
         if hasattr(self, "graphs"):
             self.graphs = None                           # captured graphs reference the context's buffers: drop them first
         self.eng.close()

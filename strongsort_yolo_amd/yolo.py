@@ -289,10 +289,13 @@ class YOLO:
             self._key = key
             self._frame_index = 0
             H, W = image.shape[:2]
-            self._h_rows = torch.empty(p.out.shape[1], 8).pin_memory()
-            self._h_dets = torch.empty(p.dets.shape[1], p.dets.shape[2]).pin_memory()
-            self._h_cnt = torch.zeros(2, dtype=torch.int32).pin_memory()
-            self._d_cnt = torch.zeros(2, dtype=torch.int32, device=p.dev)
+            # one pinned buffer the device writes the frame's counts, detection rows and track rows into (csrc ss_pack_results): the host
+            # reads it after the call's one synchronisation, no copies in between
+            nd, no = p.dets.shape[1] * p.dets.shape[2], p.out.shape[1] * p.out.shape[2]
+            self._h_res = torch.zeros(2 + nd + no).pin_memory()
+            self._h_cnt = self._h_res[:2].view(torch.int32)
+            self._h_dets = self._h_res[2:2 + nd].view(p.dets.shape[1], p.dets.shape[2])
+            self._h_rows = self._h_res[2 + nd:].view(p.out.shape[1], p.out.shape[2])
             self._h_proto = torch.empty(p.proto.shape[1:], dtype=p.proto.dtype).pin_memory() if p.nm else None
         return self._pipe
 
@@ -304,12 +307,7 @@ class YOLO:
         if self._fill is not None:
             self._fill(pipe, 0, self._frame_index)
         pipe.step(track=track)
-        self._d_cnt[0:1].copy_(pipe.ndets)
-        self._h_dets.copy_(pipe.dets[0], non_blocking=True)
-        if track:
-            self._d_cnt[1:2].copy_(pipe.nout)
-            self._h_rows.copy_(pipe.out[0], non_blocking=True)
-        self._h_cnt.copy_(self._d_cnt, non_blocking=True)
+        pipe.eng.pack_results(pipe.ndets, pipe.dets[0], pipe.nout if track else None, pipe.out[0] if track else None, self._h_res)
         if pipe.nm:
             self._h_proto.copy_(pipe.proto[0], non_blocking=True)
         torch.cuda.current_stream(pipe.dev).synchronize()            # the one synchronisation of the call

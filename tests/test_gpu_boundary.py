@@ -457,3 +457,30 @@ def test_yolo_segmentation_masks_follow_the_boxes():
         m2.close()
     for (b0, p0), (b1, p1) in zip(*outs):
         assert np.array_equal(b0, b1) and len(p0) == len(p1) and all(np.array_equal(u, v) for u, v in zip(p0, p1))
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pack_results_writes_counts_and_rows_into_one_buffer(pinned):
+    """ss_pack_results (the per-frame call's result hand-over): counts as int32 bits, n detection rows, m track rows at their fixed
+    offsets; rows past the counts are left alone; a pinned host buffer is written by the kernel itself."""
+    from tests.gpu_util import engine
+    eng = engine(StrongSortConfig())
+    dev = eng.device
+    g = torch.Generator().manual_seed(5)
+    dets = torch.randn(128, 6, generator=g).to(dev)
+    out = torch.randn(64, 8, generator=g).to(dev)
+    for n, m, with_out in ((0, 0, True), (17, 9, True), (128, 64, True), (500, 70, True), (23, 0, False)):
+        nd = torch.tensor([n], dtype=torch.int32, device=dev)
+        no = torch.tensor([m], dtype=torch.int32, device=dev)
+        dst = torch.full((2 + dets.numel() + out.numel(),), -7.0)
+        dst = dst.pin_memory() if pinned else dst.to(dev)
+        eng.pack_results(nd, dets, no if with_out else None, out if with_out else None, dst)
+        torch.cuda.synchronize()
+        h = dst.cpu()
+        cn, cm = min(n, 128), (min(m, 64) if with_out else 0)
+        assert h[:2].view(torch.int32).tolist() == [cn, cm]
+        assert torch.equal(h[2:2 + cn * 6].view(cn, 6), dets.cpu()[:cn])
+        assert (h[2 + cn * 6:2 + 128 * 6] == -7.0).all()
+        assert torch.equal(h[2 + 128 * 6:2 + 128 * 6 + cm * 8].view(cm, 8), out.cpu()[:cm])
+        assert (h[2 + 128 * 6 + cm * 8:] == -7.0).all()
+    eng.close()

@@ -24,7 +24,6 @@ for i, nm in enumerate(("detect", "reid", "tracker")):
     print(f"{nm} graph + sync: %.3f ms" % t(lambda: (p.graph[i].replay(), sync())))
 def body():
     p.eng.upload(p.frames[0], img); p.step(track=True)
-    m._d_cnt[0:1].copy_(p.ndets); m._h_dets.copy_(p.dets[0], non_blocking=True); m._d_cnt[1:2].copy_(p.nout)
-    m._h_rows.copy_(p.out[0], non_blocking=True); m._h_cnt.copy_(m._d_cnt, non_blocking=True); sync()
+    p.eng.pack_results(p.ndets, p.dets[0], p.nout, p.out[0], m._h_res); sync()
 print("_run body without check_errors / Results: %.3f ms" % t(body))
 print("check_errors: %.3f ms" % t(lambda: p.eng.check_errors()))

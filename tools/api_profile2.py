@@ -13,8 +13,7 @@ p = m._pipe
 steps = [
  ("upload", lambda i: p.eng.upload(p.frames[0], imgs[i % 8])),
  ("step", lambda i: p.step(track=True)),
- ("d2h", lambda i: (m._d_cnt[0:1].copy_(p.ndets), m._h_dets.copy_(p.dets[0], non_blocking=True), m._d_cnt[1:2].copy_(p.nout),
-                     m._h_rows.copy_(p.out[0], non_blocking=True), m._h_cnt.copy_(m._d_cnt, non_blocking=True))),
+ ("results", lambda i: p.eng.pack_results(p.ndets, p.dets[0], p.nout, p.out[0], m._h_res)),
  ("sync", lambda i: torch.cuda.current_stream().synchronize()),
 ]
 acc = {k: 0.0 for k, _ in steps}
