@@ -314,6 +314,32 @@ def place_ok(c: int, ctot: int) -> bool:
     return c % 8 == 0 and ctot % 8 == 0
 
 
+class decode_into:
+    """`with decode_into(buf):` — the head decode launched inside (this thread; v8_decode here and in fused32) writes its row tensor
+    [B, 4 + nc (+ n_ext), A] float32 straight into `buf` when shape, dtype and device match, instead of a fresh tensor the caller then
+    copies (the frame pipeline's static NMS input: 54 MB per 32 frames copied once more)."""
+    _tls = threading.local()
+
+    def __init__(self, buf):
+        self.buf = buf
+
+    def __enter__(self):
+        self.prev = getattr(decode_into._tls, "buf", None)
+        decode_into._tls.buf = self.buf
+        return self
+
+    def __exit__(self, *exc):
+        decode_into._tls.buf = self.prev
+        return False
+
+    @staticmethod
+    def target(shape, device):
+        b = getattr(decode_into._tls, "buf", None)
+        if b is not None and tuple(b.shape) == tuple(shape) and b.dtype == torch.float32 and b.device == device and b.is_contiguous():
+            return b
+        return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
 def v8_decode(boxes, clss, box_bias, cls_bias, strides, nc, ext=None, n_ext=0, ext_mode=0):
     """DFL + dist2bbox + sigmoid + level concat of the anchor-free head in one launch -> [B, 4+nc(+n_ext), A] float32.
     ext: the third branch's three outputs [B, >= n_ext, H, W] (bias added), decoded as keypoint triplets (ext_mode 1) or copied raw
@@ -322,7 +348,7 @@ def v8_decode(boxes, clss, box_bias, cls_bias, strides, nc, ext=None, n_ext=0, e
     B = boxes[0].shape[0]
     H = (C.c_int * 3)(*[t.shape[2] for t in boxes]); W = (C.c_int * 3)(*[t.shape[3] for t in boxes])
     A = sum(t.shape[2] * t.shape[3] for t in boxes)
-    pred = torch.empty(B, 4 + nc + n_ext, A, dtype=torch.float32, device=boxes[0].device)
+    pred = decode_into.target((B, 4 + nc + n_ext, A), boxes[0].device)
     arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
     if n_ext or clss[0].shape[1] != nc:                  # a third branch, or class tensors padded past nc channels
         ext = [_cl(t) for t in ext] if n_ext else clss

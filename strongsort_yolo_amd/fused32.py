@@ -13,6 +13,7 @@ import threading
 import torch
 
 from . import lib as _lib
+from . import fused as _fused
 
 ENABLED = True          # A/B: False sends fp32 CUDA tensors to PyTorch-ROCm's library convolutions (the round-4 accuracy mode)
 
@@ -269,7 +270,7 @@ def v8_decode(boxes, clss, strides, nc, ext=None, n_ext=0, ext_mode=0):
     ext = [_cl(t) for t in ext] if n_ext else None
     B = boxes[0].shape[0]
     A = sum(t.shape[2] * t.shape[3] for t in boxes)
-    pred = torch.empty(B, 4 + nc + n_ext, A, dtype=torch.float32, device=boxes[0].device)
+    pred = _fused.decode_into.target((B, 4 + nc + n_ext, A), boxes[0].device)
     arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
     ints = lambda v: (C.c_int * 3)(*v)
     _ck(_lib.load().ss_op32_v8_decode(_st(pred), arr(boxes), arr(clss), arr(ext) if n_ext else None, n_ext, ext[0].shape[1] if n_ext else 0, ext_mode,

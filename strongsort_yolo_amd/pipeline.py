@@ -115,13 +115,20 @@ class FramePipeline:
             e.cmc_estimate(self.frames, 1, self.warps)
         if self.run_nets:
             e.letterbox_batch(self.frames, g, half=self.half, pad_value=self.dcfg.pad_value, out=self.lb, channels_last=True)
-            pred = self._pred(self.detector(self.lb), self.proto)    # [S, 4+nc+nk+nm, A]
-            if self.det_source == "detector":
+            with self._decode_into(self.pred_in):
+                pred = self._pred(self.detector(self.lb), self.proto)    # [S, 4+nc+nk+nm, A]
+            if self.det_source == "detector" and pred.data_ptr() != self.pred_in.data_ptr():
                 self.pred_in.copy_(pred)
         e.nms_batch(self.pred_in, self.nc, self.dcfg, self.geom_dev, n_extra=self.nx, rows=self.dets, keep=self.keep,
                     count=self.ndets, max_det=self.max_det)
         if self.nx:
             self.dets6.copy_(self.dets[:, :, :6])
+
+    def _decode_into(self, buf):
+        """The head's decode launch writes the NMS input in place (fused.decode_into) when the detector feeds the NMS."""
+        import contextlib
+        from . import fused
+        return fused.decode_into(buf) if self.det_source == "detector" else contextlib.nullcontext()
 
     @staticmethod
     def _pred(out, proto_dst):
@@ -437,19 +444,21 @@ class OverlappedPipeline(FramePipeline):
             self._keep(b, "pyr", self.detector.forward_backbone(b.lb))
 
     def _s_head(self, b):
-        pred = self._pred(self.detector.forward_head(*b.pyr), b.proto)
+        with self._decode_into(b.pred_in):
+            pred = self._pred(self.detector.forward_head(*b.pyr), b.proto)
         if self.keep_net_outputs:
             b.head_out = pred
-        if self.det_source == "detector":
+        if self.det_source == "detector" and pred.data_ptr() != b.pred_in.data_ptr():
             b.pred_in.copy_(pred)
 
     def _s_detector(self, b):
         if self.run_nets:
             self._letterbox(b)
-            pred = self._pred(self.detector(b.lb), b.proto)
+            with self._decode_into(b.pred_in):
+                pred = self._pred(self.detector(b.lb), b.proto)
             if self.keep_net_outputs:
                 b.head_out = pred
-            if self.det_source == "detector":
+            if self.det_source == "detector" and pred.data_ptr() != b.pred_in.data_ptr():
                 b.pred_in.copy_(pred)
 
     def _nms_crop(self, b):
