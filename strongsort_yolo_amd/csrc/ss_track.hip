@@ -679,7 +679,12 @@ __global__ __launch_bounds__(256) void k_group_prep(SSDev dev)
                 int4* rec = dev.items + ((size_t)x * dev.items_cap + lbase[x] + pos) * SS_RECI4;
                 int tw[SS_RECT];
                 if (j < ngp) {
-                    const int t0 = (int)((long long)j * ttot / ngp), t1 = (int)((long long)(j + 1) * ttot / ngp), nt = t1 - t0;
+                    // the cut points carry a per-pair offset: WHICH ranges get the extra tile of a division with remainder rotates from pair
+                    // to pair (the same ranges of every pair did, and range j always lives on list j & 7: two lists carried 752 and 744 tiles
+                    // against 692 on the others, their workgroups one step longer than the rest of the launch); a range still starts within
+                    // one tile of the same place for every pair, so its part of the gallery stays in its XCD's L2
+                    const int off = (pp * 5) % ngp;
+                    const int t0 = (int)(((long long)j * ttot + off) / ngp), t1 = (int)(((long long)(j + 1) * ttot + off) / ngp), nt = t1 - t0;
 #pragma unroll
                     for (int u = 0; u < SS_RECT; ++u) tw[u] = u < nt ? tlw[t0 + u] : 0;
                     rec[0] = make_int4(s, plw[pp].x, plw[pp].y, nt << 16);

@@ -62,3 +62,16 @@ for i0, i1 in [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (
 nts = tl[act, 13] & 0xffff
 print("tiles per record (first record of every workgroup):", dict(zip(*np.unique(nts, return_counts=True))), " composite records:", int((tl[act, 13] >> 32).sum()),
       " records per list:", sorted(set(tl[act, 14].tolist())))
+
+# per XCD list (workgroup b serves list b % 8): is the start-up / finish spread systematic?
+print("per XCD: median us of record / staged / done, tiles of its records (sum), latest done")
+for x in range(8):
+    m = act.copy(); m[np.arange(512) % 8 != x] = False
+    r = (tl[m] - t0) / 100.0
+    print(f"  xcd {x}: record {np.median(r[:, 1]):5.2f}  staged {np.median(r[:, 3]):5.2f}  done {np.median(r[:, 12]):5.2f}  max done {r[:, 12].max():5.2f}  tiles {int((tl[m, 13] & 0xffff).sum())}")
+# ... and by position inside the list (dispatch order): quartiles of the workgroup index
+q = np.arange(512) // 8
+for lo in range(0, 64, 16):
+    m = act & (q >= lo) & (q < lo + 16)
+    r = (tl[m] - t0) / 100.0
+    print(f"  list positions {lo:2d}-{lo + 15:2d}: entry {np.median(r[:, 0]):5.2f}  record {np.median(r[:, 1]):5.2f}  staged {np.median(r[:, 3]):5.2f}  done {np.median(r[:, 12]):5.2f}  max done {r[:, 12].max():5.2f}")
