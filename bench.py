@@ -970,11 +970,19 @@ def main():
         pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
         barrier()
         t0, c0 = time.perf_counter(), time.thread_time()
+        if overlap and os.environ.get("SS_PIPE_TRACE"):
+            pipe.trace = []                          # stage / tracker boundaries as timing events (a diagnostic: a few more event records per step)
         run(PREFILL + WF, total)                     # exactly K timed steps (K * frames_per_step frames per stream)
         t_enq = time.perf_counter() - t0             # host wall time to enqueue the K steps (the GPU may still be working; includes the
         t_enq_cpu = time.thread_time() - c0          # time the runtime blocks on full hardware queues) and the CPU time this thread used for it
         barrier()
         dt = time.perf_counter() - t0
+        if overlap and pipe.trace:
+            tr, pipe.trace = pipe.trace, None
+            ref = tr[0][2]
+            print("overlap timeline (ms from the first mark; SS_PIPE_TRACE):", file=sys.stderr)
+            for name, k, ev in tr:
+                print(f"  {ref.elapsed_time(ev):9.3f}  {name:13s} group starting at frame {k}", file=sys.stderr)
         assoc_ms, assoc_n = pipe.eng.assoc_timing(False)
         assoc_order_us = pipe.eng.assoc_timing_values().astype(np.float64) * 1e3         # in launch order
         assoc_each_us = np.sort(assoc_order_us)

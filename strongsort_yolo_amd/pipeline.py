@@ -605,7 +605,9 @@ class OverlappedPipeline(FramePipeline):
                 st.wait_event(self.ev[j - 1][i])
             if j == self.n - 1 and self.defer:
                 self._flush_track(st)                            # the previous group's tracker call, now that stage 0 moved on
+            self._mark(f"stage{j}_start", frame_idx, st)
             self.graphs[j][i].replay()
+            self._mark(f"stage{j}_end", frame_idx, st)
             if j == self.n - 1 and self.defer:
                 self._pending_track = i
             elif j == self.n - 1 and self.sT is not None:        # tracker of this group on its own stream
@@ -631,11 +633,21 @@ class OverlappedPipeline(FramePipeline):
         ev.record(self.sR if self.sR is not None else st)
         self._res_ev = ev
 
+    trace = None                                                 # a list: (name, group, timing event) of every stage / tracker boundary (tools/overlap_timeline.py)
+
+    def _mark(self, name, k, st):
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(st)
+            self.trace.append((name, k, ev))
+
     def _flush_track(self, st):
         i = self._pending_track
         if i is not None:
             self._pending_track = None
+            self._mark("track_start", self.base[i], st)
             self._track_b(self.bufs[i], self.valid[i], self.base[i])
+            self._mark("track_end", self.base[i], st)
             self._mark_tracked(i, st)
             self._gate = self.assoc_ev is not None
 
