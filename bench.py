@@ -713,10 +713,10 @@ def front_rooflines(pipe, n_img, mean_dets, reps=20):
     else:
         t = timed(lambda: e.crop_norm_batch(b.frames, b.dets6, pipe.RB, counts=b.ndets, half=pipe.reid_half, out=b.crops, channels_last=True))
     ncrop = int(b.ndets.clamp(max=pipe.RB).sum().item())
-    by = ncrop * 3 * 256 * 128 * (2 if pipe.reid_half else 4)
+    by = ncrop * 3 * 256 * 128 * b.crops.element_size()
     out["crop"] = {"kernel": "k_crop_hwc8 (a4)", "crops": ncrop, "algorithmic_bytes": by, "mean_call_us": round(t * 1e6, 2),
-                   "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4),
-                   "note": "output bytes only (D x 3 x 256 x 128 halfs); the source boxes are read from L2"}
+                   "achieved_GBps": round(by / t / 1e9, 1), "frac_of_8TBps": round(by / t / 8e12, 4), "element": str(b.crops.dtype).replace("torch.", ""),
+                   "note": "output bytes only (D x 3 x 256 x 128 elements: bytes with the fp32 ReID network, whose stem normalises them; halfs in the f16 mode); the source boxes are read from L2"}
     e._ck(e.L.ss_set_hip_stream(e.ctx, __import__("ctypes").c_void_p(pipe.sB.cuda_stream)))
     return out
 

@@ -93,6 +93,8 @@ int ss_overlay(ss_ctx* ctx, void* hip_stream, uint8_t* d_frames, int batch, long
  * channels-last [out_h][out_w][3] (what the NHWC convolutions read) instead of three planes. */
 #define SS_DST_F16 1
 #define SS_DST_HWC 2
+#define SS_DST_U8 4   /* ss_crop_norm* with SS_DST_HWC only: uint8 output [n][256][128][3] = the rounded bilinear value per RGB channel BEFORE
+                         /255 and mean / std (256 x 3 possible results: the consumer applies them — ss_op32_stem_u8); a quarter of the float bytes */
 int ss_letterbox(ss_ctx* ctx, const uint8_t* d_src, int h, int w, int row_stride, void* d_dst,
                  int dst_flags, int out_h, int out_w, int new_h, int new_w, int pad_top, int pad_left,
                  int pad_value);
@@ -439,6 +441,9 @@ int ss_op32_set_option(const char* name, int value);
 /* conv 7x7 / 2 (3 -> 16) + bias + ReLU + max pool 3x3 / 2: d_x [N][256][128][3] -> d_y [N][64][32][16]; d_w [16][148] with
  * k = (ky * 7 + kx) * 3 + c and a zero in column 147. */
 int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid);
+/* The same operator on BYTE crops [N][256][128][3] (ss_crop_norm_batch / _packed with SS_DST_HWC | SS_DST_U8): /255, mean and std are applied
+ * while the rows are staged, from a table built with ss_crop_norm's own expression - outputs bit-equal to ss_op32_stem on the float crops. */
+int ss_op32_stem_u8(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid);
 /* d_out[n][f] = relu(sum_c d_w[f][c] * mean_hw(d_x[n][.][c]) + d_bias[f]), C == 128. */
 int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F,
                  const int* d_nvalid);

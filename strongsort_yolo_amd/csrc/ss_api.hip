@@ -821,6 +821,7 @@ extern "C" int ss_crop_norm_batch(ss_ctx* c, const uint8_t* frames, int batch, l
 {
     if (!c || !frames || !dets || !out || batch < 0 || n < 0 || (long long)batch * n > 65535)
         return fail(c, SS_ERR_INVALID, "ss_crop_norm: bad argument (batch * n <= 65535)");
+    if ((out_flags & 4) && !(out_flags & 2)) return fail(c, SS_ERR_INVALID, "ss_crop_norm: SS_DST_U8 needs SS_DST_HWC");
     ss_launch_crop(frames, batch, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_counts, out,
                    out_flags, c->stream, nullptr);
     HIPCHK(c, hipGetLastError());

@@ -29,6 +29,10 @@ __device__ inline float ss_bilerp_u8(float p00, float p01, float p10, float p11,
 template <typename T> __device__ inline T ss_cvt(float v);
 template <> __device__ inline float ss_cvt<float>(float v) { return v; }
 template <> __device__ inline __half ss_cvt<__half>(float v) { return __float2half(v); }
+// uint8_t output of the crop kernel: the rounded bilinear value itself (0..255), BEFORE the normalisation — the 256 x 3 possible outputs of
+// ((q / 255) - mean) / sd are applied by the consumer (k32_stemW's staging) from the same expression, so the crops travel as a quarter of the bytes
+template <typename T> struct ss_is_u8 { static constexpr bool value = false; };
+template <> struct ss_is_u8<uint8_t> { static constexpr bool value = true; };
 
 // =================================================================================================
 // a1 letterbox: one thread per output pixel column pair; writes 3 planes
@@ -170,7 +174,8 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
     for (int i = tid; i < 768; i += 256) {
         const int c = i >> 8;
         const float q = (float)(i & 255) / 255.0f;
-        lut[i] = ss_cvt<T>((q - mean[c]) / sd[c]);
+        if constexpr (ss_is_u8<T>::value) lut[i] = (uint8_t)(i & 255);
+        else lut[i] = ss_cvt<T>((q - mean[c]) / sd[c]);
     }
     // source rows of this band (uniform): first row's upper tap .. last row's lower tap
     int ra0, ra1, rb0, rb1; float fa, fb;
@@ -283,11 +288,18 @@ __global__ __launch_bounds__(256) void k_crop_hwc8(const uint8_t* __restrict__ s
         }
         continue;
     }
-    constexpr int NV = 24 * sizeof(T) / 16;
-    uint4* out = reinterpret_cast<uint4*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);
-    const uint4* ov = reinterpret_cast<const uint4*>(o);
+    if constexpr (ss_is_u8<T>::value) {                          // 24 bytes: three 8-byte stores (a group starts at a multiple of 24 bytes)
+        uint2* out = reinterpret_cast<uint2*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);
+        const uint2* ov = reinterpret_cast<const uint2*>(o);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = ov[v];
+        for (int v = 0; v < 3; ++v) out[v] = ov[v];
+    } else {
+        constexpr int NV = 24 * sizeof(T) / 16;
+        uint4* out = reinterpret_cast<uint4*>(dst + (slot * out_h * out_w + (size_t)y * out_w + xg) * 3);
+        const uint4* ov = reinterpret_cast<const uint4*>(o);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) out[v] = ov[v];
+    }
     }
 }
 
@@ -363,6 +375,7 @@ void ss_launch_crop(const uint8_t* frame, int batch, long long frame_batch_strid
     if (n <= 0 || batch <= 0) return;
     if (flags & 2) {
         dim3 grid(1, 16 / CROP_RPT, n * batch), block(256);
+        if (flags & 4) { hipLaunchKernelGGL(k_crop_hwc8<uint8_t>, grid, block, 768 + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (uint8_t*)out, d_off); return; }
         if (flags & 1) hipLaunchKernelGGL(k_crop_hwc8<__half>, grid, block, 768 * sizeof(__half) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (__half*)out, d_off);
         else           hipLaunchKernelGGL(k_crop_hwc8<float>, grid, block, 768 * sizeof(float) + CROP_LDS_BYTES + 8, st, frame, frame_batch_stride, h, w, stride, dets, det_stride, dets_batch_stride, n, d_count, (float*)out, d_off);
         return;

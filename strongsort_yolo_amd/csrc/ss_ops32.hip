@@ -958,24 +958,67 @@ __global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict_
 // weight registers are loaded once per workgroup, and a wave runs TWO tiles side by side (independent accumulator chains: a dependent MFMA
 // issues 40 cycles after its predecessor, an independent one 32).  Per band: [matrix] barrier [store new rows, pool] barrier.  Every sum
 // keeps k32_stem's order (k = 0 .. 147 into one accumulator), so the two kernels agree bit for bit.
+// U8: the crops arrive as bytes (ss_crop_norm* with SS_DST_U8: the rounded bilinear value per RGB channel, NHWC) and the staging applies
+// ((q / 255) - mean) / sd from a 3 x 256 table built with a4's own expression (csrc/ss_front.hip k_crop_hwc8) — the floats that reach the
+// ring are the float crop's, bit for bit, and the crops cross HBM as a quarter of the bytes (the crop launch 147 -> 94 us per 862 crops).
 #define STW_THREADS 512
-__global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const float* __restrict__ x, const float* __restrict__ w /*[16][148]*/,
+template <bool U8>
+__global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const void* __restrict__ xv, const float* __restrict__ w /*[16][148]*/,
                                                             const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img, int nb)
 {
     constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, RING = 24, CSP = 16, RV = Wd * 3 / 4;   // RV: data vectors of an input row (96)
+    constexpr int RB = Wd * 3 / 16;                          // U8: 16-byte vectors of an input row (24)
     extern __shared__ __attribute__((aligned(16))) float smem32[];
     float* __restrict__ In = smem32;                         // [24][404] ring of input rows
     float* __restrict__ Cs = In + RING * ST_ROWP;            // [9][64][16] ring of convolution rows after bias + ReLU
+    float* __restrict__ Lut = Cs + 9 * OW * CSP;             // U8: [3][256]
     const int img = blockIdx.y, b0 = blockIdx.x * nb;
     if (n_img && img >= *n_img) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kq = lane >> 4, n = lane & 15;
-    const float* xi = x + (size_t)img * H * Wd * 3;
+    const float* xi = reinterpret_cast<const float*>(xv) + (size_t)img * H * Wd * 3;
+    const uint8_t* xb = reinterpret_cast<const uint8_t*>(xv) + (size_t)img * H * Wd * 3;
     auto inrow = [&](int iy) { return iy < 0 ? 0 : (iy >= H ? H - 1 : iy); };
     if (tid < RING * 5) {                                    // the rows' zero borders (3 vectors left, 2 right), written once
         const int r = tid / 5, j = tid - 5 * r;
         st4(In + r * ST_ROWP + 4 * (j < 3 ? j : RV + j), zero4());
     }
-    {   // the first band's 23 rows (ring rows 0 .. 22): every vector requested before the first LDS store
+    // U8: 16 bytes of a row (vector c16: positions 16 c16 .. + 15, channel = position mod 3 = (c16 + j) mod 3) -> 16 floats of the ring row
+    auto cvt16 = [&](f4 (&f)[4], const uint4 v, int c16, bool ok) __attribute__((always_inline)) {
+        const int c0 = c16 % 3, o0 = c0 * 256, o1 = (c0 == 2 ? 0 : c0 + 1) * 256, o2 = (c0 == 0 ? 2 : c0 - 1) * 256;
+        const unsigned wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = 4 * q + e;
+                const int b = (int)((wv[q] >> (8 * e)) & 255u);
+                f[q][e] = ok ? Lut[(j % 3 == 0 ? o0 : j % 3 == 1 ? o1 : o2) + b] : 0.f;
+            }
+    };
+    auto put16 = [&](float* dst, const uint4 v, int c16, bool ok) __attribute__((always_inline)) {
+        f4 f[4];
+        cvt16(f, v, c16, ok);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st4(dst + 4 * q, f[q]);
+    };
+    if (U8) {
+        const float mean[3] = { 0.485f, 0.456f, 0.406f }, sd[3] = { 0.229f, 0.224f, 0.225f };
+        for (int i = tid; i < 768; i += STW_THREADS) { const int c = i >> 8; const float q = (float)(i & 255) / 255.0f; Lut[i] = (q - mean[c]) / sd[c]; }
+        __syncthreads();
+        constexpr int TOT = 23 * RB, NIT = (TOT + STW_THREADS - 1) / STW_THREADS;
+        const int iy0 = 16 * b0 - 5;
+        uint4 v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = min(tid + u * STW_THREADS, TOT - 1), lr = i / RB, c16 = i - lr * RB;
+            v[u] = *reinterpret_cast<const uint4*>(xb + (size_t)inrow(iy0 + lr) * (Wd * 3) + 16 * c16);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * STW_THREADS, lr = i / RB, c16 = i - lr * RB, iy = iy0 + lr;
+            if (i < TOT) put16(In + lr * ST_ROWP + 12 + 16 * c16, v[u], c16, iy >= 0 && iy < H);
+        }
+    } else {   // the first band's 23 rows (ring rows 0 .. 22): every vector requested before the first LDS store
         constexpr int TOT = 23 * RV, NIT = (TOT + STW_THREADS - 1) / STW_THREADS;
         const int iy0 = 16 * b0 - 5;
         f4 v[NIT];
@@ -1002,12 +1045,18 @@ __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const float* __restr
         const int band = b0 + bi, cy0 = 8 * band - 1, iy0 = 16 * band - 5;
         const bool more = bi + 1 < nb;
         __syncthreads();                                     // this band's rows are in the ring; the previous band's pool is done with Cs
-        f4 pf[3];
+        f4 pf[U8 ? 1 : 3];
+        uint4 pb = { 0u, 0u, 0u, 0u };
         if (more) {
+            if (U8) {                                        // the next band's 16 new rows: 384 vectors of 16 bytes
+                const int i = min(tid, 16 * RB - 1), j = i / RB, c16 = i - j * RB;
+                pb = *reinterpret_cast<const uint4*>(xb + (size_t)inrow(iy0 + 23 + j) * (Wd * 3) + 16 * c16);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {                    // the next band's 16 new rows: 1 536 vectors
-                const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV;
-                pf[u] = ld4(xi + (size_t)inrow(iy0 + 23 + j) * (Wd * 3) + 4 * c4);
+                for (int u = 0; u < 3; ++u) {                // the next band's 16 new rows: 1 536 vectors
+                    const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV;
+                    pf[u] = ld4(xi + (size_t)inrow(iy0 + 23 + j) * (Wd * 3) + 4 * c4);
+                }
             }
         }
         const int first = bi ? 1 : 0;                        // convolution row 0 of a later band is the previous band's row 8
@@ -1054,11 +1103,19 @@ __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const float* __restr
         }
         __syncthreads();                                     // Cs complete; local rows 0 .. 15 of the ring are dead
         if (more) {
+            if (U8) {
+                if (tid < 16 * RB) {
+                    const int j = tid / RB, c16 = tid - j * RB, iy = iy0 + 23 + j;
+                    int r = base + 23 + j; r = r >= RING ? r - RING : r; r = r >= RING ? r - RING : r;
+                    put16(In + r * ST_ROWP + 12 + 16 * c16, pb, c16, iy >= 0 && iy < H);
+                }
+            } else {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV, iy = iy0 + 23 + j;
-                int r = base + 23 + j; r = r >= RING ? r - RING : r; r = r >= RING ? r - RING : r;
-                st4(In + r * ST_ROWP + 12 + 4 * c4, (iy >= 0 && iy < H) ? pf[u] : zero4());
+                for (int u = 0; u < 3; ++u) {
+                    const int i = tid + u * STW_THREADS, j = i / RV, c4 = i - j * RV, iy = iy0 + 23 + j;
+                    int r = base + 23 + j; r = r >= RING ? r - RING : r; r = r >= RING ? r - RING : r;
+                    st4(In + r * ST_ROWP + 12 + 4 * c4, (iy >= 0 && iy < H) ? pf[u] : zero4());
+                }
             }
         }
         {
@@ -1568,15 +1625,31 @@ extern "C" int ss_op32_tail(void* stream, const void* const* d_ys, const float* 
     return SS_ERR_INVALID;
 }
 
+static int stem_bands(int N) { return g_stem_walk > 0 ? g_stem_walk : (N >= 1024 ? 16 : N >= 512 ? 8 : N >= 128 ? 4 : 2); }   // bands a workgroup walks down (measured at 1 024 / 860 / 430 / 28 crops: tools/stem32_time.py)
+
+// The stem on BYTE crops [N][256][128][3] (ss_crop_norm* with SS_DST_U8): the normalisation happens while the rows are staged.
+extern "C" int ss_op32_stem_u8(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid)
+{
+    if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
+    constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16 + 768) * 4;
+    static unsigned long long attr = 0;
+    const int nb = stem_bands(N);
+    if (!lds_attr_once((const void*)k32_stemW<true>, attr)) return SS_ERR_HIP;
+    hipLaunchKernelGGL(k32_stemW<true>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w,
+                       (const float*)d_bias, (float*)d_y, N, d_nvalid, nb);
+    OP32_CHECK();
+    return SS_OK;
+}
+
 extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid)
 {
     if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
     constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16) * 4;
     static unsigned long long attr = 0, attr_w = 0;
-    const int nb = g_stem_walk > 0 ? g_stem_walk : (g_stem_walk < 0 ? 0 : (N >= 1024 ? 16 : N >= 512 ? 8 : N >= 128 ? 4 : 2));   // bands a workgroup walks down (measured at 1 024 / 860 / 430 / 28 crops: tools/stem32_time.py); -1: one band, k32_stem
+    const int nb = g_stem_walk < 0 ? 0 : stem_bands(N);      // -1: one band per workgroup, k32_stem
     if (nb) {
-        if (!lds_attr_once((const void*)k32_stemW, attr_w)) return SS_ERR_HIP;
-        hipLaunchKernelGGL(k32_stemW, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, (const float*)d_x, (const float*)d_w,
+        if (!lds_attr_once((const void*)k32_stemW<false>, attr_w)) return SS_ERR_HIP;
+        hipLaunchKernelGGL(k32_stemW<false>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w,
                            (const float*)d_bias, (float*)d_y, N, d_nvalid, nb);
         OP32_CHECK();
         return SS_OK;

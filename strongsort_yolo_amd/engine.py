@@ -404,7 +404,7 @@ class TrackerEngine:
         if out is None:
             out = torch.empty(B * n, 3, 256, 128, dtype=torch.float16 if half else torch.float32, device=self.device,
                               memory_format=torch.channels_last if channels_last else torch.contiguous_format)
-        flags = (_lib.DST_F16 if half else 0) | (_lib.DST_HWC if channels_last else 0)
+        flags = (_lib.DST_U8 if out.dtype == torch.uint8 else _lib.DST_F16 if half else 0) | (_lib.DST_HWC if channels_last else 0)
         self._ck(self.L.ss_crop_norm_batch(self.ctx, _ptr(frames), B, frames.stride(0), H, W, frames.stride(1), _ptr(dets),
                                            dets.stride(1), dets.stride(0), n, _ptr(counts), _ptr(out), flags))
         return out
@@ -412,9 +412,10 @@ class TrackerEngine:
     def crop_norm_packed(self, frames: torch.Tensor, dets: torch.Tensor, n: int, counts: torch.Tensor, offsets: torch.Tensor,
                          out: torch.Tensor, half: bool = True):
         """Packed crops (channels-last `out` [B*n,3,256,128]): offsets int32 [B+1] <- exclusive prefix of min(counts, n); crop d
-        of image i at slot offsets[i] + d; offsets[B] = crops in total."""
+        of image i at slot offsets[i] + d; offsets[B] = crops in total.  A uint8 `out` receives the rounded bilinear values before
+        the normalisation (SS_DST_U8: the fp32 ReID stem applies /255, mean and std itself)."""
         B, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
-        flags = (_lib.DST_F16 if half else 0) | _lib.DST_HWC
+        flags = ((_lib.DST_U8 if out.dtype == torch.uint8 else _lib.DST_F16 if half else 0)) | _lib.DST_HWC
         self._ck(self.L.ss_crop_norm_packed(self.ctx, _ptr(frames), B, frames.stride(0), H, W, frames.stride(1), _ptr(dets),
                                             dets.stride(1), dets.stride(0), n, _ptr(counts), _ptr(offsets), _ptr(out), flags))
         return out

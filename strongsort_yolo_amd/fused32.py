@@ -89,9 +89,39 @@ def _cached(mod, name, like, build):
     return t
 
 
+def usable_u8(x) -> bool:
+    """Byte crops (engine.crop_norm_* into a uint8 tensor: the rounded bilinear values, NHWC) the stem normalises itself."""
+    return (ENABLED and isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.uint8 and x.dim() == 4 and tuple(x.shape[1:]) == (3, 256, 128)
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+_MEAN, _STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+_LUT = {}
+
+
+def crops_from_u8(x):
+    """Byte crops -> the float crops a4 would have written, channels-last: ((q / 255) - mean) / sd per value with IEEE float32 operations.
+    The 3 x 256 table is computed on the HOST (numpy): PyTorch-ROCm's device division is not correctly rounded (322 of the 768 entries
+    come out one ulp off), a4's and k32_stemW's are (csrc/Makefile: -fhip-fp32-correctly-rounded-divide-sqrt)."""
+    import numpy as np
+    lut = _LUT.get(x.device)
+    if lut is None:
+        q = np.arange(256, dtype=np.float32) / np.float32(255.0)
+        tab = np.stack([(q - np.float32(m)) / np.float32(sd) for m, sd in zip(_MEAN, _STD)]).astype(np.float32)      # [3, 256]
+        lut = _LUT[x.device] = torch.from_numpy(tab).to(x.device)
+    idx = x.long()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last)
+    for c in range(3):
+        out[:, c] = lut[c][idx[:, c]]
+    return out
+
+
 def stem(x, cbr):
-    """relu(conv7x7/2(x) + b) -> max pool 3x3/2: x [N, 3, 256, 128] channels-last float -> [N, 16, 64, 32]."""
-    x = _cl(x)
+    """relu(conv7x7/2(x) + b) -> max pool 3x3/2: x [N, 3, 256, 128] channels-last float (or uint8 byte crops) -> [N, 16, 64, 32]."""
+    if x.dtype != torch.uint8:
+        x = _cl(x)
     n, _, h, w = x.shape
     conv = cbr.conv
 
@@ -102,7 +132,8 @@ def stem(x, cbr):
 
     wk = _cached(cbr, "_w32_stem", conv.weight, build)
     y = torch.empty((n, 16, h // 4, w // 4), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _ck(_lib.load().ss_op32_stem(_st(x), _p(x), _p(wk), _p(conv.bias), _p(y), n, h, w, _nvp(x)))
+    fn = _lib.load().ss_op32_stem_u8 if x.dtype == torch.uint8 else _lib.load().ss_op32_stem
+    _ck(fn(_st(x), _p(x), _p(wk), _p(conv.bias), _p(y), n, h, w, _nvp(x)))
     return y
 
 

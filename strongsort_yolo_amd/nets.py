@@ -1013,6 +1013,13 @@ class OSNet(nn.Module):
     def _part(self, k, x):
         """The backbone as 10 consecutive parts, so a frame pipeline can cut it anywhere to balance its stages.  The state
         between parts is a tensor or a tuple of tensors (see _block_part)."""
+        if k == 0 and isinstance(x, torch.Tensor) and x.dtype == torch.uint8:      # byte crops (a4 with SS_DST_U8): the fp32 stem normalises them itself
+            if fused32.usable_u8(x):
+                if getattr(self, "_ok32", None) is None:
+                    self._ok32 = fused32.osnet_ok(self, torch.empty(1, 3, 256, 128, device=x.device))
+                if self._ok32:
+                    return self._part32(0, x)
+            x = fused32.crops_from_u8(x).to(self.conv1.conv.weight.dtype)
         if self._fp32_kernels(x):
             first = x[0] if isinstance(x, tuple) else x
             want = {0: (256, 128), 1: (64, 32), 2: (64, 32), 4: (32, 16), 5: (32, 16), 7: (16, 8), 8: (16, 8)}.get(k)

@@ -39,7 +39,7 @@ class FramePipeline:
                  half: bool = True, reid_batch: int = 32, cfg: Optional[StrongSortConfig] = None,
                  dcfg: Optional[DetectConfig] = None, det_source: str = "detector", feat_source: str = "reid",
                  graph: str = "all", debug: bool = False, run_nets: bool = True, seed: int = 0, detect_only_rows: int = 0, cmc: bool = False,
-                 reid_half: Optional[bool] = None):
+                 reid_half: Optional[bool] = None, crops_u8: bool = True):
         self.cfg, self.dcfg = cfg or StrongSortConfig(), dcfg or DetectConfig()
         self.S, (self.H, self.W) = n_streams, frame_hw
         self.eng = TrackerEngine(self.cfg, n_streams, device, debug=debug)
@@ -51,6 +51,10 @@ class FramePipeline:
         # the reference passes no half=, yolo_multi_model.py:41).  Default: as the detector.
         self.reid_half = half if reid_half is None else bool(reid_half)
         self.reid_dtype = torch.float16 if self.reid_half else torch.float32
+        # fp32 ReID: the crops cross HBM as BYTES (the rounded bilinear values; SS_DST_U8) and the fp32 stem applies /255, mean and std while
+        # it stages them - the same floats, a quarter of the bytes (crops_u8=False: A/B switch, float crops)
+        from . import fused32 as _f32
+        self.crops_dtype = torch.uint8 if (not self.reid_half and crops_u8 and run_nets and _f32.ENABLED) else self.reid_dtype
         self.det_source, self.feat_source, self.run_nets = det_source, feat_source, run_nets
         self.RB = reid_batch
         if reid_batch > MAX_DETS:
@@ -89,7 +93,7 @@ class FramePipeline:
         self.proto = torch.zeros(S, self.nm, g.out_h // 4, g.out_w // 4, dtype=self.dtype, device=dev) if self.nm else None
         self.keep = torch.zeros(S, self.det_rows, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.reid_dtype, device=dev).contiguous(memory_format=torch.channels_last)
+        self.crops = torch.zeros(S * self.RB, 3, 256, 128, dtype=self.crops_dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.feats_in = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.img_hw = torch.tensor([[self.H, self.W]] * S, dtype=torch.int32, device=dev)
         self.out, self.nout = self.eng.out, self.eng.nout
@@ -274,7 +278,7 @@ class _Bufs:
         self.proto = torch.zeros(S, p.nm, p.geom.out_h // 4, p.geom.out_w // 4, dtype=p.dtype, device=dev) if p.nm else None
         self.keep = torch.zeros(S, MAX_DETS, dtype=torch.int32, device=dev)
         self.ndets = torch.zeros(S, dtype=torch.int32, device=dev)
-        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.reid_dtype, device=dev).contiguous(memory_format=torch.channels_last)
+        self.crops = torch.zeros(S * p.RB, 3, 256, 128, dtype=p.crops_dtype, device=dev).contiguous(memory_format=torch.channels_last)
         self.anchor_gt = torch.zeros(S, p.n_anchors, dtype=torch.int64, device=dev)
         self.gt_feats = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)
         self.feats_v = torch.zeros(S, MAX_DETS, FEAT_DIM, dtype=torch.float32, device=dev)    # what the tracker reads

@@ -292,3 +292,33 @@ def test_nms_classes_override(eng):
             assert set(rrows[:, 5].astype(int).tolist()) <= set(classes) and (k > 0) == (79 not in classes)
     finally:
         eng.nms_set_classes(None)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_crop_norm_byte_output_is_the_float_crop_before_normalisation(eng, packed):
+    """SS_DST_U8: the crop kernel hands over the rounded bilinear bytes; ((q / 255) - mean) / sd applied to them (fused32.crops_from_u8, the
+    expression k32_stemW's staging uses) gives the float crops bit for bit — large boxes (global-load path), clipped and sub-pixel ones included."""
+    from strongsort_yolo_amd import fused32
+    W, H, B, n = 1280, 720, 3, 32
+    rng = np.random.default_rng(31)
+    frames = torch.from_numpy(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)).to(eng.device)
+    x1 = rng.uniform(-10, W - 40, (B, n)); y1 = rng.uniform(-10, H - 60, (B, n))
+    bw = rng.uniform(0.3, 500, (B, n)); bh = rng.uniform(0.3, 650, (B, n))
+    dets = np.stack([x1, y1, x1 + bw, y1 + bh, np.ones((B, n)), np.zeros((B, n))], 2).astype(np.float32)
+    dets = torch.from_numpy(dets).to(eng.device)
+    counts = torch.tensor([32, 0, 17], dtype=torch.int32, device=eng.device)
+    mk = lambda dt: torch.zeros(B * n, 3, 256, 128, dtype=dt, device=eng.device).contiguous(memory_format=torch.channels_last)
+    f32, u8 = mk(torch.float32), mk(torch.uint8)
+    if packed:
+        off = torch.zeros(B + 1, dtype=torch.int32, device=eng.device)
+        eng.crop_norm_packed(frames, dets, n, counts, off, f32, half=False)
+        eng.crop_norm_packed(frames, dets, n, counts, off, u8)
+        k = int(off[B].item())
+        assert k == 49
+        a, b = f32[:k], fused32.crops_from_u8(u8[:k])
+    else:
+        eng.crop_norm_batch(frames, dets, n, counts=counts, half=False, out=f32, channels_last=True)
+        eng.crop_norm_batch(frames, dets, n, counts=counts, out=u8, channels_last=True)
+        sel = torch.cat([torch.arange(0, 32), torch.arange(64, 81)]).to(eng.device)
+        a, b = f32[sel], fused32.crops_from_u8(u8[sel])
+    assert bits_equal(a.cpu().numpy(), b.cpu().numpy())

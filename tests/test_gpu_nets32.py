@@ -93,6 +93,28 @@ def test_stem_walking_form_equals_band_form(walk):
         fused32.set_option("stem_walk", 0)
 
 
+@pytest.mark.parametrize("n", [3, 140, 600])
+def test_stem_on_byte_crops_equals_stem_on_float_crops(n):
+    """k32_stemW<true> (byte crops, /255 + mean + std applied while the rows are staged) == the float form on fused32.crops_from_u8 of the same
+    bytes, bit for bit, at 2 / 4 / 8 bands per workgroup and with a valid-image count below the batch."""
+    from strongsort_yolo_amd import fused32, nets
+    g = torch.Generator().manual_seed(n)
+    m = nets.ConvBR(3, 16, 7, 2, 3)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn(m.conv.weight.shape, generator=g) * 0.2)
+        m.conv.bias.copy_(torch.randn(16, generator=g))
+    m = m.to(DEV)
+    xb = torch.randint(0, 256, (n, 3, 256, 128), dtype=torch.uint8, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    ref = fused32.stem(fused32.crops_from_u8(xb), m)
+    got = fused32.stem(xb, m)
+    assert got.cpu().numpy().tobytes() == ref.cpu().numpy().tobytes()
+    nv = torch.tensor([max(1, n // 3)], dtype=torch.int32, device=DEV)
+    with fused32.valid_images(nv):
+        part = fused32.stem(xb, m)
+    k = int(nv.item())
+    assert part[:k].cpu().numpy().tobytes() == ref[:k].cpu().numpy().tobytes()
+
+
 def _block(c1, c2, seed):
     from strongsort_yolo_amd import nets
     g = torch.Generator().manual_seed(seed)

@@ -17,16 +17,16 @@ for name, (bw, bh) in {"boxes 60x140": (60, 140), "boxes 110x260": (110, 260), "
     x1 = torch.rand(B, n, generator=g) * (W - bw - 2); y1 = torch.rand(B, n, generator=g) * (H - bh - 2)
     w = bw * (0.7 + 0.6 * torch.rand(B, n, generator=g)); h = bh * (0.7 + 0.6 * torch.rand(B, n, generator=g))
     dets = torch.stack([x1, y1, (x1 + w).clamp(max=W - 1), (y1 + h).clamp(max=H - 1), torch.ones(B, n), torch.zeros(B, n)], 2).to(dev).contiguous()
-    for half in (True, False):
-        out = torch.empty(B * n, 3, 256, 128, dtype=torch.float16 if half else torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+    for half in (True, False, "u8"):
+        out = torch.empty(B * n, 3, 256, 128, dtype=torch.uint8 if half == "u8" else torch.float16 if half else torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
         s = torch.cuda.current_stream(dev)
         for _ in range(3):
-            eng.crop_norm_packed(frames, dets, n, counts, offs, out, half=half)
+            eng.crop_norm_packed(frames, dets, n, counts, offs, out, half=half is True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
         for _ in range(reps):
-            eng.crop_norm_packed(frames, dets, n, counts, offs, out, half=half)
+            eng.crop_norm_packed(frames, dets, n, counts, offs, out, half=half is True)
         e1.record(s); s.synchronize()
-        res[f"{name} {'f16' if half else 'f32'}"] = round(e0.elapsed_time(e1) / reps * 1e3, 1)
-        res[f"{name} {'f16' if half else 'f32'} checksum"] = float(out[: int(offs[B])].float().sum())
+        res[f"{name} {'u8' if half == 'u8' else 'f16' if half else 'f32'}"] = round(e0.elapsed_time(e1) / reps * 1e3, 1)
+        res[f"{name} {'u8' if half == 'u8' else 'f16' if half else 'f32'} checksum"] = float(out[: int(offs[B])].float().sum())
 print({"crops": int(offs[B]), "us": res})

@@ -30,4 +30,21 @@ for N in Ns:
             e1.record(s); s.synchronize()
         row[{-1: "band_form_us", 0: "auto_us"}.get(walk, f"walk{walk}_us")] = round(e0.elapsed_time(e1) * 1e3 / reps / 4, 1)
     fused32.set_option("stem_walk", 0)
+    xb = torch.randint(0, 256, (N, 3, 256, 128), dtype=torch.uint8, device=dev).contiguous(memory_format=torch.channels_last)
+    s = torch.cuda.Stream()
+    with torch.no_grad(), torch.cuda.stream(s):
+        for _ in range(2):
+            fused32.stem(xb, stem)
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(4):
+                fused32.stem(xb, stem)
+        g.replay(); s.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        for _ in range(reps):
+            g.replay()
+        e1.record(s); s.synchronize()
+    row["byte_crops_auto_us"] = round(e0.elapsed_time(e1) * 1e3 / reps / 4, 1)
     print(json.dumps(row))
