@@ -1202,6 +1202,7 @@ def main():
                                        ("fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)")),
                     "frames_per_s": round(S * A2.KF / A2.dt, 2), "ms_per_step": round(A2.dt / A2.K * 1e3, 4), "ms_per_step_distribution": A2.step_ms, "steps": A2.K, "warmup": A2.Wm, "frames_per_step": FPS,
                     "ratio_to_default": round((S * A2.KF / A2.dt) / (S * KF / dt), 4),
+                    "host_enqueue_ms_per_step": round(A2.t_enq / A2.K * 1e3, 3), "host_enqueue_cpu_ms_per_step": round(A2.t_enq_cpu / A2.K * 1e3, 3),
                     "id_match_rate": round(a_same / max(a_tot, 1), 6), "frames_bit_exact": f"{a_exact}/{A2.total}", "frames_bit_exact_timed": f"{a_exact_timed}/{a_ntimed}",
                     "distance_err": t.get("cost_matrix_cosine_max_abs_err"), "embedding_err": t.get("embedding_unit_max_abs_err"),
                     "true_path_id_match_rate": t.get("id_match_rate"), "within_north_star_bound_1e-4": t.get("within_bound"),

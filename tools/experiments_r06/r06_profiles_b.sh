@@ -8,7 +8,7 @@ bash tools/pmc_assoc.sh c4_s1_f32 1 32 k_assoc 100 1920 1080 > $out/pmc_c4_s1_f3
 python - <<'PY'
 import json, os
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
-res = {"_note": "rocprofv3 --pmc passes (tools/pmc_assoc.sh: SQ group, TCC hit/miss, FETCH_SIZE, WRITE_SIZE in separate runs) over tools/batched_assoc.py <streams> <frame_batch> [identities W H] (tracker-only loop, 160 frames: galleries full), round-6 binary (k_assoc unchanged since round 5); means over the last 3 k_assoc launches. hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024. Keys: <workload>_s<streams>_f<frames> (bench.py roofline.traffic) and <workload>_b<streams>_f<frames> (roofline_batched); workload c2 = 30 identities at 1280x720 (presets c2, c3, c5, c6 share it), c4 = 100 identities at 1920x1080."}
+res = {"_note": "rocprofv3 --pmc passes (tools/pmc_assoc.sh: SQ group, TCC hit/miss, FETCH_SIZE, WRITE_SIZE in separate runs) over tools/batched_assoc.py <streams> <frame_batch> [identities W H] (tracker-only loop, 160 frames: galleries full), round-6 final binary (k_assoc as in round 5; k_group_prep rotates the remainder tiles of a pair over its ranges); means over the last 3 k_assoc launches. hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md HBM section) + WRITE_SIZE*1024. Keys: <workload>_s<streams>_f<frames> (bench.py roofline.traffic) and <workload>_b<streams>_f<frames> (roofline_batched); workload c2 = 30 identities at 1280x720 (presets c2, c3, c5, c6 share it), c4 = 100 identities at 1920x1080."}
 for tag in ("c2_s1_f32", "c2_b32_f32", "c4_s1_f32"):
     try:
         res[tag] = json.load(open(f"{root}/pmc_{tag}/summary.json"))
