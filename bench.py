@@ -798,7 +798,8 @@ def main():
     ap.add_argument("--reid-fp32", action="store_true", help="(the default since round 6) ReID crops + OSNet-x0.25 with fp32 activations on the hand-written fp32 kernels (csrc/ss_ops32.hip): the configuration that meets north_star's 1e-4 on the true ReID path")
     ap.add_argument("--det-fp32", action="store_true", help="the detector in fp32 too — every network operation of the path in fp32 (the default line carries this measurement as `all_fp32`)")
     ap.add_argument("--no-accuracy-mode", action="store_true", help="skip the second, shorter timed run in the other ReID precision (`throughput_mode`; `accuracy_mode` with --reid-f16) and `all_fp32`")
-    ap.add_argument("--accuracy-steps", type=int, default=10, help="timed steps of that second run")
+    ap.add_argument("--accuracy-steps", type=int, default=20, help="timed steps of that second run")
+    ap.add_argument("--legs-in-process", action="store_true", help="run `throughput_mode` / `all_fp32` as further pipelines of THIS process (until round 6; a later pipeline of a process can be up to 2 x slower) instead of fresh child processes")
     ap.add_argument("--check-frames", type=int, default=-1, help="frames (from the start of the run) compared with the oracle; -1: all of them, the timed ones included")
     ap.add_argument("--tracker-stream", action="store_true", help="tracker on its own HIP stream + a third buffer set (measured slower)")
     ap.add_argument("--defer-track", type=int, default=1, help="1: the tracker call of a group is enqueued after the last stage's stream has waited for stage 0 of the next group (it then runs beside the start of that group, away from the OSNet row-stream kernel)")
@@ -1143,6 +1144,7 @@ def main():
             "dtype": ("f32 association / f64 Kalman+LSAP (" + ("fp32 detector convs" if args.det_fp32 else "f16 detector convs") + ", fp32 ReID network on own v_mfma_f32 kernels)" if args.reid_fp32 else
                       "f32 association / f64 Kalman+LSAP (f16 detector+ReID convs: throughput mode, misses the 1e-4 float bound)"), "data": "synthetic",
             "reid_precision": "fp32 (hand-written kernels, csrc/ss_ops32.hip)" if args.reid_fp32 else "f16 (hand-written kernels, csrc/ss_ops.hip)",
+            "detector_precision": ("fp32, hand-written kernels (csrc/ss_ops32.hip k32_conv)" if getattr(pipe.detector, "_own32", False) else "fp32, PyTorch-ROCm library convolutions") if args.det_fp32 else "f16 (hand-written kernels, csrc/ss_ops.hip)",
             "config": {"workload": (f"configs[{CONFIG_INDEX[args.preset]}]" if CONFIG_INDEX[args.preset] is not None else "reference default model (yolo_multi_model.py:17)") + f": {detector} + StrongSORT(OSNet-x0.25), {W}x{H}, "
                                    f"{n_ids} identities (~{Dm:.1f} det/frame), {S} stream(s) per GPU, gallery {cfg.nn_budget} rows",
                        "streams_per_gpu": S, "graph": args.graph, "frame_pipeline": (f"{pipe.n}-stage frame pipeline on {pipe.n} HIP streams" + (" + tracker stream" if pipe.sT is not None else "")) if overlap else "sequential", "frame_batch": FB, "nets": not args.no_nets, "prefill_frames": PREFILL,
@@ -1190,13 +1192,48 @@ def main():
             tp = (res.get("reid_f16_vs_f32") or {})
             tp32, tp16 = tp.get("fp32_reid_mode") or {}, tp
 
+            def child_line(extra):
+                """The same command as this run with `extra` switches, no side legs, in a FRESH process: a pipeline that is not the first of
+                its process can run up to 2 x slower (its tracker call 3 ms instead of 0.7 beside stage A — the state of the process's
+                hardware queues decides how the one-workgroup chain kernels are scheduled; round 6: 6 600 - 10 000 frames/s in-process against
+                13 200 as a process of its own, same code), and the question these legs answer is what the OTHER precision does as a run."""
+                import subprocess
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(2, args.accuracy_steps)), "--warmup", "2", "--preset", args.preset,
+                       "--streams", str(args.streams), "--graph", args.graph, "--frame-batch", str(args.frame_batch), "--overlap", str(args.overlap),
+                       "--groups-per-step", str(args.groups_per_step), "--defer-track", str(args.defer_track), "--no-cpu-baseline", "--no-batched", "--no-api-path",
+                       "--no-reid-check", "--no-accuracy-mode"] + extra
+                for kv in args.pipe: cmd += ["--pipe", kv]
+                for kv in args.opt: cmd += ["--opt", kv]
+                for kv in args.fused: cmd += ["--fused", kv]
+                env = dict(os.environ)
+                for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SS_PIPE_TRACE"):
+                    env.pop(k, None)
+                env["SS_BENCH_CHILD"] = "1"
+                out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+                if out.returncode != 0 or not lines:
+                    raise RuntimeError(f"child bench failed (rc {out.returncode}): {out.stderr[-300:]}")
+                return json.loads(lines[-1])
+
             def other_mode(other_half):
+                t = tp16 if other_half else tp32
+                if not args.legs_in_process:
+                    c = child_line(["--reid-f16"] if other_half else [])
+                    return {
+                        "reid_precision": c["reid_precision"], "frames_per_s": c["value"], "ms_per_step": c["ms_per_step"], "ms_per_step_distribution": c.get("ms_per_step_distribution"),
+                        "steps": c["steps"], "warmup": c["warmup"], "frames_per_step": c["frames_per_step"], "ratio_to_default": round(c["value"] / (S * KF / dt), 4),
+                        "process": "a fresh process running this command with " + ("--reid-f16" if other_half else "the fp32 ReID network") + " and no side legs",
+                        "id_match_rate": c["id_match_rate"], "frames_bit_exact": c["frames_bit_exact"], "frames_bit_exact_timed": c.get("frames_bit_exact_timed"),
+                        "distance_err": t.get("cost_matrix_cosine_max_abs_err"), "embedding_err": t.get("embedding_unit_max_abs_err"),
+                        "true_path_id_match_rate": t.get("id_match_rate"), "within_north_star_bound_1e-4": t.get("within_bound"),
+                        "net_outputs_check": c.get("net_outputs_check"), "association_launch_us": (c.get("roofline") or {}).get("mean_launch_us"),
+                        "note": "same workload, same pipeline, same checks as the default line in the other ReID precision; distance_err / true_path_id_match_rate: "
+                                "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32)"}
                 A2 = timed_pipeline(other_half, max(2, args.accuracy_steps), 2)
                 a_same, a_tot, a_exact, a_exact_timed, a_ntimed = id_check(A2, A2.total)
                 a_nets = net_outputs_check(A2.pipe)
                 on_own = bool(getattr(A2.pipe.reid, "_ok32", False))
                 A2.pipe.close()
-                t = tp16 if other_half else tp32
                 return {
                     "reid_precision": ("f16 activations, hand-written kernels (csrc/ss_ops.hip)" if other_half else
                                        ("fp32 activations + weights, hand-written kernels (csrc/ss_ops32.hip, v_mfma_f32_16x16x4_f32)" if on_own else "fp32 on the library convolutions (own kernels NOT used)")),
@@ -1211,6 +1248,11 @@ def main():
                             "150 frames of the true ReID data path against the CPU fp32 network + C-oracle tracker (reid_f16_vs_f32)"}
 
             def all_fp32():
+                if not args.legs_in_process:
+                    c = child_line(["--det-fp32"])
+                    return {"detector": c.get("detector_precision"), "reid": c["reid_precision"],
+                            "frames_per_s": c["value"], "ms_per_step": c["ms_per_step"], "ms_per_step_distribution": c.get("ms_per_step_distribution"), "steps": c["steps"],
+                            "id_match_rate": c["id_match_rate"], "frames_bit_exact": c["frames_bit_exact"], "process": "a fresh process running this command with --det-fp32 and no side legs"}
                 A3 = timed_pipeline(False, max(2, args.accuracy_steps), 3, half=False)
                 b_same, b_tot, b_exact, b_exact_timed, b_ntimed = id_check(A3, A3.total)
                 det_own = bool(getattr(A3.pipe.detector, "_own32", False))
