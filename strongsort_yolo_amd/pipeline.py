@@ -310,7 +310,7 @@ class OverlappedPipeline(FramePipeline):
 
     def __init__(self, *a, n_stages: int = 2, frame_batch: int = 1, reid_split: Optional[int] = None,
                  tracker_stream: bool = False, defer_track: bool = False, keep_net_outputs: bool = False, pack_crops: bool = True,
-                 assoc_gate: bool = True, track_priority: bool = True, skip_tracker: bool = False, chain_cus: int = 0, **kw):
+                 assoc_gate: bool = True, track_priority: bool = False, skip_tracker: bool = False, chain_cus: int = 0, **kw):
         kw = dict(kw)
         # keep_net_outputs: every buffer set keeps a reference to the head tensor and the embeddings its graphs produce
         # (b.head_out / b.emb_out: tensors of the graph's private pool, same address at every replay) even when the synthetic
@@ -359,9 +359,12 @@ class OverlappedPipeline(FramePipeline):
             st += [self._s_nms_crop_reid_select]
         self.stages = st
         self.n = len(st)
-        # the last stage carries the tracker's short dependent launches and the association kernel: its stream gets high
-        # priority, so their workgroups are dispatched ahead of the other stream's network kernels (measured at frame batch
-        # 32: association launch 61 -> 50 us beside the network kernels, 8640 -> 8790 frames/s; track_priority=False: A/B)
+        # track_priority=True gives the last stage's stream (the tracker's short dependent launches, the association kernel) high
+        # priority.  OFF by default since round 6: with the association launch alone on the chip (assoc_gate) the first two pipelines
+        # of a process run the same with and without it (13 700 / 8 900 frames/s, f16 / fp32 ReID), and from the THIRD pipeline a process
+        # creates on, the high-priority stream makes things worse — the tracker call takes 0.9-3.1 ms instead of 1.4-1.6 and the step
+        # 3.3-3.8 ms instead of 2.3 (f16), 4.4-5.0 instead of 3.6 (fp32): tools/pipeline_reuse.py.  (An application re-creates its
+        # pipeline whenever `model.overrides` change; bench.py's side legs did.)
         hi = bool(track_priority)
         # chain_cus = n > 0: the tracker's per-frame chain (one- to 64-workgroup kernels, ~27 us a frame, strictly dependent) is
         # detached onto a library stream that owns n compute units (n / 8 per XCD), every stream of this pipeline is created without
