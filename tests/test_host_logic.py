@@ -96,3 +96,35 @@ def test_pose_head_decodes_keypoints_like_ultralytics():
     assert torch.allclose(k[:, 0], (raw[0, :, 0] * 2 + g[0]) * g[2], atol=1e-5)
     assert torch.allclose(k[:, 1], (raw[0, :, 1] * 2 + g[1]) * g[2], atol=1e-5)
     assert torch.allclose(k[:, 2], raw[0, :, 2].sigmoid(), atol=1e-6)
+
+
+def test_byte_crop_table_is_the_oracle_crop_normalisation():
+    """fused32.crops_from_u8 (the host form of what k32_stemW's staging applies to byte crops): on a constant-colour frame every crop pixel is
+    ((v / 255) - mean) / sd of that colour — the C oracle's crop_norm and the table give the same float32 bits for all 256 values of every channel
+    (the table is built with IEEE operations on the host; PyTorch-ROCm's device division is not correctly rounded)."""
+    import numpy as np
+    import torch
+    from oracle import cexact
+    from strongsort_yolo_amd import fused32
+    for v0 in range(0, 256, 5):
+        bgr = np.array([v0, (v0 * 7 + 3) % 256, (v0 * 13 + 11) % 256], np.uint8)
+        img = np.broadcast_to(bgr, (64, 48, 3)).copy()
+        ref = cexact.crop_norm(img, np.array([[4.0, 6.0, 40.0, 60.0, 1.0, 0.0]], np.float32))      # [1, 3, 256, 128] RGB
+        rgb = bgr[::-1].copy()
+        x = torch.from_numpy(np.broadcast_to(rgb.reshape(1, 3, 1, 1), (1, 3, 256, 128)).copy()).contiguous(memory_format=torch.channels_last)
+        got = fused32.crops_from_u8(x).numpy()
+        assert got.tobytes() == np.ascontiguousarray(ref).tobytes()
+
+
+def test_decode_into_hands_out_the_callers_buffer_only_when_it_fits():
+    import torch
+    from strongsort_yolo_amd import fused
+    buf = torch.zeros(2, 84, 100)
+    assert fused.decode_into.target((2, 84, 100), buf.device).data_ptr() != buf.data_ptr()          # no block active: a fresh tensor
+    with fused.decode_into(buf):
+        assert fused.decode_into.target((2, 84, 100), buf.device).data_ptr() == buf.data_ptr()
+        assert fused.decode_into.target((2, 85, 100), buf.device).data_ptr() != buf.data_ptr()      # another shape: a fresh tensor
+        with fused.decode_into(None):
+            assert fused.decode_into.target((2, 84, 100), buf.device).data_ptr() != buf.data_ptr()
+        assert fused.decode_into.target((2, 84, 100), buf.device).data_ptr() == buf.data_ptr()      # the outer block is restored
+    assert fused.decode_into.target((2, 84, 100), buf.device).data_ptr() != buf.data_ptr()
