@@ -444,6 +444,10 @@ int ss_op32_stem(void* stream, const void* d_x, const void* d_w, const void* d_b
 /* The same operator on BYTE crops [N][256][128][3] (ss_crop_norm_batch / _packed with SS_DST_HWC | SS_DST_U8): /255, mean and std are applied
  * while the rows are staged, from a table built with ss_crop_norm's own expression - outputs bit-equal to ss_op32_stem on the float crops. */
 int ss_op32_stem_u8(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid);
+/* ... and with the first OSBlock's conv1 (1x1, 16 -> 16, + bias + ReLU) applied to the pooled pixels by the same launch: d_y1 [N][64][32][16] =
+ * relu(W1 d_y + b1), bit-equal to ss_op32_pointwise on d_y (the stem's output is not read back).  x_u8 != 0: byte crops. */
+int ss_op32_stem_conv1(void* stream, const void* d_x, int x_u8, const void* d_w, const void* d_bias, void* d_y, const void* d_w1, const void* d_b1,
+                       void* d_y1, int N, int H, int W, const int* d_nvalid);
 /* d_out[n][f] = relu(sum_c d_w[f][c] * mean_hw(d_x[n][.][c]) + d_bias[f]), C == 128. */
 int ss_op32_head(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_out, int N, int HW, int C, int F,
                  const int* d_nvalid);

@@ -964,7 +964,8 @@ __global__ __launch_bounds__(C32_THREADS) void k32_stem(const float* __restrict_
 #define STW_THREADS 512
 template <bool U8>
 __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const void* __restrict__ xv, const float* __restrict__ w /*[16][148]*/,
-                                                            const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img, int nb)
+                                                            const float* __restrict__ bias, float* __restrict__ y, int Nimg, const int* __restrict__ n_img, int nb,
+                                                            const float* __restrict__ w1 /*[16][16] or null*/, const float* __restrict__ b1, float* __restrict__ y1)
 {
     constexpr int H = 256, Wd = 128, OW = 64, PH = 64, PW = 32, RING = 24, CSP = 16, RV = Wd * 3 / 4;   // RV: data vectors of an input row (96)
     constexpr int RB = Wd * 3 / 16;                          // U8: 16-byte vectors of an input row (24)
@@ -1040,6 +1041,13 @@ __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const void* __restri
 #pragma unroll
     for (int s = 0; s < 37; ++s) asm volatile("" ::"v"(a[s]));
     asm volatile("" ::"v"(bb[0]), "v"(bb[1]), "v"(bb[2]), "v"(bb[3]));   // the weights have arrived HERE: inside the loop their wait would also cover the rows requested ahead
+    // the first OSBlock's conv1 (1x1, 16 -> 16, + bias + ReLU) on the pooled pixels, from the same launch: the pool threads of a wave hold a
+    // 16-pixel tile in the B layout (lane (q, n): chunk q of pixel n), k32_pw's four-MFMA chain runs on it — x1 bit-equal to k32_pw's, x0 not re-read
+    f4 wc1 = zero4(), bc1 = zero4();
+    if (w1) {
+        wc1 = ld4(w1 + n * 16 + 4 * kq); bc1 = ld4(b1 + 4 * kq);
+        asm volatile("" ::"v"(wc1[0]), "v"(wc1[1]), "v"(wc1[2]), "v"(wc1[3]), "v"(bc1[0]), "v"(bc1[1]), "v"(bc1[2]), "v"(bc1[3]));
+    }
     int base = 0;
     for (int bi = 0; bi < nb; ++bi) {
         const int band = b0 + bi, cy0 = 8 * band - 1, iy0 = 16 * band - 5;
@@ -1119,7 +1127,7 @@ __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const void* __restri
             }
         }
         {
-            const int q = tid & 3, pxl = (tid >> 2) & 31, prl = tid >> 7;
+            const int q = kq, pxl = 16 * (wave & 1) + n, prl = wave >> 1;       // a wave = 16 pixels of one pooled row x 4 channel chunks (lane (q, n))
             f4 m = f4{ -INFINITY, -INFINITY, -INFINITY, -INFINITY };
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -1133,7 +1141,14 @@ __global__ __launch_bounds__(STW_THREADS, 4) void k32_stemW(const void* __restri
                     m = max4(m, ld4(Cs + (slot * OW + cx) * CSP + 4 * q));
                 }
             }
-            st4(y + (((size_t)img * PH + 4 * band + prl) * PW + pxl) * 16 + 4 * q, m);
+            const size_t po = (((size_t)img * PH + 4 * band + prl) * PW + pxl) * 16 + 4 * q;
+            st4(y + po, m);
+            if (w1) {
+                f4 acc = zero4();
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = MFMA4(wc1[e], m[e], acc);
+                st4(y1 + po, relu4(acc + bc1));
+            }
         }
         base += 16; base = base >= RING ? base - RING : base;
     }
@@ -1628,6 +1643,28 @@ extern "C" int ss_op32_tail(void* stream, const void* const* d_ys, const float* 
 static int stem_bands(int N) { return g_stem_walk > 0 ? g_stem_walk : (N >= 1024 ? 16 : N >= 512 ? 8 : N >= 128 ? 4 : 2); }   // bands a workgroup walks down (measured at 1 024 / 860 / 430 / 28 crops: tools/stem32_time.py)
 
 // The stem on BYTE crops [N][256][128][3] (ss_crop_norm* with SS_DST_U8): the normalisation happens while the rows are staged.
+// ... and with the first block's conv1 (1x1, 16 -> 16, bias, ReLU) applied to the pooled pixels in the same launch: d_y1 = relu(W1 d_y + b1), bit-equal
+// to ss_op32_pointwise on d_y.  x_u8: byte crops (ss_op32_stem_u8) or float crops.
+extern "C" int ss_op32_stem_conv1(void* stream, const void* d_x, int x_u8, const void* d_w, const void* d_bias, void* d_y, const void* d_w1, const void* d_b1,
+                                  void* d_y1, int N, int H, int W, const int* d_nvalid)
+{
+    if (!d_x || !d_w || !d_bias || !d_y || !d_w1 || !d_b1 || !d_y1 || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
+    constexpr size_t lds = (size_t)(24 * ST_ROWP + (2 * ST_PR + 1) * 64 * 16 + 768) * 4;
+    static unsigned long long attr8 = 0, attr32 = 0;
+    const int nb = stem_bands(N);
+    if (x_u8) {
+        if (!lds_attr_once((const void*)k32_stemW<true>, attr8)) return SS_ERR_HIP;
+        hipLaunchKernelGGL(k32_stemW<true>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w, (const float*)d_bias, (float*)d_y, N,
+                           d_nvalid, nb, (const float*)d_w1, (const float*)d_b1, (float*)d_y1);
+    } else {
+        if (!lds_attr_once((const void*)k32_stemW<false>, attr32)) return SS_ERR_HIP;
+        hipLaunchKernelGGL(k32_stemW<false>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w, (const float*)d_bias, (float*)d_y, N,
+                           d_nvalid, nb, (const float*)d_w1, (const float*)d_b1, (float*)d_y1);
+    }
+    OP32_CHECK();
+    return SS_OK;
+}
+
 extern "C" int ss_op32_stem_u8(void* stream, const void* d_x, const void* d_w, const void* d_bias, void* d_y, int N, int H, int W, const int* d_nvalid)
 {
     if (!d_x || !d_w || !d_bias || !d_y || N < 1 || N > 65535 || H != 256 || W != 128) return SS_ERR_INVALID;
@@ -1636,7 +1673,7 @@ extern "C" int ss_op32_stem_u8(void* stream, const void* d_x, const void* d_w, c
     const int nb = stem_bands(N);
     if (!lds_attr_once((const void*)k32_stemW<true>, attr)) return SS_ERR_HIP;
     hipLaunchKernelGGL(k32_stemW<true>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w,
-                       (const float*)d_bias, (float*)d_y, N, d_nvalid, nb);
+                       (const float*)d_bias, (float*)d_y, N, d_nvalid, nb, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     OP32_CHECK();
     return SS_OK;
 }
@@ -1650,7 +1687,7 @@ extern "C" int ss_op32_stem(void* stream, const void* d_x, const void* d_w, cons
     if (nb) {
         if (!lds_attr_once((const void*)k32_stemW<false>, attr_w)) return SS_ERR_HIP;
         hipLaunchKernelGGL(k32_stemW<false>, dim3(16 / nb, N), dim3(STW_THREADS), lds, (hipStream_t)stream, d_x, (const float*)d_w,
-                           (const float*)d_bias, (float*)d_y, N, d_nvalid, nb);
+                           (const float*)d_bias, (float*)d_y, N, d_nvalid, nb, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
         OP32_CHECK();
         return SS_OK;
     }

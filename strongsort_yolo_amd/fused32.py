@@ -118,8 +118,12 @@ def crops_from_u8(x):
     return out
 
 
-def stem(x, cbr):
-    """relu(conv7x7/2(x) + b) -> max pool 3x3/2: x [N, 3, 256, 128] channels-last float (or uint8 byte crops) -> [N, 16, 64, 32]."""
+STEM_CONV1 = True       # A/B: the first OSBlock's conv1 from the stem's launch (False: a k32_pw launch that reads the stem's output back)
+
+
+def stem(x, cbr, conv1=None):
+    """relu(conv7x7/2(x) + b) -> max pool 3x3/2: x [N, 3, 256, 128] channels-last float (or uint8 byte crops) -> [N, 16, 64, 32].
+    conv1 (a ConvBR 16 -> 16, 1x1, ReLU: the first OSBlock's): -> (y, relu(conv1(y))) from ONE launch."""
     if x.dtype != torch.uint8:
         x = _cl(x)
     n, _, h, w = x.shape
@@ -132,9 +136,16 @@ def stem(x, cbr):
 
     wk = _cached(cbr, "_w32_stem", conv.weight, build)
     y = torch.empty((n, 16, h // 4, w // 4), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if conv1 is not None:
+        c1 = conv1.conv
+        if STEM_CONV1 and c1.in_channels == 16 and c1.out_channels == 16 and c1.kernel_size == (1, 1) and conv1.relu and c1.bias is not None:
+            y1 = torch.empty_like(y)
+            _ck(_lib.load().ss_op32_stem_conv1(_st(x), _p(x), int(x.dtype == torch.uint8), _p(wk), _p(conv.bias), _p(y), _p(_w_nk(conv1, c1)), _p(c1.bias), _p(y1),
+                                               n, h, w, _nvp(x)))
+            return y, y1
     fn = _lib.load().ss_op32_stem_u8 if x.dtype == torch.uint8 else _lib.load().ss_op32_stem
     _ck(fn(_st(x), _p(x), _p(wk), _p(conv.bias), _p(y), n, h, w, _nvp(x)))
-    return y
+    return y if conv1 is None else (y, pointwise(y, conv1, conv1.conv, relu=True))
 
 
 def _w_nk(mod, conv):

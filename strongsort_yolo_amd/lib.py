@@ -25,7 +25,7 @@ EXPORTS = [
     "ss_check_errors", "ss_set_option", "ss_feat_normalize", "ss_ema", "ss_kf_predict", "ss_kf_update", "ss_kf_project", "ss_kf_initiate",
     "ss_gallery_pack", "ss_assoc_cost", "ss_iou_cost", "ss_lsap", "ss_get_tracks", "ss_get_debug",
     "ss_get_gallery", "ss_max_group_frames", "ss_track_join", "ss_stream_create", "ss_stream_destroy", "ss_assoc_timing", "ss_assoc_timing_values", "ss_assoc_inkernel_timing", "ss_assoc_timeline", "ss_op_bias_act_f16", "ss_op_bias_act_place_f16", "ss_op_pointwise_f16", "ss_op_conv3x3_f16", "ss_op_bottleneck_f16", "ss_op_conv_group_f16", "ss_op_head_f16", "ss_op_v8_decode_f16", "ss_op_v8_decode_ext_f16", "ss_op_dwconv3x3_f16", "ss_op_lightconv_f16", "ss_op_osnet_stem_f16", "ss_op_conv0_f16", "ss_op_osnet_streams_f16", "ss_op_osnet_streams_bands", "ss_op_dwtab_bytes", "ss_op_dwtab_f16", "ss_op_gate_apply_f16", "ss_op_osnet_tail_f16", "ss_op_gate_sum_f16", "ss_op_avgpool2_f16", "ss_op_upcat_f16", "ss_op_sppf_pools_f16", "ss_op_psa_attention_f16", "ss_op_osnet_head_f16", "ss_op_maxpool_f16",
-    "ss_op32_pointwise", "ss_op32_chains_bands", "ss_op32_chains", "ss_op32_tail", "ss_op32_stem", "ss_op32_stem_u8", "ss_op32_head", "ss_op32_set_option", "ss_op32_conv", "ss_op32_conv0", "ss_op32_upcat", "ss_op32_v8_decode", "ss_op32_sppf_pools",
+    "ss_op32_pointwise", "ss_op32_chains_bands", "ss_op32_chains", "ss_op32_tail", "ss_op32_stem", "ss_op32_stem_u8", "ss_op32_stem_conv1", "ss_op32_head", "ss_op32_set_option", "ss_op32_conv", "ss_op32_conv0", "ss_op32_upcat", "ss_op32_v8_decode", "ss_op32_sppf_pools",
 ]
 
 
@@ -164,6 +164,7 @@ def load():
     L.ss_op32_tail.argtypes = [vp, C.POINTER(vp), vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp]
     L.ss_op32_stem.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
     L.ss_op32_stem_u8.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
+    L.ss_op32_stem_conv1.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, i, i, vp]
     L.ss_op32_head.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.ss_op32_set_option.argtypes = [C.c_char_p, i]
     L.ss_op32_conv.argtypes = [vp, vp, i, vp, vp, vp, i, vp, i, i, i, i, i, i, i, i, i]

@@ -987,9 +987,7 @@ class OSNet(nn.Module):
         block's conv1); a second block -> (the ConvBR after it [+ 2x2 average],); parts 3, 6, 9 only unwrap."""
         f = fused32
         if k == 0:
-            x0 = f.stem(s, self.conv1)
-            c1 = self.conv2[0].conv1
-            return (x0, f.pointwise(x0, c1, c1.conv, relu=True))
+            return f.stem(s, self.conv1, self.conv2[0].conv1)      # (x0, the first block's conv1 of x0) from one launch
         if k in (1, 2, 4, 5, 7, 8):
             blk, nxt, pool = self._blocks(k)
             x, x1 = s if (isinstance(s, tuple) and len(s) == 2) else (s[0] if isinstance(s, tuple) else s, None)

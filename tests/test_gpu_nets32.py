@@ -115,6 +115,31 @@ def test_stem_on_byte_crops_equals_stem_on_float_crops(n):
     assert part[:k].cpu().numpy().tobytes() == ref[:k].cpu().numpy().tobytes()
 
 
+@pytest.mark.parametrize("u8", [False, True])
+@pytest.mark.parametrize("n", [5, 200])
+def test_stem_with_the_first_blocks_conv1_in_the_same_launch(n, u8):
+    """ss_op32_stem_conv1: (x0, relu(conv1(x0))) from one launch == the stem launch + k32_pw on its output, bit for bit (byte and float crops)."""
+    from strongsort_yolo_amd import fused32, nets
+    g = torch.Generator().manual_seed(100 + n)
+    m, c1 = nets.ConvBR(3, 16, 7, 2, 3), nets.ConvBR(16, 16, 1)
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn(m.conv.weight.shape, generator=g) * 0.2); m.conv.bias.copy_(torch.randn(16, generator=g))
+        c1.conv.weight.copy_(torch.randn(c1.conv.weight.shape, generator=g) * 0.3); c1.conv.bias.copy_(torch.randn(16, generator=g) * 0.5)
+    m, c1 = m.to(DEV), c1.to(DEV)
+    xb = torch.randint(0, 256, (n, 3, 256, 128), dtype=torch.uint8, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    x = xb if u8 else fused32.crops_from_u8(xb)
+    try:
+        fused32.STEM_CONV1 = False
+        y_ref, y1_ref = fused32.stem(x, m, c1)
+        fused32.STEM_CONV1 = True
+        y, y1 = fused32.stem(x, m, c1)
+    finally:
+        fused32.STEM_CONV1 = True
+    assert y.cpu().numpy().tobytes() == y_ref.cpu().numpy().tobytes()
+    assert y1.cpu().numpy().tobytes() == y1_ref.cpu().numpy().tobytes()
+    assert float(y1.abs().max()) > 0
+
+
 def _block(c1, c2, seed):
     from strongsort_yolo_amd import nets
     g = torch.Generator().manual_seed(seed)
