@@ -657,6 +657,66 @@ __global__ __launch_bounds__(1024) void k_nms_rest(NmsBatch nb, int N, int nc, i
         if (tid == 0) { w.counters[1] = SS_ERR_CAPACITY; w.counters[0] = 0; }
         n = 0;
     }
+    if (n <= 64) {
+        // ---- small images (the usual case: ~30 candidates at the reference's thresholds): ONE wave does the three phases in registers ----
+        // sort = a 64-lane bitonic network on shuffles (keys are unique: any correct sort gives the order of the LDS sort below), boxes /
+        // areas with the same expressions, the IoU row of candidate i against every later one as one 64-bit word per lane, the greedy scan
+        // of phase C on that word.  No barrier, no round trip through the global workspace (the general path: 15+ barriers, boxes / areas /
+        // bit matrix written and read back; 37 us per call for ~30 candidates per image, latency only).
+        if (wv == 0) {
+            unsigned long long key = l < n ? w.keys[l] : ~0ull;
+            auto shfl64 = [](unsigned long long v, int src) {
+                const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src), hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+                return ((unsigned long long)hi << 32) | lo;
+            };
+#pragma unroll
+            for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+                for (int strd = size >> 1; strd > 0; strd >>= 1) {
+                    const unsigned long long other = shfl64(key, l ^ strd);
+                    const bool lower = (l & strd) == 0, up = (l & size) == 0;       // ascending blocks where (l & size) == 0 (size 64: the whole wave)
+                    const bool take_min = lower == up;
+                    key = take_min ? (key < other ? key : other) : (key > other ? key : other);
+                }
+            float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, ai = 0.f;
+            if (l < n) {
+                w.keys[l] = key;
+                const int a = (int)(key & 0xffffffffu);
+                float cx = pred[a], cy = pred[(size_t)N + a], bw = pred[(size_t)2 * N + a], bh = pred[(size_t)3 * N + a];
+                float hw = bw / 2.0f, hh = bh / 2.0f;
+                float off = agnostic ? 0.0f : (float)w.cand_cls[a] * max_wh;
+                x1 = (cx - hw) + off; y1 = (cy - hh) + off; x2 = (cx + hw) + off; y2 = (cy + hh) + off;
+                ai = (x2 - x1) * (y2 - y1);
+                sbw[l * 4] = x1; sbw[l * 4 + 1] = y1; sbw[l * 4 + 2] = x2; sbw[l * 4 + 3] = y2; saw[l] = ai;
+            }
+            SS_WAVE_SYNC();
+            unsigned long long bits = 0;
+            if (l < n) {
+                for (int q = 0; q < n; ++q) {
+                    if (q <= l) continue;
+                    float xx1 = fmaxf(x1, sbw[q * 4]), yy1 = fmaxf(y1, sbw[q * 4 + 1]);
+                    float xx2 = fminf(x2, sbw[q * 4 + 2]), yy2 = fminf(y2, sbw[q * 4 + 3]);
+                    float iw = fmaxf(0.0f, xx2 - xx1), ih = fmaxf(0.0f, yy2 - yy1);
+                    float inter = iw * ih;
+                    float iou = inter / (ai + saw[q] - inter);
+                    if (iou > iou_thres) bits |= 1ull << q;
+                }
+            }
+            unsigned long long rw = 0;
+            int kept = 0;
+            const int cap = min(max_det, 1024);
+            for (int q = 0; q < n && kept < cap; ++q) {
+                if (!((rw >> q) & 1ull)) {
+                    if (l == 0) kept_sorted[kept] = q;
+                    ++kept;
+                    rw |= shfl64(bits, q);
+                }
+            }
+            if (l == 0) { s_kept = kept; *count = kept; w.counters[0] = 0; }
+        }
+        __threadfence_block();
+        __syncthreads();
+    } else {
     int np = 1; while (np < n) np <<= 1;
     for (int i = tid; i < np; i += 1024) k[i] = i < n ? w.keys[i] : ~0ull;
     __syncthreads();
@@ -757,6 +817,7 @@ __global__ __launch_bounds__(1024) void k_nms_rest(NmsBatch nb, int N, int nc, i
         if (l == 0) { s_kept = kept; *count = kept; w.counters[0] = 0; }     // re-arm the candidate counter for the next call
     }
     __syncthreads();
+    }                                                            // (n > 64)
     const int kept = s_kept;
     for (int kk = tid; kk < kept; kk += 1024) {
         const int i = kept_sorted[kk];

@@ -322,3 +322,30 @@ def test_crop_norm_byte_output_is_the_float_crop_before_normalisation(eng, packe
         sel = torch.cat([torch.arange(0, 32), torch.arange(64, 81)]).to(eng.device)
         a, b = f32[sel], fused32.crops_from_u8(u8[sel])
     assert bits_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+@pytest.mark.parametrize("n_cand", [0, 1, 2, 17, 40, 63, 64, 65, 130])
+@pytest.mark.parametrize("agnostic", [False, True])
+def test_nms_small_candidate_counts_one_wave_path(eng, n_cand, agnostic):
+    """Up to 64 candidates an image is handled by ONE wave in registers (shuffle sort, IoU word per lane, greedy scan); 65 and more take the
+    workgroup path.  Both against the oracle: heavily overlapping boxes, equal scores (ties broken by anchor index), two classes."""
+    from dataclasses import replace
+    dcfg = replace(DetectConfig(), agnostic_nms=agnostic)
+    N, nc = 1344, 2
+    rng = np.random.default_rng(1000 + n_cand)
+    pred = np.zeros((4 + nc, N), np.float32)
+    pred[0] = rng.uniform(0, 320, N); pred[1] = rng.uniform(0, 256, N); pred[2] = rng.uniform(10, 60, N); pred[3] = rng.uniform(10, 60, N)
+    idx = rng.choice(N, n_cand, replace=False)
+    centres = rng.uniform(60, 200, (max(1, n_cand // 5 + 1), 2))
+    for j, a in enumerate(idx):                                  # clusters of ~5 boxes around a few centres: most pairs inside a cluster overlap
+        c = centres[j % len(centres)]
+        pred[0, a], pred[1, a] = c[0] + rng.uniform(-6, 6), c[1] + rng.uniform(-6, 6)
+        pred[2, a], pred[3, a] = 40 + rng.uniform(-4, 4), 50 + rng.uniform(-4, 4)
+        pred[4 + (j % nc), a] = [0.9, 0.9, 0.8, 0.8, 0.7][j % 5] if j % 7 else float(rng.uniform(0.4, 0.95))   # equal scores inside clusters
+    rows, keep, count = eng.nms(torch.from_numpy(pred).to(eng.device), nc, dcfg, 1.0, 0.0, 0.0, 320, 256)
+    k = int(count.item())
+    rkeep, rrows = cexact.nms(pred, nc, dcfg.conf, dcfg.iou, agnostic, dcfg.max_wh, dcfg.max_nms, dcfg.max_det)
+    assert k == len(rkeep) and np.array_equal(keep.cpu().numpy()[:k], rkeep)
+    assert bits_equal(rows.cpu().numpy()[:k, :6], cexact.scale_boxes(rrows, 1.0, 0.0, 0.0, 320, 256))
+    if n_cand:
+        assert 0 < k <= n_cand

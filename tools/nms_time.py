@@ -1,5 +1,5 @@
 """Batched NMS (a3) of 32 yolov8n head tensors [84][5040] with ~30 kept boxes each: microseconds per call by HIP events.
-usage: python tools/nms_time.py [reps=50]"""
+usage: python tools/nms_time.py [reps=50] [identities=30]"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from strongsort_yolo_amd.config import StrongSortConfig, DetectConfig
@@ -12,7 +12,8 @@ W, H, nc, B = 1280, 720, 80, 32
 g = letterbox_geometry(H, W)
 gain, px, py = scale_geometry(g, H, W)
 N = sum((g.out_h // s) * (g.out_w // s) for s in (8, 16, 32))
-st, rng = make_stream(5, W, H, 30), np.random.default_rng(2)
+NID = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+st, rng = make_stream(5, W, H, NID), np.random.default_rng(2)
 preds = np.stack([synth_prediction(st.next_frame().dets, N, nc, gain, (px, py), rng)[0] for _ in range(B)])
 pred = torch.from_numpy(preds).to(dev)
 rows, keep, count = torch.zeros(B, 128, 6, device=dev), torch.zeros(B, 128, dtype=torch.int32, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
