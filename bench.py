@@ -974,6 +974,10 @@ def main():
         torch.cuda.synchronize()
         pipe.eng.assoc_timing(True)                  # arm per-dispatch HIP events on the association kernel
         pipe.eng.assoc_inkernel_timing(True)         # ... and the kernel's own first-start / last-end stamps
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()                                 # no collector pause inside the timed region (the enqueue loop runs ~1 step ahead of the GPU: a pause of a few ms starves it; 20 steps are 75 ms)
         barrier()
         t0, c0 = time.perf_counter(), time.thread_time()
         if overlap and os.environ.get("SS_PIPE_TRACE"):
@@ -983,6 +987,8 @@ def main():
         t_enq_cpu = time.thread_time() - c0          # time the runtime blocks on full hardware queues) and the CPU time this thread used for it
         barrier()
         dt = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         if overlap and pipe.trace:
             tr, pipe.trace = pipe.trace, None
             ref = tr[0][2]
