@@ -968,6 +968,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
 
+        # The in-kernel stamps are armed BEFORE the prefill: the switch is part of the tracker's launch parameters, and the library's chain graphs
+        # are keyed by those — armed only at the start of the timed region (until round 6) every buffer set's combination was NEW there: its first
+        # group went out as 64 plain launches and its second paid a graph capture + instantiation on the host (several ms; two of eight 20-step
+        # runs caught an 11 ms tracker call and came out 8-13 % low).  Prefill + warm-up now see every combination twice; the timed steps only replay.
+        pipe.eng.assoc_inkernel_timing(True)
         run(0, PREFILL)                              # untimed: galleries reach nn_budget rows
         run(PREFILL, PREFILL + WF)                   # W untimed warm-up steps
         drain()
